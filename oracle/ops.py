@@ -1,0 +1,337 @@
+"""CPU oracle for the relational-GNN hot path -- TEST INFRASTRUCTURE ONLY.
+
+A plain-PyTorch (CPU, fp32 or fp64) restatement of what each
+``torch.ops.torch_hrt.*`` op on the hot path computes, one function per op,
+with the reference's argument order and its in-place, caller-allocated-output
+convention.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; the product (``het_amd``) never
+does.
+
+PARITY STATUS: the reference's CUDA path cannot be built
+or run here (no nvcc, empty third_party/ submodules) and the reference ships no
+arithmetic test vectors, so for the floating-point ops this restatement follows
+the CUDA sources as text (file:line cited per function) and is "parity
+unpinned", except:
+  * layouts (integer, exact) and the ``exp`` / ``sum`` outputs of the fused GAT
+    forward are pinned by golden vectors generated from the reference's own
+    importable Python (tests/golden/make_golden.py).
+Where the CUDA code deviates from the reference's own stated intent (its DSL
+specs hrt/pyctor/examples/inter-op-dsl/*.inter-op and in-code TODO/FIXMEs) the
+oracle implements the INTENDED semantics; each such position is listed in
+DESIGN.md ("Reference quirks") with its SURVEY.md section-9 id.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------
+def rel_of_position(rel_ptrs: Tensor) -> Tensor:
+    """Relation id of every position of a relation-bucketed list (the device
+    code recovers it by searching ``rel_ptrs``: hrt/include/utils.cu.h:94-121)."""
+    R = rel_ptrs.numel() - 1
+    return torch.repeat_interleave(torch.arange(R, dtype=torch.int64), rel_ptrs[1:] - rel_ptrs[:-1])
+
+
+def _search_rows(rel_ptrs_u: Tensor, nodes_u: Tensor, rel: Tensor, node: Tensor, num_nodes_bound: int) -> Tensor:
+    """Row of (rel, node) in a per-relation sorted unique list
+    (``find_relational_compact_as_of_node_index`` with binary search,
+    hrt/include/kernel_enums.h:101-119)."""
+    key_u = rel_of_position(rel_ptrs_u) * num_nodes_bound + nodes_u
+    key = rel * num_nodes_bound + node
+    pos = torch.searchsorted(key_u, key)
+    assert bool((key_u[pos] == key).all()), "(relation, node) pair missing from the unique list"
+    return pos
+
+
+def _gat_rows(kind: int, d: Dict[str, Tensor], rel_ptrs, row, col, eids):
+    """(src_row, dst_row): rows of feat/el (src side) and er (dst side) for each
+    edge position.  RGATKernelsSeparateCOO.cu.h:139-189 and kernel_enums.h."""
+    if kind == 0:
+        return eids, eids
+    rel = rel_of_position(rel_ptrs)
+    bound = int(max(row.max(), col.max())) + 1 if row.numel() else 1
+    if kind == 1:  # Enabled: one two-sided unique list, binary search
+        rp, nodes = d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices"]
+        return _search_rows(rp, nodes, rel, row, bound), _search_rows(rp, nodes, rel, col, bound)
+    if kind == 3:  # EnabledWithDualList: separate src / dst unique lists
+        rp_c = d.get("unique_srcs_and_dests_rel_ptrs_col", d.get("unique_srcs_and_dests_rel_col"))
+        return (
+            _search_rows(d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices_row"], rel, row, bound),
+            _search_rows(rp_c, d["unique_srcs_and_dests_node_indices_col"], rel, col, bound),
+        )
+    if kind == 4:  # EnabledWithDualListWithDirectIndexing: inverse index by edata idx
+        return d["edata_idx_to_inverse_idx_row"][eids], d["edata_idx_to_inverse_idx_col"][eids]
+    raise NotImplementedError(
+        "CompactAsOfNodeKind 2 maps src and dst through the same per-edge inverse index in the "
+        "reference (kernel_enums.h:117) and is not reachable from its models")
+
+
+# --------------------------------------------------------------------------
+# a1/a2  segment GEMM with gather / scatter lists
+# --------------------------------------------------------------------------
+def _matmul_lists(d: Dict[str, Tensor], kind: int):
+    if kind == 0:
+        return d["separate_coo_rel_ptrs"], d["separate_coo_node_indices"], d["separate_coo_eids"]
+    if kind == 1:
+        rp = d["unique_srcs_and_dests_rel_ptrs"]
+        return rp, d["unique_srcs_and_dests_node_indices"], torch.arange(int(rp[-1]), dtype=torch.int64)
+    raise NotImplementedError(f"CompactAsOfNodeKind {kind} (the reference asserts, RGNNOps.inc.h:292-294)")
+
+
+def rgnn_relational_matmul(d, kind: int, W: Tensor, x: Tensor, ret: Tensor, in1head: bool) -> None:
+    """ret[scatter[i], h, :] = x[gather[i], (h), :] @ W[rel(i), h]   (plain store)
+
+    RGNNOps.inc.h:238-295 -> _RelationalMatMul :93-236 ->
+    my_shmem_sgemm_func.cu.h:504-531 (kind 0), :635-664 (gather == scatter),
+    :671-704 (kind 1: gather by the unique (rel, node) list, dense output rows).
+    Per-head semantics for in1head == False are the intended ones."""
+    rp, g, s = _matmul_lists(d, kind)
+    R, H, K, D = W.shape
+    retv = ret.view(-1, H, D)
+    for r in range(R):
+        a, b = int(rp[r]), int(rp[r + 1])
+        if a == b:
+            continue
+        xin = x.reshape(x.shape[0], -1)[g[a:b]]
+        if in1head:
+            out = torch.einsum("nk,hkd->nhd", xin.view(-1, K), W[r])
+        else:
+            out = torch.einsum("nhk,hkd->nhd", xin.view(-1, H, K), W[r])
+        retv[s[a:b]] = out
+
+
+def backward_rgnn_relational_matmul(d, kind: int, Wt: Tensor, x: Tensor, gradout: Tensor,
+                                    grad_x: Tensor, grad_W: Tensor, in1head: bool) -> None:
+    """grad_x[gather[i]] += sum_h gradout[scatter[i], h] @ Wt[r, h]   (heads summed iff in1head)
+    grad_W[r, h]      += x[gather[i], (h)]^T (x) gradout[scatter[i], h]
+
+    RGNNOps.inc.h:946-1010 -> :756-944; kernels my_shmem_sgemm_func.cu.h:711-776.
+    Wt is W with its last two dims transposed ([R, H, D, K])."""
+    rp, g, s = _matmul_lists(d, kind)
+    R, H, D, K = Wt.shape
+    go = gradout.reshape(-1, H, D)
+    gx = grad_x.view(grad_x.shape[0], -1)
+    for r in range(R):
+        a, b = int(rp[r]), int(rp[r + 1])
+        if a == b:
+            continue
+        gr = go[s[a:b]]
+        xin = x.reshape(x.shape[0], -1)[g[a:b]]
+        if in1head:
+            gx.index_add_(0, g[a:b], torch.einsum("nhd,hdk->nk", gr, Wt[r]))
+            grad_W[r] += torch.einsum("nk,nhd->hkd", xin.view(-1, K), gr)
+        else:
+            gx.index_add_(0, g[a:b], torch.einsum("nhd,hdk->nhk", gr, Wt[r]).reshape(b - a, H * K))
+            grad_W[r] += torch.einsum("nhk,nhd->hkd", xin.view(-1, H, K), gr)
+
+
+# --------------------------------------------------------------------------
+# a3  contiguous-segment GEMM
+# --------------------------------------------------------------------------
+def rgnn_relational_matmul_no_scatter_gather_list(offsets: Tensor, W: Tensor, x: Tensor, ret: Tensor) -> None:
+    """Rows offsets[t]:offsets[t+1] use W[t]:  ret[i, h, :] = x[i, (h), :] @ W[t, h].
+    x is [rows, K] (one head shared by all weight heads) or [rows, H, K].
+    RGNNOps.inc.h:21-88; kernel my_shmem_sgemm_func.cu.h:538-564."""
+    T, H, K, D = W.shape
+    n = x.shape[0]
+    per_head = x.numel() == n * H * K and H > 1
+    retv = ret.view(n, H, D)
+    for t in range(T):
+        a, b = int(offsets[t]), int(offsets[t + 1])
+        if a == b:
+            continue
+        if per_head:
+            retv[a:b] = torch.einsum("nhk,hkd->nhd", x[a:b].reshape(-1, H, K), W[t])
+        else:
+            retv[a:b] = torch.einsum("nk,hkd->nhd", x[a:b].reshape(-1, K), W[t])
+
+
+def backward_rgnn_relational_matmul_no_scatter_gather_list(offsets: Tensor, Wt: Tensor, x: Tensor, gradout: Tensor,
+                                                            grad_x: Tensor, grad_W: Tensor) -> None:
+    """RGNNOps.inc.h:660-753; kernels my_shmem_sgemm_func.cu.h:571-628."""
+    T, H, D, K = Wt.shape
+    n = x.shape[0]
+    per_head = x.numel() == n * H * K and H > 1
+    go = gradout.reshape(n, H, D)
+    for t in range(T):
+        a, b = int(offsets[t]), int(offsets[t + 1])
+        if a == b:
+            continue
+        if per_head:
+            grad_x.view(n, H, K)[a:b] += torch.einsum("nhd,hdk->nhk", go[a:b], Wt[t])
+            grad_W[t] += torch.einsum("nhk,nhd->hkd", x[a:b].reshape(-1, H, K), go[a:b])
+        else:
+            grad_x.view(n, K)[a:b] += torch.einsum("nhd,hdk->nk", go[a:b], Wt[t])
+            grad_W[t] += torch.einsum("nk,nhd->hkd", x[a:b].reshape(-1, K), go[a:b])
+
+
+# --------------------------------------------------------------------------
+# a4/a5  fused GAT: edge softmax over all in-edges of a destination + aggregation
+# --------------------------------------------------------------------------
+def _leaky_exp(z: Tensor, slope: float) -> Tensor:
+    # gatLeakyReluExp, GAT/FusedGAT.cu.h:23-26: val > 0 ? exp(val) : exp(slope * val)
+    return torch.exp(torch.where(z > 0, z, z * slope))
+
+
+def relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, kind: int, d, feat, el, er,
+                                      sum_, exp, ret, slope: float) -> None:
+    """exp[eid, h]   = leaky_exp(el[srow, h] + er[drow, h])
+    sum[dst, h]   = SUM over ALL in-edges of dst (every relation) of exp   (no max-subtraction)
+    ret[dst,h,:]  = SUM exp[eid,h] / sum[dst,h] * feat[srow, h, :]
+
+    RGATOps.inc.h:170-245 -> :19-167; kernels RGAT/RGATKernelsSeparateCOO.cu.h:117-204
+    (exp + sum) and :17-100 (aggregation).  ``sum`` and ``ret`` are zeroed here: the
+    reference accumulates into ``new_empty`` buffers."""
+    H = el.shape[1]
+    srow, drow = _gat_rows(kind, d, rel_ptrs, row, col, eids)
+    e = _leaky_exp(el.reshape(el.shape[0], H)[srow] + er.reshape(er.shape[0], H)[drow], slope)  # [E, H] by position
+    exp.view(-1, H)[eids] = e
+    sum_.zero_()
+    sum_.view(-1, H).index_add_(0, col, e)
+    a = e / sum_.view(-1, H)[col]
+    ret.zero_()
+    N = ret.shape[0]
+    ret.view(N, H, -1).index_add_(0, col, a.unsqueeze(-1) * feat.reshape(feat.shape[0], H, -1)[srow])
+
+
+def backward_relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, kind: int, d, feat, el, er,
+                                               sum_, exp, ret, gradout, grad_feat, grad_el, grad_er,
+                                               slope: float) -> None:
+    """a = exp[eid,h] / sum[dst,h]
+    grad_feat[srow,h,:] += a * gradout[dst,h,:]
+    t = SUM_d gradout[dst,h,d] * (feat[srow,h,d] - ret[dst,h,d]) * a * (z > 0 ? 1 : slope),  z = el[srow,h]+er[drow,h]
+    grad_el[srow,h] += t ;  grad_er[drow,h] += t
+
+    RGATOps.inc.h:465-551; kernel RGAT/RGATBackwardKernelsSeparateCOO.cu.h:9-117
+    (gradLeaky: GAT/FusedGATBackward.cu.h)."""
+    H = el.shape[1]
+    N = ret.shape[0]
+    srow, drow = _gat_rows(kind, d, rel_ptrs, row, col, eids)
+    a = exp.view(-1, H)[eids] / sum_.view(-1, H)[col]  # [E, H]
+    go = gradout.reshape(N, H, -1)[col]  # [E, H, D]
+    f = feat.reshape(feat.shape[0], H, -1)
+    grad_feat.view(feat.shape[0], H, -1).index_add_(0, srow, a.unsqueeze(-1) * go)
+    z = el.reshape(el.shape[0], H)[srow] + er.reshape(er.shape[0], H)[drow]
+    dleaky = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+    t = (go * (f[srow] - ret.view(N, H, -1)[col])).sum(-1) * a * dleaky
+    grad_el.view(-1, H).index_add_(0, srow, t)
+    grad_er.view(-1, H).index_add_(0, drow, t)
+
+
+def relational_fused_gat_csr(in_row_ptrs, in_col, in_eids, in_reltypes, uniq_rel_ptrs, uniq_node_idx,
+                             feat, el, er, sum_, exp, ret, slope: float, compact: bool = False) -> None:
+    """Vertex-parallel twin over the in-CSR (rows = dst, col_indices = src):
+    same math as the separate-COO op.  RGATOps.inc.h:251-277; kernels
+    GAT/FusedGAT.cu.h:107-116, 213-222."""
+    N = in_row_ptrs.numel() - 1
+    dst = torch.repeat_interleave(torch.arange(N, dtype=torch.int64), in_row_ptrs[1:] - in_row_ptrs[:-1])
+    H = el.shape[1]
+    if compact:
+        bound = N
+        srow = _search_rows(uniq_rel_ptrs, uniq_node_idx, in_reltypes, in_col, bound)
+        drow = _search_rows(uniq_rel_ptrs, uniq_node_idx, in_reltypes, dst, bound)
+    else:
+        srow = drow = in_eids
+    e = _leaky_exp(el.reshape(el.shape[0], H)[srow] + er.reshape(er.shape[0], H)[drow], slope)
+    exp.view(-1, H)[in_eids] = e
+    sum_.zero_()
+    sum_.view(-1, H).index_add_(0, dst, e)
+    ret.zero_()
+    ret.view(N, H, -1).index_add_(0, dst, (e / sum_.view(-1, H)[dst]).unsqueeze(-1) * feat.reshape(feat.shape[0], H, -1)[srow])
+
+
+def backward_relational_fused_gat_csr(out_row_ptrs, out_col, out_eids, out_reltypes, uniq_rel_ptrs, uniq_node_idx,
+                                      feat, el, er, sum_, exp, ret, gradout, grad_feat, grad_el, grad_er,
+                                      slope: float, compact: bool = False) -> None:
+    """Backward over the out-CSR (rows = src, col_indices = dst).
+    RGATOps.inc.h:430-460; kernels GAT/FusedGATBackward.cu.h:138-362."""
+    N = out_row_ptrs.numel() - 1
+    src = torch.repeat_interleave(torch.arange(N, dtype=torch.int64), out_row_ptrs[1:] - out_row_ptrs[:-1])
+    dst = out_col
+    H = el.shape[1]
+    if compact:
+        srow = _search_rows(uniq_rel_ptrs, uniq_node_idx, out_reltypes, src, N)
+        drow = _search_rows(uniq_rel_ptrs, uniq_node_idx, out_reltypes, dst, N)
+    else:
+        srow = drow = out_eids
+    a = exp.view(-1, H)[out_eids] / sum_.view(-1, H)[dst]
+    go = gradout.reshape(N, H, -1)[dst]
+    f = feat.reshape(feat.shape[0], H, -1)
+    grad_feat.view(feat.shape[0], H, -1).index_add_(0, srow, a.unsqueeze(-1) * go)
+    z = el.reshape(el.shape[0], H)[srow] + er.reshape(er.shape[0], H)[drow]
+    dleaky = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+    t = (go * (f[srow] - ret.view(N, H, -1)[dst])).sum(-1) * a * dleaky
+    grad_el.view(-1, H).index_add_(0, srow, t)
+    grad_er.view(-1, H).index_add_(0, drow, t)
+
+
+# --------------------------------------------------------------------------
+# a7/a8  fused RGCN layer
+# --------------------------------------------------------------------------
+def rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, W, norm, ret) -> None:
+    """ret[col[i], :] += (x[row[i], :] * norm[eids[i]]) @ W[rel(i)]
+    RGCNOps.inc.h:84-138; kernel my_shmem_sgemm_func_rgcn_hgt.cu.h:597-625.
+    ``ret`` is accumulated into (Python zero-fills it, rgcn_layers_and_funcs.py:578-583)."""
+    R = W.shape[0]
+    nv = norm.reshape(-1)
+    for r in range(R):
+        a, b = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a == b:
+            continue
+        msg = (x[row[a:b]] * nv[eids[a:b]].unsqueeze(-1)) @ W[r]
+        ret.index_add_(0, col[a:b], msg)
+
+
+def backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, Wt, norm, grad_norm, grad_x, gradout, grad_W) -> None:
+    """grad_x[row[i]] += (gradout[col[i]] * norm[eids[i]]) @ Wt[r]       (intended direction, SURVEY Q3:
+                        the CUDA code gathers gradout by row and scatters to col)
+    grad_W[r]       += (x[row[i]] * norm[eids[i]])^T (x) gradout[col[i]]
+    grad_norm is left untouched (the reference disables that output,
+    my_shmem_sgemm_func_rgcn_hgt.cu.h:680-684).  RGCNOps.inc.h:368-467."""
+    R = Wt.shape[0]
+    nv = norm.reshape(-1)
+    for r in range(R):
+        a, b = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a == b:
+            continue
+        sc = nv[eids[a:b]].unsqueeze(-1)
+        g = gradout[col[a:b]] * sc
+        grad_x.index_add_(0, row[a:b], g @ Wt[r])
+        grad_W[r] += (x[row[a:b]]).t() @ g
+
+
+# --------------------------------------------------------------------------
+# a9  RGCN aggregation of a compact (relation, src) feature tensor
+# --------------------------------------------------------------------------
+def _rgcn_compact_rows(d, direct: bool, rel_ptrs, row, eids):
+    if direct:
+        return d["inverse_indices_row"][eids]
+    bound = int(row.max()) + 1 if row.numel() else 1
+    return _search_rows(d["rel_ptrs_row"], d["node_indices_row"], rel_of_position(rel_ptrs), row, bound)
+
+
+def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(eids, rel_ptrs, row, col, d, feat, enorm, ret,
+                                                               direct: bool) -> None:
+    """ret[col[i], :] += enorm[eids[i]] * feat[compact_row(rel(i), row[i]), :]
+    RGCNOps.inc.h:24-82; kernel RGCN/RGCNKernelsEdgeParallel.cu.h:20-92 (which indexes feat by
+    the raw src id -- its own TODO; intended mapping used here).  ``ret`` zeroed
+    here (allocated with th.empty by the caller, rgcn_layers_and_funcs.py:763-768)."""
+    fr = _rgcn_compact_rows(d, direct, rel_ptrs, row, eids)
+    ret.zero_()
+    ret.view(ret.shape[0], -1).index_add_(0, col, enorm.reshape(-1)[eids].unsqueeze(-1) * feat.reshape(feat.shape[0], -1)[fr])
+
+
+def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(eids, rel_ptrs, row, col, d, feat, enorm, ret,
+                                                                        gradout, grad_feat, direct: bool) -> None:
+    """grad_feat[compact_row, :] += enorm[eids[i]] * gradout[col[i], :]
+    RGCNOps.inc.h:303-366; kernel RGCN/RGCNBackwardKernelsEdgeParallel.cu.h:21-92."""
+    fr = _rgcn_compact_rows(d, direct, rel_ptrs, row, eids)
+    grad_feat.view(grad_feat.shape[0], -1).index_add_(
+        0, fr, enorm.reshape(-1)[eids].unsqueeze(-1) * gradout.reshape(gradout.shape[0], -1)[col])

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's own
+importable Python (run in the build container, where /root/reference exists;
+the GPU box only sees the committed .npz files).
+
+What is pinned:
+  * layouts, exactly (int64): integrated COO -> separate COO (bucketed by
+    relation, sorted by eid), out-CSR, transposed CSR, single-sided and
+    two-sided unique (relation, node) lists with inverse indices -- computed
+    by the reference's
+      hrt/python/testing/adjacency_manipulation.py
+      hrt/python/utils/coo_sorters.py
+      hrt/python/utils_lite/mydgl_graph_methods.py
+      hrt/python/utils_lite/sparse_matrix_converters.py
+    loaded by file path (their packages import DGL, which is absent here);
+  * the ``exp`` and ``sum`` outputs of the fused GAT forward, computed by
+    hrt/python/testing/ref_kernels_lite/ref_rgat.py (its ``ret`` is never
+    written by that file, so ``ret`` is NOT pinned by it).
+
+Two graphs: the 4-node toy graph of SURVEY.md section 10 and a slice of the
+only real topology shipped with the reference, hrt/data/ogbn_mag_0.1/*.npy
+(first 4096 edges of each of the six relation files).
+
+Usage: python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference/hrt"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+adj = load("python/testing/adjacency_manipulation.py", "ref_adj")
+sorters = load("python/utils/coo_sorters.py", "ref_sorters")
+methods = load("python/utils_lite/mydgl_graph_methods.py", "ref_methods")
+conv = load("python/utils_lite/sparse_matrix_converters.py", "ref_conv")
+ref_rgat = load("python/testing/ref_kernels_lite/ref_rgat.py", "ref_rgat")
+
+
+def layouts(row, col, rel, eids, num_rels):
+    out = {"row": row, "col": col, "rel": rel, "eids": eids}
+    rp, r, c, e = adj.convert_integrated_coo_to_separate_coo(row, col, rel, eids)
+    rp, r, c, e = sorters.sort_coo_by_etype_eids_torch_tensors(rp, r, c, e)
+    out.update(sep_rel_ptrs=rp, sep_row=r, sep_col=c, sep_eids=e)
+    nr, pr, nc, pc, ir, ic = methods.generate_separate_unique_node_indices_single_sided_for_each_etype(
+        num_rels, rp, r, c, get_inverse_idx=True)
+    out.update(ss_node_indices_row=nr, ss_rel_ptrs_row=pr, ss_node_indices_col=nc, ss_rel_ptrs_col=pc,
+               ss_inverse_indices_row=ir, ss_inverse_indices_col=ic)
+    nu, pu, iu = methods.generate_separate_unique_node_indices_for_each_etype(num_rels, rp, r, c, get_inverse_idx=True)
+    out.update(ts_node_indices=nu, ts_rel_ptrs=pu, ts_inverse_indices=iu)
+    # out-CSR by the reference converter; its argsort is not stable, so only the
+    # order-independent parts (row_ptrs, and the per-row multiset) are compared.
+    ptr, ccol, crel, ceid = conv.coo2csr(row, col, rel, eids, torch_flag=True)
+    out.update(csr_row_ptrs=ptr, csr_col=ccol, csr_rel=crel, csr_eids=ceid)
+    tptr, tcol, teid, trel = adj.transpose_csr(ptr, ccol, ceid, crel)
+    out.update(tcsr_row_ptrs=tptr, tcsr_col=tcol, tcsr_eids=teid, tcsr_rel=trel)
+    return out
+
+
+def gat_exp_sum(lay, num_nodes, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    E = lay["sep_row"].numel()
+    el = torch.randn(E, H, generator=g)
+    er = torch.randn(E, H, generator=g)
+    feat = torch.randn(max(E, num_nodes), H, 2, generator=g)  # only feeds the (discarded) ret
+    s = torch.zeros(num_nodes, H)
+    exp = torch.zeros(E, H)
+    ret = torch.zeros(num_nodes, H, 2)
+    # the reference function is written for eids == arange (canonicalised separate COO)
+    eids = torch.arange(E)
+    ref_rgat.relational_fused_gat_separate_coo(eids, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"],
+                                              feat, el, er, s, exp, ret, 0.2)
+    return {"gat_el": el, "gat_er": er, "gat_exp": exp, "gat_sum": s, "gat_slope": torch.tensor(0.2)}
+
+
+def save(name, d):
+    arrs = {}
+    for k, v in d.items():
+        a = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        arrs[k] = a
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    print(name, {k: tuple(a.shape) for k, a in arrs.items()})
+
+
+def main():
+    # toy graph
+    row = torch.tensor([0, 1, 2, 2, 3, 0])
+    col = torch.tensor([1, 2, 0, 3, 1, 3])
+    rel = torch.tensor([0, 0, 1, 1, 0, 1])
+    eids = torch.arange(6)
+    lay = layouts(row, col, rel, eids, 2)
+    lay.update(gat_exp_sum(lay, 4, 2, seed=1))
+    lay["num_nodes"], lay["num_rels"] = torch.tensor(4), torch.tensor(2)
+    save("toy.npz", lay)
+
+    # slice of the shipped ogbn_mag_0.1 topology; interleave the relations so the
+    # integrated COO is NOT relation-sorted and eids are a non-trivial permutation
+    names = ["cited", "citing", "has", "is-about", "writing", "written-by"]
+    rows, cols, rels = [], [], []
+    for r, n in enumerate(names):
+        a = np.load(os.path.join(REF, "data/ogbn_mag_0.1", f"{n}_coo_2.npy"))[:, :4096].astype(np.int64)
+        rows.append(a[0]); cols.append(a[1]); rels.append(np.full(a.shape[1], r, dtype=np.int64))
+    row = torch.from_numpy(np.concatenate(rows)); col = torch.from_numpy(np.concatenate(cols))
+    rel = torch.from_numpy(np.concatenate(rels))
+    perm = torch.randperm(row.numel(), generator=torch.Generator().manual_seed(7))
+    row, col, rel = row[perm], col[perm], rel[perm]
+    eids = torch.randperm(row.numel(), generator=torch.Generator().manual_seed(8))
+    lay = layouts(row, col, rel, eids, 6)
+    n = int(max(row.max(), col.max())) + 1
+    lay.update(gat_exp_sum(lay, n, 4, seed=2))
+    lay["num_nodes"], lay["num_rels"] = torch.tensor(n), torch.tensor(6)
+    save("mag01_slice.npz", lay)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,245 @@
+"""The CPU oracle checked against (i) the golden exp/sum vectors produced by the
+reference's ref_rgat.py and (ii) torch autograd of an independent plain
+formulation in fp64 (backward ops)."""
+import pytest
+import torch
+
+from het_amd.graph import HetGraph
+from het_amd.synth import IntegratedCOO, make_random
+from oracle import ops as O
+
+torch.manual_seed(0)
+F64 = torch.float64
+
+
+def _graph(seed=0, n=23, r=3, e=97, empty_rel=False):
+    coo = make_random(n, r + (1 if empty_rel else 0), e, seed=seed)
+    if empty_rel:  # make the middle relation empty
+        coo.rel[coo.rel == 1] = 0
+        coo.rel = torch.sort(coo.rel).values
+    return HetGraph.from_integrated_coo(coo)
+
+
+@pytest.mark.parametrize("which", ["toy", "mag"])
+def test_gat_exp_sum_golden(which, golden_toy, golden_mag):
+    gold = golden_toy if which == "toy" else golden_mag
+    n = int(gold["num_nodes"])
+    el, er = gold["gat_el"], gold["gat_er"]
+    E, H = el.shape
+    feat = torch.randn(E, H, 3)
+    s, exp, ret = torch.empty(n, H), torch.empty(E, H), torch.empty(n, H, 3)
+    O.relational_fused_gat_separate_coo(torch.arange(E), gold["sep_rel_ptrs"], gold["sep_row"], gold["sep_col"],
+                                        0, {}, feat, el, er, s, exp, ret, float(gold["gat_slope"]))
+    torch.testing.assert_close(exp, gold["gat_exp"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(s, gold["gat_sum"], rtol=1e-5, atol=1e-6)
+    # rows of the attention matrix sum to one for every destination with in-edges
+    a = exp / s[gold["sep_col"]]
+    tot = torch.zeros(n, H).index_add_(0, gold["sep_col"], a)
+    has = torch.zeros(n, dtype=torch.bool); has[gold["sep_col"]] = True
+    torch.testing.assert_close(tot[has], torch.ones_like(tot[has]), rtol=1e-5, atol=1e-5)
+
+
+def _plain_matmul(rp, gather, scatter, W, x, in1head, nrows_out):
+    R, H, K, D = W.shape
+    out = torch.zeros(nrows_out, H, D, dtype=W.dtype)
+    rel = O.rel_of_position(rp)
+    xin = x[gather]
+    Wp = W[rel]  # [n,H,K,D]
+    if in1head:
+        y = torch.einsum("nk,nhkd->nhd", xin, Wp)
+    else:
+        y = torch.einsum("nhk,nhkd->nhd", xin, Wp)
+    return out.index_put((scatter,), y)
+
+
+@pytest.mark.parametrize("kind,in1head", [(0, True), (0, False), (1, True)])
+@pytest.mark.parametrize("empty_rel", [False, True])
+def test_matmul_fwd_bwd_vs_autograd(kind, in1head, empty_rel):
+    g = _graph(seed=3, empty_rel=empty_rel)
+    s = g.get_separate_coo_original()
+    R, H, K, D = g.get_num_rels(), 2, 5, 3
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    W = torch.randn(R, H, K, D, dtype=F64, requires_grad=True)
+    if kind == 0:
+        perm = torch.randperm(E)
+        d = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"],
+             "separate_coo_eids": perm}
+        rp, gather, scatter, nout = s["rel_ptrs"], s["row_indices"], perm, E
+    else:
+        u = g.get_separate_unique_node_indices_single_sided()
+        d = {"unique_srcs_and_dests_rel_ptrs": u["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": u["node_indices_row"]}
+        rp, gather, nout = u["rel_ptrs_row"], u["node_indices_row"], int(u["rel_ptrs_row"][-1])
+        scatter = torch.arange(nout)
+    x = torch.randn(N, K, dtype=F64, requires_grad=True) if in1head else torch.randn(N, H, K, dtype=F64, requires_grad=True)
+    ref = _plain_matmul(rp, gather, scatter, W, x, in1head, nout)
+    ret = torch.zeros(nout, H, D, dtype=F64)
+    O.rgnn_relational_matmul(d, kind, W.detach(), x.detach(), ret, in1head)
+    torch.testing.assert_close(ret, ref.detach())
+    go = torch.randn_like(ref)
+    gW_ref, gx_ref = torch.autograd.grad(ref, (W, x), go)
+    gx, gW = torch.zeros_like(x), torch.zeros_like(W)
+    O.backward_rgnn_relational_matmul(d, kind, W.detach().transpose(2, 3).contiguous(), x.detach(), go, gx, gW, in1head)
+    torch.testing.assert_close(gx, gx_ref)
+    torch.testing.assert_close(gW, gW_ref)
+
+
+@pytest.mark.parametrize("H,per_head", [(1, False), (3, False), (3, True)])
+def test_matmul_no_scatter_gather(H, per_head):
+    offsets = torch.tensor([0, 4, 4, 11, 17])
+    T, K, D, n = 4, 6, 5, 17
+    W = torch.randn(T, H, K, D, dtype=F64, requires_grad=True)
+    x = torch.randn(n, H, K, dtype=F64, requires_grad=True) if per_head else torch.randn(n, K, dtype=F64, requires_grad=True)
+    seg = O.rel_of_position(offsets)
+    ref = torch.einsum("nhk,nhkd->nhd", x, W[seg]) if per_head else torch.einsum("nk,nhkd->nhd", x, W[seg])
+    ret = torch.zeros(n, H, D, dtype=F64)
+    O.rgnn_relational_matmul_no_scatter_gather_list(offsets, W.detach(), x.detach(), ret)
+    torch.testing.assert_close(ret, ref.detach())
+    go = torch.randn_like(ref)
+    gW_ref, gx_ref = torch.autograd.grad(ref, (W, x), go)
+    gx, gW = torch.zeros_like(x), torch.zeros_like(W)
+    O.backward_rgnn_relational_matmul_no_scatter_gather_list(offsets, W.detach().transpose(2, 3).contiguous(), x.detach(), go, gx, gW)
+    torch.testing.assert_close(gx, gx_ref)
+    torch.testing.assert_close(gW, gW_ref)
+
+
+def _gat_dict(g, kind):
+    if kind == 0:
+        return {}, {}
+    if kind == 1:
+        u = g.get_separate_unique_node_indices()
+        d = {"unique_srcs_and_dests_rel_ptrs": u["rel_ptrs"], "unique_srcs_and_dests_node_indices": u["node_indices"]}
+        return d, d
+    if kind == 3:
+        u = g.get_separate_unique_node_indices_single_sided()
+        d = {"unique_srcs_and_dests_rel_ptrs": u["rel_ptrs_row"], "unique_srcs_and_dests_rel_ptrs_col": u["rel_ptrs_col"],
+             "unique_srcs_and_dests_node_indices_row": u["node_indices_row"],
+             "unique_srcs_and_dests_node_indices_col": u["node_indices_col"]}
+        db = dict(d); db["unique_srcs_and_dests_rel_col"] = db.pop("unique_srcs_and_dests_rel_ptrs_col")
+        return d, db
+    u = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    d = {"edata_idx_to_inverse_idx_row": u["inverse_indices_row"], "edata_idx_to_inverse_idx_col": u["inverse_indices_col"]}
+    return d, d
+
+
+def _gat_sizes(g, kind):
+    E = g.get_num_edges()
+    if kind == 0:
+        return E, E
+    if kind == 1:
+        u = int(g.get_separate_unique_node_indices()["rel_ptrs"][-1])
+        return u, u
+    ss = g.get_separate_unique_node_indices_single_sided()
+    return int(ss["rel_ptrs_row"][-1]), int(ss["rel_ptrs_col"][-1])
+
+
+def _plain_gat(g, kind, feat, el, er, slope):
+    s = g.get_separate_coo_original()
+    d, _ = _gat_dict(g, kind)
+    srow, drow = O._gat_rows(kind, d, s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"])
+    z = torch.nn.functional.leaky_relu(el[srow] + er[drow], slope)
+    N = g.get_num_nodes()
+    col = s["col_indices"]
+    # softmax over all in-edges of a destination, via a dense max-shifted formulation
+    zmax = torch.full((N, z.shape[1]), -1e30, dtype=z.dtype).scatter_reduce(0, col.unsqueeze(-1).expand_as(z), z, "amax")
+    ez = torch.exp(z - zmax[col])
+    den = torch.zeros(N, z.shape[1], dtype=z.dtype).index_add(0, col, ez)
+    a = ez / den[col]
+    return torch.zeros(N, *feat.shape[1:], dtype=feat.dtype).index_add(0, col, a.unsqueeze(-1) * feat[srow])
+
+
+@pytest.mark.parametrize("kind", [0, 1, 3, 4])
+def test_fused_gat_fwd_bwd_vs_autograd(kind):
+    g = _graph(seed=5, n=19, r=3, e=83)
+    s = g.get_separate_coo_original()
+    H, D, slope = 2, 4, 0.2
+    ns, nd = _gat_sizes(g, kind)
+    feat = torch.randn(ns, H, D, dtype=F64, requires_grad=True)
+    el = torch.randn(ns, H, dtype=F64, requires_grad=True)
+    er = torch.randn(nd, H, dtype=F64, requires_grad=True)
+    ref = _plain_gat(g, kind, feat, el, er, slope)
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    sm, ex, ret = torch.empty(N, H, dtype=F64), torch.empty(E, H, dtype=F64), torch.empty(N, H, D, dtype=F64)
+    df, db = _gat_dict(g, kind)
+    args = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], kind)
+    O.relational_fused_gat_separate_coo(*args, df, feat.detach(), el.detach(), er.detach(), sm, ex, ret, slope)
+    torch.testing.assert_close(ret, ref.detach())
+    go = torch.randn_like(ref)
+    gf_ref, gl_ref, gr_ref = torch.autograd.grad(ref, (feat, el, er), go)
+    gf, gl, gr = torch.zeros_like(feat), torch.zeros_like(el), torch.zeros_like(er)
+    O.backward_relational_fused_gat_separate_coo(*args, db, feat.detach(), el.detach(), er.detach(), sm, ex, ret, go, gf, gl, gr, slope)
+    torch.testing.assert_close(gf, gf_ref)
+    torch.testing.assert_close(gl, gl_ref)
+    torch.testing.assert_close(gr, gr_ref)
+
+
+def test_fused_gat_csr_matches_coo():
+    g = _graph(seed=6, n=17, r=2, e=61)
+    s = g.get_separate_coo_original()
+    H, D, slope = 3, 2, 0.2
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    feat, el, er = torch.randn(E, H, D, dtype=F64), torch.randn(E, H, dtype=F64), torch.randn(E, H, dtype=F64)
+    out = []
+    for csr in (False, True):
+        sm, ex, ret = torch.empty(N, H, dtype=F64), torch.empty(E, H, dtype=F64), torch.empty(N, H, D, dtype=F64)
+        gf, gl, gr = torch.zeros_like(feat), torch.zeros_like(el), torch.zeros_like(er)
+        go = torch.randn(N, H, D, dtype=F64, generator=torch.Generator().manual_seed(1))
+        if csr:
+            i, o = g.get_in_csr(), g.get_out_csr()
+            dummy = torch.zeros(0, dtype=torch.int64)
+            O.relational_fused_gat_csr(i["row_ptrs"], i["col_indices"], i["eids"], i["rel_types"], dummy, dummy, feat, el, er, sm, ex, ret, slope, False)
+            O.backward_relational_fused_gat_csr(o["row_ptrs"], o["col_indices"], o["eids"], o["rel_types"], dummy, dummy, feat, el, er, sm, ex, ret, go, gf, gl, gr, slope, False)
+        else:
+            a = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], 0, {})
+            O.relational_fused_gat_separate_coo(*a, feat, el, er, sm, ex, ret, slope)
+            O.backward_relational_fused_gat_separate_coo(*a, feat, el, er, sm, ex, ret, go, gf, gl, gr, slope)
+        out.append((sm, ex, ret, gf, gl, gr))
+    for a, b in zip(*out):
+        torch.testing.assert_close(a, b)
+
+
+def test_rgcn_layer_fwd_bwd_vs_autograd():
+    g = _graph(seed=7, n=21, r=4, e=90, empty_rel=True)
+    s = g.get_separate_coo_original()
+    R, K, D = g.get_num_rels(), 6, 5
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    x = torch.randn(N, K, dtype=F64, requires_grad=True)
+    W = torch.randn(R, K, D, dtype=F64, requires_grad=True)
+    norm = torch.rand(E, 1, dtype=F64)
+    rel = O.rel_of_position(s["rel_ptrs"])
+    msg = torch.einsum("nk,nkd->nd", x[s["row_indices"]] * norm[s["eids"]], W[rel])
+    ref = torch.zeros(N, D, dtype=F64).index_add(0, s["col_indices"], msg)
+    ret = torch.zeros(N, D, dtype=F64)
+    a = (s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"])
+    O.rgcn_layer1_separate_coo(*a, x.detach(), W.detach(), norm, ret)
+    torch.testing.assert_close(ret, ref.detach())
+    go = torch.randn_like(ref)
+    gx_ref, gW_ref = torch.autograd.grad(ref, (x, W), go)
+    gx, gW, gn = torch.zeros_like(x), torch.zeros_like(W), torch.zeros_like(norm)
+    O.backward_rgcn_layer1_separate_coo(*a, x.detach(), W.detach().transpose(1, 2).contiguous(), norm, gn, gx, go, gW)
+    torch.testing.assert_close(gx, gx_ref)
+    torch.testing.assert_close(gW, gW_ref)
+    assert float(gn.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_rgcn_compact_aggregation(direct):
+    g = _graph(seed=8, n=15, r=3, e=70)
+    s = g.get_separate_coo_original()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    ssi = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    U, D = int(ss["rel_ptrs_row"][-1]), 4
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    feat = torch.randn(U, D, dtype=F64, requires_grad=True)
+    enorm = torch.rand(E, 1, dtype=F64)
+    d = {"inverse_indices_row": ssi["inverse_indices_row"]} if direct else \
+        {"rel_ptrs_row": ss["rel_ptrs_row"], "node_indices_row": ss["node_indices_row"]}
+    ref = torch.zeros(N, D, dtype=F64).index_add(0, s["col_indices"], enorm[s["eids"]] * feat[ssi["inverse_indices_row"][s["eids"]]])
+    ret = torch.empty(N, D, dtype=F64)
+    a = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], d)
+    O.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*a, feat.detach(), enorm, ret, direct)
+    torch.testing.assert_close(ret, ref.detach())
+    go = torch.randn_like(ref)
+    (gf_ref,) = torch.autograd.grad(ref, (feat,), go)
+    gf = torch.zeros_like(feat)
+    O.backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*a, feat.detach(), enorm, ret, go, gf, direct)
+    torch.testing.assert_close(gf, gf_ref)
