@@ -1,0 +1,72 @@
+"""ctypes binding of libhet_amd.so (the C ABI declared in include/het_amd.h).
+
+The library is built in-tree by ``het_amd/csrc/Makefile`` (``__graft_entry__.build``)
+and must be present: there is no CPU or PyTorch fallback behind the ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhet_amd.so")
+
+P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
+
+# name -> argtypes, in the order of include/het_amd.h
+_SIGNATURES = {
+    "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
+    "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_backward_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, INT, P, P],
+    "het_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_backward_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, P],
+    "het_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P],
+    "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P],
+    "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
+    "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
+    "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P],
+    "het_backward_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P, P],
+    "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P],
+    "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, INT, P],
+}
+
+
+class HetError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libhet_amd.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HetError(
+                f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C het_amd/csrc). het_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.het_build_info.restype = C.c_char_p
+        L.het_last_error.restype = C.c_char_p
+        L.het_grouping_destroy.argtypes = [P]
+        L.het_grouping_destroy.restype = None
+        L.het_grouping_num_segments.argtypes = [P]
+        L.het_grouping_num_segments.restype = I64
+        for name, args in _SIGNATURES.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = INT
+        _lib = L
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise HetError(f"{name} failed (code {rc}): {L.het_last_error().decode()}")
+
+
+def build_info() -> str:
+    return lib().het_build_info().decode()

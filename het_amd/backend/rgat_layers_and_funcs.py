@@ -1,0 +1,149 @@
+"""Fused GAT (hetero edge-softmax + aggregation) behind torch.autograd; mirrors
+/root/reference/hrt/python/backend/rgat_layers_and_funcs.py (classes :8-648,
+wrappers :651-890)."""
+import torch as th
+
+from ..kernels import K
+
+__all__ = [
+    "RelationalFusedGatCSR", "RelationalFusedGatSeparateCOO",
+    "RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeList",
+    "RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeListDirectIndexing",
+    "relational_fused_gat_csr", "relational_fused_gat_separate_coo",
+    "relational_fused_gat_compact_as_of_node_separate_coo_dual_unique_node_list",
+    "relational_fused_gat_compact_as_of_node_separate_coo_single_sided",
+]
+
+
+class RelationalFusedGatCSR(th.autograd.Function):
+    # reference: rgat_layers_and_funcs.py:8-115
+    @staticmethod
+    def forward(ctx, incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes, outcsr_row_ptr, outcsr_col_indices,
+                outcsr_eids, outcsr_reltypes, unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices,
+                feat_src, el, er, s, exp, ret, slope):
+        ctx.save_for_backward(outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes,
+                              unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, feat_src, el, er, s,
+                              exp, ret)
+        ctx.slope = slope
+        K.relational_fused_gat_csr(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes,
+                                   unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, feat_src, el, er,
+                                   s, exp, ret, slope, False)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        (outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes, u_rel_ptrs, u_nodes, feat_src, el, er, s,
+         exp, ret) = ctx.saved_tensors
+        grad_el = th.zeros_like(el, memory_format=th.contiguous_format)
+        grad_er = th.zeros_like(er, memory_format=th.contiguous_format)
+        grad_feat_src = th.zeros_like(feat_src, memory_format=th.contiguous_format)
+        K.backward_relational_fused_gat_csr(outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes, u_rel_ptrs,
+                                            u_nodes, feat_src, el, er, s, exp, ret, gradout.contiguous(), grad_feat_src,
+                                            grad_el, grad_er, ctx.slope, False)
+        return (None,) * 10 + (grad_feat_src, grad_el, grad_er, None, None, None, None)
+
+
+class _FusedGatSeparateCOO(th.autograd.Function):
+    """Shared body of the separate-COO classes: ``kind`` and the two dicts select the row maps."""
+
+    @staticmethod
+    def forward(ctx, eids, rel_ptrs, row, col, kind, fwd_dict, bwd_dict, feat_src, el, er, s, exp, ret, slope):
+        ctx.save_for_backward(eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret)
+        ctx.kind, ctx.bwd_dict, ctx.slope = kind, bwd_dict, slope
+        K.relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, kind, fwd_dict, feat_src, el, er, s, exp, ret, slope)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret = ctx.saved_tensors
+        if ctx.kind == 0:  # every gradient row is written exactly once by the op: no zero-fill needed
+            grad_el, grad_er, grad_feat_src = th.empty_like(el), th.empty_like(er), th.empty_like(feat_src)
+        else:
+            grad_el = th.zeros_like(el, memory_format=th.contiguous_format)
+            grad_er = th.zeros_like(er, memory_format=th.contiguous_format)
+            grad_feat_src = th.zeros_like(feat_src, memory_format=th.contiguous_format)
+        K.backward_relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, ctx.kind, ctx.bwd_dict, feat_src, el, er,
+                                                     s, exp, ret, gradout.contiguous(), grad_feat_src, grad_el, grad_er,
+                                                     ctx.slope)
+        return None, None, None, None, None, None, None, grad_feat_src, grad_el, grad_er, None, None, None, None
+
+
+class RelationalFusedGatSeparateCOO:
+    # reference: rgat_layers_and_funcs.py:233-322
+    @staticmethod
+    def apply(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices, feat_src,
+              el, er, s, exp, ret, slope):
+        return _FusedGatSeparateCOO.apply(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
+                                          separate_coo_col_indices, 0, {}, {}, feat_src, el, er, s, exp, ret, slope)
+
+
+class RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeList:
+    # reference: rgat_layers_and_funcs.py:325-438 (kind 3; note the backward's dict key spelling)
+    @staticmethod
+    def apply(eids, rel_ptrs, row, col, rel_ptr_row, node_indices_row, rel_ptr_col, node_indices_col, feat_src, el, er,
+              s, exp, ret, slope):
+        fwd = {"unique_srcs_and_dests_rel_ptrs": rel_ptr_row, "unique_srcs_and_dests_rel_ptrs_col": rel_ptr_col,
+               "unique_srcs_and_dests_node_indices_row": node_indices_row,
+               "unique_srcs_and_dests_node_indices_col": node_indices_col}
+        bwd = {"unique_srcs_and_dests_rel_ptrs": rel_ptr_row, "unique_srcs_and_dests_rel_col": rel_ptr_col,
+               "unique_srcs_and_dests_node_indices_row": node_indices_row,
+               "unique_srcs_and_dests_node_indices_col": node_indices_col}
+        return _FusedGatSeparateCOO.apply(eids, rel_ptrs, row, col, 3, fwd, bwd, feat_src, el, er, s, exp, ret, slope)
+
+
+class RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeListDirectIndexing:
+    # reference: rgat_layers_and_funcs.py:441-544 (kind 4)
+    @staticmethod
+    def apply(eids, rel_ptrs, row, col, inverse_indices_row, inverse_indices_col, feat_src, el, er, s, exp, ret, slope):
+        d = {"edata_idx_to_inverse_idx_row": inverse_indices_row, "edata_idx_to_inverse_idx_col": inverse_indices_col}
+        return _FusedGatSeparateCOO.apply(eids, rel_ptrs, row, col, 4, d, d, feat_src, el, er, s, exp, ret, slope)
+
+
+def _alloc(g, feat, el):
+    exp = el.new_empty([g.get_num_edges()] + list(el.size()[1:]))
+    s = el.new_empty([g.get_num_nodes()] + list(el.size()[1:]))
+    ret = th.empty([g.get_num_nodes()] + list(feat.size()[1:]), dtype=feat.dtype, device=feat.device)
+    return exp, s, ret
+
+
+def relational_fused_gat_csr(graph, feat_src, el, er, slope):
+    # reference: rgat_layers_and_funcs.py:651-683
+    i, o = graph.get_in_csr(), graph.get_out_csr()
+    u = graph.get_separate_unique_node_indices()
+    exp, s, ret = _alloc(graph, feat_src, el)
+    return RelationalFusedGatCSR.apply(i["row_ptrs"], i["col_indices"], i["eids"], i["rel_types"], o["row_ptrs"],
+                                       o["col_indices"], o["eids"], o["rel_types"], u["rel_ptrs"], u["node_indices"],
+                                       feat_src.contiguous(), el.contiguous(), er.contiguous(), s, exp, ret, slope)
+
+
+def relational_fused_gat_separate_coo(g, feat, el, er, negative_slope):
+    # reference: rgat_layers_and_funcs.py:725-749
+    d = g.get_separate_coo_original()
+    exp, s, ret = _alloc(g, feat, el)
+    return RelationalFusedGatSeparateCOO.apply(d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"],
+                                               feat.contiguous(), el.contiguous(), er.contiguous(), s, exp, ret,
+                                               negative_slope)
+
+
+def relational_fused_gat_compact_as_of_node_separate_coo_dual_unique_node_list(g, feat_compact, el_compact, er_compact,
+                                                                               negative_slope):
+    # reference: rgat_layers_and_funcs.py:752-789
+    return relational_fused_gat_compact_as_of_node_separate_coo_single_sided(g, feat_compact, el_compact, er_compact,
+                                                                             negative_slope, False)
+
+
+def relational_fused_gat_compact_as_of_node_separate_coo_single_sided(g, feat_compact, el_compact, er_compact,
+                                                                      negative_slope, compact_direct_indexing_flag):
+    # reference: rgat_layers_and_funcs.py:826-890
+    d = g.get_separate_coo_original()
+    exp, s, ret = _alloc(g, feat_compact, el_compact)
+    f, l, r = feat_compact.contiguous(), el_compact.contiguous(), er_compact.contiguous()
+    if compact_direct_indexing_flag:
+        inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+        return RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeListDirectIndexing.apply(
+            d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"], inv["inverse_indices_row"],
+            inv["inverse_indices_col"], f, l, r, s, exp, ret, negative_slope)
+    ss = g.get_separate_unique_node_indices_single_sided()
+    return RelationalFusedGatCompactAsOfNodeSeparateCOODualUniqueNodeList.apply(
+        d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"], ss["rel_ptrs_row"], ss["node_indices_row"],
+        ss["rel_ptrs_col"], ss["node_indices_col"], f, l, r, s, exp, ret, negative_slope)

@@ -1,0 +1,103 @@
+"""RGCN ops behind torch.autograd; mirrors
+/root/reference/hrt/python/backend/rgcn_layers_and_funcs.py:481-824."""
+import torch as th
+
+from ..kernels import K
+
+__all__ = [
+    "RgcnLayer1SeparateCoo", "rgcn_layer1_separate_coo", "RGCNNodeMeanAggregationCompactAsOfNodeSeparateCOO",
+    "RGCNNodeMeanAggregationCompactAsOfNodeDirectIndexingSeparateCOO",
+    "rgcn_node_mean_aggregation_compact_as_of_node_separate_coo_single_sided",
+]
+
+
+class RgcnLayer1SeparateCoo(th.autograd.Function):
+    # reference: rgcn_layers_and_funcs.py:481-567 (the out-CSR arguments are carried but unused there too)
+    @staticmethod
+    def forward(ctx, separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices,
+                outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes, x, weight, norm, ret):
+        ctx.save_for_backward(separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices,
+                              separate_coo_col_indices, weight, norm, x)
+        K.rgcn_layer1_separate_coo(separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices,
+                                   separate_coo_col_indices, x, weight, norm, ret)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        rel_ptrs, eids, row, col, weight, norm, x = ctx.saved_tensors
+        grad_x = th.zeros_like(x, memory_format=th.contiguous_format)
+        grad_weight = th.zeros_like(weight, memory_format=th.contiguous_format)
+        grad_norm = th.zeros_like(norm, memory_format=th.contiguous_format)
+        K.backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, th.transpose(weight, 1, 2).contiguous(), norm,
+                                            grad_norm, grad_x, gradout.contiguous(), grad_weight)
+        return None, None, None, None, None, None, None, None, grad_x, grad_weight, grad_norm, None
+
+
+def rgcn_layer1_separate_coo(graph, x, weight, norm):
+    # reference: rgcn_layers_and_funcs.py:570-601
+    s = graph.get_separate_coo_original()
+    o = graph.get_out_csr()
+    ret = th.zeros((graph.get_num_nodes(), weight.size(2)), dtype=weight.dtype, device=weight.device)
+    return RgcnLayer1SeparateCoo.apply(s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], o["row_ptrs"],
+                                       o["col_indices"], o["eids"], o["rel_types"], x.contiguous(), weight.contiguous(),
+                                       norm.contiguous(), ret)
+
+
+class _RGCNCompactAgg(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, eids, rel_ptrs, row, col, map_a, map_b, feat_src, enorm, ret, direct):
+        ctx.save_for_backward(eids, rel_ptrs, row, col, map_a, map_b, feat_src, enorm, ret)
+        ctx.direct = direct
+        d = {"inverse_indices_row": map_a} if direct else {"rel_ptrs_row": map_a, "node_indices_row": map_b}
+        K.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(eids, rel_ptrs, row, col, d, feat_src, enorm, ret, direct)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        eids, rel_ptrs, row, col, map_a, map_b, feat_src, enorm, ret = ctx.saved_tensors
+        d = {"inverse_indices_row": map_a} if ctx.direct else {"rel_ptrs_row": map_a, "node_indices_row": map_b}
+        grad_feat_src = th.zeros_like(feat_src, memory_format=th.contiguous_format)
+        K.backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
+            eids, rel_ptrs, row, col, d, feat_src, enorm, ret, gradout.contiguous(), grad_feat_src, ctx.direct)
+        return None, None, None, None, None, None, grad_feat_src, None, None, None
+
+
+class RGCNNodeMeanAggregationCompactAsOfNodeSeparateCOO(th.autograd.Function):
+    # reference: rgcn_layers_and_funcs.py:604-681
+    @staticmethod
+    def forward(ctx, separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                separate_unique_node_indices_rel_ptrs, separate_unique_node_indices_node_indices, feat_src, enorm, ret):
+        raise RuntimeError("use .apply")
+
+    @classmethod
+    def apply(cls, eids, rel_ptrs, row, col, u_rel_ptrs, u_node_indices, feat_src, enorm, ret):  # noqa: D102
+        return _RGCNCompactAgg.apply(eids, rel_ptrs, row, col, u_rel_ptrs, u_node_indices, feat_src, enorm, ret, False)
+
+
+class RGCNNodeMeanAggregationCompactAsOfNodeDirectIndexingSeparateCOO(th.autograd.Function):
+    # reference: rgcn_layers_and_funcs.py:684-754
+    @staticmethod
+    def forward(ctx, *a):
+        raise RuntimeError("use .apply")
+
+    @classmethod
+    def apply(cls, eids, rel_ptrs, row, col, inverse_indices_row, feat_src, enorm, ret):  # noqa: D102
+        return _RGCNCompactAgg.apply(eids, rel_ptrs, row, col, inverse_indices_row, inverse_indices_row, feat_src, enorm,
+                                     ret, True)
+
+
+def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo_single_sided(g, feat_compact_src, enorm,
+                                                                            compact_direct_indexing_flag):
+    # reference: rgcn_layers_and_funcs.py:782-824
+    s = g.get_separate_coo_original()
+    ret = th.empty([g.get_num_nodes()] + list(feat_compact_src.size()[1:]), dtype=feat_compact_src.dtype,
+                   device=feat_compact_src.device)
+    if compact_direct_indexing_flag:
+        inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+        return RGCNNodeMeanAggregationCompactAsOfNodeDirectIndexingSeparateCOO.apply(
+            s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], inv["inverse_indices_row"],
+            feat_compact_src.contiguous(), enorm.contiguous(), ret)
+    ss = g.get_separate_unique_node_indices_single_sided()
+    return RGCNNodeMeanAggregationCompactAsOfNodeSeparateCOO.apply(
+        s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], ss["rel_ptrs_row"], ss["node_indices_row"],
+        feat_compact_src.contiguous(), enorm.contiguous(), ret)

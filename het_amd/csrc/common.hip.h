@@ -1,0 +1,99 @@
+// Shared device/host helpers for libhet_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/het_amd.h"
+
+typedef int64_t idx_t;
+
+#define HET_WAVE 64
+
+// ---- host-side error plumbing ------------------------------------------------
+void het_set_error(const char* fmt, ...);
+
+#define HET_REQUIRE(cond, ...)             \
+  do {                                     \
+    if (!(cond)) {                         \
+      het_set_error(__VA_ARGS__);          \
+      return HET_ERR_INVALID_ARG;          \
+    }                                      \
+  } while (0)
+
+#define HET_LAUNCH_CHECK(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess) {                                                          \
+      het_set_error("%s: kernel launch failed: %s", name, hipGetErrorString(e__));    \
+      return HET_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+#define HET_HIP(call)                                                                 \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      het_set_error("%s failed: %s", #call, hipGetErrorString(e__));                  \
+      return HET_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -----------------------------------------------------------
+// Segment s with ptrs[s] <= i < ptrs[s+1]; ptrs non-decreasing, empty segments allowed.
+__device__ __forceinline__ int find_segment(const idx_t* __restrict__ ptrs, int n, idx_t i) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (ptrs[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Index of `key` in the sorted list a[0..n) (the key is present by construction).
+__device__ __forceinline__ idx_t lower_bound_idx(const idx_t* __restrict__ a, idx_t n, idx_t key) {
+  idx_t lo = 0, hi = n;
+  while (lo < hi) {
+    idx_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Row of a compact (relation, node) tensor for one edge end
+// (reference: find_relational_compact_as_of_node_index, include/kernel_enums.h:101-119).
+//   kind 0: eid;  kind 1/3: a = rel_ptrs of the unique list, b = its node ids (binary search);
+//   kind 4: a = inverse index by edata idx.
+__device__ __forceinline__ idx_t compact_row(int kind, const idx_t* __restrict__ a, const idx_t* __restrict__ b,
+                                             int rel, idx_t node, idx_t eid) {
+  if (kind == HET_KIND_DISABLED) return eid;
+  if (kind == HET_KIND_DUAL_LIST_DIRECT_INDEX) return a[eid];
+  idx_t base = a[rel];
+  return base + lower_bound_idx(b + base, a[rel + 1] - base, node);
+}
+
+// Map a global tile id onto (relation, row range): relation r owns ceil(n_r / tile_rows) tiles.
+// All lanes execute the same uniform loop (scalar loads).
+__device__ __forceinline__ bool tile_to_relation(const idx_t* __restrict__ rel_ptrs, int R, int tile_rows, long t,
+                                                 int& r, idx_t& row_begin, idx_t& row_end) {
+  long acc = 0;
+  for (int i = 0; i < R; ++i) {
+    idx_t a = rel_ptrs[i], b = rel_ptrs[i + 1];
+    long nt = (b - a + tile_rows - 1) / tile_rows;
+    if (t < acc + nt) {
+      r = i;
+      row_begin = a + (t - acc) * tile_rows;
+      row_end = row_begin + tile_rows < b ? row_begin + tile_rows : b;
+      return true;
+    }
+    acc += nt;
+  }
+  return false;
+}
+
+__device__ __forceinline__ float leaky_exp(float z, float slope) {
+  // gatLeakyReluExp, DGLHackKernel/GAT/FusedGAT.cu.h:23-26
+  return z > 0.f ? expf(z) : expf(slope * z);
+}

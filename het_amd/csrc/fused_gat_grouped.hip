@@ -1,0 +1,208 @@
+// Destination-grouped RGAT kernels: one wave (64 lanes) per work item of a
+// het_grouping by destination.  A feature row of X = H*D floats is covered by
+// LPR = X/4 lanes holding a float4 each, so a wave streams 64/LPR edges per
+// step; partial sums are combined with xor-shuffles and every destination row
+// is written once -- no float atomics except for hub destinations whose
+// segment was split over several items (> HET_ITEM_MAX in-edges).
+#include "fused_gat.hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// exp[eid,h] = leaky_exp(el[srow,h] + er[drow,h]) -- pure streaming, no sum.
+__global__ __launch_bounds__(kBlock) void HET_gat_exp_edge(EdgeView v, RowMaps m, const float* __restrict__ el,
+                                                            const float* __restrict__ er, float* __restrict__ exp,
+                                                            int H, float slope) {
+  const int64_t total = (int64_t)v.E * H, stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const idx_t i = t / H;
+    const int h = (int)(t - i * H);
+    const idx_t eid = v.eids[i];
+    idx_t srow = eid, drow = eid;
+    if (m.kind != HET_KIND_DISABLED) {
+      const bool need_nodes = m.kind == HET_KIND_ENABLED || m.kind == HET_KIND_DUAL_LIST;
+      ev_rows(v, m, i, eid, need_nodes ? ev_src(v, i) : 0, need_nodes ? ev_dst(v, i) : 0, srow, drow);
+    }
+    exp[eid * H + h] = leaky_exp(el[srow * H + h] + er[drow * H + h], slope);
+  }
+}
+
+struct Items {
+  const int32_t *seg, *begin, *end, *seg_ptr, *seg_key;
+  int64_t n;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, const int32_t* __restrict__ p_eid,
+                                                                     const int32_t* __restrict__ p_srow,
+                                                                     const float* __restrict__ feat,
+                                                                     const float* __restrict__ exp,
+                                                                     float* __restrict__ sum, float* __restrict__ ret,
+                                                                     int H, int D) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t v = it.seg_key[seg];
+  const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t X = (int64_t)H * D;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f;
+#pragma unroll 2
+  for (int j = b + slot; j < e; j += EPW) {
+    const int64_t eid = p_eid[j];
+    const int64_t srow = p_srow ? (int64_t)p_srow[j] : eid;
+    const float w = exp[eid * H + h];
+    const float4 f = ld4(feat + srow * X + x);
+    acc.x = fmaf(w, f.x, acc.x);
+    acc.y = fmaf(w, f.y, acc.y);
+    acc.z = fmaf(w, f.z, acc.z);
+    acc.w = fmaf(w, f.w, acc.w);
+    ssum += w;
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  float* rp = ret + v * X + x;
+  if (whole) {
+    const float inv = 1.f / ssum;
+    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    if (x % D == 0) sum[v * H + h] = ssum;
+  } else {  // hub destination: unnormalised partials, normalised by HET_gat_normalize_split
+    atomicAdd(rp + 0, acc.x);
+    atomicAdd(rp + 1, acc.y);
+    atomicAdd(rp + 2, acc.z);
+    atomicAdd(rp + 3, acc.w);
+    if (x % D == 0) atomicAdd(&sum[v * H + h], ssum);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t* __restrict__ split_seg,
+                                                                   const int32_t* __restrict__ seg_key,
+                                                                   int64_t num_split, const float* __restrict__ sum,
+                                                                   float* __restrict__ ret, int H, int D) {
+  const int64_t X = (int64_t)H * D, total = num_split * X;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t k = t / X;
+    const int x = (int)(t - k * X);
+    const int64_t v = seg_key[split_seg[k]];
+    ret[v * X + x] /= sum[v * H + x / D];
+  }
+}
+
+// Backward for kind 0 (feat/el/er rows are edge rows): gradout[dst], ret[dst], sum[dst]
+// are loaded once per destination; grad_feat / grad_el / grad_er rows are written
+// exactly once with plain stores.  DL = D/4 lanes share a head.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
+    Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
+    const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
+    const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
+    float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t v = it.seg_key[seg];
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t X = (int64_t)H * D;
+  const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
+  const float sinv = 1.f / sum[v * H + h];
+  for (int j = b + slot; j < e; j += EPW) {
+    const int64_t eid = p_eid[j];
+    const float a = exp[eid * H + h] * sinv;
+    const float z = el[eid * H + h] + er[eid * H + h];
+    const float4 f = ld4(feat + eid * X + x);
+    st4(grad_feat + eid * X + x, make_float4(a * g.x, a * g.y, a * g.z, a * g.w));
+    float tt = g.x * (f.x - r.x) + g.y * (f.y - r.y) + g.z * (f.z - r.z) + g.w * (f.w - r.w);
+    for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
+    if ((sub & (DL - 1)) == 0) {
+      tt *= a * (z > 0.f ? 1.f : slope);
+      grad_el[eid * H + h] = tt;
+      grad_er[eid * H + h] = tt;
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t b = ceil_div64(total, kBlock);
+  const int64_t cap = 256 * 64;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+
+// shapes the grouped kernels cover: D a power of two >= 4, X/4 a power of two <= 64
+inline bool grouped_shape_ok(int H, int D) {
+  const int64_t X = (int64_t)H * D;
+  return is_pow2(D) && D >= 4 && is_pow2(X) && X / 4 <= 64;
+}
+
+}  // namespace
+
+#define HET_DISPATCH_LPR(LPRV, CALL)           \
+  switch (LPRV) {                              \
+    case 1: { constexpr int LPR = 1; CALL; break; }   \
+    case 2: { constexpr int LPR = 2; CALL; break; }   \
+    case 4: { constexpr int LPR = 4; CALL; break; }   \
+    case 8: { constexpr int LPR = 8; CALL; break; }   \
+    case 16: { constexpr int LPR = 16; CALL; break; } \
+    case 32: { constexpr int LPR = 32; CALL; break; } \
+    default: { constexpr int LPR = 64; CALL; break; } \
+  }
+
+int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
+                        const float* el, const float* er, float* sum, float* exp, float* ret, int H, int D,
+                        float slope, hipStream_t s) {
+  const bool have_rows = m.kind == HET_KIND_DISABLED || g->p1 != nullptr;
+  if (!grouped_shape_ok(H, D) || !g->p0 || !have_rows || g->E != v.E || g->R != 0)
+    return gat_forward_edge(v, m, feat, el, er, sum, exp, ret, H, D, slope, s);
+  const int64_t X = (int64_t)H * D;
+  // destinations without in-edges keep zero rows; split (hub) destinations accumulate atomically
+  HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * v.N * H, s));
+  HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * v.N * X, s));
+  if (v.E == 0) return HET_OK;
+  hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
+  HET_LAUNCH_CHECK("HET_gat_exp_edge");
+  Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
+  const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
+  const int32_t* srow = m.kind == HET_KIND_DISABLED ? nullptr : g->p1;
+  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_gat_aggregate_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
+                                                    g->p0, srow, feat, exp, sum, ret, H, D));
+  HET_LAUNCH_CHECK("HET_gat_aggregate_grouped");
+  if (g->num_split > 0) {
+    hipLaunchKernelGGL(HET_gat_normalize_split, dim3(grid_for(g->num_split * X)), dim3(kBlock), 0, s, g->split_seg,
+                       g->seg_key, g->num_split, sum, ret, H, D);
+    HET_LAUNCH_CHECK("HET_gat_normalize_split");
+  }
+  return HET_OK;
+}
+
+int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
+                         const float* el, const float* er, const float* sum, const float* exp, const float* ret,
+                         const float* gradout, float* grad_feat, float* grad_el, float* grad_er, int H, int D,
+                         float slope, hipStream_t s) {
+  if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0)
+    return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
+  if (v.E == 0) return HET_OK;
+  const int64_t X = (int64_t)H * D;
+  Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
+  const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
+  HET_DISPATCH_LPR((int)(X / 4),
+                   hipLaunchKernelGGL(HET_gat_backward_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, g->p0, feat, el,
+                                      er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope));
+  HET_LAUNCH_CHECK("HET_gat_backward_grouped");
+  return HET_OK;
+}

@@ -1,0 +1,218 @@
+// Device-side construction of het_grouping (radix sort + run-length encode via hipCUB).
+#include <hipcub/hipcub.hpp>
+
+#include "grouping.hip.h"
+
+namespace {
+
+__global__ void HET_grouping_make_keys(const idx_t* __restrict__ rel_ptrs, int R, const idx_t* __restrict__ keys,
+                                       int64_t E, int kb, uint64_t* __restrict__ out, int32_t* __restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t r = R > 0 ? (uint64_t)find_segment(rel_ptrs, R, i) : 0;
+    out[i] = (r << kb) | (uint64_t)keys[i];
+    vals[i] = (int32_t)i;
+  }
+}
+
+__global__ void HET_grouping_segments(const uint64_t* __restrict__ uniq, const int32_t* __restrict__ counts,
+                                      int64_t S, int64_t E, int kb, int R, int32_t* __restrict__ seg_ptr,
+                                      int32_t* __restrict__ seg_key, int32_t* __restrict__ seg_rel_ptr,
+                                      int32_t* __restrict__ nitems) {
+  const uint64_t mask = (kb >= 64) ? ~0ull : ((1ull << kb) - 1);
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
+    seg_key[s] = (int32_t)(uniq[s] & mask);
+    nitems[s] = (counts[s] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
+    if (s == 0) seg_ptr[S] = (int32_t)E;
+  }
+  // relation -> first segment (tiny: one thread per relation boundary)
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (R > 0 && gid <= R) {
+    const uint64_t want = (uint64_t)gid << kb;
+    int64_t lo = 0, hi = S;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if (uniq[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    seg_rel_ptr[gid] = (int32_t)lo;
+  }
+}
+
+__global__ void HET_grouping_items(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ item_off,
+                                   const int32_t* __restrict__ nitems, int64_t S, int32_t* __restrict__ item_seg,
+                                   int32_t* __restrict__ item_begin, int32_t* __restrict__ item_end,
+                                   int32_t* __restrict__ split_seg, int32_t* __restrict__ split_count) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t b = seg_ptr[s], e = seg_ptr[s + 1], n = nitems[s], o = item_off[s];
+    for (int32_t t = 0; t < n; ++t) {
+      item_seg[o + t] = (int32_t)s;
+      item_begin[o + t] = b + t * HET_ITEM_MAX;
+      item_end[o + t] = (b + (t + 1) * HET_ITEM_MAX < e) ? b + (t + 1) * HET_ITEM_MAX : e;
+    }
+    if (n > 1) split_seg[atomicAdd(split_count, 1)] = (int32_t)s;
+  }
+}
+
+__global__ void HET_grouping_payload(const int32_t* __restrict__ perm, const idx_t* __restrict__ src, int64_t E,
+                                     int32_t* __restrict__ dst) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (int64_t)gridDim.x * blockDim.x)
+    dst[j] = (int32_t)src[perm[j]];
+}
+
+int bits_for(int64_t n) {  // bits to represent values in [0, n)
+  int b = 1;
+  while (b < 63 && (1ll << b) < n) ++b;
+  return b;
+}
+
+unsigned blocks_for(int64_t n) {
+  int64_t b = ceil_div64(n, 256);
+  return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+struct Scratch {  // frees device temporaries on every exit path
+  void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n = 0;
+  ~Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
+  hipError_t alloc(void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+    if (e == hipSuccess) p[n++] = *out;
+    return e;
+  }
+};
+
+}  // namespace
+
+extern "C" void het_grouping_destroy(het_grouping* g) {
+  if (!g) return;
+  void* ptrs[] = {g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
+                  g->split_seg, g->p0, g->p1};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete g;
+}
+
+extern "C" int64_t het_grouping_num_segments(const het_grouping* g) { return g ? g->S : -1; }
+
+extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* keys,
+                                   int64_t num_positions, int64_t key_bound, const int64_t* payload0,
+                                   const int64_t* payload1, het_stream stream, het_grouping** out) {
+  const char* op = "het_grouping_create";
+  HET_REQUIRE(out, "%s: out is NULL", op);
+  *out = nullptr;
+  HET_REQUIRE(num_positions >= 0 && num_positions < (1ll << 31), "%s: num_positions out of range", op);
+  HET_REQUIRE(key_bound >= 1 && key_bound < (1ll << 31), "%s: key_bound out of range", op);
+  HET_REQUIRE(num_positions == 0 || keys, "%s: keys is NULL", op);
+  HET_REQUIRE(rel_ptrs ? (num_rels > 0 && num_rels < (1 << 20)) : true, "%s: bad num_rels", op);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t E = num_positions;
+  const int R = rel_ptrs ? (int)num_rels : 0;
+  const int kb = bits_for(key_bound), rb = R > 0 ? bits_for(R) : 0;
+
+  het_grouping* g = new het_grouping;
+  g->E = E; g->R = R; g->key_bound = key_bound;
+  struct Guard { het_grouping* g; ~Guard() { if (g) het_grouping_destroy(g); } } guard{g};
+#define GALLOC(field, count) HET_HIP(hipMalloc((void**)&g->field, sizeof(int32_t) * ((count) > 0 ? (count) : 1)))
+  GALLOC(perm, E);
+  if (R > 0) GALLOC(seg_rel_ptr, R + 1);
+
+  Scratch tmp;
+  uint64_t *keys_in = nullptr, *keys_out = nullptr, *uniq = nullptr;
+  int32_t *vals_in = nullptr, *counts = nullptr, *d_scalars = nullptr, *nitems = nullptr, *item_off = nullptr;
+  HET_HIP(tmp.alloc((void**)&keys_in, sizeof(uint64_t) * E));
+  HET_HIP(tmp.alloc((void**)&keys_out, sizeof(uint64_t) * E));
+  HET_HIP(tmp.alloc((void**)&vals_in, sizeof(int32_t) * E));
+  HET_HIP(tmp.alloc((void**)&d_scalars, sizeof(int32_t) * 4));
+  HET_HIP(hipMemsetAsync(d_scalars, 0, sizeof(int32_t) * 4, s));
+
+  int32_t h_runs = 0;
+  if (E > 0) {
+    hipLaunchKernelGGL(HET_grouping_make_keys, dim3(blocks_for(E)), dim3(256), 0, s, rel_ptrs, R, keys, E, kb, keys_in, vals_in);
+    HET_LAUNCH_CHECK("HET_grouping_make_keys");
+    size_t tb = 0;
+    HET_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, g->perm, (int)E, 0, kb + rb, s));
+    void* t0 = nullptr;
+    HET_HIP(hipMalloc(&t0, tb ? tb : 4));
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(t0, tb, keys_in, keys_out, vals_in, g->perm, (int)E, 0, kb + rb, s);
+    // keys_in is dead after the sort: reuse it for the unique keys, vals_in for the run lengths
+    uniq = keys_in;
+    counts = vals_in;
+    size_t tb2 = 0;
+    if (e == hipSuccess) e = hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, keys_out, uniq, counts, d_scalars, (int)E, s);
+    if (e == hipSuccess && tb2 > tb) {
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(t0);
+      t0 = nullptr;
+      e = hipMalloc(&t0, tb2);
+    }
+    if (e == hipSuccess) e = hipcub::DeviceRunLengthEncode::Encode(t0, tb2, keys_out, uniq, counts, d_scalars, (int)E, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_runs, d_scalars, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(t0);
+    HET_HIP(e);
+  }
+  const int64_t S = h_runs;
+  g->S = S;
+  GALLOC(seg_ptr, S + 1);
+  GALLOC(seg_key, S);
+  HET_HIP(tmp.alloc((void**)&nitems, sizeof(int32_t) * S));
+  HET_HIP(tmp.alloc((void**)&item_off, sizeof(int32_t) * S));
+  if (S == 0) {
+    HET_HIP(hipMemsetAsync(g->seg_ptr, 0, sizeof(int32_t), s));
+    if (R > 0) HET_HIP(hipMemsetAsync(g->seg_rel_ptr, 0, sizeof(int32_t) * (R + 1), s));
+    GALLOC(item_seg, 0); GALLOC(item_begin, 0); GALLOC(item_end, 0); GALLOC(split_seg, 0);
+  } else {
+    size_t tb = 0;
+    HET_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, g->seg_ptr, (int)S, s));
+    void* t0 = nullptr;
+    HET_HIP(hipMalloc(&t0, tb ? tb : 4));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(t0, tb, counts, g->seg_ptr, (int)S, s);
+    if (e == hipSuccess) {
+      const int64_t n = S > R + 1 ? S : R + 1;
+      hipLaunchKernelGGL(HET_grouping_segments, dim3(blocks_for(n)), dim3(256), 0, s, uniq, counts, S, E, kb, R,
+                         g->seg_ptr, g->seg_key, g->seg_rel_ptr, nitems);
+      e = hipGetLastError();
+    }
+    size_t tb2 = 0;
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, nitems, item_off, (int)S, s);
+    if (e == hipSuccess && tb2 > tb) {
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(t0);
+      t0 = nullptr;
+      e = hipMalloc(&t0, tb2);
+    }
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t0, tb2, nitems, item_off, (int)S, s);
+    int32_t last_off = 0, last_n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&last_off, item_off + (S - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last_n, nitems + (S - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(t0);
+    HET_HIP(e);
+    g->num_items = (int64_t)last_off + last_n;
+    GALLOC(item_seg, g->num_items);
+    GALLOC(item_begin, g->num_items);
+    GALLOC(item_end, g->num_items);
+    GALLOC(split_seg, E / HET_ITEM_MAX + 1);  // a split segment has > HET_ITEM_MAX positions
+    hipLaunchKernelGGL(HET_grouping_items, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, item_off, nitems, S,
+                       g->item_seg, g->item_begin, g->item_end, g->split_seg, d_scalars + 1);
+    HET_LAUNCH_CHECK("HET_grouping_items");
+    int32_t h_split = 0;
+    HET_HIP(hipMemcpyAsync(&h_split, d_scalars + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HET_HIP(hipStreamSynchronize(s));
+    g->num_split = h_split;
+  }
+  if (payload0 && E > 0) {
+    GALLOC(p0, E);
+    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload0, E, g->p0);
+    HET_LAUNCH_CHECK("HET_grouping_payload");
+  }
+  if (payload1 && E > 0) {
+    GALLOC(p1, E);
+    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload1, E, g->p1);
+    HET_LAUNCH_CHECK("HET_grouping_payload");
+  }
+  HET_HIP(hipStreamSynchronize(s));  // temporaries are freed on return
+#undef GALLOC
+  guard.g = nullptr;
+  *out = g;
+  return HET_OK;
+}

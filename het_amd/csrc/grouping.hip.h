@@ -1,0 +1,27 @@
+// het_grouping: positions of an index list sorted by (relation, key), with the
+// segments (runs of equal (relation, key)) and a list of wave-sized work items.
+#pragma once
+#include "common.hip.h"
+
+// Segments longer than this are split into several work items so that no single
+// wave serialises a hub node (degree skew: a few destinations own 1e5+ edges).
+constexpr int HET_ITEM_MAX = 256;
+
+struct het_grouping {
+  int64_t E = 0;           // positions
+  int64_t S = 0;           // segments
+  int64_t num_items = 0;   // work items (>= S)
+  int64_t num_split = 0;   // segments that were split into > 1 item
+  int64_t key_bound = 0;
+  int R = 0;               // 0: grouped by key only
+  int32_t* perm = nullptr;       // [E]   position at sorted rank j (stable)
+  int32_t* seg_ptr = nullptr;    // [S+1] sorted-rank range of segment s
+  int32_t* seg_key = nullptr;    // [S]   key of segment s
+  int32_t* seg_rel_ptr = nullptr;// [R+1] segment range of relation r (R > 0)
+  int32_t* item_seg = nullptr;   // [num_items] segment of the item
+  int32_t* item_begin = nullptr; // [num_items+1] sorted-rank range [item_begin[t], item_end[t])
+  int32_t* item_end = nullptr;
+  int32_t* split_seg = nullptr;  // [num_split] segments that own several items
+  int32_t* p0 = nullptr;         // [E] payload0[perm[j]] or NULL
+  int32_t* p1 = nullptr;         // [E] payload1[perm[j]] or NULL
+};

@@ -1,0 +1,174 @@
+// C ABI of the typed linear projections (segment GEMM ops) and the fused RGCN layer.
+#include "seg_gemm.hip.h"
+#include "seg_gemm_mfma.hip.h"
+
+namespace {
+
+int check_matmul(const char* op, int64_t kind, const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather,
+                 const int64_t* scatter, int64_t num_rows, int64_t H, int64_t K, int64_t D) {
+  if (kind != HET_KIND_DISABLED && kind != HET_KIND_ENABLED) {
+    het_set_error("%s: CompactAsOfNodeKind %lld not supported (the reference asserts, RGNNOps.inc.h:292-294)", op,
+                  (long long)kind);
+    return HET_ERR_UNSUPPORTED;
+  }
+  HET_REQUIRE(num_rels > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0, "%s: bad sizes", op);
+  HET_REQUIRE(H * K < (1ll << 31) && H * D < (1ll << 31) && num_rels < (1ll << 31), "%s: dims too large", op);
+  HET_REQUIRE(rel_ptrs && (num_rows == 0 || gather), "%s: null index pointer", op);
+  HET_REQUIRE(kind == HET_KIND_ENABLED || num_rows == 0 || scatter, "%s: kind 0 needs separate_coo_eids", op);
+  return HET_OK;
+}
+
+}  // namespace
+
+extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                                          const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+                                          const float* weights, const float* x, float* ret, int64_t H, int64_t K,
+                                          int64_t D, int in1head, het_stream stream) {
+  const char* op = "rgnn_relational_matmul";
+  if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
+  HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
+  hipStream_t s = (hipStream_t)stream;
+  const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
+  if (in1head && mfma_fwd_supported((int)K, (int)(H * D)))
+    return launch_seg_gemm_mfma_fwd(x, K, gather_idx, weights, H * K * D, (int)H, (int)D, ret, H * D, scatter, rel_ptrs,
+                                    (int)num_rels, num_rows, (int)K, s);
+  SegGemmArgs a;
+  a.A = x; a.gather = gather_idx; a.B = weights; a.C = ret; a.scatter = scatter;
+  a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_rows; a.KA = (int)K;
+  a.b_rel_stride = H * K * D; a.c_ld = H * D;
+  if (in1head) {
+    a.a_ld = K; a.b_headcat = 1; a.headcat_d = (int)D; a.NB = (int)(H * D); a.heads_z = 1;
+  } else {
+    a.a_ld = H * K; a.a_head_stride = K; a.b_head_stride = K * D; a.c_head_stride = D; a.NB = (int)D; a.heads_z = (int)H;
+  }
+  return launch_seg_gemm(a, s);
+}
+
+extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                                                   const int64_t* gather_idx, const int64_t* scatter_idx,
+                                                   int64_t num_rows, const float* weights_t, const float* x,
+                                                   const float* gradout, float* grad_x, float* grad_w, int64_t H,
+                                                   int64_t K, int64_t D, int in1head,
+                                                   const het_grouping* by_rel_gather, het_stream stream) {
+  const char* op = "backward_rgnn_relational_matmul";
+  if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
+  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
+  hipStream_t s = (hipStream_t)stream;
+  const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
+  (void)by_rel_gather;
+  // grad_x[gather] += gradout[scatter] . Wt[r]
+  SegGemmArgs a;
+  a.A = gradout; a.gather = scatter; a.B = weights_t; a.C = grad_x; a.scatter = gather_idx; a.atomic = 1;
+  a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_rows;
+  a.b_rel_stride = H * D * K; a.a_ld = H * D; a.NB = (int)K;
+  if (in1head) {
+    a.KA = (int)(H * D); a.c_ld = K; a.heads_z = 1;  // Wt[r] read as one [H*D, K] matrix: heads summed
+  } else {
+    a.KA = (int)D; a.a_head_stride = D; a.b_head_stride = D * K; a.c_ld = H * K; a.c_head_stride = K; a.heads_z = (int)H;
+  }
+  if (int rc = launch_seg_gemm(a, s)) return rc;
+  // grad_w[r,h] += x[gather]^T (x) gradout[scatter]
+  SegDwArgs w;
+  w.A = x; w.gather = gather_idx; w.G = gradout; w.g_gather = scatter; w.dW = grad_w;
+  w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_rows;
+  w.dw_rel_stride = H * K * D; w.g_ld = H * D; w.KA = (int)K;
+  if (in1head) {
+    w.a_ld = K; w.headcat = 1; w.headcat_d = (int)D; w.NB = (int)(H * D); w.heads_z = 1;
+  } else {
+    w.a_ld = H * K; w.a_head_stride = K; w.g_head_stride = D; w.dw_head_stride = K * D; w.NB = (int)D; w.heads_z = (int)H;
+  }
+  return launch_seg_dw(w, s);
+}
+
+extern "C" int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* offsets, int64_t num_types,
+                                                                 int64_t num_rows, const float* weights,
+                                                                 const float* x, float* ret, int64_t H, int64_t K,
+                                                                 int64_t D, int x_per_head, het_stream stream) {
+  const char* op = "rgnn_relational_matmul_no_scatter_gather_list";
+  HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
+  HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
+  hipStream_t s = (hipStream_t)stream;
+  if (!x_per_head && mfma_fwd_supported((int)K, (int)(H * D)))
+    return launch_seg_gemm_mfma_fwd(x, K, nullptr, weights, H * K * D, (int)H, (int)D, ret, H * D, nullptr, offsets,
+                                    (int)num_types, num_rows, (int)K, s);
+  SegGemmArgs a;
+  a.A = x; a.B = weights; a.C = ret; a.seg_ptrs = offsets; a.num_segs = (int)num_types; a.num_rows = num_rows;
+  a.KA = (int)K; a.b_rel_stride = H * K * D; a.c_ld = H * D;
+  if (!x_per_head) {
+    a.a_ld = K; a.b_headcat = 1; a.headcat_d = (int)D; a.NB = (int)(H * D); a.heads_z = 1;
+  } else {
+    a.a_ld = H * K; a.a_head_stride = K; a.b_head_stride = K * D; a.c_head_stride = D; a.NB = (int)D; a.heads_z = (int)H;
+  }
+  return launch_seg_gemm(a, s);
+}
+
+extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
+    const int64_t* offsets, int64_t num_types, int64_t num_rows, const float* weights_t, const float* x,
+    const float* gradout, float* grad_x, float* grad_w, int64_t H, int64_t K, int64_t D, int x_per_head,
+    het_stream stream) {
+  const char* op = "backward_rgnn_relational_matmul_no_scatter_gather_list";
+  HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
+  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
+  hipStream_t s = (hipStream_t)stream;
+  SegGemmArgs a;  // rows are disjoint: plain "+=" without atomics would do, atomics keep one code path
+  a.A = gradout; a.B = weights_t; a.C = grad_x; a.atomic = 1;
+  a.seg_ptrs = offsets; a.num_segs = (int)num_types; a.num_rows = num_rows;
+  a.b_rel_stride = H * D * K; a.a_ld = H * D; a.NB = (int)K;
+  if (!x_per_head) {
+    a.KA = (int)(H * D); a.c_ld = K; a.heads_z = 1;
+  } else {
+    a.KA = (int)D; a.a_head_stride = D; a.b_head_stride = D * K; a.c_ld = H * K; a.c_head_stride = K; a.heads_z = (int)H;
+  }
+  if (int rc = launch_seg_gemm(a, s)) return rc;
+  SegDwArgs w;
+  w.A = x; w.G = gradout; w.dW = grad_w; w.seg_ptrs = offsets; w.num_segs = (int)num_types; w.num_rows = num_rows;
+  w.dw_rel_stride = H * K * D; w.g_ld = H * D; w.KA = (int)K;
+  if (!x_per_head) {
+    w.a_ld = K; w.headcat = 1; w.headcat_d = (int)D; w.NB = (int)(H * D); w.heads_z = 1;
+  } else {
+    w.a_ld = H * K; w.a_head_stride = K; w.g_head_stride = D; w.dw_head_stride = K * D; w.NB = (int)D; w.heads_z = (int)H;
+  }
+  return launch_seg_dw(w, s);
+}
+
+// ---- fused RGCN layer --------------------------------------------------------------------
+extern "C" int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
+                                            const int64_t* col, int64_t num_rels, int64_t num_edges,
+                                            int64_t num_nodes, const float* x, const float* weights,
+                                            const float* norm, float* ret, int64_t K, int64_t D,
+                                            const het_grouping* by_rel_dst, het_stream stream) {
+  const char* op = "rgcn_layer1_separate_coo";
+  HET_REQUIRE(num_rels > 0 && num_edges >= 0 && num_nodes >= 0 && K > 0 && D > 0, "%s: bad sizes", op);
+  HET_REQUIRE(rel_ptrs && (num_edges == 0 || (eids && row && col && x && weights && norm && ret)), "%s: null pointer", op);
+  (void)by_rel_dst;
+  SegGemmArgs a;
+  a.A = x; a.a_ld = K; a.gather = row; a.row_scale = norm; a.scale_idx = eids;
+  a.B = weights; a.b_rel_stride = K * D; a.C = ret; a.c_ld = D; a.scatter = col; a.atomic = 1;
+  a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_edges; a.KA = (int)K; a.NB = (int)D;
+  return launch_seg_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
+                                                     const int64_t* col, int64_t num_rels, int64_t num_edges,
+                                                     int64_t num_nodes, const float* x, const float* weights_t,
+                                                     const float* norm, float* grad_norm, float* grad_x,
+                                                     const float* gradout, float* grad_w, int64_t K, int64_t D,
+                                                     const het_grouping* by_rel_src, const het_grouping* by_rel_dst,
+                                                     het_stream stream) {
+  const char* op = "backward_rgcn_layer1_separate_coo";
+  HET_REQUIRE(num_rels > 0 && num_edges >= 0 && num_nodes >= 0 && K > 0 && D > 0, "%s: bad sizes", op);
+  HET_REQUIRE(rel_ptrs && (num_edges == 0 || (eids && row && col && x && weights_t && norm && grad_x && gradout && grad_w)),
+              "%s: null pointer", op);
+  (void)grad_norm; (void)by_rel_src; (void)by_rel_dst;
+  hipStream_t s = (hipStream_t)stream;
+  SegGemmArgs a;  // grad_x[row] += (gradout[col] * norm) . Wt[r]
+  a.A = gradout; a.a_ld = D; a.gather = col; a.row_scale = norm; a.scale_idx = eids;
+  a.B = weights_t; a.b_rel_stride = D * K; a.C = grad_x; a.c_ld = K; a.scatter = row; a.atomic = 1;
+  a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_edges; a.KA = (int)D; a.NB = (int)K;
+  if (int rc = launch_seg_gemm(a, s)) return rc;
+  SegDwArgs w;  // grad_w[r] += (x[row] * norm)^T (x) gradout[col]
+  w.A = x; w.a_ld = K; w.gather = row; w.row_scale = norm; w.scale_idx = eids;
+  w.G = gradout; w.g_ld = D; w.g_gather = col; w.dW = grad_w; w.dw_rel_stride = K * D;
+  w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_edges; w.KA = (int)K; w.NB = (int)D;
+  return launch_seg_dw(w, s);
+}

@@ -1,0 +1,149 @@
+// Segment GEMM on the matrix cores: C[cs(i), :] (+)= scale(i) * A[ga(i), :] . B_r
+//
+// Workgroup = 4 waves; the relation's K x X weight is staged once in LDS and
+// reused for a chunk of up to 512 rows (4 steps of 128 rows, 32 rows per wave).
+// Per wave and step: 32 gathered rows are loaded coalesced (K/4 lanes x float4
+// per row) into a padded LDS tile, read back as MFMA A fragments with
+// ds_read_b128, and multiplied with v_mfma_f32_32x32x2_f32 into X/32
+// accumulators.  The k index is permuted between the two lane halves
+// (half h owns k in [h*K/2, (h+1)*K/2)) -- A and B use the same permutation, so
+// the sum is unchanged while every lane's fragment is one contiguous half row.
+#include "seg_gemm_mfma.hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kChunkRows = 512;
+
+template <int K, int NT, bool ATOMIC>
+__global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
+  constexpr int X = NT * 32, KH = K / 2, LDA = K + 4, LPRW = K / 4, RPI = 64 / LPRW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunkRows, blockIdx.x, r, rb, re)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Bs = smem;                                  // [K][X]
+  float* As = smem + K * X + wave * 32 * LDA;        // [32][LDA] per wave
+  idx_t* crow = reinterpret_cast<idx_t*>(smem + K * X + 4 * 32 * LDA) + wave * 32;
+
+  {
+    const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
+    const int Dh = a.headcat_d;
+    for (int e = tid; e < K * X; e += 256) {
+      const int k = e / X, n = e - k * X;
+      float v;
+      if (a.b_headcat) {
+        const int h = n / Dh, d = n - h * Dh;
+        v = Bm[(int64_t)h * K * Dh + (int64_t)k * Dh + d];
+      } else {
+        v = Bm[e];
+      }
+      Bs[e] = v;
+    }
+  }
+  __syncthreads();
+
+  const int row = lane & 31, half = lane >> 5;
+  for (idx_t base = rb; base < re; base += 128) {
+    const idx_t wb = base + wave * 32;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rloc = it * RPI + lane / LPRW, c4 = (lane % LPRW) * 4;
+      const idx_t i = wb + rloc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < re) {
+        const idx_t ar = a.gather ? a.gather[i] : i;
+        v = *reinterpret_cast<const float4*>(a.A + ar * a.a_ld + c4);
+        if (a.row_scale) {
+          const float sc = a.row_scale[a.scale_idx ? a.scale_idx[i] : i];
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+      }
+      *reinterpret_cast<float4*>(&As[rloc * LDA + c4]) = v;
+    }
+    if (lane < 32) {
+      const idx_t i = wb + lane;
+      crow[lane] = i < re ? (a.scatter ? a.scatter[i] : i) : (idx_t)-1;
+    }
+    __syncthreads();
+
+    float af[KH];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(&As[row * LDA + half * KH + q * 4]);
+      af[4 * q + 0] = t.x; af[4 * q + 1] = t.y; af[4 * q + 2] = t.z; af[4 * q + 3] = t.w;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KH; ++s) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float b = Bs[(half * KH + s) * X + nt * 32 + row];
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b, acc[nt], 0, 0, 0);
+      }
+    }
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rloc = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+      const idx_t cr = crow[rloc];
+      if (cr < 0) continue;
+      float* p = a.C + cr * a.c_ld + row;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (ATOMIC) atomicAdd(p + nt * 32, acc[nt][reg]); else p[nt * 32] = acc[nt][reg];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int K, int NT>
+int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
+  constexpr int X = NT * 32, LDA = K + 4;
+  const size_t lds = sizeof(float) * (K * X + 4 * 32 * LDA) + sizeof(idx_t) * 4 * 32;
+  const int64_t gx = ceil_div64(a.num_rows, kChunkRows) + a.num_segs;
+  HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
+  dim3 grid((unsigned)gx), block(256);
+  if (a.atomic) {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, true>), grid, block, lds, s, a);
+  } else {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false>), grid, block, lds, s, a);
+  }
+  HET_LAUNCH_CHECK("HET_seg_gemm_mfma");
+  return HET_OK;
+}
+
+template <int K>
+int launch_k(const MfmaGemmArgs& a, hipStream_t s) {
+  switch (a.X) {
+    case 32: return launch_kx<K, 1>(a, s);
+    case 64: return launch_kx<K, 2>(a, s);
+    default: return launch_kx<K, 4>(a, s);
+  }
+}
+
+}  // namespace
+
+bool mfma_shape_supported(int K, int X) {
+  return (K == 32 || K == 64 || K == 128) && (X == 32 || X == 64 || X == 128);
+}
+
+int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  HET_REQUIRE(mfma_shape_supported(a.K, a.X), "segment GEMM (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
+  HET_REQUIRE(a.a_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "segment GEMM (MFMA): A rows must be 16-byte aligned");
+  switch (a.K) {
+    case 32: return launch_k<32>(a, s);
+    case 64: return launch_k<64>(a, s);
+    default: return launch_k<128>(a, s);
+  }
+}

@@ -1,0 +1,39 @@
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) segment GEMM for the feature-width shapes
+// (K, X in {32, 64, 128}); everything else goes through seg_gemm.hip.
+#pragma once
+#include "common.hip.h"
+
+struct MfmaGemmArgs {
+  const float* A = nullptr;       // [*, K] rows, gathered
+  int64_t a_ld = 0;
+  const idx_t* gather = nullptr;  // NULL: identity
+  const float* row_scale = nullptr;
+  const idx_t* scale_idx = nullptr;
+  const float* B = nullptr;       // per segment: plain [K][X], or head-concatenated [Hc][K][Dh]
+  int64_t b_rel_stride = 0;
+  int b_headcat = 0, headcat_d = 1;
+  float* C = nullptr;             // [*, X]
+  int64_t c_ld = 0;
+  const idx_t* scatter = nullptr; // NULL: identity
+  int atomic = 0;
+  const idx_t* seg_ptrs = nullptr;
+  int num_segs = 0;
+  int64_t num_rows = 0;
+  int K = 0, X = 0;
+};
+
+bool mfma_shape_supported(int K, int X);
+int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s);
+
+// forward projection with one input head: C[scatter(i), (h,d)] = A[gather(i), :] . W[r, h, :, d]
+inline bool mfma_fwd_supported(int K, int X) { return mfma_shape_supported(K, X); }
+inline int launch_seg_gemm_mfma_fwd(const float* x, int64_t x_ld, const idx_t* gather, const float* W,
+                                    int64_t w_rel_stride, int H, int D, float* ret, int64_t ret_ld,
+                                    const idx_t* scatter, const idx_t* seg_ptrs, int num_segs, int64_t num_rows,
+                                    int K, hipStream_t s) {
+  MfmaGemmArgs a;
+  a.A = x; a.a_ld = x_ld; a.gather = gather; a.B = W; a.b_rel_stride = w_rel_stride; a.b_headcat = 1; a.headcat_d = D;
+  a.C = ret; a.c_ld = ret_ld; a.scatter = scatter; a.seg_ptrs = seg_ptrs; a.num_segs = num_segs; a.num_rows = num_rows;
+  a.K = K; a.X = H * D;
+  return launch_seg_gemm_mfma(a, s);
+}

@@ -1,0 +1,391 @@
+"""``K = torch.ops.torch_hrt``: the reference's custom-op namespace, served by
+libhet_amd.so.
+
+The reference loads ``libtorch_hrt.so`` and calls its kernels as
+``torch.ops.torch_hrt.<name>(...)`` (hrt/python/kernels/__init__.py:4-16; op list:
+``m.def`` lines of hrt/include/DGLHackKernel/OpExport/*.inc.h).  This module
+defines ops with the same names, argument order and argument meaning in the same
+namespace and implements them by calling the C ABI of include/het_amd.h on the
+current torch stream.  Tensor arguments are only unwrapped to device pointers
+here; all arithmetic happens in the HIP library.  CPU tensors are rejected for
+the compute ops (there is no CPU path); the five layout converters are torch
+index ops and run on either device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, graph as _graph, plan as _plan
+
+Tensor = torch.Tensor
+NAMESPACE = "torch_hrt"
+_libdef = torch.library.Library(NAMESPACE, "DEF")
+_registered: List[str] = []
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(name: str, floats=(), ints=()):
+    for t in floats:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.HetError(f"{name}: expected contiguous float32 GPU tensors, got {t.dtype} on {t.device}"
+                                f"{'' if t.is_contiguous() else ' (non-contiguous)'}")
+    for t in ints:
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise _lib.HetError(f"{name}: expected contiguous int64 GPU tensors, got {t.dtype} on {t.device}")
+
+
+def _op(schema: str):
+    name = schema.split("(")[0]
+
+    def deco(fn):
+        _libdef.define(schema)
+        _libdef.impl(name, fn, "CompositeExplicitAutograd")
+        _registered.append(name)
+        return fn
+
+    return deco
+
+
+def _call(dev_tensor: Tensor, cname: str, *args):
+    with torch.cuda.device(dev_tensor.device):
+        _lib.call(cname, *args)
+
+
+# ------------------------------------------------------------------------------------
+# info + layout converters
+# ------------------------------------------------------------------------------------
+@_op("build_debug_info() -> ()")
+def build_debug_info():
+    print(_lib.build_info())
+
+
+@_op("transpose_csr(Tensor row_ptrs, Tensor col_indices, Tensor eids, Tensor rel_types) -> Tensor[]")
+def transpose_csr(row_ptrs, col_indices, eids, rel_types):
+    # DataConverters.inc.h:283-344: returns (row_ptrs, col_indices, eids, rel_types) of the transpose
+    return list(_graph.transpose_csr(row_ptrs, col_indices, eids, rel_types))
+
+
+@_op("convert_integrated_coo_to_separate_coo(Tensor row_indices, Tensor col_indices, Tensor rel_types, Tensor eids, "
+     "int num_nodes, int num_rels) -> Tensor[]")
+def convert_integrated_coo_to_separate_coo(row_indices, col_indices, rel_types, eids, num_nodes, num_rels):
+    # DataConverters.inc.h:216-281 -> MyHyb.h:1047-1096 (bucket by relation; buckets kept in eid order)
+    return list(_graph.integrated_coo_to_separate_coo(row_indices, col_indices, rel_types, eids, num_rels))
+
+
+@_op("convert_integrated_csr_to_separate_coo(Tensor row_ptrs, Tensor col_indices, Tensor rel_types, Tensor eids) -> Tensor[]")
+def convert_integrated_csr_to_separate_coo(row_ptrs, col_indices, rel_types, eids):
+    # DataConverters.inc.h:10-77 -> MyHyb.h:1099-1150
+    rows = _graph.csr_to_coo_rows(row_ptrs)
+    num_rels = int(rel_types.max().item()) + 1 if rel_types.numel() else 1
+    return list(_graph.integrated_coo_to_separate_coo(rows, col_indices, rel_types, eids, num_rels))
+
+
+def _separate_csr(rows, cols, rels, eids, num_rows, num_rels):
+    o = torch.sort(rels * num_rows + rows, stable=True).indices
+    counts = torch.bincount(rels[o] * num_rows + rows[o], minlength=num_rows * num_rels)
+    row_ptrs = torch.zeros(num_rows * num_rels + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(counts, 0, out=row_ptrs[1:])
+    rel_ptrs = row_ptrs[::num_rows].contiguous()
+    return [rel_ptrs, row_ptrs, cols[o], eids[o]]
+
+
+@_op("convert_integrated_csr_to_separate_csr(Tensor row_ptrs, Tensor col_indices, Tensor rel_types, Tensor eids) -> Tensor[]")
+def convert_integrated_csr_to_separate_csr(row_ptrs, col_indices, rel_types, eids):
+    # DataConverters.inc.h:79-145: one CSR per relation, row pointers concatenated ([R*N+1])
+    rows = _graph.csr_to_coo_rows(row_ptrs)
+    num_rels = int(rel_types.max().item()) + 1 if rel_types.numel() else 1
+    return _separate_csr(rows, col_indices, rel_types, eids, row_ptrs.numel() - 1, num_rels)
+
+
+@_op("convert_integrated_coo_to_separate_csr(Tensor row_indices, Tensor col_indices, Tensor rel_types, Tensor eids, "
+     "int num_nodes, int num_rels) -> Tensor[]")
+def convert_integrated_coo_to_separate_csr(row_indices, col_indices, rel_types, eids, num_nodes, num_rels):
+    # DataConverters.inc.h:147-214
+    return _separate_csr(row_indices, col_indices, rel_types, eids, num_nodes, num_rels)
+
+
+# ------------------------------------------------------------------------------------
+# segment GEMM ops
+# ------------------------------------------------------------------------------------
+def _matmul_lists(d: Dict[str, Tensor], kind: int):
+    if kind == 0:
+        return d["separate_coo_rel_ptrs"], d["separate_coo_node_indices"], d["separate_coo_eids"]
+    if kind == 1:
+        return d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices"], None
+    raise _lib.HetError(f"rgnn_relational_matmul: CompactAsOfNodeKind {kind} not supported "
+                        "(the reference asserts, RGNNOps.inc.h:292-294)")
+
+
+@_op("rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights, Tensor node_feat, "
+     "Tensor(a!) ret, bool InputNumHeadOneFlag) -> ()")
+def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, InputNumHeadOneFlag):
+    rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
+    _chk("rgnn_relational_matmul", (weights, node_feat, ret), tuple(t for t in (rp, g, s) if t is not None))
+    R, H, K, D = weights.shape
+    _call(ret, "het_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
+          _p(ret), H, K, D, int(InputNumHeadOneFlag), _stream(ret))
+
+
+@_op("backward_rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights_transposed, "
+     "Tensor node_feat, Tensor gradout, Tensor(a!) grad_node_feat, Tensor(b!) grad_weights, bool InputNumHeadOneFlag) -> ()")
+def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat,
+                                    grad_weights, InputNumHeadOneFlag):
+    rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
+    _chk("backward_rgnn_relational_matmul", (weights_transposed, node_feat, gradout, grad_node_feat, grad_weights),
+         tuple(t for t in (rp, g, s) if t is not None))
+    R, H, D, K = weights_transposed.shape
+    _call(gradout, "het_backward_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(),
+          _p(weights_transposed), _p(node_feat), _p(gradout), _p(grad_node_feat), _p(grad_weights), H, K, D,
+          int(InputNumHeadOneFlag), None, _stream(gradout))
+
+
+@_op("rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights, Tensor inputs, "
+     "Tensor(a!) ret) -> ()")
+def rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, weights, inputs, ret):
+    _chk("rgnn_relational_matmul_no_scatter_gather_list", (weights, inputs, ret), (ntype_offset_ptrs,))
+    T, H, K, D = weights.shape
+    n = inputs.shape[0]
+    per_head = int(H > 1 and inputs.numel() == n * H * K)
+    _call(ret, "het_rgnn_relational_matmul_no_scatter_gather_list", _p(ntype_offset_ptrs), T, n, _p(weights),
+          _p(inputs), _p(ret), H, K, D, per_head, _stream(ret))
+
+
+@_op("backward_rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights_transposed, "
+     "Tensor inputs, Tensor gradout, Tensor(a!) grad_input, Tensor(b!) grad_weights) -> ()")
+def backward_rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, weights_transposed, inputs, gradout,
+                                                           grad_input, grad_weights):
+    _chk("backward_rgnn_relational_matmul_no_scatter_gather_list",
+         (weights_transposed, inputs, gradout, grad_input, grad_weights), (ntype_offset_ptrs,))
+    T, H, D, K = weights_transposed.shape
+    n = inputs.shape[0]
+    per_head = int(H > 1 and inputs.numel() == n * H * K)
+    _call(gradout, "het_backward_rgnn_relational_matmul_no_scatter_gather_list", _p(ntype_offset_ptrs), T, n,
+          _p(weights_transposed), _p(inputs), _p(gradout), _p(grad_input), _p(grad_weights), H, K, D, per_head,
+          _stream(gradout))
+
+
+# ------------------------------------------------------------------------------------
+# fused GAT (edge softmax + aggregation)
+# ------------------------------------------------------------------------------------
+def _gat_maps(kind: int, d: Dict[str, Tensor], backward: bool):
+    """Flatten the op's dict into (row_a, row_b, col_a, col_b); key names as the launchers read them
+    (RGATOps.inc.h:180-236 forward, :476-540 backward -- the backward spells the dual-list column
+    pointer key 'unique_srcs_and_dests_rel_col')."""
+    if kind == 0:
+        return None, None, None, None
+    if kind == 1:
+        rp, nodes = d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices"]
+        return rp, nodes, rp, nodes
+    if kind == 3:
+        rpc = d.get("unique_srcs_and_dests_rel_ptrs_col")
+        if rpc is None:
+            rpc = d["unique_srcs_and_dests_rel_col"]
+        return (d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices_row"], rpc,
+                d["unique_srcs_and_dests_node_indices_col"])
+    if kind == 4:
+        return d["edata_idx_to_inverse_idx_row"], None, d["edata_idx_to_inverse_idx_col"], None
+    raise _lib.HetError(f"relational_fused_gat: CompactAsOfNodeKind {kind} is not supported")
+
+
+_derived: Dict[tuple, tuple] = {}
+
+
+def _src_rows_by_position(kind, maps, rel_ptrs, row, eids):
+    """feat row of every edge position for the compact kinds (cached per graph)."""
+    ra, rb = maps[0], maps[1]
+    key = (kind, ra.data_ptr(), ra._version, None if rb is None else rb.data_ptr(), row.data_ptr(), eids.data_ptr())
+    hit = _derived.get(key)
+    if hit is not None:
+        return hit[0]
+    if kind == 4:
+        srow = ra[eids]
+    else:
+        R = rel_ptrs.numel() - 1
+        bound = int(max(int(row.max().item()), int(rb.max().item()))) + 1
+        rel_e = torch.repeat_interleave(torch.arange(R, device=row.device), rel_ptrs[1:] - rel_ptrs[:-1])
+        rel_u = torch.repeat_interleave(torch.arange(R, device=row.device), ra[1:] - ra[:-1])
+        srow = torch.searchsorted(rel_u * bound + rb, rel_e * bound + row)
+    srow = srow.contiguous()
+    if len(_derived) > 16:
+        _derived.clear()
+    _derived[key] = (srow, (ra, rb, row, eids))
+    return srow
+
+
+def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
+    if not _plan.enabled:
+        return None
+    srow = None if kind == 0 else _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
+    return _plan.get_grouping(None, col, num_nodes, eids, srow)
+
+
+@_op("relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+     "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, int IntKind, "
+     "Dict(str, Tensor) args_tensor_dict, Tensor feat_src, Tensor el, Tensor er, Tensor(a!) sum, Tensor(b!) exp, "
+     "Tensor(c!) ret, float slope) -> ()")
+def relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
+                                      separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er, sum, exp,
+                                      ret, slope):
+    name = "relational_fused_gat_separate_coo"
+    maps = _gat_maps(IntKind, args_tensor_dict, False)
+    _chk(name, (feat_src, el, er, sum, exp, ret),
+         (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
+         + tuple(m for m in maps if m is not None))
+    E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
+    D = feat_src.numel() // (feat_src.shape[0] * H) if feat_src.numel() else ret.numel() // max(1, N * H)
+    g = _by_dst(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                separate_coo_eids, N)
+    _call(ret, "het_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
+          _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
+          H, D, float(slope), None if g is None else g.handle, _stream(ret))
+
+
+@_op("backward_relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+     "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, int IntKind, "
+     "Dict(str, Tensor) args_tensor_dict, Tensor feat_src, Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, "
+     "Tensor gradout, Tensor(a!) grad_feat_src, Tensor(b!) grad_el, Tensor(c!) grad_er, float slope) -> ()")
+def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
+                                               separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er,
+                                               sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, slope):
+    name = "backward_relational_fused_gat_separate_coo"
+    maps = _gat_maps(IntKind, args_tensor_dict, True)
+    _chk(name, (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er),
+         (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
+         + tuple(m for m in maps if m is not None))
+    E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
+    D = ret.numel() // max(1, N * H)
+    g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                separate_coo_eids, N) if IntKind == 0 else None
+    _call(ret, "het_backward_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
+          _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
+          _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D, float(slope),
+          None if g is None else g.handle, None, _stream(ret))
+
+
+@_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "
+     "Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, Tensor feat_src, Tensor el, "
+     "Tensor er, Tensor(a!) sum, Tensor(b!) exp, Tensor(c!) ret, float slope, bool CompactAsOfNodeFlag=False) -> ()")
+def relational_fused_gat_csr(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes,
+                             unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, feat_src, el, er, sum,
+                             exp, ret, slope, CompactAsOfNodeFlag=False):
+    _chk("relational_fused_gat_csr", (feat_src, el, er, sum, exp, ret),
+         (incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes))
+    N, E, H = incsr_row_ptr.numel() - 1, incsr_eids.numel(), el.shape[1]
+    D = ret.numel() // max(1, N * H)
+    _call(ret, "het_relational_fused_gat_csr", _p(incsr_row_ptr), _p(incsr_col_indices), _p(incsr_eids),
+          _p(incsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),
+          max(0, unique_srcs_and_dests_rel_ptrs.numel() - 1), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
+          H, D, float(slope), int(CompactAsOfNodeFlag), _stream(ret))
+
+
+@_op("backward_relational_fused_gat_csr(Tensor outcsr_row_ptr, Tensor outcsr_col_indices, Tensor outcsr_eids, "
+     "Tensor outcsr_reltypes, Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, "
+     "Tensor feat_src, Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, "
+     "Tensor(a!) grad_feat_src, Tensor(b!) grad_el, Tensor(c!) grad_er, float slope, bool CompactAsOfNodeFlag=False) -> ()")
+def backward_relational_fused_gat_csr(outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes,
+                                      unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, feat_src, el,
+                                      er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, slope,
+                                      CompactAsOfNodeFlag=False):
+    _chk("backward_relational_fused_gat_csr", (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er),
+         (outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes))
+    N, E, H = outcsr_row_ptr.numel() - 1, outcsr_eids.numel(), el.shape[1]
+    D = ret.numel() // max(1, N * H)
+    _call(ret, "het_backward_relational_fused_gat_csr", _p(outcsr_row_ptr), _p(outcsr_col_indices), _p(outcsr_eids),
+          _p(outcsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),
+          max(0, unique_srcs_and_dests_rel_ptrs.numel() - 1), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
+          _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D, float(slope), int(CompactAsOfNodeFlag),
+          _stream(ret))
+
+
+# ------------------------------------------------------------------------------------
+# RGCN
+# ------------------------------------------------------------------------------------
+@_op("rgcn_layer1_separate_coo(Tensor separate_coo_relptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+     "Tensor separate_coo_col_indices, Tensor node_feat_input, Tensor weights, Tensor edge_norm, "
+     "Tensor(a!) node_feat_output) -> ()")
+def rgcn_layer1_separate_coo(separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices,
+                             separate_coo_col_indices, node_feat_input, weights, edge_norm, node_feat_output):
+    _chk("rgcn_layer1_separate_coo", (node_feat_input, weights, edge_norm, node_feat_output),
+         (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
+    R, K, D = weights.shape
+    _call(node_feat_output, "het_rgcn_layer1_separate_coo", _p(separate_coo_relptrs), _p(separate_coo_eids),
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(),
+          node_feat_output.shape[0], _p(node_feat_input), _p(weights), _p(edge_norm), _p(node_feat_output), K, D, None,
+          _stream(node_feat_output))
+
+
+@_op("backward_rgcn_layer1_separate_coo(Tensor separate_coo_relptrs, Tensor separate_coo_eids, "
+     "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor node_feat_input, "
+     "Tensor weights_transposed, Tensor edge_norm, Tensor(a!) grad_edge_norm, Tensor(b!) delta_node_feat_input, "
+     "Tensor delta_node_feat_output, Tensor(c!) delta_weights) -> ()")
+def backward_rgcn_layer1_separate_coo(separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices,
+                                      separate_coo_col_indices, node_feat_input, weights_transposed, edge_norm,
+                                      grad_edge_norm, delta_node_feat_input, delta_node_feat_output, delta_weights):
+    _chk("backward_rgcn_layer1_separate_coo",
+         (node_feat_input, weights_transposed, edge_norm, delta_node_feat_input, delta_node_feat_output, delta_weights),
+         (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
+    R, D, K = weights_transposed.shape
+    _call(delta_weights, "het_backward_rgcn_layer1_separate_coo", _p(separate_coo_relptrs), _p(separate_coo_eids),
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(),
+          delta_node_feat_output.shape[0], _p(node_feat_input), _p(weights_transposed), _p(edge_norm),
+          _p(grad_edge_norm), _p(delta_node_feat_input), _p(delta_node_feat_output), _p(delta_weights), K, D, None, None,
+          _stream(delta_weights))
+
+
+def _rgcn_maps(d: Dict[str, Tensor], direct: bool):
+    if direct:
+        return d["inverse_indices_row"], None
+    return d["rel_ptrs_row"], d["node_indices_row"]
+
+
+@_op("rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+     "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Dict(str, Tensor) args_tensor_dict, "
+     "Tensor feat_src, Tensor enorm, Tensor(a!) ret, bool DirectIndexFlag) -> ()")
+def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate_coo_eids, separate_coo_rel_ptrs,
+                                                               separate_coo_row_indices, separate_coo_col_indices,
+                                                               args_tensor_dict, feat_src, enorm, ret, DirectIndexFlag):
+    a, b = _rgcn_maps(args_tensor_dict, DirectIndexFlag)
+    _chk("rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", (feat_src, enorm, ret),
+         (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices, a)
+         + ((b,) if b is not None else ()))
+    N = ret.shape[0]
+    _call(ret, "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", _p(separate_coo_eids),
+          _p(separate_coo_rel_ptrs), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
+          separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), N, _p(a), _p(b), _p(feat_src), _p(enorm), _p(ret),
+          ret.numel() // max(1, N), int(DirectIndexFlag), _stream(ret))
+
+
+@_op("backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(Tensor separate_coo_eids, "
+     "Tensor separate_coo_rel_ptrs, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, "
+     "Dict(str, Tensor) args_tensor_dict, Tensor feat_src, Tensor enorm, Tensor ret, Tensor gradout, "
+     "Tensor(a!) grad_feat_src, bool DirectIndexFlag) -> ()")
+def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate_coo_eids, separate_coo_rel_ptrs,
+                                                                        separate_coo_row_indices,
+                                                                        separate_coo_col_indices, args_tensor_dict,
+                                                                        feat_src, enorm, ret, gradout, grad_feat_src,
+                                                                        DirectIndexFlag):
+    a, b = _rgcn_maps(args_tensor_dict, DirectIndexFlag)
+    _chk("backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", (feat_src, enorm, ret, gradout, grad_feat_src),
+         (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices, a)
+         + ((b,) if b is not None else ()))
+    N = ret.shape[0]
+    _call(ret, "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", _p(separate_coo_eids),
+          _p(separate_coo_rel_ptrs), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
+          separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), N, _p(a), _p(b), _p(feat_src), _p(enorm), _p(ret),
+          _p(gradout), _p(grad_feat_src), ret.numel() // max(1, N), int(DirectIndexFlag), _stream(ret))
+
+
+K = getattr(torch.ops, NAMESPACE)
+REGISTERED_OPS = tuple(_registered)

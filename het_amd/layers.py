@@ -1,0 +1,164 @@
+"""Layer modules: the op compositions of the reference's model scripts, without
+DGL.  Parameter names, shapes, initialisation and the order of ``B.*`` calls
+follow the reference so that a state_dict and the kernel sequence line up:
+
+  HET_RGATLayer                       hrt/python/RGAT/models.py:16-385
+  HET_EglRelGraphConv_EdgeParallel    hrt/python/RGCN/RGCN.py:194-350
+  HET_RelGraphEmbed                   hrt/python/RGNNUtils/RGNNUtils.py:78-119
+"""
+from __future__ import annotations
+
+import torch as th
+import torch.nn as nn
+
+from . import backend as B
+
+
+class HET_RelGraphEmbed(nn.Module):
+    """Learnable node embeddings used as input features (RGNNUtils.py:78-119)."""
+
+    def __init__(self, num_nodes: int, embed_size: int):
+        super().__init__()
+        self.embeds = nn.Parameter(th.Tensor(num_nodes, embed_size))
+        nn.init.xavier_uniform_(self.embeds)
+
+    def forward(self):
+        return self.embeds
+
+
+class HET_RGATLayer(nn.Module):
+    """Relational graph attention layer (RGAT/models.py:16-385)."""
+
+    def __init__(self, in_feat, out_feat, num_rels, num_heads, *, bias=True, activation=None, self_loop=False,
+                 compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
+                 multiply_among_weights_first_flag=False, gat_edge_parallel_flag=True, dropout=0.5,
+                 leaky_relu_slope=0.2):
+        super().__init__()
+        assert out_feat % num_heads == 0, "out_feat must be a multiple of num_heads"
+        self.in_feat, self.out_feat, self.num_rels, self.num_heads = in_feat, out_feat, num_rels, num_heads
+        self.bias, self.activation, self.self_loop = bias, activation, self_loop
+        self.compact_as_of_node_flag = compact_as_of_node_flag
+        self.compact_direct_indexing_flag = compact_direct_indexing_flag
+        self.multiply_among_weights_first_flag = multiply_among_weights_first_flag
+        self.gat_edge_parallel_flag = gat_edge_parallel_flag
+        self.leaky_relu_slope = leaky_relu_slope
+        self.conv_weights = nn.Parameter(th.Tensor(num_rels, num_heads, in_feat, out_feat // num_heads))
+        self.attn_l = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
+        self.attn_r = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
+        if bias:
+            self.h_bias = nn.Parameter(th.Tensor(out_feat))
+        if self_loop:
+            self.loop_weight = nn.Parameter(th.Tensor(in_feat, out_feat))
+        self.dropout = nn.Dropout(dropout)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        if self.bias:
+            nn.init.zeros_(self.h_bias)
+        if self.self_loop:
+            nn.init.xavier_uniform_(self.loop_weight, gain=gain)
+        nn.init.xavier_uniform_(self.conv_weights, gain=gain)
+        nn.init.xavier_uniform_(self.attn_l, gain=gain)
+        nn.init.xavier_uniform_(self.attn_r, gain=gain)
+
+    def _w_attn_r(self):
+        dk = self.out_feat // self.num_heads
+        return th.bmm(self.conv_weights.view(-1, self.in_feat, dk), self.attn_r.view(-1, dk, 1)).view(
+            -1, self.num_heads, self.in_feat, 1)
+
+    def forward(self, g, inputs: th.Tensor):
+        if self.compact_as_of_node_flag:  # models.py:152-263
+            ss = g.get_separate_unique_node_indices_single_sided()
+            d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"],
+                     "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
+            d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"],
+                     "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+            feat_compact = B.rgnn_relational_matmul(d_row, self.conv_weights, inputs, True, 1)
+            el_compact = B.rgnn_relational_matmul_no_scatter_gather_list(
+                ss["rel_ptrs_row"], self.attn_l.unsqueeze(-1), feat_compact)
+            if self.multiply_among_weights_first_flag:
+                er_compact = B.rgnn_relational_matmul(d_col, self._w_attn_r(), inputs, True, 1)
+            else:
+                feat_compact_dst = B.rgnn_relational_matmul(d_col, self.conv_weights, inputs, True, 1)
+                er_compact = B.rgnn_relational_matmul_no_scatter_gather_list(
+                    ss["rel_ptrs_col"], self.attn_r.unsqueeze(-1), feat_compact_dst)
+            if not self.gat_edge_parallel_flag:
+                raise NotImplementedError("single-sided unique node lists need the edge-parallel op (models.py:253-256)")
+            h = B.relational_fused_gat_compact_as_of_node_separate_coo_single_sided(
+                g, feat_compact, el_compact.view(el_compact.shape[0], self.num_heads),
+                er_compact.view(er_compact.shape[0], self.num_heads), self.leaky_relu_slope,
+                self.compact_direct_indexing_flag)
+        else:  # models.py:265-372
+            s = g.get_separate_coo_original()
+            by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"],
+                      "separate_coo_eids": s["eids"]}
+            by_dst = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"],
+                      "separate_coo_eids": s["eids"]}
+            by_eid = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"],
+                      "separate_coo_eids": s["eids"]}
+            feat_src_per_edge = B.rgnn_relational_matmul(by_src, self.conv_weights, inputs, True, 0)
+            el = B.rgnn_relational_matmul(by_eid, self.attn_l.unsqueeze(-1), feat_src_per_edge, False, 0)
+            if self.multiply_among_weights_first_flag:
+                # one input head, [R,H,K,1] weight (the reference passes False here, models.py:310-326,
+                # which only works for num_heads == 1)
+                er = B.rgnn_relational_matmul(by_dst, self._w_attn_r(), inputs, True, 0)
+            else:
+                feat_dst_per_edge = B.rgnn_relational_matmul(by_dst, self.conv_weights, inputs, True, 0)
+                er = B.rgnn_relational_matmul(by_eid, self.attn_r.unsqueeze(-1), feat_dst_per_edge, False, 0)
+            el, er = el.view(-1, self.num_heads), er.view(-1, self.num_heads)
+            if self.gat_edge_parallel_flag:
+                h = B.relational_fused_gat_separate_coo(g, feat_src_per_edge, el, er, self.leaky_relu_slope)
+            else:
+                h = B.relational_fused_gat_csr(g, feat_src_per_edge, el, er, self.leaky_relu_slope)
+        h = h.view(-1, self.out_feat)  # models.py:377-385
+        if self.self_loop:
+            h = h + th.matmul(inputs, self.loop_weight)
+        if self.bias:
+            h = h + self.h_bias
+        if self.activation:
+            h = self.activation(h)
+        return self.dropout(h)
+
+
+class HET_EglRelGraphConv_EdgeParallel(nn.Module):
+    """RGCN layer on the fused separate-COO op (RGCN/RGCN.py:194-350)."""
+
+    def __init__(self, in_feat, out_feat, num_rels, num_bases=-1, *, bias=True, activation=None,
+                 compact_as_of_node_flag=False, compact_direct_indexing_flag=False, dropout=0.0):
+        super().__init__()
+        self.in_feat, self.out_feat, self.num_rels = in_feat, out_feat, num_rels
+        self.num_bases = num_rels if num_bases <= 0 or num_bases > num_rels else num_bases
+        self.bias, self.activation = bias, activation
+        self.compact_as_of_node_flag = compact_as_of_node_flag
+        self.compact_direct_indexing_flag = compact_direct_indexing_flag
+        gain = nn.init.calculate_gain("relu")
+        self.weight = nn.Parameter(th.Tensor(self.num_bases, in_feat, out_feat))
+        nn.init.xavier_uniform_(self.weight, gain=gain)
+        if self.num_bases < num_rels:
+            self.w_comp = nn.Parameter(th.Tensor(num_rels, self.num_bases))
+            nn.init.xavier_uniform_(self.w_comp, gain=gain)
+        if bias:
+            self.h_bias = nn.Parameter(th.zeros(out_feat))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, g, x, norm):
+        if self.num_bases < self.num_rels:  # basis decomposition, RGCN.py:286-301
+            weight = th.matmul(self.w_comp, self.weight.view(self.num_bases, -1)).view(
+                self.num_rels, self.in_feat, self.out_feat)
+        else:
+            weight = self.weight
+        if self.compact_as_of_node_flag:  # RGCN.py:310-336
+            ss = g.get_separate_unique_node_indices_single_sided()
+            d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"],
+                     "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
+            feat_compact = B.rgnn_relational_matmul(d_row, weight.unsqueeze(1), x, True, 1)
+            node_repr = B.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo_single_sided(
+                g, feat_compact.view(feat_compact.shape[0], -1), norm, self.compact_direct_indexing_flag)
+        else:
+            node_repr = B.rgcn_layer1_separate_coo(g, x, weight, norm)
+        if self.bias:
+            node_repr = node_repr + self.h_bias
+        if self.activation:
+            node_repr = self.activation(node_repr)
+        return self.dropout(node_repr)

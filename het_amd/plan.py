@@ -1,0 +1,81 @@
+"""Cache of device-side groupings (``het_grouping``) keyed by the identity of the
+index tensors they were built from.
+
+The reference ops receive bare index tensors on every call; their atomics-based
+kernels need no preprocessing.  Our segmented-reduction kernels want the edge
+list grouped by destination / by (relation, node).  That grouping is a pure
+function of the index tensors, so it is built once (on the device, by
+``het_grouping_create``) and looked up by tensor identity afterwards.  An entry
+holds strong references to its source tensors, which pins their storage: a
+``data_ptr`` can therefore never be recycled for different contents while the
+entry is alive, and ``_version`` catches in-place edits.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_MAX_ENTRIES = 32
+_cache: "OrderedDict[tuple, Grouping]" = OrderedDict()
+enabled = True  # tests flip this to exercise the atomics kernels
+
+
+class Grouping:
+    def __init__(self, handle: C.c_void_p, keep):
+        self.handle = handle
+        self._keep = keep  # source tensors, kept alive with the handle
+
+    @property
+    def num_segments(self) -> int:
+        return int(_lib.lib().het_grouping_num_segments(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().het_grouping_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _ident(t: Optional[torch.Tensor]):
+    return None if t is None else (t.data_ptr(), t.numel(), t._version)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound: int,
+                 payload0: Optional[torch.Tensor] = None, payload1: Optional[torch.Tensor] = None) -> Optional[Grouping]:
+    """Grouping of the positions of ``keys`` by (relation, key) -- by key alone when
+    ``rel_ptrs`` is None.  Returns None when groupings are disabled."""
+    if not enabled:
+        return None
+    k = (_ident(rel_ptrs), _ident(keys), int(key_bound), _ident(payload0), _ident(payload1), keys.device.index)
+    g = _cache.get(k)
+    if g is not None:
+        _cache.move_to_end(k)
+        return g
+    for t in (rel_ptrs, keys, payload0, payload1):
+        if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise _lib.HetError("groupings need contiguous int64 tensors on the GPU")
+    out = C.c_void_p()
+    stream = C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream)
+    with torch.cuda.device(keys.device):
+        _lib.call("het_grouping_create", _ptr(rel_ptrs), 0 if rel_ptrs is None else rel_ptrs.numel() - 1,
+                  _ptr(keys), keys.numel(), int(key_bound), _ptr(payload0), _ptr(payload1), stream, C.byref(out))
+    g = Grouping(out, (rel_ptrs, keys, payload0, payload1))
+    _cache[k] = g
+    while len(_cache) > _MAX_ENTRIES:
+        _cache.popitem(last=False)
+    return g
+
+
+def clear():
+    _cache.clear()

@@ -1,0 +1,222 @@
+/*
+ * het_amd.h -- C ABI of libhet_amd.so: MI355X (gfx950) kernels for the
+ * relational-GNN hot path of K-Wu/HET (segment GEMM, hetero edge-softmax,
+ * gather-scatter aggregation; forward and backward).
+ *
+ * The reference exposes this path as torch custom ops registered with
+ * TORCH_LIBRARY_FRAGMENT(torch_hrt, m) (a dispatcher boundary, not a C ABI:
+ * the .inc.h files under hrt/include/DGLHackKernel/OpExport/).  Every entry point below is the
+ * plain-pointer form of one of those ops: same name (prefixed het_), same
+ * argument meaning, with each at::Tensor replaced by its device pointer and
+ * sizes, and each torch::Dict<string, Tensor> flattened into named pointers.
+ * het_amd/kernels.py re-registers the ops under torch.ops.torch_hrt.* on top of
+ * this ABI; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (as the reference, RGNNOps.inc.h:191-199, RGATOps.inc.h:35-48):
+ *   - all pointers are DEVICE pointers to contiguous buffers on the current HIP
+ *     device; floats are fp32, indices int64;
+ *   - outputs are caller-allocated; "+=" in a comment means accumulated into,
+ *     "=" means overwritten (no pre-zeroing needed);
+ *   - launches go to `stream` (a hipStream_t; NULL = default stream), nothing
+ *     synchronises the host, nothing allocates -- except het_grouping_create;
+ *   - return value 0 = ok; otherwise an HET_ERR_* code, message in
+ *     het_last_error() (thread-local).  Arguments are validated on the host
+ *     before any launch (the reference only has compiled-out asserts).
+ *
+ * Paths in comments are relative to /root/reference/hrt/.
+ */
+#ifndef HET_AMD_H
+#define HET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HET_OK 0
+#define HET_ERR_INVALID_ARG 1
+#define HET_ERR_HIP 2
+#define HET_ERR_UNSUPPORTED 3
+
+typedef void* het_stream; /* hipStream_t */
+
+/* CompactAsOfNodeKind, include/kernel_enums.h:6-14 (the int the ops take) */
+#define HET_KIND_DISABLED 0
+#define HET_KIND_ENABLED 1
+#define HET_KIND_DIRECT_INDEX 2
+#define HET_KIND_DUAL_LIST 3
+#define HET_KIND_DUAL_LIST_DIRECT_INDEX 4
+
+/* replaces torch.ops.torch_hrt.build_debug_info (buildutils/genutils/gen_headers.py:17-41) */
+const char* het_build_info(void);
+const char* het_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Groupings: a one-time, device-side preprocessing of an index list that the
+ * fast paths use to replace float atomics by segmented reductions.  A grouping
+ * sorts the E positions of a relation-bucketed list by (relation, key[i]) --
+ * or by key[i] alone when rel_ptrs is NULL -- and records the segments.  It has
+ * no counterpart in the reference (which uses atomicAdd everywhere, e.g.
+ * RGAT/RGATKernelsSeparateCOO.cu.h:77,195); every op accepts NULL instead and
+ * then runs its atomics-based kernel.  Allocates device memory (hipMalloc) and
+ * synchronises `stream` once; destroy with het_grouping_destroy.
+ * ------------------------------------------------------------------------ */
+typedef struct het_grouping het_grouping;
+/* payload0/payload1 (optional, [E]): per-position int64 arrays that are carried along in sorted
+ * order (stored as int32), so that a grouped kernel reads them coalesced instead of chasing
+ * perm -> array.  Each op documents what it expects there. */
+int het_grouping_create(const int64_t* rel_ptrs /* [R+1] or NULL */, int64_t num_rels,
+                        const int64_t* keys /* [E] */, int64_t num_positions, int64_t key_bound,
+                        const int64_t* payload0, const int64_t* payload1,
+                        het_stream stream, het_grouping** out);
+void het_grouping_destroy(het_grouping* g);
+/* number of segments (distinct (relation, key) pairs) */
+int64_t het_grouping_num_segments(const het_grouping* g);
+
+/* ------------------------------------------------------------------------
+ * a1  rgnn_relational_matmul            OpExport/RGNNOps.inc.h:238-295
+ *   kind 0: ret[scatter_idx[i], h, :] = x[gather_idx[i], (h), :] . W[r(i), h]    i in [0, num_rows)
+ *           (dict keys separate_coo_rel_ptrs / separate_coo_node_indices / separate_coo_eids)
+ *   kind 1: ret[i, h, :] = x[gather_idx[i], (h), :] . W[r(i), h]   scatter_idx = NULL
+ *           (dict keys unique_srcs_and_dests_rel_ptrs / unique_srcs_and_dests_node_indices)
+ *   W [R,H,K,D]; x [*, K] if in1head else [*, H, K]; ret [*, H, D].
+ * ------------------------------------------------------------------------ */
+int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                               const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+                               const float* weights, const float* x, float* ret,
+                               int64_t H, int64_t K, int64_t D, int in1head, het_stream stream);
+
+/* a2  backward_rgnn_relational_matmul   OpExport/RGNNOps.inc.h:946-1010
+ *   grad_x[gather_idx[i], (h), :] += gradout[scatter_idx[i], h, :] . Wt[r, h]   (heads summed iff in1head)
+ *   grad_w[r, h]                  += x[gather_idx[i], (h), :]^T (x) gradout[scatter_idx[i], h, :]
+ *   weights_t [R,H,D,K].  by_rel_gather: optional grouping of the rows by
+ *   (relation, gather_idx) (het_grouping_create(rel_ptrs, R, gather_idx, ...)). */
+int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                                        const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+                                        const float* weights_t, const float* x, const float* gradout,
+                                        float* grad_x, float* grad_w,
+                                        int64_t H, int64_t K, int64_t D, int in1head,
+                                        const het_grouping* by_rel_gather, het_stream stream);
+
+/* a3  rgnn_relational_matmul_no_scatter_gather_list / backward_...   RGNNOps.inc.h:21-88, 660-753
+ *   rows offsets[t]:offsets[t+1] use W[t]; x is [rows, K] (x_per_head = 0) or [rows, H, K]. */
+int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* offsets, int64_t num_types, int64_t num_rows,
+                                                      const float* weights, const float* x, float* ret,
+                                                      int64_t H, int64_t K, int64_t D, int x_per_head,
+                                                      het_stream stream);
+int het_backward_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* offsets, int64_t num_types,
+                                                               int64_t num_rows, const float* weights_t,
+                                                               const float* x, const float* gradout,
+                                                               float* grad_x, float* grad_w,
+                                                               int64_t H, int64_t K, int64_t D, int x_per_head,
+                                                               het_stream stream);
+
+/* ------------------------------------------------------------------------
+ * a4  relational_fused_gat_separate_coo    OpExport/RGATOps.inc.h:170-245
+ *   exp[eids[i], h]  = leaky_exp(el[srow(i), h] + er[drow(i), h])
+ *   sum[col[i], h]   = SUM_i exp            (all in-edges of the destination, every relation)
+ *   ret[col[i],h,:]  = SUM_i exp/sum * feat[srow(i), h, :]
+ *   sum, exp, ret are overwritten (zeroed internally; the reference accumulates into
+ *   uninitialised buffers).
+ * Row maps by kind (dict of the reference op flattened into four pointers):
+ *   kind 0  srow = drow = eids[i]                               all four NULL
+ *   kind 1  srow/drow = row of (r(i), row[i]) / (r(i), col[i]) in the unique list
+ *           map_row_a = map_col_a = unique_srcs_and_dests_rel_ptrs [R+1]
+ *           map_row_b = map_col_b = unique_srcs_and_dests_node_indices
+ *   kind 3  map_row_a/b = unique_srcs_and_dests_rel_ptrs / ..._node_indices_row
+ *           map_col_a/b = unique_srcs_and_dests_rel_ptrs_col / ..._node_indices_col
+ *   kind 4  srow = map_row_a[eids[i]], drow = map_col_a[eids[i]]
+ *           (edata_idx_to_inverse_idx_row / _col); map_*_b NULL
+ *   feat [n_src_rows, H, D]; el [n_src_rows, H]; er [n_dst_rows, H]; sum [N,H]; exp [E,H]; ret [N,H,D].
+ *   by_dst: optional grouping of the positions by col: het_grouping_create(NULL, 0, col, E, N,
+ *   payload0 = eids, payload1 = NULL or the feat row of every position (srow), ...).
+ * ------------------------------------------------------------------------ */
+int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row,
+                                          const int64_t* col, int64_t num_rels, int64_t num_edges,
+                                          int64_t num_nodes, int64_t kind,
+                                          const int64_t* map_row_a, const int64_t* map_row_b,
+                                          const int64_t* map_col_a, const int64_t* map_col_b,
+                                          const float* feat, const float* el, const float* er,
+                                          float* sum, float* exp, float* ret,
+                                          int64_t H, int64_t D, double slope,
+                                          const het_grouping* by_dst, het_stream stream);
+
+/* a5  backward_relational_fused_gat_separate_coo   OpExport/RGATOps.inc.h:465-551
+ *   a = exp[eids[i],h] / sum[col[i],h]
+ *   grad_feat[srow,h,:] += a * gradout[col[i],h,:]
+ *   t = SUM_d gradout[col[i],h,d] * (feat[srow,h,d] - ret[col[i],h,d]) * a * (z > 0 ? 1 : slope)
+ *   grad_el[srow,h] += t ; grad_er[drow,h] += t
+ *   n_src_rows / n_dst_rows: leading sizes of feat/el and er (E for kind 0). */
+int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
+                                                   const int64_t* row, const int64_t* col, int64_t num_rels,
+                                                   int64_t num_edges, int64_t num_nodes, int64_t kind,
+                                                   const int64_t* map_row_a, const int64_t* map_row_b,
+                                                   const int64_t* map_col_a, const int64_t* map_col_b,
+                                                   const float* feat, const float* el, const float* er,
+                                                   const float* sum, const float* exp, const float* ret,
+                                                   const float* gradout, float* grad_feat, float* grad_el,
+                                                   float* grad_er, int64_t H, int64_t D, double slope,
+                                                   const het_grouping* by_dst, const het_grouping* by_rel_src,
+                                                   het_stream stream);
+
+/* a6  relational_fused_gat_csr / backward_relational_fused_gat_csr   RGATOps.inc.h:251-277, 430-460
+ *   forward over the in-CSR (rows = dst, col_indices = src); backward over the out-CSR
+ *   (rows = src, col_indices = dst).  compact != 0: feat/el/er rows are (relation, node) rows of
+ *   the unique list (uniq_rel_ptrs, uniq_node_idx), binary-searched. */
+int het_relational_fused_gat_csr(const int64_t* in_row_ptrs, const int64_t* in_col, const int64_t* in_eids,
+                                 const int64_t* in_reltypes, int64_t num_nodes, int64_t num_edges,
+                                 const int64_t* uniq_rel_ptrs, const int64_t* uniq_node_idx, int64_t num_rels,
+                                 const float* feat, const float* el, const float* er,
+                                 float* sum, float* exp, float* ret, int64_t H, int64_t D, double slope,
+                                 int compact, het_stream stream);
+int het_backward_relational_fused_gat_csr(const int64_t* out_row_ptrs, const int64_t* out_col,
+                                          const int64_t* out_eids, const int64_t* out_reltypes,
+                                          int64_t num_nodes, int64_t num_edges,
+                                          const int64_t* uniq_rel_ptrs, const int64_t* uniq_node_idx,
+                                          int64_t num_rels, const float* feat, const float* el, const float* er,
+                                          const float* sum, const float* exp, const float* ret,
+                                          const float* gradout, float* grad_feat, float* grad_el, float* grad_er,
+                                          int64_t H, int64_t D, double slope, int compact, het_stream stream);
+
+/* ------------------------------------------------------------------------
+ * a7  rgcn_layer1_separate_coo            OpExport/RGCNOps.inc.h:84-138
+ *   ret[col[i], :] += (x[row[i], :] * norm[eids[i]]) . W[r(i)]        W [R,K,D]
+ *   by_rel_dst: optional grouping of the positions by (relation, col).
+ * a8  backward_rgcn_layer1_separate_coo   OpExport/RGCNOps.inc.h:368-467
+ *   grad_x[row[i], :] += (gradout[col[i], :] * norm[eids[i]]) . Wt[r]   (intended direction)
+ *   grad_w[r]         += (x[row[i], :] * norm[eids[i]])^T (x) gradout[col[i], :]
+ *   grad_norm is not written (disabled in the reference, my_shmem_sgemm_func_rgcn_hgt.cu.h:680-684).
+ * ------------------------------------------------------------------------ */
+int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
+                                 const int64_t* col, int64_t num_rels, int64_t num_edges, int64_t num_nodes,
+                                 const float* x, const float* weights, const float* norm, float* ret,
+                                 int64_t K, int64_t D, const het_grouping* by_rel_dst, het_stream stream);
+int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
+                                          const int64_t* col, int64_t num_rels, int64_t num_edges,
+                                          int64_t num_nodes, const float* x, const float* weights_t,
+                                          const float* norm, float* grad_norm, float* grad_x,
+                                          const float* gradout, float* grad_w, int64_t K, int64_t D,
+                                          const het_grouping* by_rel_src, const het_grouping* by_rel_dst,
+                                          het_stream stream);
+
+/* a9  rgcn_node_mean_aggregation_compact_as_of_node_separate_coo (+ backward)  RGCNOps.inc.h:24-82, 303-366
+ *   ret[col[i], :]        = SUM_i enorm[eids[i]] * feat[crow(i), :]            (ret overwritten)
+ *   grad_feat[crow(i), :] += enorm[eids[i]] * gradout[col[i], :]
+ *   crow(i) = map_a[eids[i]] if direct (inverse_indices_row), else the row of (r(i), row[i]) in the
+ *   unique list map_a = rel_ptrs_row [R+1], map_b = node_indices_row  (intended mapping). */
+int het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
+    const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
+    int64_t num_edges, int64_t num_nodes, const int64_t* map_a, const int64_t* map_b, const float* feat,
+    const float* enorm, float* ret, int64_t X, int direct, het_stream stream);
+int het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
+    const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
+    int64_t num_edges, int64_t num_nodes, const int64_t* map_a, const int64_t* map_b, const float* feat,
+    const float* enorm, const float* ret, const float* gradout, float* grad_feat, int64_t X, int direct,
+    het_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HET_AMD_H */

@@ -1,0 +1,63 @@
+"""Layer-level CPU oracle -- TEST INFRASTRUCTURE ONLY (see oracle/ops.py).
+
+Plain-PyTorch message passing (index_select -> per-relation matmul ->
+leaky_relu / exp -> index_add), differentiable by torch autograd, restating what
+one HET layer computes end to end (reference compositions:
+hrt/python/RGAT/models.py:265-385, hrt/python/RGCN/RGCN.py:264-350).  It is the
+checker for the layer-level parity tests and the timed ``cpu_baseline`` of
+bench.py ("port": the reference's own CPU fallback is its DGL model, which cannot
+run without DGL).  HET semantics: the edge softmax normalises over ALL in-edges
+of a destination, across relations (RGAT/RGATKernelsSeparateCOO.cu.h:190-196),
+unlike DGL's per-relation HeteroGraphConv.
+"""
+import torch
+
+
+def rel_of_position(rel_ptrs):
+    R = rel_ptrs.numel() - 1
+    return torch.repeat_interleave(torch.arange(R, device=rel_ptrs.device), rel_ptrs[1:] - rel_ptrs[:-1])
+
+
+def rgat_layer(x, conv_weights, attn_l, attn_r, rel_ptrs, row, col, num_nodes, slope=0.2,
+               loop_weight=None, h_bias=None):
+    """x [N,K]; conv_weights [R,H,K,D]; attn_l/attn_r [R,H,D]; separate COO (eids = arange).  Returns [N, H*D]."""
+    R, H, K, D = conv_weights.shape
+    feat = x.new_empty((row.numel(), H, D))
+    el = x.new_empty((row.numel(), H))
+    er = x.new_empty((row.numel(), H))
+    parts_f, parts_l, parts_r = [], [], []
+    for r in range(R):
+        a, b = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        Wr = conv_weights[r].permute(1, 0, 2).reshape(K, H * D)
+        fs = (x[row[a:b]] @ Wr).view(-1, H, D)
+        fd = (x[col[a:b]] @ Wr).view(-1, H, D)
+        parts_f.append(fs)
+        parts_l.append((fs * attn_l[r]).sum(-1))
+        parts_r.append((fd * attn_r[r]).sum(-1))
+    feat, el, er = torch.cat(parts_f), torch.cat(parts_l), torch.cat(parts_r)
+    z = el + er
+    e = torch.exp(torch.where(z > 0, z, z * slope))
+    den = torch.zeros(num_nodes, H, dtype=x.dtype, device=x.device).index_add(0, col, e)
+    a = e / den[col]
+    h = torch.zeros(num_nodes, H, D, dtype=x.dtype, device=x.device).index_add(0, col, a.unsqueeze(-1) * feat)
+    h = h.view(num_nodes, H * D)
+    if loop_weight is not None:
+        h = h + x @ loop_weight
+    if h_bias is not None:
+        h = h + h_bias
+    return h
+
+
+def rgcn_layer(x, weight, norm, rel_ptrs, row, col, num_nodes, h_bias=None):
+    """x [N,K]; weight [R,K,D]; norm [E] or [E,1] (eids = arange).  Returns [N, D]."""
+    R = weight.shape[0]
+    nv = norm.reshape(-1, 1)
+    out = torch.zeros(num_nodes, weight.shape[2], dtype=x.dtype, device=x.device)
+    for r in range(R):
+        a, b = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a == b:
+            continue
+        out = out.index_add(0, col[a:b], (x[row[a:b]] * nv[a:b]) @ weight[r])
+    if h_bias is not None:
+        out = out + h_bias
+    return out

@@ -1,0 +1,295 @@
+"""GPU parity: every torch_hrt op (served by libhet_amd.so through the C ABI)
+against the fp64 CPU oracle on the same seeded inputs."""
+import pytest
+import torch
+
+from oracle import ops as O
+from tests.util import assert_close, cpu, mag_graph, random_graph, to64
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    import het_amd.kernels as k
+    return k.K
+
+
+@pytest.fixture(params=[True, False], ids=["grouped", "atomics"])
+def plan_mode(request):
+    import het_amd.plan as plan
+    old = plan.enabled
+    plan.enabled = request.param
+    plan.clear()
+    yield request.param
+    plan.enabled = old
+    plan.clear()
+
+
+def _dev(d):
+    return {k: v.to(DEV) for k, v in d.items()}
+
+
+# ---------------------------------------------------------------- segment GEMM
+SHAPES = [  # (H, K, D, in1head)
+    (1, 16, 16, True),    # AIFB-sized RGCN-style projection (generic kernel)
+    (4, 64, 16, True),    # RGAT C3 projection (MFMA path, X = 64)
+    (2, 64, 64, True),    # X = 128 MFMA
+    (1, 32, 32, True),    # smallest MFMA shape
+    (4, 16, 1, False),    # attention vector: el = <feat, attn> per head
+    (3, 7, 5, False),     # odd everything, per-head input
+    (3, 7, 5, True),      # odd, shared input
+    (8, 8, 8, False),     # HGT relation_att shape
+]
+
+
+@pytest.mark.parametrize("H,Kd,D,in1head", SHAPES)
+@pytest.mark.parametrize("kind", [0, 1])
+def test_rgnn_relational_matmul_fwd_bwd(K, H, Kd, D, in1head, kind):
+    g = random_graph(seed=11)
+    s = g.get_separate_coo_original()
+    R, N, E = g.get_num_rels(), g.get_num_nodes(), g.get_num_edges()
+    gen = torch.Generator().manual_seed(5)
+    W = torch.randn(R, H, Kd, D, generator=gen)
+    x = torch.randn(N, Kd, generator=gen) if in1head else torch.randn(N, H, Kd, generator=gen)
+    if kind == 0:
+        d = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"],
+             "separate_coo_eids": torch.randperm(E, generator=gen)}
+        nout = E
+    else:
+        u = g.get_separate_unique_node_indices_single_sided()
+        d = {"unique_srcs_and_dests_rel_ptrs": u["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": u["node_indices_row"]}
+        nout = int(u["rel_ptrs_row"][-1])
+    ref = torch.zeros(nout, H, D, dtype=torch.float64)
+    O.rgnn_relational_matmul(d, kind, to64(W), to64(x), ref, in1head)
+    ret = torch.full((nout, H, D), float("nan"), device=DEV)
+    K.rgnn_relational_matmul(_dev(d), kind, W.to(DEV), x.to(DEV), ret, in1head)
+    assert_close(ret, ref, what="ret")
+
+    go = torch.randn(nout, H, D, generator=gen)
+    gx_ref, gW_ref = torch.zeros_like(to64(x)), torch.zeros_like(to64(W))
+    O.backward_rgnn_relational_matmul(d, kind, to64(W).transpose(2, 3).contiguous(), to64(x), to64(go), gx_ref, gW_ref, in1head)
+    gx, gW = torch.zeros_like(x, device=DEV), torch.zeros_like(W, device=DEV)
+    K.backward_rgnn_relational_matmul(_dev(d), kind, W.transpose(2, 3).contiguous().to(DEV), x.to(DEV), go.to(DEV), gx, gW, in1head)
+    assert_close(gx, gx_ref, what="grad_x")
+    assert_close(gW, gW_ref, what="grad_W")
+
+
+def test_matmul_gather_equals_scatter_list(K):
+    """el = feat_edge . attn with node_indices and eids the SAME tensor
+    (the reference dispatches on data_ptr equality, RGNNOps.inc.h:253)."""
+    g = random_graph(seed=12)
+    s = g.get_separate_coo_original()
+    R, E, H, D = g.get_num_rels(), g.get_num_edges(), 4, 16
+    feat = torch.randn(E, H, D)
+    attn = torch.randn(R, H, D, 1)
+    eids = s["eids"]
+    d = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+    ref = torch.zeros(E, H, 1, dtype=torch.float64)
+    O.rgnn_relational_matmul(d, 0, to64(attn), to64(feat), ref, False)
+    ret = torch.empty(E, H, 1, device=DEV)
+    e_dev = eids.to(DEV)
+    K.rgnn_relational_matmul({"separate_coo_rel_ptrs": s["rel_ptrs"].to(DEV), "separate_coo_node_indices": e_dev,
+                              "separate_coo_eids": e_dev}, 0, attn.to(DEV), feat.to(DEV), ret, False)
+    assert_close(ret, ref)
+
+
+@pytest.mark.parametrize("H,Kd,D,per_head", [(1, 64, 64, False), (1, 16, 16, False), (4, 16, 1, True), (3, 6, 5, False), (8, 8, 8, True)])
+def test_matmul_no_scatter_gather(K, H, Kd, D, per_head):
+    offsets = torch.tensor([0, 130, 130, 131, 700, 1023])
+    T, n = 5, 1023
+    gen = torch.Generator().manual_seed(3)
+    W = torch.randn(T, H, Kd, D, generator=gen)
+    x = torch.randn(n, H, Kd, generator=gen) if per_head else torch.randn(n, Kd, generator=gen)
+    ref = torch.zeros(n, H, D, dtype=torch.float64)
+    O.rgnn_relational_matmul_no_scatter_gather_list(offsets, to64(W), to64(x), ref)
+    ret = torch.full((n, H, D), float("nan"), device=DEV)
+    K.rgnn_relational_matmul_no_scatter_gather_list(offsets.to(DEV), W.to(DEV), x.to(DEV), ret)
+    assert_close(ret, ref)
+    go = torch.randn(n, H, D, generator=gen)
+    gx_ref, gW_ref = torch.zeros_like(to64(x)), torch.zeros_like(to64(W))
+    O.backward_rgnn_relational_matmul_no_scatter_gather_list(offsets, to64(W).transpose(2, 3).contiguous(), to64(x), to64(go), gx_ref, gW_ref)
+    gx, gW = torch.zeros_like(x, device=DEV), torch.zeros_like(W, device=DEV)
+    K.backward_rgnn_relational_matmul_no_scatter_gather_list(offsets.to(DEV), W.transpose(2, 3).contiguous().to(DEV), x.to(DEV), go.to(DEV), gx, gW)
+    assert_close(gx, gx_ref, what="grad_x")
+    assert_close(gW, gW_ref, what="grad_W")
+
+
+def test_matmul_empty(K):
+    """No rows at all, and a relation list made only of empty relations."""
+    rp = torch.zeros(4, dtype=torch.int64, device=DEV)
+    e = torch.zeros(0, dtype=torch.int64, device=DEV)
+    W = torch.randn(3, 2, 8, 4, device=DEV)
+    x = torch.randn(5, 8, device=DEV)
+    ret = torch.zeros(0, 2, 4, device=DEV)
+    K.rgnn_relational_matmul({"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": e, "separate_coo_eids": e}, 0, W, x, ret, True)
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- fused GAT
+def _gat_case(g, kind, H, D, seed):
+    from tests.test_oracle import _gat_dict, _gat_sizes
+    s = g.get_separate_coo_original()
+    ns, nd = _gat_sizes(g, kind)
+    gen = torch.Generator().manual_seed(seed)
+    feat = torch.randn(ns, H, D, generator=gen)
+    el = torch.randn(ns, H, generator=gen)
+    er = torch.randn(nd, H, generator=gen)
+    go = torch.randn(g.get_num_nodes(), H, D, generator=gen)
+    df, db = _gat_dict(g, kind)
+    return s, feat, el, er, go, df, db
+
+
+@pytest.mark.parametrize("kind", [0, 1, 3, 4])
+@pytest.mark.parametrize("H,D", [(4, 16), (1, 64), (3, 5), (8, 8), (2, 2)])
+def test_fused_gat_separate_coo(K, plan_mode, kind, H, D):
+    g = random_graph(seed=21, n=300, r=4, e=5000)
+    s, feat, el, er, go, df, db = _gat_case(g, kind, H, D, seed=9)
+    N, E, slope = g.get_num_nodes(), g.get_num_edges(), 0.2
+    idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    sm_r, ex_r, ret_r = (torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64),
+                         torch.empty(N, H, D, dtype=torch.float64))
+    O.relational_fused_gat_separate_coo(*idx, kind, df, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, slope)
+    gf_r, gl_r, gr_r = torch.zeros_like(to64(feat)), torch.zeros_like(to64(el)), torch.zeros_like(to64(er))
+    O.backward_relational_fused_gat_separate_coo(*idx, kind, db, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r,
+                                                 to64(go), gf_r, gl_r, gr_r, slope)
+    didx = tuple(t.to(DEV) for t in idx)
+    # outputs start as garbage: the op must overwrite sum / exp / ret
+    sm, ex, ret = (torch.full((N, H), 7.0, device=DEV), torch.full((E, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV))
+    f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
+    K.relational_fused_gat_separate_coo(*didx, kind, _dev(df), f, l, r_, sm, ex, ret, slope)
+    assert_close(ex, ex_r, what="exp")
+    assert_close(sm, sm_r, what="sum")
+    assert_close(ret, ret_r, what="ret")
+    fill = float("nan") if kind == 0 else 0.0  # kind 0 gradients are overwritten, the others accumulated
+    gf, gl, gr = (torch.full_like(f, fill), torch.full_like(l, fill), torch.full_like(r_, fill))
+    K.backward_relational_fused_gat_separate_coo(*didx, kind, _dev(db), f, l, r_, sm, ex, ret, go.to(DEV), gf, gl, gr, slope)
+    assert_close(gf, gf_r, what="grad_feat")
+    assert_close(gl, gl_r, what="grad_el")
+    assert_close(gr, gr_r, what="grad_er")
+
+
+def test_fused_gat_hub_destination(K, plan_mode):
+    """One destination with thousands of in-edges (its segment is split over several work
+    items), many destinations with none, and eids a non-trivial permutation."""
+    from het_amd.graph import HetGraph
+    from het_amd.synth import IntegratedCOO
+    gen = torch.Generator().manual_seed(4)
+    N, E, R, H, D = 500, 6000, 3, 4, 16
+    col = torch.randint(0, 40, (E,), generator=gen)
+    col[: E // 2] = 7  # hub
+    row = torch.randint(0, N, (E,), generator=gen)
+    rel = torch.sort(torch.randint(0, R, (E,), generator=gen)).values
+    g = HetGraph.from_integrated_coo(IntegratedCOO(N, R, torch.tensor([0, N]), row, col, rel, torch.randperm(E, generator=gen)))
+    s, feat, el, er, go, df, db = _gat_case(g, 0, H, D, seed=2)
+    idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    sm_r, ex_r, ret_r = (torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64),
+                         torch.empty(N, H, D, dtype=torch.float64))
+    O.relational_fused_gat_separate_coo(*idx, 0, {}, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, 0.2)
+    didx = tuple(t.to(DEV) for t in idx)
+    sm, ex, ret = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(N, H, D, device=DEV)
+    K.relational_fused_gat_separate_coo(*didx, 0, {}, feat.to(DEV), el.to(DEV), er.to(DEV), sm, ex, ret, 0.2)
+    assert_close(sm, sm_r, what="sum")
+    assert_close(ret, ret_r, what="ret")
+    assert float(ret[41:].abs().max()) == 0.0  # destinations without in-edges
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_fused_gat_csr(K, compact):
+    g = random_graph(seed=23, n=200, r=3, e=2500, empty_rel=False)
+    i, o, u = g.get_in_csr(), g.get_out_csr(), g.get_separate_unique_node_indices()
+    N, E, H, D, slope = g.get_num_nodes(), g.get_num_edges(), 2, 8, 0.2
+    n_rows = int(u["rel_ptrs"][-1]) if compact else E
+    gen = torch.Generator().manual_seed(1)
+    feat, el, er = torch.randn(n_rows, H, D, generator=gen), torch.randn(n_rows, H, generator=gen), torch.randn(n_rows, H, generator=gen)
+    go = torch.randn(N, H, D, generator=gen)
+    sm_r, ex_r, ret_r = (torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64), torch.empty(N, H, D, dtype=torch.float64))
+    O.relational_fused_gat_csr(i["row_ptrs"], i["col_indices"], i["eids"], i["rel_types"], u["rel_ptrs"], u["node_indices"],
+                               to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, slope, compact)
+    gf_r, gl_r, gr_r = torch.zeros_like(to64(feat)), torch.zeros_like(to64(el)), torch.zeros_like(to64(er))
+    O.backward_relational_fused_gat_csr(o["row_ptrs"], o["col_indices"], o["eids"], o["rel_types"], u["rel_ptrs"], u["node_indices"],
+                                        to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, to64(go), gf_r, gl_r, gr_r, slope, compact)
+    D_ = lambda d, ks: [d[k].to(DEV) for k in ks]
+    sm, ex, ret = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(N, H, D, device=DEV)
+    f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
+    K.relational_fused_gat_csr(*D_(i, ["row_ptrs", "col_indices", "eids", "rel_types"]), *D_(u, ["rel_ptrs", "node_indices"]),
+                               f, l, r_, sm, ex, ret, slope, compact)
+    assert_close(sm, sm_r, what="sum")
+    assert_close(ex, ex_r, what="exp")
+    assert_close(ret, ret_r, what="ret")
+    gf, gl, gr = torch.zeros_like(f), torch.zeros_like(l), torch.zeros_like(r_)
+    K.backward_relational_fused_gat_csr(*D_(o, ["row_ptrs", "col_indices", "eids", "rel_types"]), *D_(u, ["rel_ptrs", "node_indices"]),
+                                        f, l, r_, sm, ex, ret, go.to(DEV), gf, gl, gr, slope, compact)
+    assert_close(gf, gf_r, what="grad_feat")
+    assert_close(gl, gl_r, what="grad_el")
+    assert_close(gr, gr_r, what="grad_er")
+
+
+def test_gat_golden_exp_sum(K, golden_mag):
+    """exp / sum against the vectors produced by the reference's ref_rgat.py."""
+    gold = golden_mag
+    n = int(gold["num_nodes"])
+    el, er = gold["gat_el"], gold["gat_er"]
+    E, H = el.shape
+    feat = torch.randn(E, H, 4)
+    sm, ex, ret = torch.empty(n, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(n, H, 4, device=DEV)
+    K.relational_fused_gat_separate_coo(torch.arange(E, device=DEV), gold["sep_rel_ptrs"].to(DEV), gold["sep_row"].to(DEV),
+                                        gold["sep_col"].to(DEV), 0, {}, feat.to(DEV), el.to(DEV), er.to(DEV), sm, ex, ret,
+                                        float(gold["gat_slope"]))
+    torch.testing.assert_close(cpu(ex), gold["gat_exp"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cpu(sm), gold["gat_sum"], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- RGCN
+@pytest.mark.parametrize("Kd,D", [(16, 16), (64, 64), (7, 3)])
+def test_rgcn_layer1(K, Kd, D):
+    g = random_graph(seed=31)
+    s = g.get_separate_coo_original()
+    R, N, E = g.get_num_rels(), g.get_num_nodes(), g.get_num_edges()
+    gen = torch.Generator().manual_seed(8)
+    x, W, norm = torch.randn(N, Kd, generator=gen), torch.randn(R, Kd, D, generator=gen), torch.rand(E, 1, generator=gen)
+    go = torch.randn(N, D, generator=gen)
+    a = (s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"])
+    ref = torch.zeros(N, D, dtype=torch.float64)
+    O.rgcn_layer1_separate_coo(*a, to64(x), to64(W), to64(norm), ref)
+    gx_r, gW_r, gn_r = torch.zeros(N, Kd, dtype=torch.float64), torch.zeros(R, Kd, D, dtype=torch.float64), torch.zeros(E, 1, dtype=torch.float64)
+    O.backward_rgcn_layer1_separate_coo(*a, to64(x), to64(W).transpose(1, 2).contiguous(), to64(norm), gn_r, gx_r, to64(go), gW_r)
+    da = tuple(t.to(DEV) for t in a)
+    ret = torch.zeros(N, D, device=DEV)
+    K.rgcn_layer1_separate_coo(*da, x.to(DEV), W.to(DEV), norm.to(DEV), ret)
+    assert_close(ret, ref, what="ret")
+    gx, gW, gn = torch.zeros(N, Kd, device=DEV), torch.zeros(R, Kd, D, device=DEV), torch.zeros(E, 1, device=DEV)
+    K.backward_rgcn_layer1_separate_coo(*da, x.to(DEV), W.transpose(1, 2).contiguous().to(DEV), norm.to(DEV), gn, gx, go.to(DEV), gW)
+    assert_close(gx, gx_r, what="grad_x")
+    assert_close(gW, gW_r, what="grad_W")
+    assert float(gn.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_rgcn_compact_aggregation(K, direct):
+    g = random_graph(seed=32)
+    s = g.get_separate_coo_original()
+    ss, ssi = g.get_separate_unique_node_indices_single_sided(), g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    U, X, N, E = int(ss["rel_ptrs_row"][-1]), 16, g.get_num_nodes(), g.get_num_edges()
+    gen = torch.Generator().manual_seed(6)
+    feat, enorm, go = torch.randn(U, X, generator=gen), torch.rand(E, 1, generator=gen), torch.randn(N, X, generator=gen)
+    d = {"inverse_indices_row": ssi["inverse_indices_row"]} if direct else {"rel_ptrs_row": ss["rel_ptrs_row"], "node_indices_row": ss["node_indices_row"]}
+    a = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    ref, gf_r = torch.empty(N, X, dtype=torch.float64), torch.zeros(U, X, dtype=torch.float64)
+    O.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*a, d, to64(feat), to64(enorm), ref, direct)
+    O.backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*a, d, to64(feat), to64(enorm), ref, to64(go), gf_r, direct)
+    da = tuple(t.to(DEV) for t in a)
+    ret, gf = torch.full((N, X), 3.0, device=DEV), torch.zeros(U, X, device=DEV)
+    K.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*da, _dev(d), feat.to(DEV), enorm.to(DEV), ret, direct)
+    K.backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*da, _dev(d), feat.to(DEV), enorm.to(DEV), ret, go.to(DEV), gf, direct)
+    assert_close(ret, ref, what="ret")
+    assert_close(gf, gf_r, what="grad_feat")
+
+
+# ---------------------------------------------------------------- error behaviour
+def test_cpu_tensors_are_rejected(K):
+    from het_amd._lib import HetError
+    e = torch.zeros(1, dtype=torch.int64)
+    with pytest.raises((HetError, RuntimeError)):
+        K.rgcn_layer1_separate_coo(torch.tensor([0, 1]), e, e, e, torch.randn(2, 4), torch.randn(1, 4, 4), torch.rand(1), torch.zeros(2, 4))
