@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one RGAT layer, forward + backward, on an ogbn-mag-shaped graph.
+
+Metric (BASELINE.json): million edges/s (fwd+bwd) of one RGAT layer, ogbn-mag, feat=64.
+A step = layer forward (segment GEMMs, edge softmax, aggregation, self-loop GEMM, bias) plus
+``out.backward(grad)`` of the same layer; no optimizer step (the reference folds optimizer.step()
+into its backward time, hrt/python/RGNNUtils/RGNNUtils.py:304-311 -- deviation stated here and in
+DESIGN.md).  Inputs are synthetic (het_amd/synth.py): no dataset can be downloaded.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the mag-like graph (1.0 = full ogbn-mag size)")
+    p.add_argument("--heads", type=int, default=4)
+    p.add_argument("--feat", type=int, default=64)
+    p.add_argument("--variant", default="default", choices=["default", "compact", "compact_mulfirst", "mulfirst"],
+                   help="reference layer flags: default = per-edge projections (the reference's default flags); "
+                        "compact = --compact_as_of_node_flag --compact_direct_indexing_flag")
+    p.add_argument("--edge-order", default="src", choices=["src", "random"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample")
+    return p.parse_args()
+
+
+def layer_flags(variant):
+    return dict(compact_as_of_node_flag=variant.startswith("compact"),
+                compact_direct_indexing_flag=variant.startswith("compact"),
+                multiply_among_weights_first_flag=variant.endswith("mulfirst"))
+
+
+def gat_bwd_bytes(E, N, H, X):
+    """Algorithmic bytes of backward_relational_fused_gat_separate_coo, kind 0:
+    per edge reads col,eids (8 B each), el,er,exp (H floats each), feat (X); writes grad_el, grad_er (H),
+    grad_feat (X); per node reads sum (H), ret, gradout (X each)."""
+    return E * (2 * 8 + 4 * (3 * H + X) + 4 * (2 * H + X)) + N * 4 * (H + 2 * X)
+
+
+def cpu_baseline(args):
+    """The oracle's plain-PyTorch RGAT layer (HET semantics) timed on the host cores, fwd+bwd, on a
+    bounded sample (a mag-like graph at --cpu-scale)."""
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_mag_like
+    from oracle import layers as OL
+    g = HetGraph.from_integrated_coo(make_mag_like(scale=args.cpu_scale, edge_order=args.edge_order), full=False)
+    s = g.get_separate_coo_original()
+    N, R, H, K = g.get_num_nodes(), g.get_num_rels(), args.heads, args.feat
+    D = K // H
+    torch.manual_seed(0)
+    x = (torch.randn(N, K) * 0.1).requires_grad_(True)
+    W = (torch.randn(R, H, K, D) * 0.1).requires_grad_(True)
+    al = (torch.randn(R, H, D) * 0.1).requires_grad_(True)
+    ar = (torch.randn(R, H, D) * 0.1).requires_grad_(True)
+    lw = (torch.randn(K, K) * 0.1).requires_grad_(True)
+    go = torch.randn(N, K)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        out = OL.rgat_layer(x, W, al, ar, s["rel_ptrs"], s["row_indices"], s["col_indices"], N, 0.2, lw, None)
+        torch.autograd.grad(out, [x, W, al, ar, lw], go)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(g.get_num_edges() / med / 1e6, 3), "unit": "million edges/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/layers.py rgat_layer fwd+bwd (torch CPU fp32, HET cross-relation softmax) on a mag-like "
+                      f"graph at scale {args.cpu_scale} ({g.get_num_edges()} edges, {N} nodes), median of 3 after 1 warm-up; "
+                      f"os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from het_amd import kernels as HK
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+
+    coo = make_mag_like(scale=args.scale, edge_order=args.edge_order)
+    E_global, N_global = coo.num_edges, coo.num_nodes
+    H, K = args.heads, args.feat
+    X = K
+    torch.manual_seed(0)
+    if world > 1:
+        from het_amd.dist import DistRGAT
+        runner = DistRGAT(coo, K, X, H, dev, **layer_flags(args.variant))
+        step = runner.step
+        E_local, N_local = runner.num_local_edges, runner.num_local_nodes
+    else:
+        for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+            setattr(coo, f, getattr(coo, f).to(dev))
+        g = HetGraph.from_integrated_coo(coo, full=args.variant.startswith("compact"))
+        layer = HET_RGATLayer(K, X, g.get_num_rels(), H, self_loop=True, dropout=0.0, **layer_flags(args.variant)).to(dev)
+        embed = torch.nn.Parameter(torch.empty(N_global, K, device=dev))
+        torch.nn.init.xavier_uniform_(embed)
+        go = torch.randn(N_global, X, device=dev)
+        E_local, N_local = E_global, N_global
+
+        def step():
+            for p in layer.parameters():
+                p.grad = None
+            embed.grad = None
+            out = layer(g, embed)
+            out.backward(go)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    bwd_name = "het_backward_relational_fused_gat_separate_coo"
+    HK.event_timers[bwd_name] = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev = HK.event_timers.pop(bwd_name)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = E_global / (dt / args.steps) / 1e6
+
+    roofline = None
+    if ev and not args.variant.startswith("compact"):
+        k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        nbytes = gat_bwd_bytes(E_local, N_local, H, X)
+        ach = nbytes / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "HET_gat_backward_grouped (backward_relational_fused_gat_separate_coo, kind 0)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy_6.29TBs": round(ach / HBM_COPY_GBS, 4), "traffic": None,
+                    "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes}
+
+    if rank == 0:
+        out = {
+            "metric": "million edges/s (fwd+bwd) RGAT layer, ogbn-mag feat=64",
+            "value": round(value, 2), "unit": "million edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RGAT layer fwd+bwd, ogbn-mag-shaped synthetic graph (N={N_global}, E={E_global}, R=4), "
+                                   f"feat={K}, heads={H}, self_loop, no optimizer step, layer flags: {args.variant}",
+                       "edge_order": args.edge_order, "scale": args.scale,
+                       "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,9 +56,22 @@ def _op(schema: str):
     return deco
 
 
+# Optional per-entry-point device timing (bench.py): name -> list of (start, end) events recorded on
+# the stream the kernels are launched on.  Empty = no overhead.
+event_timers: Dict[str, list] = {}
+
+
 def _call(dev_tensor: Tensor, cname: str, *args):
     with torch.cuda.device(dev_tensor.device):
+        rec = event_timers.get(cname)
+        if rec is None:
+            _lib.call(cname, *args)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         _lib.call(cname, *args)
+        b.record()
+        rec.append((a, b))
 
 
 # ------------------------------------------------------------------------------------
