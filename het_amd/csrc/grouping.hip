@@ -17,10 +17,12 @@ __global__ void HET_grouping_make_keys(const idx_t* __restrict__ rel_ptrs, int R
 __global__ void HET_grouping_segments(const uint64_t* __restrict__ uniq, const int32_t* __restrict__ counts,
                                       int64_t S, int64_t E, int kb, int R, int32_t* __restrict__ seg_ptr,
                                       int32_t* __restrict__ seg_key, int32_t* __restrict__ seg_rel_ptr,
+                                      idx_t* __restrict__ seg_key64, idx_t* __restrict__ seg_rel_ptr64,
                                       int32_t* __restrict__ nitems) {
   const uint64_t mask = (kb >= 64) ? ~0ull : ((1ull << kb) - 1);
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
     seg_key[s] = (int32_t)(uniq[s] & mask);
+    seg_key64[s] = (idx_t)(uniq[s] & mask);
     nitems[s] = (counts[s] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
     if (s == 0) seg_ptr[S] = (int32_t)E;
   }
@@ -34,6 +36,7 @@ __global__ void HET_grouping_segments(const uint64_t* __restrict__ uniq, const i
       if (uniq[mid] < want) lo = mid + 1; else hi = mid;
     }
     seg_rel_ptr[gid] = (int32_t)lo;
+    seg_rel_ptr64[gid] = (idx_t)lo;
   }
 }
 
@@ -84,7 +87,7 @@ struct Scratch {  // frees device temporaries on every exit path
 
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
-  void* ptrs[] = {g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
+  void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
                   g->split_seg, g->p0, g->p1};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -114,6 +117,7 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
 #define GALLOC(field, count) HET_HIP(hipMalloc((void**)&g->field, sizeof(int32_t) * ((count) > 0 ? (count) : 1)))
   GALLOC(perm, E);
   if (R > 0) GALLOC(seg_rel_ptr, R + 1);
+  if (R > 0) HET_HIP(hipMalloc((void**)&g->seg_rel_ptr64, sizeof(idx_t) * (R + 1)));
 
   Scratch tmp;
   uint64_t *keys_in = nullptr, *keys_out = nullptr, *uniq = nullptr;
@@ -154,11 +158,13 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
   g->S = S;
   GALLOC(seg_ptr, S + 1);
   GALLOC(seg_key, S);
+  HET_HIP(hipMalloc((void**)&g->seg_key64, sizeof(idx_t) * (S > 0 ? S : 1)));
   HET_HIP(tmp.alloc((void**)&nitems, sizeof(int32_t) * S));
   HET_HIP(tmp.alloc((void**)&item_off, sizeof(int32_t) * S));
   if (S == 0) {
     HET_HIP(hipMemsetAsync(g->seg_ptr, 0, sizeof(int32_t), s));
     if (R > 0) HET_HIP(hipMemsetAsync(g->seg_rel_ptr, 0, sizeof(int32_t) * (R + 1), s));
+    if (R > 0) HET_HIP(hipMemsetAsync(g->seg_rel_ptr64, 0, sizeof(idx_t) * (R + 1), s));
     GALLOC(item_seg, 0); GALLOC(item_begin, 0); GALLOC(item_end, 0); GALLOC(split_seg, 0);
   } else {
     size_t tb = 0;
@@ -169,7 +175,7 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     if (e == hipSuccess) {
       const int64_t n = S > R + 1 ? S : R + 1;
       hipLaunchKernelGGL(HET_grouping_segments, dim3(blocks_for(n)), dim3(256), 0, s, uniq, counts, S, E, kb, R,
-                         g->seg_ptr, g->seg_key, g->seg_rel_ptr, nitems);
+                         g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->seg_key64, g->seg_rel_ptr64, nitems);
       e = hipGetLastError();
     }
     size_t tb2 = 0;

@@ -18,6 +18,8 @@ struct het_grouping {
   int32_t* seg_ptr = nullptr;    // [S+1] sorted-rank range of segment s
   int32_t* seg_key = nullptr;    // [S]   key of segment s
   int32_t* seg_rel_ptr = nullptr;// [R+1] segment range of relation r (R > 0)
+  idx_t* seg_key64 = nullptr;    // [S]   seg_key as int64 (gather / scatter list of the segment GEMMs)
+  idx_t* seg_rel_ptr64 = nullptr;// [R+1] seg_rel_ptr as int64
   int32_t* item_seg = nullptr;   // [num_items] segment of the item
   int32_t* item_begin = nullptr; // [num_items+1] sorted-rank range [item_begin[t], item_end[t])
   int32_t* item_end = nullptr;

@@ -1,6 +1,8 @@
 // C ABI of the typed linear projections (segment GEMM ops) and the fused RGCN layer.
 #include "seg_gemm.hip.h"
 #include "seg_gemm_mfma.hip.h"
+#include "seg_rowdot.hip.h"
+#include "seg_reduce.hip.h"
 
 namespace {
 
@@ -29,9 +31,15 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
   HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
-  if (in1head && mfma_fwd_supported((int)K, (int)(H * D)))
+  if (in1head && mfma_fwd_supported((int)K, (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     return launch_seg_gemm_mfma_fwd(x, K, gather_idx, weights, H * K * D, (int)H, (int)D, ret, H * D, scatter, rel_ptrs,
                                     (int)num_rels, num_rows, (int)K, s);
+  if (!in1head && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    RowDotArgs q;
+    q.A = x; q.gather = gather_idx; q.W = weights; q.out = ret; q.scatter = scatter; q.seg_ptrs = rel_ptrs;
+    q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
+    return launch_rowdot_fwd(q, s);
+  }
   SegGemmArgs a;
   a.A = x; a.gather = gather_idx; a.B = weights; a.C = ret; a.scatter = scatter;
   a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_rows; a.KA = (int)K;
@@ -49,13 +57,60 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
                                                    int64_t num_rows, const float* weights_t, const float* x,
                                                    const float* gradout, float* grad_x, float* grad_w, int64_t H,
                                                    int64_t K, int64_t D, int in1head,
-                                                   const het_grouping* by_rel_gather, het_stream stream) {
+                                                   const het_grouping* by_rel_gather, void* workspace,
+                                                   int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
-  (void)by_rel_gather;
+  if (!in1head && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+    RowDotArgs q;
+    q.A = x; q.gather = gather_idx; q.W = weights_t; q.scatter = scatter; q.go = gradout; q.seg_ptrs = rel_ptrs;
+    q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
+    // same condition as the reference's ACGatherScatterListIdentical dispatch (RGNNOps.inc.h:253): the
+    // gather list IS the edge-id list, so every input row belongs to one position
+    q.unique_rows = (kind == HET_KIND_DISABLED && gather_idx == scatter_idx);
+    q.out = grad_x;
+    if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
+    q.out = grad_w;
+    return launch_rowdot_bwd_dw(q, s);
+  }
+  const het_grouping* g = by_rel_gather;
+  if (in1head && g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
+      mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
+      segment_sum_supported((int)(H * D)) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H * D &&
+      (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+    // Rows that share (relation, gather_idx) share x row and weight: by linearity sum their gradout rows
+    // first (one pass over gradout), then run both GEMMs on the S distinct (relation, node) rows only.
+    float* gsum = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s)) return rc;
+    MfmaGemmArgs m;
+    m.A = gsum; m.a_ld = H * D; m.B = weights_t; m.b_rel_stride = H * D * K;
+    m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64; m.atomic = 1;
+    m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)(H * D); m.X = (int)K;
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = gsum; w.g_ld = H * D;
+    w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
+    w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S; w.K = (int)K; w.X = (int)(H * D);
+    return launch_seg_dw_mfma(w, s);
+  }
+  if (in1head && mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
+      (reinterpret_cast<uintptr_t>(gradout) & 15) == 0) {
+    // grad_x[gather] += gradout[scatter] . Wt[r]: Wt[r] read as one [H*D, K] matrix (heads summed by the GEMM)
+    MfmaGemmArgs m;
+    m.A = gradout; m.a_ld = H * D; m.gather = scatter; m.B = weights_t; m.b_rel_stride = H * D * K;
+    m.C = grad_x; m.c_ld = K; m.scatter = gather_idx; m.atomic = 1;
+    m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = x; w.a_ld = K; w.gather = gather_idx; w.G = gradout; w.g_ld = H * D; w.g_gather = scatter;
+    w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
+    w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_rows; w.K = (int)K; w.X = (int)(H * D);
+    return launch_seg_dw_mfma(w, s);
+  }
   // grad_x[gather] += gradout[scatter] . Wt[r]
   SegGemmArgs a;
   a.A = gradout; a.gather = scatter; a.B = weights_t; a.C = grad_x; a.scatter = gather_idx; a.atomic = 1;
@@ -88,9 +143,15 @@ extern "C" int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* 
   HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
   HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
-  if (!x_per_head && mfma_fwd_supported((int)K, (int)(H * D)))
+  if (!x_per_head && mfma_fwd_supported((int)K, (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     return launch_seg_gemm_mfma_fwd(x, K, nullptr, weights, H * K * D, (int)H, (int)D, ret, H * D, nullptr, offsets,
                                     (int)num_types, num_rows, (int)K, s);
+  if ((x_per_head || H == 1) && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    RowDotArgs q;
+    q.A = x; q.W = weights; q.out = ret; q.seg_ptrs = offsets; q.num_segs = (int)num_types; q.num_rows = num_rows;
+    q.H = (int)H; q.K = (int)K;
+    return launch_rowdot_fwd(q, s);
+  }
   SegGemmArgs a;
   a.A = x; a.B = weights; a.C = ret; a.seg_ptrs = offsets; a.num_segs = (int)num_types; a.num_rows = num_rows;
   a.KA = (int)K; a.b_rel_stride = H * K * D; a.c_ld = H * D;
@@ -110,6 +171,16 @@ extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
   HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
+  if ((x_per_head || H == 1) && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+    RowDotArgs q;
+    q.A = x; q.W = weights_t; q.go = gradout; q.seg_ptrs = offsets; q.num_segs = (int)num_types; q.num_rows = num_rows;
+    q.H = (int)H; q.K = (int)K; q.unique_rows = 1;
+    q.out = grad_x;
+    if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
+    q.out = grad_w;
+    return launch_rowdot_bwd_dw(q, s);
+  }
   SegGemmArgs a;  // rows are disjoint: plain "+=" without atomics would do, atomics keep one code path
   a.A = gradout; a.B = weights_t; a.C = grad_x; a.atomic = 1;
   a.seg_ptrs = offsets; a.num_segs = (int)num_types; a.num_rows = num_rows;

@@ -104,6 +104,100 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------
+// One workgroup = 4 waves owns a chunk of rows of one relation; every wave walks a quarter of the
+// chunk two rows per MFMA step (lane half h reads row 2s+h: 32 consecutive floats of the A row as
+// the MFMA A operand -- A is used transposed, feature index on the M axis -- and 32 consecutive
+// floats of the G row as the B operand), accumulating the full K x X product in KT*NT 32x32
+// accumulators.  The four partial products are summed through LDS and flushed with one atomic
+// add per element and workgroup.
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) {
+  constexpr int K = KT * 32, X = NT * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][KT*NT*16][64] partials of waves 1..3
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, chunk, blockIdx.x, r, rb, re)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  const idx_t n = re - rb, q = ((n + 3) / 4 + 1) & ~(idx_t)1;  // rows per wave, even
+  const idx_t wb = rb + wave * q, we = (wb + q < re) ? wb + q : re;
+  f32x16 acc[KT][NT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[kt][nt][e] = 0.f;
+#pragma unroll 2
+  for (idx_t i0 = wb; i0 < we; i0 += 2) {
+    const idx_t i = i0 + half;
+    float av[KT], gv[NT];
+    if (i < we) {
+      const idx_t ar = a.gather ? a.gather[i] : i, gr = a.g_gather ? a.g_gather[i] : i;
+      const float sc = a.row_scale ? a.row_scale[a.scale_idx ? a.scale_idx[i] : i] : 1.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) av[kt] = a.A[ar * a.a_ld + kt * 32 + col] * sc;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) gv[nt] = a.G[gr * a.g_ld + nt * 32 + col];
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) av[kt] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) gv[nt] = 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], gv[nt], acc[kt][nt], 0, 0, 0);
+  }
+  constexpr int NACC = KT * NT * 16;
+  if (wave > 0) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) smem[((wave - 1) * NACC + (kt * NT + nt) * 16 + e) * 64 + lane] = acc[kt][nt][e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* __restrict__ out = a.dW + (int64_t)r * a.dw_rel_stride;
+    const int Dh = a.headcat_d;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int o = ((kt * NT + nt) * 16 + e) * 64 + lane;
+          const float v = acc[kt][nt][e] + smem[o] + smem[NACC * 64 + o] + smem[2 * NACC * 64 + o];
+          const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, nn = nt * 32 + col;
+          int64_t off;
+          if (a.headcat) {
+            const int h = nn / Dh, d = nn - h * Dh;
+            off = (int64_t)h * K * Dh + (int64_t)k * Dh + d;
+          } else {
+            off = (int64_t)k * X + nn;
+          }
+          atomicAdd(out + off, v);
+        }
+  }
+}
+
+template <int KT, int NT>
+int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(float) * 3 * KT * NT * 16 * 64;
+  int64_t chunk = ceil_div64(a.num_rows, 1024);  // about 1024 workgroups
+  if (chunk < 512) chunk = 512;
+  chunk = (chunk + 7) & ~7ll;
+  const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
+  HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx), dim3(256), lds, s, a, (int)chunk);
+  HET_LAUNCH_CHECK("HET_seg_dw_mfma");
+  return HET_OK;
+}
+
 template <int K, int NT>
 int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   constexpr int X = NT * 32, LDA = K + 4;
@@ -146,4 +240,13 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
     case 64: return launch_k<64>(a, s);
     default: return launch_k<128>(a, s);
   }
+}
+
+bool mfma_dw_supported(int K, int X) { return (K == 32 || K == 64) && (X == 32 || X == 64); }
+
+int launch_seg_dw_mfma(const MfmaDwArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  HET_REQUIRE(mfma_dw_supported(a.K, a.X), "segment dW (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
+  if (a.K == 32) return a.X == 32 ? launch_dw_kx<1, 1>(a, s) : launch_dw_kx<1, 2>(a, s);
+  return a.X == 32 ? launch_dw_kx<2, 1>(a, s) : launch_dw_kx<2, 2>(a, s);
 }

@@ -37,3 +37,26 @@ inline int launch_seg_gemm_mfma_fwd(const float* x, int64_t x_ld, const idx_t* g
   a.K = K; a.X = H * D;
   return launch_seg_gemm_mfma(a, s);
 }
+
+// dW_r(k, n) += sum_{i in segment r} scale(i) * A[ga(i), k] * G[gg(i), n]   on the matrix cores
+// (the MFMA k dimension runs over rows).  Output layout: plain [K][X] per segment, or
+// head-concatenated [Hc][K][Dh] with n = (h, d).
+struct MfmaDwArgs {
+  const float* A = nullptr;
+  int64_t a_ld = 0;
+  const idx_t* gather = nullptr;
+  const float* row_scale = nullptr;
+  const idx_t* scale_idx = nullptr;
+  const float* G = nullptr;
+  int64_t g_ld = 0;
+  const idx_t* g_gather = nullptr;
+  float* dW = nullptr;
+  int64_t dw_rel_stride = 0;
+  int headcat = 0, headcat_d = 1;
+  const idx_t* seg_ptrs = nullptr;
+  int num_segs = 0;
+  int64_t num_rows = 0;
+  int K = 0, X = 0;
+};
+bool mfma_dw_supported(int K, int X);
+int launch_seg_dw_mfma(const MfmaDwArgs& a, hipStream_t s);

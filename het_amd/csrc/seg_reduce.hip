@@ -1,0 +1,69 @@
+// Wave-per-work-item segmented sum of gathered rows (no atomics except for split hub segments).
+#include "seg_reduce.hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restrict__ item_seg,
+                                                           const int32_t* __restrict__ item_begin,
+                                                           const int32_t* __restrict__ item_end,
+                                                           const int32_t* __restrict__ seg_ptr, int64_t num_items,
+                                                           const int32_t* __restrict__ p_row,
+                                                           const int32_t* __restrict__ p_scale,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ in, float* __restrict__ out) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= num_items) return;
+  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+  for (int j = b + slot; j < e; j += EPW) {
+    const float4 f = ld4(in + (int64_t)p_row[j] * X + x);
+    const float w = scale ? scale[p_scale[j]] : 1.f;
+    acc.x = fmaf(w, f.x, acc.x); acc.y = fmaf(w, f.y, acc.y); acc.z = fmaf(w, f.z, acc.z); acc.w = fmaf(w, f.w, acc.w);
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  if (slot != 0) return;
+  float* p = out + (int64_t)seg * X + x;
+  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) {
+    st4(p, acc);
+  } else {
+    atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
+  }
+}
+
+}  // namespace
+
+bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
+
+int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s) {
+  HET_REQUIRE(segment_sum_supported(X) && g->p0 && (!scale || g->p1), "segment sum: unsupported shape or grouping");
+  if (g->S == 0) return HET_OK;
+  if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+  const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
+#define HET_SS(L) hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, \
+                                     g->item_end, g->seg_ptr, g->num_items, g->p0, g->p1, scale, in, out)
+  switch (X / 4) {
+    case 1: HET_SS(1); break;
+    case 2: HET_SS(2); break;
+    case 4: HET_SS(4); break;
+    case 8: HET_SS(8); break;
+    case 16: HET_SS(16); break;
+    case 32: HET_SS(32); break;
+    default: HET_SS(64); break;
+  }
+#undef HET_SS
+  HET_LAUNCH_CHECK("HET_segment_sum");
+  return HET_OK;
+}

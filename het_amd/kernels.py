@@ -157,9 +157,15 @@ def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transpose
     _chk("backward_rgnn_relational_matmul", (weights_transposed, node_feat, gradout, grad_node_feat, grad_weights),
          tuple(t for t in (rp, g, s) if t is not None))
     R, H, D, K = weights_transposed.shape
+    grp, ws = None, None
+    if IntKind == 0 and InputNumHeadOneFlag and g is not s and g.data_ptr() != s.data_ptr():
+        grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
+        if grp is not None:
+            ws = torch.empty(max(1, grp.num_segments) * H * D, dtype=torch.float32, device=gradout.device)
     _call(gradout, "het_backward_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(),
           _p(weights_transposed), _p(node_feat), _p(gradout), _p(grad_node_feat), _p(grad_weights), H, K, D,
-          int(InputNumHeadOneFlag), None, _stream(gradout))
+          int(InputNumHeadOneFlag), None if grp is None else grp.handle, _p(ws), 0 if ws is None else ws.numel() * 4,
+          _stream(gradout))
 
 
 @_op("rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights, Tensor inputs, "

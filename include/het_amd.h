@@ -91,14 +91,16 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
 /* a2  backward_rgnn_relational_matmul   OpExport/RGNNOps.inc.h:946-1010
  *   grad_x[gather_idx[i], (h), :] += gradout[scatter_idx[i], h, :] . Wt[r, h]   (heads summed iff in1head)
  *   grad_w[r, h]                  += x[gather_idx[i], (h), :]^T (x) gradout[scatter_idx[i], h, :]
- *   weights_t [R,H,D,K].  by_rel_gather: optional grouping of the rows by
- *   (relation, gather_idx) (het_grouping_create(rel_ptrs, R, gather_idx, ...)). */
+ *   weights_t [R,H,D,K].  by_rel_gather: optional grouping of the rows by (relation, gather_idx):
+ *   het_grouping_create(rel_ptrs, R, gather_idx, num_rows, <rows of x>, payload0 = scatter_idx, NULL, ...);
+ *   with it, `workspace` must hold het_grouping_num_segments(g) * H * D floats (16-byte aligned). */
 int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                         const float* weights_t, const float* x, const float* gradout,
                                         float* grad_x, float* grad_w,
                                         int64_t H, int64_t K, int64_t D, int in1head,
-                                        const het_grouping* by_rel_gather, het_stream stream);
+                                        const het_grouping* by_rel_gather, void* workspace,
+                                        int64_t workspace_bytes, het_stream stream);
 
 /* a3  rgnn_relational_matmul_no_scatter_gather_list / backward_...   RGNNOps.inc.h:21-88, 660-753
  *   rows offsets[t]:offsets[t+1] use W[t]; x is [rows, K] (x_per_head = 0) or [rows, H, K]. */
