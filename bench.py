@@ -102,8 +102,10 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("HET_FORCE_DIST") == "1":
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from het_amd import kernels as HK
@@ -116,7 +118,8 @@ def main():
     H, K = args.heads, args.feat
     X = K
     torch.manual_seed(0)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("HET_FORCE_DIST") == "1"
+    if use_dist:
         from het_amd.dist import DistRGAT
         runner = DistRGAT(coo, K, X, H, dev, **layer_flags(args.variant))
         step = runner.step
@@ -188,7 +191,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or os.environ.get("HET_FORCE_DIST") == "1":
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -1,0 +1,180 @@
+"""Multi-GPU execution of one relational layer: destination-range partition with a
+halo exchange of source features (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for the tests).
+
+The reference is single-GPU (no collective anywhere in its tree); this is new design
+(SURVEY.md section 8e).  Every reduction of the forward pass -- the softmax denominator and
+the aggregation -- is keyed by the destination node, so giving each rank a contiguous
+range of destination nodes together with ALL in-edges of those nodes keeps the
+forward reductions local.  What crosses GPUs:
+
+  forward   x[halo]: features of remote source nodes, one all-to-all (point-to-point
+            xGMI links all busy at once) before the layer;
+  backward  grad_x[halo]: the reverse all-to-all, added into the owners' gradients;
+            weight gradients: all-reduce (a few hundred KiB).
+
+Ranges are balanced on in-edge count, not node count.  Local node numbering: owned
+nodes first (global id - lo), then halo nodes ordered by global id (hence grouped
+by owning rank, so the received buffer is already in halo order).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, List
+
+import torch
+import torch.distributed as dist
+
+from .graph import HetGraph
+from .synth import IntegratedCOO
+
+
+def partition_bounds(col: torch.Tensor, num_nodes: int, world: int) -> torch.Tensor:
+    """Node-id boundaries [world+1] of contiguous destination ranges with ~equal in-edge counts."""
+    indeg = torch.bincount(col, minlength=num_nodes)
+    csum = torch.cumsum(indeg, 0)
+    total = int(csum[-1]) if num_nodes else 0
+    targets = torch.arange(1, world, device=col.device, dtype=torch.float64) * (total / world)
+    cuts = torch.searchsorted(csum.to(torch.float64), targets, right=False) + 1
+    b = torch.cat([torch.zeros(1, dtype=torch.int64, device=col.device), cuts.clamp(max=num_nodes),
+                   torch.tensor([num_nodes], dtype=torch.int64, device=col.device)])
+    return torch.cummax(b, 0).values
+
+
+@dataclasses.dataclass
+class DistPlan:
+    rank: int
+    world: int
+    bounds: torch.Tensor          # [world+1] global node-id boundaries
+    n_own: int
+    n_halo: int
+    local: IntegratedCOO          # this rank's edges in local node ids (relation-major, eids = arange)
+    halo_global: torch.Tensor     # [n_halo] global ids of the halo nodes (sorted)
+    send_idx: torch.Tensor        # [sum(send_counts)] owned-local ids to send, grouped by destination rank
+    send_counts: List[int]
+    recv_counts: List[int]
+    num_global_edges: int
+    edge_cut: int                 # edges whose source lives on another rank (all ranks)
+
+    @property
+    def num_local_edges(self) -> int:
+        return self.local.num_edges
+
+    @property
+    def num_local_nodes(self) -> int:
+        return self.n_own + self.n_halo
+
+
+def build_plan(coo: IntegratedCOO, rank: int, world: int) -> DistPlan:
+    """Every rank holds the (seeded, identical) global edge list and derives its own share:
+    no communication is needed to build the plan."""
+    row, col, rel = coo.row, coo.col, coo.rel
+    N = coo.num_nodes
+    bounds = partition_bounds(col, N, world)
+    owner_dst = torch.searchsorted(bounds[1:].contiguous(), col, right=True)
+    owner_src = torch.searchsorted(bounds[1:].contiguous(), row, right=True)
+    cut = owner_dst != owner_src
+    # distinct (needing rank, remote source) pairs == halo memberships of every rank
+    pairs = torch.unique(owner_dst[cut] * N + row[cut])
+    need_rank, need_node = pairs // N, pairs % N
+    node_owner = torch.searchsorted(bounds[1:].contiguous(), need_node, right=True)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+
+    mine = need_rank == rank
+    halo_global = need_node[mine]                    # sorted by global id => grouped by owner
+    recv_counts = torch.bincount(node_owner[mine], minlength=world).tolist()
+    send_sel = node_owner == rank                    # pairs sorted by (needing rank, node)
+    send_idx = (need_node[send_sel] - lo).contiguous()
+    send_counts = torch.bincount(need_rank[send_sel], minlength=world).tolist()
+
+    e_sel = owner_dst == rank
+    l_row, l_col, l_rel = row[e_sel], col[e_sel] - lo, rel[e_sel]
+    remote = (l_row < lo) | (l_row >= hi)
+    l_row_local = torch.where(remote, (hi - lo) + torch.searchsorted(halo_global, l_row), l_row - lo)
+    n_own, n_halo = hi - lo, int(halo_global.numel())
+    local = IntegratedCOO(num_nodes=n_own + n_halo, num_rels=coo.num_rels,
+                          node_type_offsets=torch.tensor([0, n_own + n_halo], device=row.device),
+                          row=l_row_local.contiguous(), col=l_col.contiguous(), rel=l_rel.contiguous(),
+                          eids=torch.arange(int(l_row.numel()), dtype=torch.int64, device=row.device))
+    return DistPlan(rank, world, bounds, n_own, n_halo, local, halo_global, send_idx, send_counts, recv_counts,
+                    coo.num_edges, int(cut.sum()))
+
+
+class HaloExchange(torch.autograd.Function):
+    """x_own [n_own, K] -> [n_own + n_halo, K]: owned rows followed by the halo rows received from
+    their owners.  Backward sends the halo gradients home and adds them to the owners' rows."""
+
+    @staticmethod
+    def forward(ctx, x_own, plan: DistPlan, group):
+        ctx.plan, ctx.group = plan, group
+        send = x_own.index_select(0, plan.send_idx).contiguous()
+        recv = x_own.new_empty((plan.n_halo, x_own.shape[1]))
+        dist.all_to_all_single(recv, send, plan.recv_counts, plan.send_counts, group=group)
+        return torch.cat([x_own, recv], 0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        plan = ctx.plan
+        g_own = grad[: plan.n_own].clone()
+        g_halo = grad[plan.n_own:].contiguous()
+        back = grad.new_empty((int(plan.send_idx.numel()), grad.shape[1]))
+        dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=ctx.group)
+        g_own.index_add_(0, plan.send_idx, back)
+        return g_own, None, None
+
+
+class DistLayer:
+    """One layer sharded over the ranks of ``group``.  ``layer_fn(graph, x_local)`` computes the layer
+    on the local graph (HET_RGATLayer on the GPU; the CPU oracle in the gloo tests) and returns
+    [n_local, X]; rows of owned nodes are kept.  ``params`` are replicated and their gradients
+    all-reduced after backward."""
+
+    def __init__(self, coo: IntegratedCOO, layer_fn: Callable, params, group=None, full_layouts: bool = False):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.plan = build_plan(coo, self.rank, self.world)
+        self.graph = HetGraph.from_integrated_coo(self.plan.local, full=full_layouts)
+        self.layer_fn = layer_fn
+        self.params = list(params)
+
+    def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        x_local = HaloExchange.apply(x_own, self.plan, self.group)
+        return self.layer_fn(self.graph, x_local)[: self.plan.n_own]
+
+    def reduce_param_grads(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=self.group)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+class DistRGAT:
+    """bench.py's multi-GPU step: a replicated HET_RGATLayer over the local shard of the graph."""
+
+    def __init__(self, coo: IntegratedCOO, in_feat, out_feat, heads, device, **layer_flags):
+        from .layers import HET_RGATLayer
+        for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+            setattr(coo, f, getattr(coo, f).to(device))
+        torch.manual_seed(0)  # same weights on every rank
+        self.layer = HET_RGATLayer(in_feat, out_feat, coo.num_rels, heads, self_loop=True, dropout=0.0,
+                                   **layer_flags).to(device)
+        self.dl = DistLayer(coo, lambda g, x: self.layer(g, x), self.layer.parameters(),
+                            full_layouts=bool(layer_flags.get("compact_as_of_node_flag")))
+        p = self.dl.plan
+        self.embed = torch.nn.Parameter(torch.empty(p.n_own, in_feat, device=device))
+        torch.nn.init.xavier_uniform_(self.embed)
+        self.go = torch.randn(p.n_own, out_feat, device=device)
+        self.num_local_edges, self.num_local_nodes = p.num_local_edges, p.num_local_nodes
+
+    def step(self):
+        for q in self.layer.parameters():
+            q.grad = None
+        self.embed.grad = None
+        out = self.dl.forward(self.embed)
+        out.backward(self.go)
+        self.dl.reduce_param_grads()
