@@ -3,6 +3,7 @@
 wrappers :651-890)."""
 import torch as th
 
+from .. import kernels as _k
 from ..kernels import K
 
 __all__ = [
@@ -48,23 +49,30 @@ class _FusedGatSeparateCOO(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, eids, rel_ptrs, row, col, kind, fwd_dict, bwd_dict, feat_src, el, er, s, exp, ret, slope):
-        ctx.save_for_backward(eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret)
+        H = el.shape[1]
+        D = feat_src.numel() // max(1, feat_src.shape[0] * H)
+        # private extra output: exp in destination-grouped order, streamed by the backward (kind 0 only)
+        exp_sorted = th.empty_like(exp) if (kind == 0 and slope >= 0 and _k.gat_grouped_shape_ok(H, D)) else None
+        used = _k.fused_gat_forward(eids, rel_ptrs, row, col, kind, fwd_dict, feat_src, el, er, s, exp, ret, slope,
+                                    exp_sorted)
+        ctx.save_for_backward(eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret, exp_sorted if used else None)
         ctx.kind, ctx.bwd_dict, ctx.slope = kind, bwd_dict, slope
-        K.relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, kind, fwd_dict, feat_src, el, er, s, exp, ret, slope)
+        ctx.alias_ok = _k.gat_grouped_shape_ok(H, D)
         return ret
 
     @staticmethod
     def backward(ctx, gradout):
-        eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret = ctx.saved_tensors
+        eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret, exp_sorted = ctx.saved_tensors
         if ctx.kind == 0:  # every gradient row is written exactly once by the op: no zero-fill needed
-            grad_el, grad_er, grad_feat_src = th.empty_like(el), th.empty_like(er), th.empty_like(feat_src)
+            grad_el, grad_feat_src = th.empty_like(el), th.empty_like(feat_src)
+            # grad_er == grad_el element for element (both rows belong to the same edge): one buffer
+            grad_er = grad_el if ctx.alias_ok else th.empty_like(er)
         else:
             grad_el = th.zeros_like(el, memory_format=th.contiguous_format)
             grad_er = th.zeros_like(er, memory_format=th.contiguous_format)
             grad_feat_src = th.zeros_like(feat_src, memory_format=th.contiguous_format)
-        K.backward_relational_fused_gat_separate_coo(eids, rel_ptrs, row, col, ctx.kind, ctx.bwd_dict, feat_src, el, er,
-                                                     s, exp, ret, gradout.contiguous(), grad_feat_src, grad_el, grad_er,
-                                                     ctx.slope)
+        _k.fused_gat_backward(eids, rel_ptrs, row, col, ctx.kind, ctx.bwd_dict, feat_src, el, er, s, exp, ret,
+                              gradout.contiguous(), grad_feat_src, grad_el, grad_er, ctx.slope, exp_sorted)
         return None, None, None, None, None, None, None, grad_feat_src, grad_el, grad_er, None, None, None, None
 
 

@@ -6,6 +6,7 @@ transposed-weight / zero-filled-gradient protocol of ``backward`` (:43-73) and
 the wrappers that allocate the outputs (:423-493)."""
 import torch as th
 
+from .. import kernels as _k
 from ..kernels import K
 
 __all__ = [
@@ -30,12 +31,14 @@ class RgnnRelationalMatmul(th.autograd.Function):
     @staticmethod
     def backward(ctx, gradout):
         relptrs, node_indices, eids, weights, inputs = ctx.saved_tensors
-        grad_weight = th.zeros_like(weights, memory_format=th.contiguous_format)
-        grad_input = th.zeros_like(inputs, memory_format=th.contiguous_format)
-        K.backward_rgnn_relational_matmul(
+        # the reference zero-fills both and lets the op accumulate (:52-70); with accumulate=False the op
+        # overwrites them (zeroing internally only where its kernels need it)
+        grad_weight = th.empty_like(weights, memory_format=th.contiguous_format)
+        grad_input = th.empty_like(inputs, memory_format=th.contiguous_format)
+        _k.matmul_backward(
             {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids},
             0, th.transpose(weights, 2, 3).contiguous(), inputs, gradout.contiguous(), grad_input, grad_weight,
-            ctx.input_num_head_one_flag)
+            ctx.input_num_head_one_flag, accumulate=False)
         return None, None, None, grad_weight, grad_input, None, None
 
 
@@ -50,11 +53,11 @@ class RgnnRelationalMatmulNoScatterGatherList(th.autograd.Function):
     @staticmethod
     def backward(ctx, gradout):
         ntype_offset_ptrs, weights, inputs = ctx.saved_tensors
-        grad_weight = th.zeros_like(weights, memory_format=th.contiguous_format)
-        grad_input = th.zeros_like(inputs, memory_format=th.contiguous_format)
-        K.backward_rgnn_relational_matmul_no_scatter_gather_list(
+        grad_weight = th.empty_like(weights, memory_format=th.contiguous_format)
+        grad_input = th.empty_like(inputs, memory_format=th.contiguous_format)
+        _k.matmul_no_scatter_gather_backward(
             ntype_offset_ptrs, th.transpose(weights, 2, 3).contiguous(), inputs, gradout.contiguous(), grad_input,
-            grad_weight)
+            grad_weight, accumulate=False)
         return None, grad_weight, grad_input, None
 
 
@@ -74,12 +77,12 @@ class RgnnRelationalMatmulCompactAsOfNode(th.autograd.Function):
     @staticmethod
     def backward(ctx, gradout):
         rel_ptrs, node_indices, weight, node_feat = ctx.saved_tensors
-        grad_weight = th.zeros_like(weight, memory_format=th.contiguous_format)
-        grad_node_feat = th.zeros_like(node_feat, memory_format=th.contiguous_format)
-        K.backward_rgnn_relational_matmul(
+        grad_weight = th.empty_like(weight, memory_format=th.contiguous_format)
+        grad_node_feat = th.empty_like(node_feat, memory_format=th.contiguous_format)
+        _k.matmul_backward(
             {"unique_srcs_and_dests_rel_ptrs": rel_ptrs, "unique_srcs_and_dests_node_indices": node_indices},
             1, th.transpose(weight, 2, 3).contiguous(), node_feat, gradout.contiguous(), grad_node_feat, grad_weight,
-            ctx.input_num_head_one_flag)
+            ctx.input_num_head_one_flag, accumulate=False)
         return None, None, grad_weight, grad_node_feat, None, None
 
 

@@ -143,6 +143,8 @@ int gat_backward_edge(const EdgeView& v, const RowMaps& m, const float* feat, co
   if (v.E == 0) return HET_OK;
   const int64_t X = (int64_t)H * D;
   const bool unique = m.kind == HET_KIND_DISABLED, wred = is_pow2(D) && D <= 64;
+  HET_REQUIRE(grad_el != grad_er || (unique && wred),
+              "backward_relational_fused_gat: grad_er may alias grad_el only for kind 0 with a power-of-two D <= 64");
   dim3 grid(grid_for(v.E * X)), block(kBlock);
 #define HET_GAT_BWD(U, W)                                                                                        \
   hipLaunchKernelGGL((HET_gat_backward_edge<U, W>), grid, block, 0, s, v, m, feat, el, er, sum, exp, ret, gradout, \
@@ -171,8 +173,8 @@ extern "C" int het_relational_fused_gat_separate_coo(
     const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, int64_t kind, const int64_t* map_row_a, const int64_t* map_row_b,
     const int64_t* map_col_a, const int64_t* map_col_b, const float* feat, const float* el, const float* er,
-    float* sum, float* exp, float* ret, int64_t H, int64_t D, double slope, const het_grouping* by_dst,
-    het_stream stream) {
+    float* sum, float* exp, float* ret, float* exp_sorted, int64_t H, int64_t D, double slope,
+    const het_grouping* by_dst, het_stream stream) {
   const char* op = "relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(sum && ret && (num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && exp)),
@@ -184,7 +186,9 @@ extern "C" int het_relational_fused_gat_separate_coo(
   RowMaps m;
   m.kind = (int)kind; m.ra = map_row_a; m.rb = map_row_b; m.ca = map_col_a; m.cb = map_col_b;
   hipStream_t s = (hipStream_t)stream;
-  if (by_dst) return gat_forward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, (int)H, (int)D, (float)slope, s);
+  HET_REQUIRE(!exp_sorted || by_dst, "%s: exp_sorted needs the by_dst grouping", op);
+  if (by_dst)
+    return gat_forward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, (int)H, (int)D, (float)slope, s);
   return gat_forward_edge(v, m, feat, el, er, sum, exp, ret, (int)H, (int)D, (float)slope, s);
 }
 
@@ -192,9 +196,9 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
     const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, int64_t kind, const int64_t* map_row_a, const int64_t* map_row_b,
     const int64_t* map_col_a, const int64_t* map_col_b, const float* feat, const float* el, const float* er,
-    const float* sum, const float* exp, const float* ret, const float* gradout, float* grad_feat, float* grad_el,
-    float* grad_er, int64_t H, int64_t D, double slope, const het_grouping* by_dst, const het_grouping* by_rel_src,
-    het_stream stream) {
+    const float* sum, const float* exp, const float* ret, const float* exp_sorted, const float* gradout,
+    float* grad_feat, float* grad_el, float* grad_er, int64_t H, int64_t D, double slope, const het_grouping* by_dst,
+    const het_grouping* by_rel_src, het_stream stream) {
   const char* op = "backward_relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && sum && exp && ret && gradout &&
@@ -208,8 +212,8 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
   m.kind = (int)kind; m.ra = map_row_a; m.rb = map_row_b; m.ca = map_col_a; m.cb = map_col_b;
   hipStream_t s = (hipStream_t)stream;
   if (by_dst && kind == HET_KIND_DISABLED)
-    return gat_backward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, (int)H,
-                                (int)D, (float)slope, s);
+    return gat_backward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, gradout, grad_feat, grad_el,
+                                grad_er, (int)H, (int)D, (float)slope, s);
   (void)by_rel_src;
   return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, (int)H, (int)D,
                            (float)slope, s);

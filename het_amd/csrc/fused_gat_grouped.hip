@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ exp,
                                                                      float* __restrict__ sum, float* __restrict__ ret,
-                                                                     int H, int D) {
+                                                                     float* __restrict__ exp_sorted, int H, int D) {
   constexpr int EPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -53,17 +53,43 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
   const int64_t X = (int64_t)H * D;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float ssum = 0.f;
-#pragma unroll 2
-  for (int j = b + slot; j < e; j += EPW) {
-    const int64_t eid = p_eid[j];
-    const int64_t srow = p_srow ? (int64_t)p_srow[j] : eid;
-    const float w = exp[eid * H + h];
-    const float4 f = ld4(feat + srow * X + x);
-    acc.x = fmaf(w, f.x, acc.x);
-    acc.y = fmaf(w, f.y, acc.y);
-    acc.z = fmaf(w, f.z, acc.z);
-    acc.w = fmaf(w, f.w, acc.w);
-    ssum += w;
+  // U edges per lane group and step; the three dependent load phases (edge id -> exp, feat row) are each
+  // issued for all U edges before the first use, indices clamped (branch-free) and masked afterwards
+  constexpr int U = 4;
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int jc[U];
+    int64_t eid[U], srow[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * EPW;
+      jc[u] = j < e ? j : e - 1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) eid[u] = p_eid[jc[u]];
+    if (p_srow) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) srow[u] = p_srow[jc[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) srow[u] = eid[u];
+    }
+    float w[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = exp[eid[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + srow[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = j0 + u * EPW < e;
+      const float wu = ok ? w[u] : 0.f;
+      if (exp_sorted && ok && x % D == 0) exp_sorted[(int64_t)jc[u] * H + h] = wu;
+      acc.x = fmaf(wu, f[u].x, acc.x);
+      acc.y = fmaf(wu, f[u].y, acc.y);
+      acc.z = fmaf(wu, f[u].z, acc.z);
+      acc.w = fmaf(wu, f[u].w, acc.w);
+      ssum += wu;
+    }
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -105,7 +131,10 @@ __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t*
 // Backward for kind 0 (feat/el/er rows are edge rows): gradout[dst], ret[dst], sum[dst]
 // are loaded once per destination; grad_feat / grad_el / grad_er rows are written
 // exactly once with plain stores.  DL = D/4 lanes share a head.
-template <int LPR>
+// SORTED: exp is read from the by_dst-ordered copy the forward wrote (a coalesced stream) and the
+// leaky-ReLU branch is recovered from it (slope >= 0: z > 0 <=> exp(leaky(z)) > 1), so el / er are
+// not touched at all.
+template <int LPR, bool SORTED>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
@@ -121,18 +150,51 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
   const int64_t X = (int64_t)H * D;
   const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
   const float sinv = 1.f / sum[v * H + h];
-  for (int j = b + slot; j < e; j += EPW) {
-    const int64_t eid = p_eid[j];
-    const float a = exp[eid * H + h] * sinv;
-    const float z = el[eid * H + h] + er[eid * H + h];
-    const float4 f = ld4(feat + eid * X + x);
-    st4(grad_feat + eid * X + x, make_float4(a * g.x, a * g.y, a * g.z, a * g.w));
-    float tt = g.x * (f.x - r.x) + g.y * (f.y - r.y) + g.z * (f.z - r.z) + g.w * (f.w - r.w);
-    for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
-    if ((sub & (DL - 1)) == 0) {
-      tt *= a * (z > 0.f ? 1.f : slope);
-      grad_el[eid * H + h] = tt;
-      grad_er[eid * H + h] = tt;
+  constexpr int U = 2;
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int jc[U];
+    int64_t eid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * EPW;
+      jc[u] = j < e ? j : e - 1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) eid[u] = p_eid[jc[u]];
+    float ex[U], dl[U];
+    float4 f[U];
+    if (SORTED) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ex[u] = exp[(int64_t)jc[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = ld4(feat + eid[u] * X + x);
+#pragma unroll
+      for (int u = 0; u < U; ++u) dl[u] = ex[u] > 1.f ? 1.f : slope;
+    } else {
+      float zl[U], zr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ex[u] = exp[eid[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) zl[u] = el[eid[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) zr[u] = er[eid[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = ld4(feat + eid[u] * X + x);
+#pragma unroll
+      for (int u = 0; u < U; ++u) dl[u] = (zl[u] + zr[u]) > 0.f ? 1.f : slope;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = j0 + u * EPW < e;  // uniform within the LPR lanes of a slot (shuffles below stay inside it)
+      const float a = ex[u] * sinv;
+      if (ok) st4(grad_feat + eid[u] * X + x, make_float4(a * g.x, a * g.y, a * g.z, a * g.w));
+      float tt = g.x * (f[u].x - r.x) + g.y * (f[u].y - r.y) + g.z * (f[u].z - r.z) + g.w * (f[u].w - r.w);
+      for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
+      if (ok && (sub & (DL - 1)) == 0) {
+        tt *= a * dl[u];
+        grad_el[eid[u] * H + h] = tt;
+        if (grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
+      }
     }
   }
 }
@@ -164,11 +226,13 @@ inline bool grouped_shape_ok(int H, int D) {
   }
 
 int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
-                        const float* el, const float* er, float* sum, float* exp, float* ret, int H, int D,
-                        float slope, hipStream_t s) {
+                        const float* el, const float* er, float* sum, float* exp, float* ret, float* exp_sorted,
+                        int H, int D, float slope, hipStream_t s) {
   const bool have_rows = m.kind == HET_KIND_DISABLED || g->p1 != nullptr;
-  if (!grouped_shape_ok(H, D) || !g->p0 || !have_rows || g->E != v.E || g->R != 0)
+  if (!grouped_shape_ok(H, D) || !g->p0 || !have_rows || g->E != v.E || g->R != 0) {
+    HET_REQUIRE(!exp_sorted, "relational_fused_gat_separate_coo: exp_sorted needs a shape the grouped kernels cover");
     return gat_forward_edge(v, m, feat, el, er, sum, exp, ret, H, D, slope, s);
+  }
   const int64_t X = (int64_t)H * D;
   // destinations without in-edges keep zero rows; split (hub) destinations accumulate atomically
   HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * v.N * H, s));
@@ -180,7 +244,7 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
   const int32_t* srow = m.kind == HET_KIND_DISABLED ? nullptr : g->p1;
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_gat_aggregate_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
-                                                    g->p0, srow, feat, exp, sum, ret, H, D));
+                                                    g->p0, srow, feat, exp, sum, ret, exp_sorted, H, D));
   HET_LAUNCH_CHECK("HET_gat_aggregate_grouped");
   if (g->num_split > 0) {
     hipLaunchKernelGGL(HET_gat_normalize_split, dim3(grid_for(g->num_split * X)), dim3(kBlock), 0, s, g->split_seg,
@@ -192,17 +256,24 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
 
 int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
-                         const float* gradout, float* grad_feat, float* grad_el, float* grad_er, int H, int D,
-                         float slope, hipStream_t s) {
+                         const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
+                         float* grad_er, int H, int D, float slope, hipStream_t s) {
   if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0)
     return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
   if (v.E == 0) return HET_OK;
   const int64_t X = (int64_t)H * D;
   Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
-  HET_DISPATCH_LPR((int)(X / 4),
-                   hipLaunchKernelGGL(HET_gat_backward_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, g->p0, feat, el,
-                                      er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope));
+  if (exp_sorted && slope >= 0.f) {
+    HET_DISPATCH_LPR((int)(X / 4),
+                     hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
+                                        feat, el, er, sum, exp_sorted, ret, gradout, grad_feat, grad_el, grad_er, H, D,
+                                        slope));
+  } else {
+    HET_DISPATCH_LPR((int)(X / 4),
+                     hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, false>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
+                                        feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope));
+  }
   HET_LAUNCH_CHECK("HET_gat_backward_grouped");
   return HET_OK;
 }

@@ -54,9 +54,10 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
 
 extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                                    const int64_t* gather_idx, const int64_t* scatter_idx,
-                                                   int64_t num_rows, const float* weights_t, const float* x,
-                                                   const float* gradout, float* grad_x, float* grad_w, int64_t H,
-                                                   int64_t K, int64_t D, int in1head,
+                                                   int64_t num_rows, int64_t num_x_rows, const float* weights_t,
+                                                   const float* x, const float* gradout, float* grad_x,
+                                                   float* grad_w, int64_t H,
+                                                   int64_t K, int64_t D, int in1head, int accumulate,
                                                    const het_grouping* by_rel_gather, void* workspace,
                                                    int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul";
@@ -64,14 +65,25 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
-  if (!in1head && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+  HET_REQUIRE(accumulate || num_x_rows >= 0, "%s: num_x_rows needed to overwrite grad_x", op);
+  // same condition as the reference's ACGatherScatterListIdentical dispatch (RGNNOps.inc.h:253): the
+  // gather list IS the edge-id list, so every input row belongs to exactly one position
+  const bool unique = kind == HET_KIND_DISABLED && gather_idx == scatter_idx;
+  const bool rowdot = !in1head && D == 1 && rowdot_supported((int)H, (int)K) &&
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  if (!accumulate) {  // "=" semantics: zero what the kernels below accumulate into
+    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
+    // rows of x that no position gathers must read zero; with a unique row-dot list of all rows every
+    // row is stored exactly once instead
+    if (!(rowdot && unique && num_rows == num_x_rows))
+      HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_x_rows * (in1head ? K : H * K), s));
+  }
+  if (rowdot) {
     RowDotArgs q;
     q.A = x; q.gather = gather_idx; q.W = weights_t; q.scatter = scatter; q.go = gradout; q.seg_ptrs = rel_ptrs;
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
-    // same condition as the reference's ACGatherScatterListIdentical dispatch (RGNNOps.inc.h:253): the
-    // gather list IS the edge-id list, so every input row belongs to one position
-    q.unique_rows = (kind == HET_KIND_DISABLED && gather_idx == scatter_idx);
+    q.unique_rows = unique;
+    q.overwrite = !accumulate && unique && num_rows == num_x_rows;
     q.out = grad_x;
     if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
     q.out = grad_w;
@@ -166,13 +178,35 @@ extern "C" int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* 
 extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
     const int64_t* offsets, int64_t num_types, int64_t num_rows, const float* weights_t, const float* x,
     const float* gradout, float* grad_x, float* grad_w, int64_t H, int64_t K, int64_t D, int x_per_head,
-    het_stream stream) {
+    int accumulate, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul_no_scatter_gather_list";
   HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
-  if ((x_per_head || H == 1) && D == 1 && rowdot_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+  // rows are their own gather list here: every grad_x row has exactly one writer (rows outside
+  // [offsets[0], offsets[T]) have none: they are zeroed when overwriting)
+  const bool rowdot = (x_per_head || H == 1) && D == 1 && rowdot_supported((int)H, (int)K) &&
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  const bool mfma = !x_per_head && mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
+                    (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  if (!accumulate) {
+    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_types * H * K * D, s));
+    // (rows outside [offsets[0], offsets[T]) have no writer and must read zero)
+    HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_rows * (x_per_head ? H * K : K), s));
+  }
+  if (mfma) {
+    MfmaGemmArgs m;  // grad_x[i] (+)= gradout[i] . Wt[t]; plain stores would do, atomics give "+=" on both paths
+    m.A = gradout; m.a_ld = H * D; m.B = weights_t; m.b_rel_stride = H * D * K; m.C = grad_x; m.c_ld = K;
+    m.atomic = accumulate ? 1 : 0;  // every row has one writer: plain stores when overwriting
+    m.seg_ptrs = offsets; m.num_segs = (int)num_types; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = x; w.a_ld = K; w.G = gradout; w.g_ld = H * D; w.dW = grad_w; w.dw_rel_stride = H * K * D;
+    w.headcat = 1; w.headcat_d = (int)D; w.seg_ptrs = offsets; w.num_segs = (int)num_types; w.num_rows = num_rows;
+    w.K = (int)K; w.X = (int)(H * D);
+    return launch_seg_dw_mfma(w, s);
+  }
+  if (rowdot) {
     RowDotArgs q;
     q.A = x; q.W = weights_t; q.go = gradout; q.seg_ptrs = offsets; q.num_segs = (int)num_types; q.num_rows = num_rows;
     q.H = (int)H; q.K = (int)K; q.unique_rows = 1;

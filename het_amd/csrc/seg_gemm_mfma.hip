@@ -14,65 +14,122 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kChunkRows = 512;
+constexpr int kChunkRows = 2048;  // rows of one relation per workgroup (16 tiles per wave)
 
 template <int K, int NT, bool ATOMIC>
 __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
-  constexpr int X = NT * 32, KH = K / 2, LDA = K + 4, LPRW = K / 4, RPI = 64 / LPRW;
+  constexpr int X = NT * 32, KH = K / 2;
+  constexpr int LDA = K + 4, LPRA = K / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;  // A tile: rows per load instr
+  constexpr int LDC = X + 4, LPRC = X / 4, RPIC = 64 / LPRC, NITC = 32 / RPIC;  // C tile: rows per store instr
+  constexpr int WREG = 32 * (LDA > LDC ? LDA : LDC);                            // per-wave LDS floats
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int r;
   idx_t rb, re;
   if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunkRows, blockIdx.x, r, rb, re)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* Bs = smem;                                  // [K][X]
-  float* As = smem + K * X + wave * 32 * LDA;        // [32][LDA] per wave
-  idx_t* crow = reinterpret_cast<idx_t*>(smem + K * X + 4 * 32 * LDA) + wave * 32;
-
-  {
-    const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
-    const int Dh = a.headcat_d;
-    for (int e = tid; e < K * X; e += 256) {
-      const int k = e / X, n = e - k * X;
-      float v;
-      if (a.b_headcat) {
-        const int h = n / Dh, d = n - h * Dh;
-        v = Bm[(int64_t)h * K * Dh + (int64_t)k * Dh + d];
-      } else {
-        v = Bm[e];
-      }
-      Bs[e] = v;
+  // Small weights (K*X <= 64*64) live in registers: every lane keeps the KH*NT B-operand values it feeds
+  // to the MFMAs, so the MFMA loop issues back to back with no LDS read (and no barrier) in it.  Larger
+  // weights are staged once per workgroup in LDS.
+  constexpr bool B_REGS = KH * NT <= 64;
+  float* Bs = smem;                                           // [K][X] (unused when B_REGS)
+  float* Ws = smem + (B_REGS ? 0 : K * X) + wave * WREG;      // wave-private: A tile [32][LDA], then C tile [32][LDC]
+  const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
+  auto b_elem = [&](int k, int n) -> float {
+    if (a.b_headcat) {
+      const int Dh = a.headcat_d, h = n / Dh, d = n - h * Dh;
+      return Bm[(int64_t)h * K * Dh + (int64_t)k * Dh + d];
     }
+    return Bm[k * X + n];
+  };
+  float breg[B_REGS ? KH * NT : 1];
+  if (B_REGS) {
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        breg[B_REGS ? s * NT + nt : 0] = b_elem((lane >> 5) * KH + s, nt * 32 + (lane & 31));
+  } else {
+    for (int e = tid; e < K * X; e += 256) Bs[e] = b_elem(e / X, e % X);
+    __syncthreads();
   }
-  __syncthreads();
+  // From here on the four waves are independent: each walks its own 32-row tiles with a private LDS
+  // region (LDS instructions of one wave execute in order, so no barrier is needed).
 
   const int row = lane & 31, half = lane >> 5;
-  for (idx_t base = rb; base < re; base += 128) {
-    const idx_t wb = base + wave * 32;
+  const int ra = lane / LPRA, ca = (lane % LPRA) * 4;  // A-load mapping
+  const int rc = lane / LPRC, cc = (lane % LPRC) * 4;  // C-store mapping
+
+  // Loads are issued in phases of independent instructions (all row indices, then all rows) and are
+  // branch-free -- out-of-range rows are clamped to the last row and masked afterwards -- so that the
+  // compiler can keep a whole phase in flight instead of waiting after every dependent pair.
+  float4 areg[NITA];
+  auto load_tile = [&](idx_t wb) {
+    idx_t ar[NITA];
+    if (a.gather) {
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int rloc = it * RPI + lane / LPRW, c4 = (lane % LPRW) * 4;
-      const idx_t i = wb + rloc;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < re) {
-        const idx_t ar = a.gather ? a.gather[i] : i;
-        v = *reinterpret_cast<const float4*>(a.A + ar * a.a_ld + c4);
-        if (a.row_scale) {
-          const float sc = a.row_scale[a.scale_idx ? a.scale_idx[i] : i];
-          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-        }
+      for (int it = 0; it < NITA; ++it) {
+        const idx_t i = wb + it * RPIA + ra;
+        ar[it] = a.gather[i < re ? i : re - 1];
       }
-      *reinterpret_cast<float4*>(&As[rloc * LDA + c4]) = v;
+    } else {
+#pragma unroll
+      for (int it = 0; it < NITA; ++it) {
+        const idx_t i = wb + it * RPIA + ra;
+        ar[it] = i < re ? i : re - 1;
+      }
     }
-    if (lane < 32) {
-      const idx_t i = wb + lane;
-      crow[lane] = i < re ? (a.scatter ? a.scatter[i] : i) : (idx_t)-1;
+#ifdef HET_ABL_NOLOAD
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) ar[it] = ra;
+#endif
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) areg[it] = *reinterpret_cast<const float4*>(a.A + ar[it] * a.a_ld + ca);
+    if (a.row_scale) {
+      idx_t si[NITA];
+#pragma unroll
+      for (int it = 0; it < NITA; ++it) {
+        const idx_t i = wb + it * RPIA + ra, ic = i < re ? i : re - 1;
+        si[it] = a.scale_idx ? a.scale_idx[ic] : ic;
+      }
+#pragma unroll
+      for (int it = 0; it < NITA; ++it) {
+        const float sc = a.row_scale[si[it]];
+        areg[it].x *= sc; areg[it].y *= sc; areg[it].z *= sc; areg[it].w *= sc;
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      if (wb + it * RPIA + ra >= re) areg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  idx_t wb = rb + wave * 32;
+  if (wb < re) load_tile(wb);
+  for (; wb < re; wb += 128) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it)
+      *reinterpret_cast<float4*>(&Ws[(it * RPIA + ra) * LDA + ca]) = areg[it];
+    // C rows of this tile (needed in the epilogue) and the A rows of the next tile: both stay in
+    // flight while the MFMAs below run
+    idx_t crow[NITC];
+    if (a.scatter) {
+#pragma unroll
+      for (int it = 0; it < NITC; ++it) {
+        const idx_t i = wb + it * RPIC + rc;
+        crow[it] = a.scatter[i < re ? i : re - 1];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NITC; ++it) crow[it] = wb + it * RPIC + rc;
+    }
+#pragma unroll
+    for (int it = 0; it < NITC; ++it)
+      if (wb + it * RPIC + rc >= re) crow[it] = -1;
+    if (wb + 128 < re) load_tile(wb + 128);
 
     float af[KH];
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(&As[row * LDA + half * KH + q * 4]);
+      const float4 t = *reinterpret_cast<const float4*>(&Ws[row * LDA + half * KH + q * 4]);
       af[4 * q + 0] = t.x; af[4 * q + 1] = t.y; af[4 * q + 2] = t.z; af[4 * q + 3] = t.w;
     }
     f32x16 acc[NT];
@@ -84,23 +141,43 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
     for (int s = 0; s < KH; ++s) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float b = Bs[(half * KH + s) * X + nt * 32 + row];
+        const float b = B_REGS ? breg[B_REGS ? s * NT + nt : 0] : Bs[(half * KH + s) * X + nt * 32 + row];
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b, acc[nt], 0, 0, 0);
       }
     }
-    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // Epilogue: transpose through the wave's LDS region so that every output row leaves as whole
+    // 16-byte pieces (X/4 lanes x float4 per row) instead of 32 row-strided dword stores.
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    if (ATOMIC) {
+      // straight from the accumulators: one atomic instruction adds two 128-byte row segments, the shape
+      // float atomics run at full rate with (MI355X_MICROARCH.md, Global float atomics)
+      // C-row ids go through the wave's LDS region (all lanes of a store row group hold the same id)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int rloc = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-      const idx_t cr = crow[rloc];
-      if (cr < 0) continue;
-      float* p = a.C + cr * a.c_ld + row;
+      for (int it = 0; it < NITC; ++it) reinterpret_cast<idx_t*>(Ws)[it * RPIC + rc] = crow[it];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (ATOMIC) atomicAdd(p + nt * 32, acc[nt][reg]); else p[nt * 32] = acc[nt][reg];
+      for (int reg = 0; reg < 16; ++reg) {
+        const idx_t cr = reinterpret_cast<const idx_t*>(Ws)[(reg & 3) + 8 * (reg >> 2) + 4 * half];
+        if (cr < 0) continue;
+        float* p = a.C + cr * a.c_ld + row;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) atomicAdd(p + nt * 32, acc[nt][reg]);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          Ws[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LDC + nt * 32 + row] = acc[nt][reg];
+#pragma unroll
+      for (int it = 0; it < NITC; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
+        if (crow[it] < 0) continue;
+#ifdef HET_ABL_NOSTORE
+        if (a.num_rows < 0)
+#endif
+        *reinterpret_cast<float4*>(a.C + crow[it] * a.c_ld + cc) = v;
       }
     }
-    __syncthreads();
   }
 }
 
@@ -200,8 +277,9 @@ int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
 
 template <int K, int NT>
 int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
-  constexpr int X = NT * 32, LDA = K + 4;
-  const size_t lds = sizeof(float) * (K * X + 4 * 32 * LDA) + sizeof(idx_t) * 4 * 32;
+  constexpr int X = NT * 32, LDA = K + 4, LDC = X + 4;
+  constexpr bool B_REGS = (K / 2) * NT <= 64;
+  const size_t lds = sizeof(float) * ((B_REGS ? 0 : K * X) + 4 * 32 * (LDA > LDC ? LDA : LDC));
   const int64_t gx = ceil_div64(a.num_rows, kChunkRows) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
   dim3 grid((unsigned)gx), block(256);
@@ -235,6 +313,7 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   HET_REQUIRE(mfma_shape_supported(a.K, a.X), "segment GEMM (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
   HET_REQUIRE(a.a_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "segment GEMM (MFMA): A rows must be 16-byte aligned");
+  HET_REQUIRE(a.c_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0, "segment GEMM (MFMA): C rows must be 16-byte aligned");
   switch (a.K) {
     case 32: return launch_k<32>(a, s);
     case 64: return launch_k<64>(a, s);

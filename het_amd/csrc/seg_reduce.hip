@@ -23,11 +23,37 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
   const int slot = lane / LPR, x = (lane % LPR) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
-  for (int j = b + slot; j < e; j += EPW) {
-    const float4 f = ld4(in + (int64_t)p_row[j] * X + x);
-    const float w = scale ? scale[p_scale[j]] : 1.f;
-    acc.x = fmaf(w, f.x, acc.x); acc.y = fmaf(w, f.y, acc.y); acc.z = fmaf(w, f.z, acc.z); acc.w = fmaf(w, f.w, acc.w);
+  constexpr int U = 4;  // rows per lane group and step, loads issued in independent phases
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int jc[U];
+    int64_t row[U];
+    float w[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * EPW;
+      jc[u] = j < e ? j : e - 1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) row[u] = p_row[jc[u]];
+    if (scale) {
+      int si[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) si[u] = p_scale[jc[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = scale[si[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(in + row[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float wu = (j0 + u * EPW < e) ? w[u] : 0.f;
+      acc.x = fmaf(wu, f[u].x, acc.x); acc.y = fmaf(wu, f[u].y, acc.y);
+      acc.z = fmaf(wu, f[u].z, acc.z); acc.w = fmaf(wu, f[u].w, acc.w);
+    }
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {

@@ -11,6 +11,31 @@ constexpr int kChunk = 2048;  // rows of one relation per workgroup
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+constexpr int U = 4;  // rows per lane group and step; loads are issued in independent phases
+
+// Row of (step base, wave, u, slot) -- every (wave, u) pair covers EPW consecutive rows (1 KiB).
+#define HET_ROWDOT_ROWS(EPW)                                                      \
+  idx_t ic[U];                                                                    \
+  bool ok[U];                                                                     \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                 \
+    const idx_t i = base + (wave * U + u) * (EPW) + slot;                         \
+    ok[u] = i < re;                                                               \
+    ic[u] = ok[u] ? i : re - 1;                                                   \
+  }                                                                               \
+  idx_t gi[U], si[U];                                                             \
+  if (a.gather) {                                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) gi[u] = a.gather[ic[u]];        \
+  } else {                                                                        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) gi[u] = ic[u];                  \
+  }                                                                               \
+  if (a.scatter == a.gather) {                                                    \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) si[u] = gi[u];                  \
+  } else if (a.scatter) {                                                         \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) si[u] = a.scatter[ic[u]];       \
+  } else {                                                                        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) si[u] = ic[u];                  \
+  }
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_rowdot_fwd(RowDotArgs a) {
   constexpr int EPW = 64 / LPR;
@@ -21,17 +46,23 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot_fwd(RowDotArgs a) {
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, KL = a.K >> 2, h = x / a.K;
   const int HK = a.H * a.K;
   const float4 w = ld4(a.W + (int64_t)r * HK + x);
-  for (idx_t i = rb + wave * EPW + slot; i < re; i += 4 * EPW) {
-    const idx_t gi = a.gather ? a.gather[i] : i;
-    const float4 v = ld4(a.A + gi * HK + x);
-    float p = v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
-    for (int off = KL >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
-    if ((sub & (KL - 1)) == 0) a.out[(a.scatter ? a.scatter[i] : i) * a.H + h] = p;
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld4(a.A + gi[u] * HK + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float p = v[u].x * w.x + v[u].y * w.y + v[u].z * w.z + v[u].w * w.w;
+      for (int off = KL >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
+      if (ok[u] && (sub & (KL - 1)) == 0) a.out[si[u] * a.H + h] = p;
+    }
   }
 }
 
 // grad_A[g_i, h, :] += go[s_i, h] * Wt[r, h, :]
-template <int LPR, bool UNIQUE>
+// MODE 0: atomics; 1: unique rows, read-modify-write; 2: unique rows, plain store
+template <int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void HET_rowdot_bwd_dx(RowDotArgs a) {
   constexpr int EPW = 64 / LPR;
   int r;
@@ -41,16 +72,29 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot_bwd_dx(RowDotArgs a) {
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / a.K;
   const int HK = a.H * a.K;
   const float4 w = ld4(a.W + (int64_t)r * HK + x);
-  for (idx_t i = rb + wave * EPW + slot; i < re; i += 4 * EPW) {
-    const idx_t gi = a.gather ? a.gather[i] : i;
-    const float g = a.go[(a.scatter ? a.scatter[i] : i) * a.H + h];
-    float* p = a.out + gi * HK + x;
-    if (UNIQUE) {
-      float4 c = ld4(p);
-      c.x = fmaf(g, w.x, c.x); c.y = fmaf(g, w.y, c.y); c.z = fmaf(g, w.z, c.z); c.w = fmaf(g, w.w, c.w);
-      st4(p, c);
-    } else {
-      atomicAdd(p + 0, g * w.x); atomicAdd(p + 1, g * w.y); atomicAdd(p + 2, g * w.z); atomicAdd(p + 3, g * w.w);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = a.go[si[u] * a.H + h];
+    float4 c[U];
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) c[u] = ld4(a.out + gi[u] * HK + x);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float* p = a.out + gi[u] * HK + x;
+      if (MODE == 2) {
+        st4(p, make_float4(g[u] * w.x, g[u] * w.y, g[u] * w.z, g[u] * w.w));
+      } else if (MODE == 1) {
+        st4(p, make_float4(fmaf(g[u], w.x, c[u].x), fmaf(g[u], w.y, c[u].y), fmaf(g[u], w.z, c[u].z),
+                           fmaf(g[u], w.w, c[u].w)));
+      } else {
+        atomicAdd(p + 0, g[u] * w.x); atomicAdd(p + 1, g[u] * w.y);
+        atomicAdd(p + 2, g[u] * w.z); atomicAdd(p + 3, g[u] * w.w);
+      }
     }
   }
 }
@@ -66,11 +110,20 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot_bwd_dw(RowDotArgs a, int ch
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / a.K;
   const int HK = a.H * a.K;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (idx_t i = rb + wave * EPW + slot; i < re; i += 4 * EPW) {
-    const idx_t gi = a.gather ? a.gather[i] : i;
-    const float g = a.go[(a.scatter ? a.scatter[i] : i) * a.H + h];
-    const float4 v = ld4(a.A + gi * HK + x);
-    acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float g[U];
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = a.go[si[u] * a.H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld4(a.A + gi[u] * HK + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float gu = ok[u] ? g[u] : 0.f;
+      acc.x = fmaf(gu, v[u].x, acc.x); acc.y = fmaf(gu, v[u].y, acc.y);
+      acc.z = fmaf(gu, v[u].z, acc.z); acc.w = fmaf(gu, v[u].w, acc.w);
+    }
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -121,10 +174,12 @@ int launch_rowdot_fwd(const RowDotArgs& a, hipStream_t s) {
 int launch_rowdot_bwd_dx(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   dim3 grid((unsigned)(ceil_div64(a.num_rows, kChunk) + a.num_segs)), block(kBlock);
-  if (a.unique_rows) {
-    HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL((HET_rowdot_bwd_dx<LPR, true>), grid, block, 0, s, a));
+  if (a.unique_rows && a.overwrite) {
+    HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL((HET_rowdot_bwd_dx<LPR, 2>), grid, block, 0, s, a));
+  } else if (a.unique_rows) {
+    HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL((HET_rowdot_bwd_dx<LPR, 1>), grid, block, 0, s, a));
   } else {
-    HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL((HET_rowdot_bwd_dx<LPR, false>), grid, block, 0, s, a));
+    HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL((HET_rowdot_bwd_dx<LPR, 0>), grid, block, 0, s, a));
   }
   HET_LAUNCH_CHECK("HET_rowdot_bwd_dx");
   return HET_OK;

@@ -14,7 +14,8 @@ struct RowDotArgs {
   int num_segs = 0;
   int64_t num_rows = 0;
   int H = 0, K = 0;
-  int unique_rows = 0;             // bwd dX: gather rows are pairwise distinct -> plain read-modify-write
+  int unique_rows = 0;             // bwd dX: gather rows are pairwise distinct -> no atomics
+  int overwrite = 0;               // bwd dX with unique rows: store instead of read-modify-write
 };
 
 bool rowdot_supported(int H, int K);

@@ -153,19 +153,26 @@ def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, I
      "Tensor node_feat, Tensor gradout, Tensor(a!) grad_node_feat, Tensor(b!) grad_weights, bool InputNumHeadOneFlag) -> ()")
 def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat,
                                     grad_weights, InputNumHeadOneFlag):
+    matmul_backward(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat, grad_weights,
+                    InputNumHeadOneFlag, accumulate=True)
+
+
+def matmul_backward(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat, grad_weights,
+                    InputNumHeadOneFlag, accumulate: bool):
+    """backward_rgnn_relational_matmul with the choice of "+=" (the reference op's contract) or "=" outputs."""
     rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
     _chk("backward_rgnn_relational_matmul", (weights_transposed, node_feat, gradout, grad_node_feat, grad_weights),
          tuple(t for t in (rp, g, s) if t is not None))
     R, H, D, K = weights_transposed.shape
     grp, ws = None, None
-    if IntKind == 0 and InputNumHeadOneFlag and g is not s and g.data_ptr() != s.data_ptr():
+    if IntKind == 0 and InputNumHeadOneFlag and g.data_ptr() != s.data_ptr():
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
         if grp is not None:
             ws = torch.empty(max(1, grp.num_segments) * H * D, dtype=torch.float32, device=gradout.device)
     _call(gradout, "het_backward_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(),
-          _p(weights_transposed), _p(node_feat), _p(gradout), _p(grad_node_feat), _p(grad_weights), H, K, D,
-          int(InputNumHeadOneFlag), None if grp is None else grp.handle, _p(ws), 0 if ws is None else ws.numel() * 4,
-          _stream(gradout))
+          node_feat.shape[0], _p(weights_transposed), _p(node_feat), _p(gradout), _p(grad_node_feat), _p(grad_weights),
+          H, K, D, int(InputNumHeadOneFlag), int(accumulate), None if grp is None else grp.handle, _p(ws),
+          0 if ws is None else ws.numel() * 4, _stream(gradout))
 
 
 @_op("rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights, Tensor inputs, "
@@ -183,6 +190,12 @@ def rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, weights, in
      "Tensor inputs, Tensor gradout, Tensor(a!) grad_input, Tensor(b!) grad_weights) -> ()")
 def backward_rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, weights_transposed, inputs, gradout,
                                                            grad_input, grad_weights):
+    matmul_no_scatter_gather_backward(ntype_offset_ptrs, weights_transposed, inputs, gradout, grad_input, grad_weights,
+                                      accumulate=True)
+
+
+def matmul_no_scatter_gather_backward(ntype_offset_ptrs, weights_transposed, inputs, gradout, grad_input, grad_weights,
+                                      accumulate: bool):
     _chk("backward_rgnn_relational_matmul_no_scatter_gather_list",
          (weights_transposed, inputs, gradout, grad_input, grad_weights), (ntype_offset_ptrs,))
     T, H, D, K = weights_transposed.shape
@@ -190,7 +203,7 @@ def backward_rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, we
     per_head = int(H > 1 and inputs.numel() == n * H * K)
     _call(gradout, "het_backward_rgnn_relational_matmul_no_scatter_gather_list", _p(ntype_offset_ptrs), T, n,
           _p(weights_transposed), _p(inputs), _p(gradout), _p(grad_input), _p(grad_weights), H, K, D, per_head,
-          _stream(gradout))
+          int(accumulate), _stream(gradout))
 
 
 # ------------------------------------------------------------------------------------
@@ -255,6 +268,20 @@ def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
 def relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
                                       separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er, sum, exp,
                                       ret, slope):
+    fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                      IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, None)
+
+
+def gat_grouped_shape_ok(H: int, D: int) -> bool:
+    """Shapes the destination-grouped GAT kernels cover (fused_gat_grouped.hip: grouped_shape_ok)."""
+    X = H * D
+    return D >= 4 and D & (D - 1) == 0 and X & (X - 1) == 0 and X // 4 <= 64
+
+
+def fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                      IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, exp_sorted):
+    """relational_fused_gat_separate_coo plus the optional ``exp_sorted`` output ([E,H], exp in
+    destination-grouped order) that lets the backward stream instead of gather."""
     name = "relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, False)
     _chk(name, (feat_src, el, er, sum, exp, ret),
@@ -267,7 +294,8 @@ def relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, 
     _call(ret, "het_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
           _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
-          H, D, float(slope), None if g is None else g.handle, _stream(ret))
+          None if g is None else _p(exp_sorted), H, D, float(slope), None if g is None else g.handle, _stream(ret))
+    return g is not None and exp_sorted is not None
 
 
 @_op("backward_relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
@@ -277,6 +305,14 @@ def relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, 
 def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
                                                separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er,
                                                sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, slope):
+    fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                       IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
+                       grad_er, slope, None)
+
+
+def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                       IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
+                       grad_er, slope, exp_sorted):
     name = "backward_relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, True)
     _chk(name, (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er),
@@ -289,8 +325,8 @@ def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_r
     _call(ret, "het_backward_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
           _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
-          _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D, float(slope),
-          None if g is None else g.handle, None, _stream(ret))
+          None if g is None else _p(exp_sorted), _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D,
+          float(slope), None if g is None else g.handle, None, _stream(ret))
 
 
 @_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "

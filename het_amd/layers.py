@@ -113,7 +113,14 @@ class HET_RGATLayer(nn.Module):
                 h = B.relational_fused_gat_csr(g, feat_src_per_edge, el, er, self.leaky_relu_slope)
         h = h.view(-1, self.out_feat)  # models.py:377-385
         if self.self_loop:
-            h = h + th.matmul(inputs, self.loop_weight)
+            # the reference calls th.matmul here (models.py:378-379); same product through the segment GEMM
+            # with a single segment (MFMA kernel instead of a generic BLAS pick for a 64-wide GEMM)
+            key = (inputs.shape[0], inputs.device)
+            if getattr(self, "_loop_offs_key", None) != key:  # built once per (N, device): no per-step host sync
+                self._loop_offs = th.tensor([0, inputs.shape[0]], dtype=th.int64, device=inputs.device)
+                self._loop_offs_key = key
+            h = h + B.rgnn_relational_matmul_no_scatter_gather_list(
+                self._loop_offs, self.loop_weight.view(1, 1, self.in_feat, self.out_feat), inputs)
         if self.bias:
             h = h + self.h_bias
         if self.activation:

@@ -93,12 +93,16 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
  *   grad_w[r, h]                  += x[gather_idx[i], (h), :]^T (x) gradout[scatter_idx[i], h, :]
  *   weights_t [R,H,D,K].  by_rel_gather: optional grouping of the rows by (relation, gather_idx):
  *   het_grouping_create(rel_ptrs, R, gather_idx, num_rows, <rows of x>, payload0 = scatter_idx, NULL, ...);
- *   with it, `workspace` must hold het_grouping_num_segments(g) * H * D floats (16-byte aligned). */
+ *   with it, `workspace` must hold het_grouping_num_segments(g) * H * D floats (16-byte aligned).
+ *   accumulate != 0: "+=" into the caller's buffers as the reference does (its wrapper zero-fills them,
+ *   rgnn_layers_and_funcs.py:52-55); accumulate == 0: grad_x and grad_w are overwritten, no pre-zeroing
+ *   needed (saves a fill + a read-modify-write pass when every grad_x row has a single writer). */
 int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+                                        int64_t num_x_rows /* rows of x and grad_x */,
                                         const float* weights_t, const float* x, const float* gradout,
                                         float* grad_x, float* grad_w,
-                                        int64_t H, int64_t K, int64_t D, int in1head,
+                                        int64_t H, int64_t K, int64_t D, int in1head, int accumulate,
                                         const het_grouping* by_rel_gather, void* workspace,
                                         int64_t workspace_bytes, het_stream stream);
 
@@ -113,7 +117,7 @@ int het_backward_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* of
                                                                const float* x, const float* gradout,
                                                                float* grad_x, float* grad_w,
                                                                int64_t H, int64_t K, int64_t D, int x_per_head,
-                                                               het_stream stream);
+                                                               int accumulate, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * a4  relational_fused_gat_separate_coo    OpExport/RGATOps.inc.h:170-245
@@ -134,6 +138,8 @@ int het_backward_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* of
  *   feat [n_src_rows, H, D]; el [n_src_rows, H]; er [n_dst_rows, H]; sum [N,H]; exp [E,H]; ret [N,H,D].
  *   by_dst: optional grouping of the positions by col: het_grouping_create(NULL, 0, col, E, N,
  *   payload0 = eids, payload1 = NULL or the feat row of every position (srow), ...).
+ *   exp_sorted (optional, [E,H], needs by_dst): a second copy of exp in the grouping's order, which the
+ *   backward can stream instead of gathering exp / el / er by edge id.
  * ------------------------------------------------------------------------ */
 int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row,
                                           const int64_t* col, int64_t num_rels, int64_t num_edges,
@@ -141,7 +147,7 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
                                           const int64_t* map_row_a, const int64_t* map_row_b,
                                           const int64_t* map_col_a, const int64_t* map_col_b,
                                           const float* feat, const float* el, const float* er,
-                                          float* sum, float* exp, float* ret,
+                                          float* sum, float* exp, float* ret, float* exp_sorted,
                                           int64_t H, int64_t D, double slope,
                                           const het_grouping* by_dst, het_stream stream);
 
@@ -150,7 +156,10 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   grad_feat[srow,h,:] += a * gradout[col[i],h,:]
  *   t = SUM_d gradout[col[i],h,d] * (feat[srow,h,d] - ret[col[i],h,d]) * a * (z > 0 ? 1 : slope)
  *   grad_el[srow,h] += t ; grad_er[drow,h] += t
- *   n_src_rows / n_dst_rows: leading sizes of feat/el and er (E for kind 0). */
+ *   kind 0: every feat/el/er row belongs to one edge, so the three gradients are OVERWRITTEN (stores, no
+ *   atomics, no pre-zeroing needed) and grad_er may alias grad_el (same values).  Other kinds: "+=".
+ *   exp_sorted: optional copy of exp in by_dst order written by the forward (slope >= 0 required: the
+ *   leaky-ReLU branch is then recovered from exp > 1). */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
@@ -158,6 +167,7 @@ int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const in
                                                    const int64_t* map_col_a, const int64_t* map_col_b,
                                                    const float* feat, const float* el, const float* er,
                                                    const float* sum, const float* exp, const float* ret,
+                                                   const float* exp_sorted,
                                                    const float* gradout, float* grad_feat, float* grad_el,
                                                    float* grad_er, int64_t H, int64_t D, double slope,
                                                    const het_grouping* by_dst, const het_grouping* by_rel_src,
