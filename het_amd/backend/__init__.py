@@ -4,3 +4,4 @@ output-allocating wrappers with the names and signatures of the reference's
 from .rgnn_layers_and_funcs import *  # noqa: F401,F403
 from .rgat_layers_and_funcs import *  # noqa: F401,F403
 from .rgcn_layers_and_funcs import *  # noqa: F401,F403
+from .hgt_layers_and_funcs import *  # noqa: F401,F403

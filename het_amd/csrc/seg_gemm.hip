@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_generic(SegGemmArgs a) {
     bool v = i < re;
     a_rows[tid] = v ? (a.gather ? a.gather[i] : i) : -1;
     c_rows[tid] = v ? (a.scatter ? a.scatter[i] : i) : -1;
-    scl[tid] = (v && a.row_scale) ? a.row_scale[a.scale_idx ? a.scale_idx[i] : i] : 1.f;
+    scl[tid] = (v && a.row_scale) ? a.row_scale[(a.scale_idx ? a.scale_idx[i] : i) * a.scale_ld + blockIdx.z * a.scale_zs] : 1.f;
   }
   __syncthreads();
   const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride + (a.b_headcat ? 0 : (int64_t)z * a.b_head_stride);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void HET_seg_dw_generic(SegDwArgs a, int rows_
     if (valid) {
       ar = a.gather ? a.gather[i] : i;
       gr = a.g_gather ? a.g_gather[i] : i;
-      if (a.row_scale) sc = a.row_scale[a.scale_idx ? a.scale_idx[i] : i];
+      if (a.row_scale) sc = a.row_scale[(a.scale_idx ? a.scale_idx[i] : i) * a.scale_ld + z * a.scale_zs];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

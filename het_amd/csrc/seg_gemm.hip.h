@@ -21,8 +21,9 @@ struct SegGemmArgs {
   const idx_t* seg_ptrs = nullptr;  // [num_segs + 1]
   int num_segs = 0;
   int64_t num_rows = 0;
-  const float* row_scale = nullptr;  // optional per-row scale, indexed by scale_idx[i] (or i)
-  const idx_t* scale_idx = nullptr;
+  const float* row_scale = nullptr;  // optional per-row scale: row_scale[sidx(i) * scale_ld + z * scale_zs]
+  const idx_t* scale_idx = nullptr;  // sidx(i) = scale_idx[i] (NULL: i)
+  int64_t scale_ld = 1, scale_zs = 0;
   int KA = 0, NB = 0, heads_z = 1;
 };
 int launch_seg_gemm(const SegGemmArgs& a, hipStream_t s);
@@ -34,6 +35,7 @@ struct SegDwArgs {
   const idx_t* gather = nullptr;
   const float* row_scale = nullptr;
   const idx_t* scale_idx = nullptr;
+  int64_t scale_ld = 1, scale_zs = 0;
   const float* G = nullptr;
   int64_t g_ld = 0, g_head_stride = 0;
   const idx_t* g_gather = nullptr;

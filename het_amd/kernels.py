@@ -444,3 +444,169 @@ def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate
 
 K = getattr(torch.ops, NAMESPACE)
 REGISTERED_OPS = tuple(_registered)
+
+
+# ------------------------------------------------------------------------------------
+# HGT
+# ------------------------------------------------------------------------------------
+def _ip_maps(d: Dict[str, Tensor], kind: int):
+    if kind == 0:
+        return None, None
+    if kind == 1:
+        return d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices"]
+    if kind == 2:
+        return d["edata_idx_to_inverse_idx"], None
+    raise _lib.HetError(f"rgnn_inner_product_right_node: CompactAsOfNodeKind {kind} not supported")
+
+
+@_op("rgnn_inner_product_right_node_separatecoo(Dict(str, Tensor) arg_tensor_dict, int IntKind, "
+     "Tensor separate_coo_rel_ptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+     "Tensor separate_coo_col_indices, Tensor left_side_data, Tensor right_node_vectors, "
+     "Tensor(a!) edge_inner_product) -> ()")
+def rgnn_inner_product_right_node_separatecoo(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_eids,
+                                              separate_coo_row_indices, separate_coo_col_indices, left_side_data,
+                                              right_node_vectors, edge_inner_product):
+    a, b = _ip_maps(arg_tensor_dict, IntKind)
+    _chk("rgnn_inner_product_right_node_separatecoo", (left_side_data, right_node_vectors, edge_inner_product),
+         (separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices)
+         + tuple(t for t in (a, b) if t is not None))
+    H = edge_inner_product.shape[1]
+    D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
+    _call(edge_inner_product, "het_rgnn_inner_product_right_node_separatecoo", IntKind, _p(a), _p(b),
+          _p(separate_coo_rel_ptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
+          separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), _p(left_side_data), _p(right_node_vectors),
+          _p(edge_inner_product), H, D, _stream(edge_inner_product))
+
+
+@_op("backward_inner_product_right_node_separatecoo(Dict(str, Tensor) arg_tensor_dict, int IntKind, "
+     "Tensor separate_coo_rel_ptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+     "Tensor separate_coo_col_indices, Tensor left_side_data, Tensor right_node_vectors, Tensor gradout, "
+     "Tensor(a!) grad_left_side_data, Tensor(b!) grad_right_node_vectors) -> ()")
+def backward_inner_product_right_node_separatecoo(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_eids,
+                                                  separate_coo_row_indices, separate_coo_col_indices, left_side_data,
+                                                  right_node_vectors, gradout, grad_left_side_data,
+                                                  grad_right_node_vectors):
+    a, b = _ip_maps(arg_tensor_dict, IntKind)
+    _chk("backward_inner_product_right_node_separatecoo",
+         (left_side_data, right_node_vectors, gradout, grad_left_side_data, grad_right_node_vectors),
+         (separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices)
+         + tuple(t for t in (a, b) if t is not None))
+    H = gradout.shape[1]
+    D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
+    _call(gradout, "het_backward_inner_product_right_node_separatecoo", IntKind, _p(a), _p(b),
+          _p(separate_coo_rel_ptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
+          separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), _p(left_side_data), _p(right_node_vectors),
+          _p(gradout), _p(grad_left_side_data), _p(grad_right_node_vectors), H, D, _stream(gradout))
+
+
+@_op("hgt_full_graph_edge_softmax_ops_separate_coo(Tensor row_indices, Tensor col_indices, Tensor eids, Tensor rel_ptrs, "
+     "Tensor unnormalized_attn_score, Tensor mu, Tensor(a!) edgesoftmax_sum_per_node, "
+     "Tensor(b!) mu_softmax_applied_unnormalized_attn_score, Tensor(c!) normalized_attn_score) -> ()")
+def hgt_full_graph_edge_softmax_ops_separate_coo(row_indices, col_indices, eids, rel_ptrs, unnormalized_attn_score, mu,
+                                                 edgesoftmax_sum_per_node, mu_softmax_applied_unnormalized_attn_score,
+                                                 normalized_attn_score):
+    _chk("hgt_full_graph_edge_softmax_ops_separate_coo",
+         (unnormalized_attn_score, mu, edgesoftmax_sum_per_node, mu_softmax_applied_unnormalized_attn_score,
+          normalized_attn_score), (row_indices, col_indices, eids, rel_ptrs))
+    H = mu.shape[1]
+    _call(mu, "het_hgt_full_graph_edge_softmax_ops_separate_coo", _p(row_indices), _p(col_indices), _p(eids),
+          _p(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(), edgesoftmax_sum_per_node.shape[0],
+          _p(unnormalized_attn_score), _p(mu), _p(edgesoftmax_sum_per_node),
+          _p(mu_softmax_applied_unnormalized_attn_score), _p(normalized_attn_score), H, _stream(mu))
+
+
+@_op("backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(Tensor row_indices, Tensor col_indices, "
+     "Tensor eids, Tensor rel_ptrs, Tensor unnormalized_attn_score, Tensor normalized_attn_score, "
+     "Tensor grad_normalized_attn_score, Tensor mu, Tensor(a!) grad_unnormalized_attn_score, Tensor(b!) grad_mu, "
+     "Tensor(c!) sum_incoming_edges_product_softmax_score) -> ()")
+def backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
+        row_indices, col_indices, eids, rel_ptrs, unnormalized_attn_score, normalized_attn_score,
+        grad_normalized_attn_score, mu, grad_unnormalized_attn_score, grad_mu, sum_incoming_edges_product_softmax_score):
+    _chk("backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo",
+         (unnormalized_attn_score, normalized_attn_score, grad_normalized_attn_score, mu, grad_unnormalized_attn_score,
+          grad_mu, sum_incoming_edges_product_softmax_score), (row_indices, col_indices, eids, rel_ptrs))
+    H = mu.shape[1]
+    _call(mu, "het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo", _p(row_indices),
+          _p(col_indices), _p(eids), _p(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(),
+          sum_incoming_edges_product_softmax_score.shape[0], _p(unnormalized_attn_score), _p(normalized_attn_score),
+          _p(grad_normalized_attn_score), _p(mu), _p(grad_unnormalized_attn_score), _p(grad_mu),
+          _p(sum_incoming_edges_product_softmax_score), H, _stream(mu))
+
+
+@_op("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "
+     "Tensor separate_coo_eids, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor inputs, "
+     "Tensor weights, Tensor edge_norm, Tensor(a!) new_h) -> ()")
+def hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(separate_coo_relptrs, separate_coo_eids,
+                                                                        separate_coo_row_indices,
+                                                                        separate_coo_col_indices, inputs, weights,
+                                                                        edge_norm, new_h):
+    _chk("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", (inputs, weights, edge_norm, new_h),
+         (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
+    R, H, dk, dout = weights.shape
+    _call(new_h, "het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", _p(separate_coo_relptrs),
+          _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices), R,
+          separate_coo_eids.numel(), new_h.shape[0], _p(inputs), _p(weights), _p(edge_norm), _p(new_h), H, dk, dout,
+          _stream(new_h))
+
+
+@_op("backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "
+     "Tensor separate_coo_eids, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor inputs, "
+     "Tensor weights_transposed, Tensor edge_norm, Tensor new_h, Tensor(a!) grad_input, Tensor(b!) grad_weights, "
+     "Tensor(c!) grad_edge_norm, Tensor gradout) -> ()")
+def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
+        separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices, inputs,
+        weights_transposed, edge_norm, new_h, grad_input, grad_weights, grad_edge_norm, gradout):
+    _chk("backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
+         (inputs, weights_transposed, edge_norm, new_h, grad_input, grad_weights, grad_edge_norm, gradout),
+         (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
+    R, H, dout, dk = weights_transposed.shape
+    _call(gradout, "het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
+          _p(separate_coo_relptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
+          R, separate_coo_eids.numel(), new_h.shape[0], _p(inputs), _p(weights_transposed), _p(edge_norm), _p(new_h),
+          _p(grad_input), _p(grad_weights), _p(grad_edge_norm), _p(gradout), H, dk, dout, _stream(gradout))
+
+
+@_op("hgt_full_graph_hetero_attention_ops_coo(Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, "
+     "Tensor separate_coo_eids, Tensor separate_coo_relptrs, Tensor applied_klinear_node_features, "
+     "Tensor applied_qlinear_node_features, Tensor attn_score_weight, Tensor(a!) attn_score_inner_product, "
+     "Tensor(b!) unnormalized_attn_score) -> ()")
+def hgt_full_graph_hetero_attention_ops_coo(separate_coo_row_indices, separate_coo_col_indices, separate_coo_eids,
+                                            separate_coo_relptrs, applied_klinear_node_features,
+                                            applied_qlinear_node_features, attn_score_weight, attn_score_inner_product,
+                                            unnormalized_attn_score):
+    _chk("hgt_full_graph_hetero_attention_ops_coo",
+         (applied_klinear_node_features, applied_qlinear_node_features, attn_score_weight, attn_score_inner_product,
+          unnormalized_attn_score),
+         (separate_coo_row_indices, separate_coo_col_indices, separate_coo_eids, separate_coo_relptrs))
+    R, H, dk, dout = attn_score_weight.shape
+    _call(unnormalized_attn_score, "het_hgt_full_graph_hetero_attention_ops_coo", _p(separate_coo_row_indices),
+          _p(separate_coo_col_indices), _p(separate_coo_eids), _p(separate_coo_relptrs), R, separate_coo_eids.numel(),
+          _p(applied_klinear_node_features), _p(applied_qlinear_node_features), _p(attn_score_weight),
+          _p(attn_score_inner_product), _p(unnormalized_attn_score), H, dk, dout, _stream(unnormalized_attn_score))
+
+
+@_op("backward_hgt_full_graph_hetero_attention_ops_coo(Tensor incsr_row_ptrs, Tensor incsr_col_indices, "
+     "Tensor incsr_eids, Tensor incsr_reltypes, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, "
+     "Tensor separate_coo_eids, Tensor separate_coo_relptrs, Tensor(a!) grad_attn_weight, "
+     "Tensor attn_score_weight_transposed, Tensor applied_klinear_node_features, "
+     "Tensor applied_qlinear_node_features, Tensor attn_score_inner_product, Tensor grad_unnorm_attn_score, "
+     "Tensor(b!) grad_k, Tensor(c!) grad_q) -> ()")
+def backward_hgt_full_graph_hetero_attention_ops_coo(incsr_row_ptrs, incsr_col_indices, incsr_eids, incsr_reltypes,
+                                                     separate_coo_row_indices, separate_coo_col_indices,
+                                                     separate_coo_eids, separate_coo_relptrs, grad_attn_weight,
+                                                     attn_score_weight_transposed, applied_klinear_node_features,
+                                                     applied_qlinear_node_features, attn_score_inner_product,
+                                                     grad_unnorm_attn_score, grad_k, grad_q):
+    _chk("backward_hgt_full_graph_hetero_attention_ops_coo",
+         (grad_attn_weight, attn_score_weight_transposed, applied_klinear_node_features, applied_qlinear_node_features,
+          attn_score_inner_product, grad_unnorm_attn_score, grad_k, grad_q),
+         (separate_coo_row_indices, separate_coo_col_indices, separate_coo_eids, separate_coo_relptrs))
+    R, H, dout, dk = attn_score_weight_transposed.shape
+    _call(grad_k, "het_backward_hgt_full_graph_hetero_attention_ops_coo", _p(separate_coo_row_indices),
+          _p(separate_coo_col_indices), _p(separate_coo_eids), _p(separate_coo_relptrs), R, separate_coo_eids.numel(),
+          _p(grad_attn_weight), _p(attn_score_weight_transposed), _p(applied_klinear_node_features),
+          _p(applied_qlinear_node_features), _p(attn_score_inner_product), _p(grad_unnorm_attn_score), _p(grad_k),
+          _p(grad_q), H, dk, dout, _stream(grad_k))
+
+
+REGISTERED_OPS = tuple(_registered)

@@ -5,8 +5,11 @@ follow the reference so that a state_dict and the kernel sequence line up:
   HET_RGATLayer                       hrt/python/RGAT/models.py:16-385
   HET_EglRelGraphConv_EdgeParallel    hrt/python/RGCN/RGCN.py:194-350
   HET_RelGraphEmbed                   hrt/python/RGNNUtils/RGNNUtils.py:78-119
+  HET_HGTLayerHetero                  hrt/python/HGT/models.py:15-286
 """
 from __future__ import annotations
+
+import math
 
 import torch as th
 import torch.nn as nn
@@ -169,3 +172,61 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
         if self.activation:
             node_repr = self.activation(node_repr)
         return self.dropout(node_repr)
+
+
+class HET_HGTLayerHetero(nn.Module):
+    """Heterogeneous graph transformer layer (HGT/models.py:15-286): typed K/Q/V projections per node type,
+    per-relation attention and message weights, edge softmax with the relation prior as temperature, typed
+    output projection gated by sigmoid(skip).  (The multiply_among_weights_first variant, which the reference
+    restricts to one head and leaves with a FIXME, is not built.)"""
+
+    def __init__(self, num_ntypes, num_rels, in_dim, out_dim, num_heads=1, dropout=0.2, use_norm=False,
+                 hgt_fused_attn_score_flag=False, compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
+                 fused_message_mean_aggregation_flag=True):
+        super().__init__()
+        assert fused_message_mean_aggregation_flag, "only the fused message + aggregation op is built (the reference default)"
+        assert not use_norm, "use_norm is off in the reference scripts"
+        self.num_ntypes, self.num_relations, self.in_dim, self.out_dim = num_ntypes, num_rels, in_dim, out_dim
+        self.num_heads, self.d_k = num_heads, out_dim // num_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.hgt_fused_attn_score_flag = hgt_fused_attn_score_flag
+        self.compact_as_of_node_flag = compact_as_of_node_flag
+        self.compact_direct_indexing_flag = compact_direct_indexing_flag
+        self.k_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
+        self.q_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
+        self.v_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
+        self.a_linears = nn.Parameter(th.Tensor(num_ntypes, 1, out_dim, out_dim))
+        self.relation_pri = nn.Parameter(th.ones(num_rels, num_heads))
+        self.relation_att = nn.Parameter(th.Tensor(num_rels, num_heads, self.d_k, self.d_k))
+        self.relation_msg = nn.Parameter(th.Tensor(num_rels, num_heads, self.d_k, self.d_k))
+        self.skip = nn.Parameter(th.ones(num_ntypes, 1, 1, 1))
+        self.drop = nn.Dropout(dropout)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for p in (self.relation_att, self.relation_msg, self.k_linears, self.q_linears, self.v_linears, self.a_linears):
+            nn.init.xavier_uniform_(p)
+
+    def forward(self, G, h):
+        offs = G.get_original_node_type_offsets()
+        k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.k_linears, h).view(-1, self.num_heads, self.d_k)
+        q = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.q_linears, h).view(-1, self.num_heads, self.d_k)
+        v = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.v_linears, h).view(-1, self.num_heads, self.d_k)
+        if self.hgt_fused_attn_score_flag:  # models.py:172-175
+            attn_score = B.hgt_full_graph_hetero_attention_ops_coo(G, self.relation_att, k, q)
+        elif self.compact_as_of_node_flag:  # models.py:177-214
+            ss = G.get_separate_unique_node_indices_single_sided()
+            compact = B.rgnn_relational_matmul(
+                {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"],
+                 "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}, self.relation_att, q, False, 1)
+            attn_score = B.rgnn_inner_product_right_node(G, compact, k, 2 if self.compact_direct_indexing_flag else 1, "_col")
+        else:  # models.py:215-241
+            s = G.get_separate_coo_original()
+            per_edge = B.rgnn_relational_matmul(
+                {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"],
+                 "separate_coo_eids": s["eids"]}, self.relation_att, q, False, 0)
+            attn_score = B.rgnn_inner_product_right_node(G, per_edge, k, 0, "_col")
+        new_h = B.hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(
+            self.relation_msg, v, G, (self.relation_pri / self.sqrt_dk), attn_score)
+        return B.rgnn_relational_matmul_no_scatter_gather_list(
+            offs, (th.sigmoid(self.skip) * self.a_linears), new_h.view(-1, self.out_dim))

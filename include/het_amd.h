@@ -228,6 +228,73 @@ int het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
     const float* enorm, const float* ret, const float* gradout, float* grad_feat, int64_t X, int direct,
     het_stream stream);
 
+/* ------------------------------------------------------------------------
+ * a10  hgt_full_graph_edge_softmax_ops_separate_coo     OpExport/HGTOpsEdgeParallel.inc.h:18-31 -> HGTOps.inc.h:23-106
+ *   m[eids[i],h] = exp(score[eids[i],h] * mu[r(i),h]);  sum[col[i],h] = SUM_i m;  a = m / sum[col[i],h]
+ *   (denominator keyed by the DESTINATION over all E edges: intended semantics).
+ *   sum, m, a are overwritten.
+ *      backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo   HGTOps.inc.h:597-648
+ *   tmp[col[i],h] = SUM_i a*grad_a;  c = (grad_a - tmp[col[i],h]) * a
+ *   grad_score[eids[i],h] = c * mu[r,h];  grad_mu[r,h] += c * score[eids[i],h]      
+ * ------------------------------------------------------------------------ */
+int het_hgt_full_graph_edge_softmax_ops_separate_coo(const int64_t* row, const int64_t* col, const int64_t* eids,
+                                                     const int64_t* rel_ptrs, int64_t num_rels, int64_t num_edges,
+                                                     int64_t num_nodes, const float* score, const float* mu,
+                                                     float* sum, float* m, float* a, int64_t H, het_stream stream);
+int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
+    const int64_t* row, const int64_t* col, const int64_t* eids, const int64_t* rel_ptrs, int64_t num_rels,
+    int64_t num_edges, int64_t num_nodes, const float* score, const float* a, const float* grad_a, const float* mu,
+    float* grad_score, float* grad_mu, float* tmp, int64_t H, het_stream stream);
+
+/* a11  hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo (+ backward)
+ *      OpExport/HGTOpsEdgeParallel.inc.h:33-88, 295-369
+ *   new_h[col[i],h,:] += (v[row[i],h,:] * a[eids[i],h]) . W[r,h]                      W [R,H,dk,dout]
+ *   grad_v[row[i],h,:] += (gradout[col[i],h,:] * a) . Wt[r,h]     (intended direction)
+ *   grad_w[r,h]        += (v[row[i],h,:] * a)^T (x) gradout[col[i],h,:]
+ *   grad_a[eids[i],h]   = < gradout[col[i],h,:] . Wt[r,h], v[row[i],h,:] >            Wt [R,H,dout,dk] */
+int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
+    const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
+    int64_t num_edges, int64_t num_nodes, const float* v, const float* weights, const float* a, float* new_h,
+    int64_t H, int64_t dk, int64_t dout, het_stream stream);
+int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
+    const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
+    int64_t num_edges, int64_t num_nodes, const float* v, const float* weights_t, const float* a, const float* new_h,
+    float* grad_v, float* grad_w, float* grad_a, const float* gradout, int64_t H, int64_t dk, int64_t dout,
+    het_stream stream);
+
+/* a12  rgnn_inner_product_right_node_separatecoo (+ backward)    OpExport/RGNNOps.inc.h:609-658, 1131-1181
+ *   out[eids[i],h] = < left[lrow(i),h,:], right[row[i],h,:] >                               (out overwritten)
+ *   lrow(i) = eids[i] (kind 0) | row of (r(i), col[i]) in the unique list map_a = rel_ptrs, map_b = node ids
+ *             (kind 1) | map_a[eids[i]] (kind 2, edata_idx_to_inverse_idx)
+ *   grad_left[lrow(i),h,:] += gradout[eids[i],h] * right[row[i],h,:];   grad_right[row[i],h,:] += ... * left[lrow(i),h,:]
+ *   (accumulating; the reference kernel stores without atomics) */
+int het_rgnn_inner_product_right_node_separatecoo(int64_t kind, const int64_t* map_a, const int64_t* map_b,
+                                                  const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
+                                                  const int64_t* col, int64_t num_rels, int64_t num_edges,
+                                                  const float* left, const float* right, float* out, int64_t H,
+                                                  int64_t D, het_stream stream);
+int het_backward_inner_product_right_node_separatecoo(int64_t kind, const int64_t* map_a, const int64_t* map_b,
+                                                      const int64_t* rel_ptrs, const int64_t* eids,
+                                                      const int64_t* row, const int64_t* col, int64_t num_rels,
+                                                      int64_t num_edges, const float* left, const float* right,
+                                                      const float* gradout, float* grad_left, float* grad_right,
+                                                      int64_t H, int64_t D, het_stream stream);
+
+/*      hgt_full_graph_hetero_attention_ops_coo (+ backward)     OpExport/HGTOpsEdgeParallel.inc.h:95-158, 166-293
+ *   inner[eids[i],h,:] = k[row[i],h,:] . W[r,h];   score[eids[i],h] = < inner[eids[i],h,:], q[col[i],h,:] >
+ *   grad_q[col[i],h,:] += gs * inner[eids[i],h,:];  grad_k[row[i],h,:] += (gs * q[col[i],h,:]) . Wt[r,h];
+ *   grad_w[r,h] += k[row[i],h,:]^T (x) (gs * q[col[i],h,:]),   gs = grad_score[eids[i],h] */
+int het_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, const int64_t* col, const int64_t* eids,
+                                                const int64_t* rel_ptrs, int64_t num_rels, int64_t num_edges,
+                                                const float* k, const float* q, const float* weights, float* inner,
+                                                float* score, int64_t H, int64_t dk, int64_t dout, het_stream stream);
+int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, const int64_t* col, const int64_t* eids,
+                                                         const int64_t* rel_ptrs, int64_t num_rels, int64_t num_edges,
+                                                         float* grad_w, const float* weights_t, const float* k,
+                                                         const float* q, const float* inner, const float* grad_score,
+                                                         float* grad_k, float* grad_q, int64_t H, int64_t dk,
+                                                         int64_t dout, het_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,37 @@ def rgcn_layer(x, weight, norm, rel_ptrs, row, col, num_nodes, h_bias=None):
     if h_bias is not None:
         out = out + h_bias
     return out
+
+
+def hgt_layer(h, node_type_offsets, rel_ptrs, row, col, num_nodes, k_lin, q_lin, v_lin, a_lin, rel_att, rel_msg, rel_pri,
+              skip, num_heads, fused_attn=False):
+    """One HGT layer as the reference composes it (hrt/python/HGT/models.py:120-286, non-compact path).
+    k_lin/q_lin/v_lin/a_lin [T,1,in,out]; rel_att/rel_msg [R,H,dk,dk]; rel_pri [R,H]; skip [T,1,1,1].
+    Unfused score:  s = < q[dst] @ rel_att[r,h], k[src] >;  fused op:  s = < k[src] @ rel_att[r,h], q[dst] >."""
+    T = node_type_offsets.numel() - 1
+    H = num_heads
+    out_dim = k_lin.shape[3]
+    dk = out_dim // H
+
+    def typed_linear(x, W):
+        parts = []
+        for t in range(T):
+            a, b = int(node_type_offsets[t]), int(node_type_offsets[t + 1])
+            parts.append(x[a:b] @ W[t, 0])
+        return torch.cat(parts)
+
+    k = typed_linear(h, k_lin).view(-1, H, dk)
+    q = typed_linear(h, q_lin).view(-1, H, dk)
+    v = typed_linear(h, v_lin).view(-1, H, dk)
+    rel = rel_of_position(rel_ptrs)
+    if fused_attn:
+        s = (torch.einsum("nhk,nhkd->nhd", k[row], rel_att[rel]) * q[col]).sum(-1)
+    else:
+        s = (torch.einsum("nhk,nhkd->nhd", q[col], rel_att[rel]) * k[row]).sum(-1)
+    mu = (rel_pri / (dk ** 0.5))[rel]
+    m = torch.exp(s * mu)
+    den = torch.zeros(num_nodes, H, dtype=h.dtype).index_add(0, col, m)
+    a = m / den[col]
+    msg = torch.einsum("nhk,nhkd->nhd", v[row] * a.unsqueeze(-1), rel_msg[rel])
+    new_h = torch.zeros(num_nodes, H, dk, dtype=h.dtype).index_add(0, col, msg).view(num_nodes, out_dim)
+    return typed_linear(new_h, torch.sigmoid(skip) * a_lin)

@@ -335,3 +335,150 @@ def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(eids, re
     fr = _rgcn_compact_rows(d, direct, rel_ptrs, row, eids)
     grad_feat.view(grad_feat.shape[0], -1).index_add_(
         0, fr, enorm.reshape(-1)[eids].unsqueeze(-1) * gradout.reshape(gradout.shape[0], -1)[col])
+
+
+# --------------------------------------------------------------------------
+# a12  edge-wise inner product  <left[lrow(i)], right[row[i]]>   (HGT attention score, unfused path)
+# --------------------------------------------------------------------------
+def _left_rows(d, kind: int, rel_ptrs, col, eids):
+    if kind == 0:
+        return eids
+    if kind == 1:  # compact left operand: row of (relation, col[i]) in the "_col" unique list
+        bound = int(max(int(col.max()), int(d["unique_srcs_and_dests_node_indices"].max()))) + 1 if col.numel() else 1
+        return _search_rows(d["unique_srcs_and_dests_rel_ptrs"], d["unique_srcs_and_dests_node_indices"],
+                            rel_of_position(rel_ptrs), col, bound)
+    if kind == 2:
+        return d["edata_idx_to_inverse_idx"][eids]
+    raise NotImplementedError(kind)
+
+
+def rgnn_inner_product_right_node_separatecoo(d, kind: int, rel_ptrs, eids, row, col, left, right, out) -> None:
+    """out[eids[i], h] = < left[lrow(i), h, :], right[row[i], h, :] >      (out overwritten)
+    lrow(i) = eids[i] (kind 0) | row of (rel(i), col[i]) in the unique list (kind 1) | inverse index (kind 2).
+    RGNNOps.inc.h:609-658 -> :296-440; kernel RGNN/InnerProductEdgeParallel.cu.h:13-113 (which names
+    the row index "dst"; the HGT layer passes left = q[dst].W_att per edge / per (rel, dst) and
+    right = k, hrt/python/HGT/models.py:217-241)."""
+    H = out.shape[1]
+    lr = _left_rows(d, kind, rel_ptrs, col, eids)
+    l = left.reshape(left.shape[0], H, -1)[lr]
+    r = right.reshape(right.shape[0], H, -1)[row]
+    out.view(-1, H)[eids] = (l * r).sum(-1)
+
+
+def backward_inner_product_right_node_separatecoo(d, kind: int, rel_ptrs, eids, row, col, left, right, gradout,
+                                                  grad_left, grad_right) -> None:
+    """grad_left[lrow(i), h, :] += gradout[eids[i], h] * right[row[i], h, :]
+    grad_right[row[i], h, :]  += gradout[eids[i], h] * left[lrow(i), h, :]
+    Accumulating (the CUDA kernel stores without atomics and mixes up row/col, SURVEY Q8:
+    RGNN/InnerProductEdgeParallel.cu.h:119-202).  RGNNOps.inc.h:1131-1181."""
+    H = gradout.shape[1]
+    lr = _left_rows(d, kind, rel_ptrs, col, eids)
+    g = gradout.reshape(-1, H)[eids].unsqueeze(-1)
+    grad_left.view(grad_left.shape[0], H, -1).index_add_(0, lr, g * right.reshape(right.shape[0], H, -1)[row])
+    grad_right.view(grad_right.shape[0], H, -1).index_add_(0, row, g * left.reshape(left.shape[0], H, -1)[lr])
+
+
+# --------------------------------------------------------------------------
+# a10  HGT edge softmax with per-relation temperature mu
+# --------------------------------------------------------------------------
+def hgt_full_graph_edge_softmax_ops_separate_coo(row, col, eids, rel_ptrs, score, mu, sum_, m, a) -> None:
+    """m[eid,h] = exp(score[eid,h] * mu[r,h]);  sum[dst,h] = SUM over in-edges of dst;  a = m / sum[dst].
+    Denominator keyed by the DESTINATION (col) over all E edges -- the intended semantics (the CUDA code
+    keys by row_indices and drops the last edge).  HGTOpsEdgeParallel.inc.h:18-31 ->
+    HGTOps.inc.h:23-106; kernels HGT/HGTForwardKernels.cu.h:594-761."""
+    H = score.shape[1]
+    rel = rel_of_position(rel_ptrs)
+    mm = torch.exp(score.reshape(-1, H)[eids] * mu.reshape(-1, H)[rel])
+    m.view(-1, H)[eids] = mm
+    sum_.zero_()
+    sum_.view(-1, H).index_add_(0, col, mm)
+    a.view(-1, H)[eids] = mm / sum_.view(-1, H)[col]
+
+
+def backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(row, col, eids, rel_ptrs, score, a, grad_a,
+                                                                          mu, grad_score, grad_mu, tmp) -> None:
+    """tmp[dst,h] = SUM_in-edges a*grad_a;  c = (grad_a - tmp[dst]) * a;
+    grad_score[eid,h] = c * mu[r,h];  grad_mu[r,h] += SUM c * score[eid,h].
+    Intended formulas from the kernel's own comments (HGT/HGTBackwardKernels.cu.h:161-168, 309-312;
+    the code omits '* score' and loops over a fraction of the edges).  HGTOps.inc.h:597-648."""
+    H = score.shape[1]
+    rel = rel_of_position(rel_ptrs)
+    av, gv = a.reshape(-1, H)[eids], grad_a.reshape(-1, H)[eids]
+    tmp.zero_()
+    tmp.view(-1, H).index_add_(0, col, av * gv)
+    c = (gv - tmp.view(-1, H)[col]) * av
+    grad_score.view(-1, H)[eids] = c * mu.reshape(-1, H)[rel]
+    grad_mu.view(-1, H).index_add_(0, rel, c * score.reshape(-1, H)[eids])
+
+
+# --------------------------------------------------------------------------
+# a11  HGT fused message generation + attention-weighted aggregation
+# --------------------------------------------------------------------------
+def hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(rel_ptrs, eids, row, col, v, W, a, new_h) -> None:
+    """new_h[col[i], h, :] += (v[row[i], h, :] * a[eids[i], h]) @ W[r, h]        (new_h zero-filled by the caller,
+    hgt_layers_and_funcs.py:462-469).  HGTOpsEdgeParallel.inc.h:33-88; kernel
+    my_shmem_sgemm_func_rgcn_hgt.cu.h:708-740."""
+    R, H, dk, do = W.shape
+    N = new_h.shape[0]
+    for r in range(R):
+        a0, b0 = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a0 == b0:
+            continue
+        msg = torch.einsum("nhk,hkd->nhd", v.reshape(v.shape[0], H, dk)[row[a0:b0]] * a.reshape(-1, H)[eids[a0:b0]].unsqueeze(-1), W[r])
+        new_h.view(N, H, do).index_add_(0, col[a0:b0], msg)
+
+
+def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(rel_ptrs, eids, row, col, v, Wt, a,
+                                                                                 new_h, grad_v, grad_W, grad_a,
+                                                                                 gradout) -> None:
+    """grad_v[row[i],h,:] += (gradout[col[i],h,:] * a) @ Wt[r,h]      (intended direction, same quirk as SURVEY Q3)
+    grad_W[r,h]        += (v[row[i],h,:] * a)^T (x) gradout[col[i],h,:]
+    grad_a[eids[i],h]   = < gradout[col[i],h,:] @ Wt[r,h], v[row[i],h,:] >
+    HGTOpsEdgeParallel.inc.h:295-369; kernels my_shmem_sgemm_func_rgcn_hgt.cu.h:747-816."""
+    R, H, do, dk = Wt.shape
+    N = gradout.shape[0]
+    for r in range(R):
+        a0, b0 = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a0 == b0:
+            continue
+        av = a.reshape(-1, H)[eids[a0:b0]].unsqueeze(-1)
+        go = gradout.reshape(N, H, do)[col[a0:b0]]
+        vv = v.reshape(v.shape[0], H, dk)[row[a0:b0]]
+        back = torch.einsum("nhd,hdk->nhk", go, Wt[r])
+        grad_v.view(v.shape[0], H, dk).index_add_(0, row[a0:b0], back * av)
+        grad_W[r] += torch.einsum("nhk,nhd->hkd", vv * av, go)
+        grad_a.view(-1, H)[eids[a0:b0]] = (back * vv).sum(-1)
+
+
+# --------------------------------------------------------------------------
+# HGT fused attention score (alternative to a1 + a12)
+# --------------------------------------------------------------------------
+def hgt_full_graph_hetero_attention_ops_coo(row, col, eids, rel_ptrs, k, q, W, inner, score) -> None:
+    """inner[eid,h,:] = k[row[i],h,:] @ W[r,h];  score[eid,h] = < inner[eid,h,:], q[col[i],h,:] >.
+    HGTOpsEdgeParallel.inc.h:95-158; kernel my_shmem_sgemm_func_rgcn_hgt.cu.h:823-857."""
+    R, H, dk, do = W.shape
+    for r in range(R):
+        a0, b0 = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a0 == b0:
+            continue
+        inn = torch.einsum("nhk,hkd->nhd", k.reshape(k.shape[0], H, dk)[row[a0:b0]], W[r])
+        inner.view(-1, H, do)[eids[a0:b0]] = inn
+        score.view(-1, H)[eids[a0:b0]] = (inn * q.reshape(q.shape[0], H, do)[col[a0:b0]]).sum(-1)
+
+
+def backward_hgt_full_graph_hetero_attention_ops_coo(in_row_ptrs, in_col, in_eids, in_reltypes, row, col, eids, rel_ptrs,
+                                                     grad_W, Wt, k, q, inner, grad_score, grad_k, grad_q) -> None:
+    """grad_q[col[i],h,:] += gs * inner[eid,h,:];  grad_k[row[i],h,:] += gs * (q[col[i],h,:] @ Wt[r,h]);
+    grad_W[r,h] += k[row[i],h,:]^T (x) (gs * q[col[i],h,:]),   gs = grad_score[eid,h].
+    HGTOpsEdgeParallel.inc.h:166-293 (the in-CSR arguments feed its vertex-parallel dq kernel; unused here)."""
+    R, H, do, dk = Wt.shape
+    for r in range(R):
+        a0, b0 = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+        if a0 == b0:
+            continue
+        gs = grad_score.reshape(-1, H)[eids[a0:b0]].unsqueeze(-1)
+        qq = q.reshape(q.shape[0], H, do)[col[a0:b0]]
+        kk = k.reshape(k.shape[0], H, dk)[row[a0:b0]]
+        grad_q.view(q.shape[0], H, do).index_add_(0, col[a0:b0], gs * inner.reshape(-1, H, do)[eids[a0:b0]])
+        grad_k.view(k.shape[0], H, dk).index_add_(0, row[a0:b0], torch.einsum("nhd,hdk->nhk", gs * qq, Wt[r]))
+        grad_W[r] += torch.einsum("nhk,nhd->hkd", kk, gs * qq)

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-MUST_EXPORT_OPS = [  # SURVEY.md section 8(b), ops built so far
+MUST_EXPORT_OPS = [  # the 20 compute + 5 layout + 1 info ops
     "build_debug_info", "transpose_csr", "convert_integrated_csr_to_separate_csr", "convert_integrated_csr_to_separate_coo",
     "convert_integrated_coo_to_separate_csr", "convert_integrated_coo_to_separate_coo",
     "rgnn_relational_matmul", "backward_rgnn_relational_matmul", "rgnn_relational_matmul_no_scatter_gather_list",
@@ -17,6 +17,11 @@ MUST_EXPORT_OPS = [  # SURVEY.md section 8(b), ops built so far
     "rgcn_node_mean_aggregation_compact_as_of_node_separate_coo",
     "backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", "relational_fused_gat_separate_coo",
     "backward_relational_fused_gat_separate_coo", "relational_fused_gat_csr", "backward_relational_fused_gat_csr",
+    "hgt_full_graph_edge_softmax_ops_separate_coo", "backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo",
+    "hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
+    "backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
+    "hgt_full_graph_hetero_attention_ops_coo", "backward_hgt_full_graph_hetero_attention_ops_coo",
+    "rgnn_inner_product_right_node_separatecoo", "backward_inner_product_right_node_separatecoo",
 ]
 
 

@@ -87,3 +87,41 @@ def test_rgcn_layer(compact, direct, K, D, R):
     assert_close(out, ref, what="out")
     assert_close(xd.grad, gx_r, what="grad_x")
     assert_close(layer.weight.grad, gw_r, what="grad_W")
+
+
+@pytest.mark.parametrize("fused_attn,compact,direct", [(False, False, False), (True, False, False), (False, True, False),
+                                                       (False, True, True)])
+@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8)])
+def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
+    """HGT layer (BASELINE.json configs[3]: feat 64, heads 8) against the plain-PyTorch fp64 oracle."""
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_HGTLayerHetero
+    from het_amd.synth import make_random
+    coo = make_random(300, 4, 4000, seed=51, num_ntypes=3)
+    g = HetGraph.from_integrated_coo(coo)
+    torch.manual_seed(2)
+    N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
+    layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn,
+                               compact_as_of_node_flag=compact, compact_direct_indexing_flag=direct)
+    with torch.no_grad():
+        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.skip.uniform_(-1, 1)
+    h, go = torch.randn(N, in_dim) * 0.5, torch.randn(N, out_dim)
+    s = g.get_separate_coo_original()
+    names = ["k_linears", "q_linears", "v_linears", "a_linears", "relation_att", "relation_msg", "relation_pri", "skip"]
+    p = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
+    h64 = h.double().requires_grad_(True)
+    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N,
+                       p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
+                       p["relation_pri"], p["skip"], H, fused_attn=fused_attn)
+    grads_ref = torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double())
+    g.to_(DEV)
+    layer = layer.to(DEV)
+    hd = h.to(DEV).requires_grad_(True)
+    out = layer(g, hd)
+    out.backward(go.to(DEV))
+    g.cpu_()
+    assert_close(out, ref, what="out")
+    assert_close(hd.grad, grads_ref[0], what="grad_h")
+    for n, gr in zip(names, grads_ref[1:]):
+        assert_close(getattr(layer, n).grad, gr, what="grad_" + n)

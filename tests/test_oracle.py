@@ -243,3 +243,76 @@ def test_rgcn_compact_aggregation(direct):
     gf = torch.zeros_like(feat)
     O.backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(*a, feat.detach(), enorm, ret, go, gf, direct)
     torch.testing.assert_close(gf, gf_ref)
+
+
+# ---------------------------------------------------------------- HGT ops vs autograd
+def test_hgt_ops_compose_to_layer_and_match_autograd():
+    """The HGT op oracles, chained as the reference layer chains them, reproduce the plain autograd layer:
+    outputs and every gradient (edge softmax backward, fused message backward, inner product backward)."""
+    from oracle import layers as OL
+    coo = make_random(31, 3, 140, seed=9, num_ntypes=3)
+    g = HetGraph.from_integrated_coo(coo)
+    s = g.get_separate_coo_original()
+    N, E, R, T, H, Din, Dout = g.get_num_nodes(), g.get_num_edges(), 3, 3, 2, 6, 8
+    dk = Dout // H
+    gen = torch.Generator().manual_seed(3)
+    mk = lambda *sh: (torch.randn(*sh, generator=gen, dtype=F64) * 0.4).requires_grad_(True)
+    h, k_lin, q_lin, v_lin, a_lin = mk(N, Din), mk(T, 1, Din, Dout), mk(T, 1, Din, Dout), mk(T, 1, Din, Dout), mk(T, 1, Dout, Dout)
+    rel_att, rel_msg, rel_pri, skip = mk(R, H, dk, dk), mk(R, H, dk, dk), mk(R, H), mk(T, 1, 1, 1)
+    offs = g.get_original_node_type_offsets()
+    for fused in (False, True):
+        ref = OL.hgt_layer(h, offs, s["rel_ptrs"], s["row_indices"], s["col_indices"], N, k_lin, q_lin, v_lin, a_lin,
+                           rel_att, rel_msg, rel_pri, skip, H, fused_attn=fused)
+        go = torch.randn(N, Dout, generator=gen, dtype=F64)
+        leaves = [h, k_lin, q_lin, v_lin, a_lin, rel_att, rel_msg, rel_pri]
+        grads_ref = torch.autograd.grad(ref, leaves, go)
+        # --- the same layer through the op oracles, manual backward
+        idx = (s["row_indices"], s["col_indices"], s["eids"], s["rel_ptrs"])
+        d = lambda t: t.detach()
+        lin = lambda W, x: (lambda r: (O.rgnn_relational_matmul_no_scatter_gather_list(offs, d(W), d(x), r), r)[1])(torch.zeros(x.shape[0], 1, W.shape[3], dtype=F64))
+        k, q, v = (lin(W, h).view(N, H, dk) for W in (k_lin, q_lin, v_lin))
+        score = torch.zeros(E, H, dtype=F64)
+        inner = torch.zeros(E, H, dk, dtype=F64)
+        dd = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"], "separate_coo_eids": s["eids"]}
+        if fused:
+            O.hgt_full_graph_hetero_attention_ops_coo(*idx, k, q, d(rel_att), inner, score)
+        else:
+            O.rgnn_relational_matmul(dd, 0, d(rel_att), q, inner, False)
+            O.rgnn_inner_product_right_node_separatecoo({}, 0, s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], inner, k, score)
+        mu = d(rel_pri) / dk ** 0.5
+        sm, m, a = torch.zeros(N, H, dtype=F64), torch.zeros(E, H, dtype=F64), torch.zeros(E, H, dtype=F64)
+        O.hgt_full_graph_edge_softmax_ops_separate_coo(*idx, score, mu, sm, m, a)
+        new_h = torch.zeros(N, H, dk, dtype=F64)
+        O.hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], v, d(rel_msg), a, new_h)
+        Wa = d(torch.sigmoid(skip) * a_lin)
+        out = lin(Wa, new_h.view(N, Dout)).view(N, Dout)
+        torch.testing.assert_close(out, ref.detach())
+        # backward
+        g_newh, g_Wa = torch.zeros(N, Dout, dtype=F64), torch.zeros_like(Wa)
+        O.backward_rgnn_relational_matmul_no_scatter_gather_list(offs, Wa.transpose(2, 3).contiguous(), new_h.view(N, Dout), go.view(N, 1, Dout), g_newh, g_Wa)
+        g_v, g_msgW, g_a = torch.zeros_like(v), torch.zeros_like(d(rel_msg)), torch.zeros(E, H, dtype=F64)
+        O.backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
+            s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], v, d(rel_msg).transpose(2, 3).contiguous(), a, new_h, g_v, g_msgW, g_a, g_newh.view(N, H, dk))
+        g_score, g_mu, tmp = torch.zeros(E, H, dtype=F64), torch.zeros(R, H, dtype=F64), torch.zeros(N, H, dtype=F64)
+        O.backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(*idx, score, a, g_a, mu, g_score, g_mu, tmp)
+        g_k, g_q, g_att = torch.zeros_like(k), torch.zeros_like(q), torch.zeros_like(d(rel_att))
+        if fused:
+            dummy = torch.zeros(0, dtype=torch.int64)
+            O.backward_hgt_full_graph_hetero_attention_ops_coo(dummy, dummy, dummy, dummy, *idx, g_att, d(rel_att).transpose(2, 3).contiguous(), k, q, inner, g_score, g_k, g_q)
+        else:
+            g_inner = torch.zeros_like(inner)
+            O.backward_inner_product_right_node_separatecoo({}, 0, s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], inner, k, g_score, g_inner, g_k)
+            O.backward_rgnn_relational_matmul(dd, 0, d(rel_att).transpose(2, 3).contiguous(), q, g_inner, g_q, g_att, False)
+        g_h = torch.zeros(N, Din, dtype=F64)
+        gWs = []
+        for W, gx in ((k_lin, g_k), (q_lin, g_q), (v_lin, g_v)):
+            gW = torch.zeros_like(d(W))
+            O.backward_rgnn_relational_matmul_no_scatter_gather_list(offs, d(W).transpose(2, 3).contiguous(), d(h), gx.reshape(N, 1, Dout), g_h, gW)
+            gWs.append(gW)
+        torch.testing.assert_close(g_h, grads_ref[0])
+        for got, want in zip(gWs, grads_ref[1:4]):
+            torch.testing.assert_close(got, want)
+        torch.testing.assert_close(g_Wa * torch.sigmoid(d(skip)), grads_ref[4])
+        torch.testing.assert_close(g_att, grads_ref[5])
+        torch.testing.assert_close(g_msgW, grads_ref[6])
+        torch.testing.assert_close(g_mu / dk ** 0.5, grads_ref[7])
