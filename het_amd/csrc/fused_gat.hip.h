@@ -18,3 +18,13 @@ int gat_backward_grouped(const het_grouping* by_dst, const EdgeView& v, const Ro
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
                          float* grad_er, int H, int D, float slope, hipStream_t s);
+
+// Compact kinds (1/3/4): by_srow groups the positions by feat row (payload0 = eids, payload1 = col), by_drow by
+// er row (payload0 = eids).  workspace: N*2H + E*H floats.
+bool gat_backward_compact_supported(const het_grouping* by_srow, const het_grouping* by_drow, int64_t E,
+                                    int64_t n_dst_rows, int H, int D, float slope);
+int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping* by_drow, const EdgeView& v,
+                                 int64_t n_src_rows, int64_t n_dst_rows, const float* feat, const float* sum,
+                                 const float* exp, const float* ret, const float* gradout, float* grad_feat,
+                                 float* grad_el, float* grad_er, float* workspace, int H, int D, float slope,
+                                 hipStream_t s);

@@ -5,6 +5,7 @@
 // is written once -- no float atomics except for hub destinations whose
 // segment was split over several items (> HET_ITEM_MAX in-edges).
 #include "fused_gat.hip.h"
+#include "seg_reduce.hip.h"
 
 namespace {
 
@@ -199,6 +200,98 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
   }
 }
 
+// ---- backward for the compact kinds (feat / el rows shared by all out-edges of a (relation, source)) ----
+// pack[v] = { 1/sum[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }: what an edge needs from its
+// destination besides the gradout row, in one 2H-float record.
+__global__ __launch_bounds__(kBlock) void HET_gat_dst_pack(const float* __restrict__ sum, const float* __restrict__ ret,
+                                                            const float* __restrict__ gradout, float* __restrict__ pack,
+                                                            int64_t N, int H, int D) {
+  const int64_t total = N * H, stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t v = t / H;
+    const int h = (int)(t - v * H);
+    const float* g = gradout + t * D;
+    const float* r = ret + t * D;
+    float dot = 0.f;
+    for (int d = 0; d < D; ++d) dot = fmaf(g[d], r[d], dot);
+    pack[v * 2 * H + h] = 1.f / sum[t];
+    pack[v * 2 * H + H + h] = dot;
+  }
+}
+
+// Wave per work item of the grouping by feat row u (payload0 = edge id, payload1 = destination):
+//   grad_feat[u,h,:] = SUM_e a_e * gradout[dst_e,h,:]
+//   t_e = a_e * dl_e * (<gradout[dst_e,h,:], feat[u,h,:]> - <gradout, ret>[dst_e,h]);  grad_el[u,h] = SUM_e t_e
+//   tbuf[eid_e,h] = t_e   (summed per er row by a second segmented pass)
+// a_e = exp[eid,h] / sum[dst,h];  dl_e = exp > 1 ? 1 : slope  (slope >= 0: exp(leaky(z)) > 1 <=> z > 0)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_gat_backward_src_grouped(
+    Items it, const int32_t* __restrict__ p_eid, const int32_t* __restrict__ p_dst, const float* __restrict__ feat,
+    const float* __restrict__ exp, const float* __restrict__ pack, const float* __restrict__ gradout,
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, int D, float slope) {
+  constexpr int EPW = 64 / LPR, U = 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t u = it.seg_key[seg];
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t X = (int64_t)H * D;
+  const float4 f = ld4(feat + u * X + x);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc_el = 0.f;
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int jc[U];
+    int64_t eid[U], dst[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int j = j0 + q * EPW;
+      jc[q] = j < e ? j : e - 1;
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) eid[q] = p_eid[jc[q]];
+#pragma unroll
+    for (int q = 0; q < U; ++q) dst[q] = p_dst[jc[q]];
+    float ex[U], sinv[U], gr[U];
+    float4 g[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) ex[q] = exp[eid[q] * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) sinv[q] = pack[dst[q] * 2 * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) gr[q] = pack[dst[q] * 2 * H + H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + dst[q] * X + x);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const bool ok = j0 + q * EPW < e;  // uniform within a lane group
+      const float a = ok ? ex[q] * sinv[q] : 0.f;
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float t = a * (ex[q] > 1.f ? 1.f : slope) * (dot - gr[q]);
+      if (ok && (sub & (DL - 1)) == 0) tbuf[eid[q] * H + h] = t;
+      acc_el += t;  // identical in the DL lanes of a head; one of them is kept below
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    acc_el += __shfl_xor(acc_el, off);
+  }
+  if (slot != 0) return;
+  float* gp = grad_feat + u * X + x;
+  if (b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1]) {
+    st4(gp, acc);
+    if ((sub & (DL - 1)) == 0) grad_el[u * H + h] = acc_el;
+  } else {
+    atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
+    if ((sub & (DL - 1)) == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+  }
+}
+
 inline unsigned grid_for(int64_t total) {
   int64_t b = ceil_div64(total, kBlock);
   const int64_t cap = 256 * 64;
@@ -276,4 +369,37 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   }
   HET_LAUNCH_CHECK("HET_gat_backward_grouped");
   return HET_OK;
+}
+
+int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping* by_drow, const EdgeView& v,
+                                 int64_t n_src_rows, int64_t n_dst_rows, const float* feat, const float* sum,
+                                 const float* exp, const float* ret, const float* gradout, float* grad_feat,
+                                 float* grad_el, float* grad_er, float* workspace, int H, int D, float slope,
+                                 hipStream_t s) {
+  if (v.E == 0) return HET_OK;
+  const int64_t X = (int64_t)H * D;
+  float* pack = workspace;               // [N, 2H]
+  float* tbuf = workspace + v.N * 2 * H; // [E, H]
+  hipLaunchKernelGGL(HET_gat_dst_pack, dim3(grid_for(v.N * H)), dim3(kBlock), 0, s, sum, ret, gradout, pack, v.N, H, D);
+  HET_LAUNCH_CHECK("HET_gat_dst_pack");
+  // rows whose segment was split accumulate atomically: start them (all) from zero
+  HET_HIP(hipMemsetAsync(grad_el, 0, sizeof(float) * n_src_rows * H, s));
+  if (by_srow->num_split > 0 || by_srow->S != n_src_rows)
+    HET_HIP(hipMemsetAsync(grad_feat, 0, sizeof(float) * n_src_rows * X, s));
+  Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key,
+           by_srow->num_items};
+  const unsigned nb = (unsigned)ceil_div64(by_srow->num_items, kBlock / 64);
+  HET_DISPATCH_LPR((int)(X / 4),
+                   hipLaunchKernelGGL(HET_gat_backward_src_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, by_srow->p0,
+                                      by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope));
+  HET_LAUNCH_CHECK("HET_gat_backward_src_grouped");
+  // grad_er[w, :] = SUM over the edges of er row w of tbuf[eid, :]   (segments of by_drow are the er rows in order)
+  return launch_segment_sum(by_drow, tbuf, grad_er, H, nullptr, s);
+}
+
+bool gat_backward_compact_supported(const het_grouping* by_srow, const het_grouping* by_drow, int64_t E,
+                                    int64_t n_dst_rows, int H, int D, float slope) {
+  return by_srow && by_drow && grouped_shape_ok(H, D) && segment_sum_supported(H) && slope >= 0.f && by_srow->E == E &&
+         by_drow->E == E && by_srow->R == 0 && by_drow->R == 0 && by_srow->p0 && by_srow->p1 && by_drow->p0 &&
+         by_drow->S == n_dst_rows;
 }

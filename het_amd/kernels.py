@@ -254,6 +254,28 @@ def _src_rows_by_position(kind, maps, rel_ptrs, row, eids):
     return srow
 
 
+def _dst_rows_by_position(kind, maps, rel_ptrs, col, eids):
+    """er row of every edge position for the compact kinds (cached per graph)."""
+    ca, cb = maps[2], maps[3]
+    key = ("d", kind, ca.data_ptr(), ca._version, None if cb is None else cb.data_ptr(), col.data_ptr(), eids.data_ptr())
+    hit = _derived.get(key)
+    if hit is not None:
+        return hit[0]
+    if kind == 4:
+        drow = ca[eids]
+    else:
+        R = rel_ptrs.numel() - 1
+        bound = int(max(int(col.max().item()), int(cb.max().item()))) + 1
+        rel_e = torch.repeat_interleave(torch.arange(R, device=col.device), rel_ptrs[1:] - rel_ptrs[:-1])
+        rel_u = torch.repeat_interleave(torch.arange(R, device=col.device), ca[1:] - ca[:-1])
+        drow = torch.searchsorted(rel_u * bound + cb, rel_e * bound + col)
+    drow = drow.contiguous()
+    if len(_derived) > 16:
+        _derived.clear()
+    _derived[key] = (drow, (ca, cb, col, eids))
+    return drow
+
+
 def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
     if not _plan.enabled:
         return None
@@ -322,11 +344,20 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
     D = ret.numel() // max(1, N * H)
     g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                 separate_coo_eids, N) if IntKind == 0 else None
+    gs = gd = ws = None
+    if IntKind != 0 and _plan.enabled and slope >= 0 and gat_grouped_shape_ok(H, D) and H >= 4 and E > 0:
+        srow = _src_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_eids)
+        drow = _dst_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
+        gs = _plan.get_grouping(None, srow, feat_src.shape[0], separate_coo_eids, separate_coo_col_indices)
+        gd = _plan.get_grouping(None, drow, er.shape[0], separate_coo_eids, None)
+        ws = torch.empty(N * 2 * H + E * H, dtype=torch.float32, device=ret.device)
     _call(ret, "het_backward_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
           _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
           None if g is None else _p(exp_sorted), _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D,
-          float(slope), None if g is None else g.handle, None, _stream(ret))
+          float(slope), None if g is None else g.handle, None if gs is None else gs.handle,
+          None if gd is None else gd.handle, feat_src.shape[0], er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
+          _stream(ret))
 
 
 @_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "

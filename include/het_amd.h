@@ -159,7 +159,11 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   kind 0: every feat/el/er row belongs to one edge, so the three gradients are OVERWRITTEN (stores, no
  *   atomics, no pre-zeroing needed) and grad_er may alias grad_el (same values).  Other kinds: "+=".
  *   exp_sorted: optional copy of exp in by_dst order written by the forward (slope >= 0 required: the
- *   leaky-ReLU branch is then recovered from exp > 1). */
+ *   leaky-ReLU branch is then recovered from exp > 1).
+ *   Compact kinds, optional fast path (slope >= 0): by_src_row = het_grouping_create(NULL, 0, srow, E,
+ *   n_src_rows, payload0 = eids, payload1 = col) over the feat row of every position, by_dst_row likewise
+ *   over the er row (payload0 = eids), workspace of (N*2H + E*H) floats; grad_feat / grad_el / grad_er are
+ *   then overwritten.  n_src_rows / n_dst_rows: rows of feat/el and of er. */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
@@ -170,7 +174,9 @@ int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const in
                                                    const float* exp_sorted,
                                                    const float* gradout, float* grad_feat, float* grad_el,
                                                    float* grad_er, int64_t H, int64_t D, double slope,
-                                                   const het_grouping* by_dst, const het_grouping* by_rel_src,
+                                                   const het_grouping* by_dst, const het_grouping* by_src_row,
+                                                   const het_grouping* by_dst_row, int64_t n_src_rows,
+                                                   int64_t n_dst_rows, void* workspace, int64_t workspace_bytes,
                                                    het_stream stream);
 
 /* a6  relational_fused_gat_csr / backward_relational_fused_gat_csr   RGATOps.inc.h:251-277, 430-460
