@@ -40,7 +40,10 @@ def parse():
                    help="reference layer flags: default = per-edge projections (the reference's default flags); "
                         "compact = --compact_as_of_node_flag --compact_direct_indexing_flag")
     p.add_argument("--edge-order", default="src", choices=["src", "random"])
+    p.add_argument("--model", default="rgat", choices=["rgat", "rgcn", "hgt"],
+                   help="rgat = the BASELINE.json metric; rgcn / hgt time BASELINE.json configs[1] / configs[3] (single GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
     p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample")
     return p.parse_args()
 
@@ -92,6 +95,42 @@ def cpu_baseline(args):
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
+def other_variants(args, coo, dev, steps, default_ms, default_value):
+    """The same layer under the reference's other flag combinations (identical outputs; its sweep runs them too,
+    hrt/utils/_do_all_cases.sh:2-40).  Reported next to the headline, which stays on the default flags."""
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    res = {"default": {"ms_per_step": round(default_ms, 4), "million_edges_per_s": round(default_value, 2)}}
+    g = HetGraph.from_integrated_coo(coo, full=True)
+    E, N = coo.num_edges, coo.num_nodes
+    for variant in ("compact",):
+        torch.manual_seed(0)
+        layer = HET_RGATLayer(args.feat, args.feat, g.get_num_rels(), args.heads, self_loop=True, dropout=0.0,
+                              **layer_flags(variant)).to(dev)
+        embed = torch.nn.Parameter(torch.empty(N, args.feat, device=dev))
+        torch.nn.init.xavier_uniform_(embed)
+        go = torch.randn(N, args.feat, device=dev)
+
+        def step():
+            for p in layer.parameters():
+                p.grad = None
+            embed.grad = None
+            layer(g, embed).backward(go)
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[variant] = {"ms_per_step": round(dt * 1e3, 4), "million_edges_per_s": round(E / dt / 1e6, 2),
+                        "flags": "--compact_as_of_node_flag --compact_direct_indexing_flag"}
+        del layer, embed, go
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -127,8 +166,19 @@ def main():
     else:
         for f in ("row", "col", "rel", "eids", "node_type_offsets"):
             setattr(coo, f, getattr(coo, f).to(dev))
-        g = HetGraph.from_integrated_coo(coo, full=args.variant.startswith("compact"))
-        layer = HET_RGATLayer(K, X, g.get_num_rels(), H, self_loop=True, dropout=0.0, **layer_flags(args.variant)).to(dev)
+        g = HetGraph.from_integrated_coo(coo, full=args.variant.startswith("compact") or args.model == "hgt")
+        extra = ()
+        if args.model == "rgat":
+            layer = HET_RGATLayer(K, X, g.get_num_rels(), H, self_loop=True, dropout=0.0, **layer_flags(args.variant)).to(dev)
+        elif args.model == "rgcn":
+            from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
+            layer = HET_EglRelGraphConv_EdgeParallel(K, X, g.get_num_rels(),
+                                                     compact_as_of_node_flag=args.variant.startswith("compact"),
+                                                     compact_direct_indexing_flag=args.variant.startswith("compact")).to(dev)
+            extra = (torch.rand(E_global, 1, device=dev),)  # edge norm, as RGCN.py:530
+        else:
+            from het_amd.layers import HET_HGTLayerHetero
+            layer = HET_HGTLayerHetero(g.get_num_ntypes(), g.get_num_rels(), K, X, num_heads=H, dropout=0.0).to(dev)
         embed = torch.nn.Parameter(torch.empty(N_global, K, device=dev))
         torch.nn.init.xavier_uniform_(embed)
         go = torch.randn(N_global, X, device=dev)
@@ -138,7 +188,7 @@ def main():
             for p in layer.parameters():
                 p.grad = None
             embed.grad = None
-            out = layer(g, embed)
+            out = layer(g, embed, *extra)
             out.backward(go)
 
     def barrier():
@@ -166,28 +216,40 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = E_global / (dt / args.steps) / 1e6
 
+    def pmc_traffic(kernel):
+        """HBM bytes per launch from the committed PMC passes of this same command (profiles/): rocprofv3 cannot
+        run inside the timed process.  None when no profile matches this workload."""
+        path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_default.json")
+        if args.scale != 1.0 or args.variant != "default" or world != 1 or not os.path.exists(path):
+            return None
+        rec = json.load(open(path))["kernels"].get(kernel)
+        return None if rec is None else rec["hbm_bytes_per_launch"]
+
     roofline = None
-    if ev and not args.variant.startswith("compact"):
+    if ev and not args.variant.startswith("compact") and args.model == "rgat":
         k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         nbytes = gat_bwd_bytes(E_local, N_local, H, X)
         ach = nbytes / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "HET_gat_backward_grouped (backward_relational_fused_gat_separate_coo, kind 0)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "frac_of_measured_copy_6.29TBs": round(ach / HBM_COPY_GBS, 4), "traffic": None,
+                    "frac_of_measured_copy_6.29TBs": round(ach / HBM_COPY_GBS, 4),
+                    "traffic": pmc_traffic("HET_gat_backward_grouped"),
                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes}
 
     if rank == 0:
         out = {
-            "metric": "million edges/s (fwd+bwd) RGAT layer, ogbn-mag feat=64",
+            "metric": f"million edges/s (fwd+bwd) {args.model.upper()} layer, ogbn-mag feat=64",
             "value": round(value, 2), "unit": "million edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RGAT layer fwd+bwd, ogbn-mag-shaped synthetic graph (N={N_global}, E={E_global}, R=4), "
+            "config": {"workload": f"{args.model.upper()} layer fwd+bwd, ogbn-mag-shaped synthetic graph (N={N_global}, E={E_global}, R=4), "
                                    f"feat={K}, heads={H}, self_loop, no optimizer step, layer flags: {args.variant}",
                        "edge_order": args.edge_order, "scale": args.scale,
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
+            out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

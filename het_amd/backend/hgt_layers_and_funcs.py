@@ -3,6 +3,7 @@
 wrappers :425-503) and the inner-product classes of rgnn_layers_and_funcs.py:192-418, 499-591."""
 import torch as th
 
+from .. import kernels as _k
 from ..kernels import K
 
 __all__ = [
@@ -114,10 +115,10 @@ class _InnerProduct(th.autograd.Function):
     @staticmethod
     def backward(ctx, gradout):
         map_a, map_b, rel_ptrs, eids, row, col, left, right = ctx.saved_tensors
-        grad_left = th.zeros_like(left, memory_format=th.contiguous_format)
-        grad_right = th.zeros_like(right, memory_format=th.contiguous_format)
-        K.backward_inner_product_right_node_separatecoo(_ip_dict(ctx.kind, map_a, map_b), ctx.kind, rel_ptrs, eids, row,
-                                                        col, left, right, gradout.contiguous(), grad_left, grad_right)
+        grad_left = th.empty_like(left, memory_format=th.contiguous_format)
+        grad_right = th.empty_like(right, memory_format=th.contiguous_format)
+        _k.inner_product_backward(_ip_dict(ctx.kind, map_a, map_b), ctx.kind, rel_ptrs, eids, row, col, left, right,
+                                  gradout.contiguous(), grad_left, grad_right, accumulate=False)
         return None, None, None, None, None, None, None, grad_left, grad_right, None
 
 

@@ -4,6 +4,8 @@
 // per-(edge, head) row scales; the edge-wise parts are the small kernels below.
 #include "edge_view.hip.h"
 #include "seg_gemm.hip.h"
+#include "seg_gemm_mfma.hip.h"
+#include "seg_reduce.hip.h"
 
 namespace {
 
@@ -170,6 +172,184 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_grad_attn(const idx_t* __restr
   }
 }
 
+// ---- row kernels: a feature row of X = H*D floats is covered by LPR = X/4 lanes (float4 each); the DL = D/4
+// lanes of a head combine with xor-shuffles; U rows per lane group are in flight per step -----------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+constexpr int UR = 4;
+
+// out[eids[i], h] = < left[lrow(i), h, :], right[ridx[i], h, :] >,  lrow = eid or map_a[eid]
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rows_inner_product(const idx_t* __restrict__ eids,
+                                                                  const idx_t* __restrict__ map_a,
+                                                                  const idx_t* __restrict__ ridx, int64_t E,
+                                                                  const float* __restrict__ left,
+                                                                  const float* __restrict__ right,
+                                                                  float* __restrict__ out, int H, int D) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t step = (int64_t)gridDim.x * 4 * EPW * UR;
+  for (int64_t base = (int64_t)blockIdx.x * 4 * EPW * UR; base < E; base += step) {
+    idx_t eid[UR], lr[UR], rr[UR];
+    bool ok[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int64_t i = base + (wave * UR + u) * EPW + slot;
+      ok[u] = i < E;
+      const int64_t ic = ok[u] ? i : E - 1;
+      eid[u] = eids[ic];
+      rr[u] = ridx[ic];
+    }
+    if (map_a) {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) lr[u] = map_a[eid[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) lr[u] = eid[u];
+    }
+    float4 l[UR], r[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) l[u] = ld4(left + lr[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) r[u] = ld4(right + rr[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      float p = l[u].x * r[u].x + l[u].y * r[u].y + l[u].z * r[u].z + l[u].w * r[u].w;
+      for (int off = DL >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
+      if (ok[u] && (sub & (DL - 1)) == 0) out[eid[u] * H + h] = p;
+    }
+  }
+}
+
+// grad_left[lrow(i), h, :] (+)= gout[eids[i], h] * right[ridx[i], h, :]
+// MODE 0: atomics (shared rows); 1: read-modify-write (one writer per row); 2: store
+template <int LPR, int MODE>
+__global__ __launch_bounds__(kBlock) void HET_rows_inner_product_bwd_left(const idx_t* __restrict__ eids,
+                                                                           const idx_t* __restrict__ map_a,
+                                                                           const idx_t* __restrict__ ridx, int64_t E,
+                                                                           const float* __restrict__ right,
+                                                                           const float* __restrict__ gout,
+                                                                           float* __restrict__ grad_left, int H, int D) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t step = (int64_t)gridDim.x * 4 * EPW * UR;
+  for (int64_t base = (int64_t)blockIdx.x * 4 * EPW * UR; base < E; base += step) {
+    idx_t eid[UR], lr[UR], rr[UR];
+    bool ok[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int64_t i = base + (wave * UR + u) * EPW + slot;
+      ok[u] = i < E;
+      const int64_t ic = ok[u] ? i : E - 1;
+      eid[u] = eids[ic];
+      rr[u] = ridx[ic];
+    }
+    if (map_a) {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) lr[u] = map_a[eid[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) lr[u] = eid[u];
+    }
+    float g[UR];
+    float4 r[UR], c[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) g[u] = gout[eid[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) r[u] = ld4(right + rr[u] * X + x);
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < UR; ++u) c[u] = ld4(grad_left + lr[u] * X + x);
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      if (!ok[u]) continue;
+      float* p = grad_left + lr[u] * X + x;
+      if (MODE == 2) st4(p, make_float4(g[u] * r[u].x, g[u] * r[u].y, g[u] * r[u].z, g[u] * r[u].w));
+      else if (MODE == 1) st4(p, make_float4(fmaf(g[u], r[u].x, c[u].x), fmaf(g[u], r[u].y, c[u].y), fmaf(g[u], r[u].z, c[u].z), fmaf(g[u], r[u].w, c[u].w)));
+      else { atomicAdd(p, g[u] * r[u].x); atomicAdd(p + 1, g[u] * r[u].y); atomicAdd(p + 2, g[u] * r[u].z); atomicAdd(p + 3, g[u] * r[u].w); }
+    }
+  }
+}
+
+// grad_a[eids[i], h] = < gradout[col[i],h,:] . Wt[r,h], v[row[i],h,:] >  with dk == dout == DK:
+// every lane turns its 4 gradout values into partial "back" values for all DK inputs (Wt slice in registers),
+// the DK/4 lanes of the head combine them, then dot with the lane's 4 v values.
+template <int LPR, int DK>
+__global__ __launch_bounds__(kBlock) void HET_hgt_grad_attn_rows(const idx_t* __restrict__ row, const idx_t* __restrict__ col,
+                                                                  const idx_t* __restrict__ eids,
+                                                                  const idx_t* __restrict__ rel_ptrs, int R, int chunk,
+                                                                  const float* __restrict__ vfeat,
+                                                                  const float* __restrict__ Wt,
+                                                                  const float* __restrict__ gradout,
+                                                                  float* __restrict__ grad_a, int H) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, DL = DK / 4, U2 = 2;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(rel_ptrs, R, chunk, blockIdx.x, r, rb, re)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / DK, d0 = x - h * DK;
+  float w[4][DK];  // Wt[r, h, d0 + j, :]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < DK; ++k) w[j][k] = Wt[(((int64_t)r * H + h) * DK + d0 + j) * DK + k];
+  for (idx_t base = rb; base < re; base += 4 * EPW * U2) {
+    idx_t sr[U2], ds[U2], eid[U2];
+    bool ok[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const idx_t i = base + (wave * U2 + u) * EPW + slot;
+      ok[u] = i < re;
+      const idx_t ic = ok[u] ? i : re - 1;
+      sr[u] = row[ic]; ds[u] = col[ic]; eid[u] = eids[ic];
+    }
+    float4 g[U2], vv[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) g[u] = ld4(gradout + ds[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < U2; ++u) vv[u] = ld4(vfeat + sr[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      float back[DK];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) back[k] = g[u].x * w[0][k] + g[u].y * w[1][k] + g[u].z * w[2][k] + g[u].w * w[3][k];
+#pragma unroll
+      for (int off = DL >> 1; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < DK; ++k) back[k] += __shfl_xor(back[k], off);
+      // this lane's v slice covers inputs d0 .. d0+3 of the head
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const float vk = (k == d0) ? vv[u].x : (k == d0 + 1) ? vv[u].y : (k == d0 + 2) ? vv[u].z : (k == d0 + 3) ? vv[u].w : 0.f;
+        t = fmaf(back[k], vk, t);
+      }
+      for (int off = DL >> 1; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      if (ok[u] && (sub & (DL - 1)) == 0) grad_a[eid[u] * H + h] = t;
+    }
+  }
+}
+
+inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+inline bool rows_shape_ok(int64_t H, int64_t D) {  // X/4 a power of two <= 64, a head = whole float4 pieces
+  const int64_t X = H * D;
+  return D >= 4 && is_pow2(D) && is_pow2(X) && X / 4 <= 64;
+}
+
+#define HET_HGT_LPR(LPRV, CALL)                         \
+  switch (LPRV) {                                       \
+    case 1: { constexpr int LPR = 1; CALL; break; }     \
+    case 2: { constexpr int LPR = 2; CALL; break; }     \
+    case 4: { constexpr int LPR = 4; CALL; break; }     \
+    case 8: { constexpr int LPR = 8; CALL; break; }     \
+    case 16: { constexpr int LPR = 16; CALL; break; }   \
+    case 32: { constexpr int LPR = 32; CALL; break; }   \
+    default: { constexpr int LPR = 64; CALL; break; }   \
+  }
+
 int check_edges(const char* op, const idx_t* row, const idx_t* col, const idx_t* eids, const idx_t* rel_ptrs,
                 int64_t R, int64_t E, int64_t N) {
   HET_REQUIRE(R > 0 && E >= 0 && N >= 0 && E < (1ll << 31) && N < (1ll << 31), "%s: bad sizes", op);
@@ -224,10 +404,27 @@ extern "C" int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_sepa
 extern "C" int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
     const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* v, const float* weights, const float* a, float* new_h, int64_t H,
-    int64_t dk, int64_t dout, het_stream stream) {
+    int64_t dk, int64_t dout, const het_grouping* by_rel_dst, void* workspace, int64_t workspace_bytes,
+    het_stream stream) {
   const char* op = "hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, num_nodes)) return rc;
   HET_REQUIRE(H > 0 && dk > 0 && dout > 0 && (num_edges == 0 || (v && weights && a && new_h)), "%s: null data pointer", op);
+  const het_grouping* gr = by_rel_dst;
+  if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && rows_shape_ok(H, dk) &&
+      segment_sum_supported((int)(H * dk)) && mfma_shape_supported((int)(H * dk), (int)(H * dout)) && workspace &&
+      workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dk && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(new_h) & 15) == 0) {
+    // new_h[dst] += SUM_r ( SUM_{e in (r,dst)} a[e,h] * v[src_e,h,:] ) . W[r,h]: attention-weighted segment sum of
+    // the source rows per (relation, destination), then one block-diagonal row GEMM per distinct pair
+    hipStream_t s = (hipStream_t)stream;
+    float* ssum = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(gr, v, ssum, (int)(H * dk), a, s, (int)H)) return rc;
+    MfmaGemmArgs m;
+    m.A = ssum; m.a_ld = H * dk; m.B = weights; m.b_rel_stride = H * dk * dout; m.b_headcat = 2; m.headcat_d = (int)dout;
+    m.blockdiag_k = (int)dk; m.C = new_h; m.c_ld = H * dout; m.scatter = gr->seg_key64; m.atomic = 1;
+    m.seg_ptrs = gr->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = gr->S; m.K = (int)(H * dk); m.X = (int)(H * dout);
+    return launch_seg_gemm_mfma(m, s);
+  }
   SegGemmArgs g;  // new_h[col, h, :] += (v[row, h, :] * a[eid, h]) . W[r, h]
   g.A = v; g.a_ld = H * dk; g.a_head_stride = dk; g.gather = row;
   g.row_scale = a; g.scale_idx = eids; g.scale_ld = H; g.scale_zs = 1;
@@ -242,7 +439,7 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
     const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* v, const float* weights_t, const float* a, const float* new_h,
     float* grad_v, float* grad_w, float* grad_a, const float* gradout, int64_t H, int64_t dk, int64_t dout,
-    het_stream stream) {
+    const het_grouping* by_rel_src, void* workspace, int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, num_nodes)) return rc;
   HET_REQUIRE(H > 0 && dk > 0 && dout > 0 &&
@@ -251,6 +448,36 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
   (void)new_h;
   if (num_edges == 0) return HET_OK;
   hipStream_t s = (hipStream_t)stream;
+  const het_grouping* gr = by_rel_src;
+  if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && dk == dout && (dk == 4 || dk == 8 || dk == 16) &&
+      rows_shape_ok(H, dk) && segment_sum_supported((int)(H * dout)) &&
+      mfma_shape_supported((int)(H * dout), (int)(H * dk)) && mfma_dw_supported((int)(H * dk), (int)(H * dout)) && workspace &&
+      workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(grad_v) & 15) == 0) {
+    // gsum[(r,u)] = SUM over the out-edges of u in relation r of a[e,h] * gradout[dst_e,h,:]; then
+    //   grad_v[u] += gsum . Wt[r] (block diagonal),  grad_w[r,h] += v[u,h,:]^T (x) gsum[(r,u),h,:]
+    float* gsum = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(gr, gradout, gsum, (int)(H * dout), a, s, (int)H)) return rc;
+    MfmaGemmArgs m;
+    m.A = gsum; m.a_ld = H * dout; m.B = weights_t; m.b_rel_stride = H * dout * dk; m.b_headcat = 2; m.headcat_d = (int)dk;
+    m.blockdiag_k = (int)dout; m.C = grad_v; m.c_ld = H * dk; m.scatter = gr->seg_key64; m.atomic = 1;
+    m.seg_ptrs = gr->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = gr->S; m.K = (int)(H * dout); m.X = (int)(H * dk);
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = v; w.a_ld = H * dk; w.gather = gr->seg_key64; w.G = gsum; w.g_ld = H * dout; w.dW = grad_w;
+    w.dw_rel_stride = H * dk * dout; w.headcat = 2; w.headcat_d = (int)dout; w.blockdiag_k = (int)dk;
+    w.seg_ptrs = gr->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gr->S; w.K = (int)(H * dk); w.X = (int)(H * dout);
+    if (int rc = launch_seg_dw_mfma(w, s)) return rc;
+    int64_t chunk = 4096;
+    dim3 grid((unsigned)(ceil_div64(num_edges, chunk) + num_rels)), block(kBlock);
+#define HET_GA(DKV) HET_HGT_LPR((int)(H * dk / 4), hipLaunchKernelGGL((HET_hgt_grad_attn_rows<LPR, DKV>), grid, block, 0, s, \
+                                row, col, eids, rel_ptrs, (int)num_rels, (int)chunk, v, weights_t, gradout, grad_a, (int)H))
+    if (dk == 4) { HET_GA(4); } else if (dk == 8) { HET_GA(8); } else { HET_GA(16); }
+#undef HET_GA
+    HET_LAUNCH_CHECK("HET_hgt_grad_attn_rows");
+    return HET_OK;
+  }
   SegGemmArgs g;  // grad_v[row, h, :] += (gradout[col, h, :] * a[eid, h]) . Wt[r, h]
   g.A = gradout; g.a_ld = H * dout; g.a_head_stride = dout; g.gather = col;
   g.row_scale = a; g.scale_idx = eids; g.scale_ld = H; g.scale_zs = 1;
@@ -283,6 +510,15 @@ extern "C" int het_rgnn_inner_product_right_node_separatecoo(
   HET_REQUIRE((kind == 0) || (map_a && (kind == 2 || map_b)), "%s: compact kinds need their index lists", op);
   HET_REQUIRE(H > 0 && D > 0 && (num_edges == 0 || (left && right && out)), "%s: null data pointer", op);
   if (num_edges == 0) return HET_OK;
+  if (kind != HET_KIND_ENABLED && rows_shape_ok(H, D) && (reinterpret_cast<uintptr_t>(left) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(right) & 15) == 0) {
+    const unsigned nb = grid_for(num_edges * (H * D / 4));
+    HET_HGT_LPR((int)(H * D / 4), hipLaunchKernelGGL(HET_rows_inner_product<LPR>, dim3(nb), dim3(kBlock), 0,
+                                                      (hipStream_t)stream, eids, kind == 2 ? map_a : nullptr, row,
+                                                      num_edges, left, right, out, (int)H, (int)D));
+    HET_LAUNCH_CHECK("HET_rows_inner_product");
+    return HET_OK;
+  }
   EdgeView v;
   v.E = num_edges; v.eids = eids; v.rel_ptrs = rel_ptrs; v.R = (int)num_rels;
   hipLaunchKernelGGL(HET_edge_inner_product, dim3(grid_for(num_edges * H)), dim3(kBlock), 0, (hipStream_t)stream, v,
@@ -294,18 +530,48 @@ extern "C" int het_rgnn_inner_product_right_node_separatecoo(
 extern "C" int het_backward_inner_product_right_node_separatecoo(
     int64_t kind, const int64_t* map_a, const int64_t* map_b, const int64_t* rel_ptrs, const int64_t* eids,
     const int64_t* row, const int64_t* col, int64_t num_rels, int64_t num_edges, const float* left, const float* right,
-    const float* gradout, float* grad_left, float* grad_right, int64_t H, int64_t D, het_stream stream) {
+    const float* gradout, float* grad_left, float* grad_right, int64_t H, int64_t D, int accumulate,
+    const het_grouping* by_right, int64_t n_left_rows, int64_t n_right_rows, het_stream stream) {
   const char* op = "backward_inner_product_right_node_separatecoo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, 0)) return rc;
   HET_REQUIRE(kind == 0 || kind == 1 || kind == 2, "%s: unsupported CompactAsOfNodeKind %lld", op, (long long)kind);
   HET_REQUIRE((kind == 0) || (map_a && (kind == 2 || map_b)), "%s: compact kinds need their index lists", op);
   HET_REQUIRE(H > 0 && D > 0 && (num_edges == 0 || (left && right && gradout && grad_left && grad_right)),
               "%s: null data pointer", op);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t X = H * D;
+  const het_grouping* gr = by_right;
+  const bool fast = kind != HET_KIND_ENABLED && rows_shape_ok(H, D) && gr && gr->R == 0 && gr->E == num_edges && gr->p0 &&
+                    gr->p1 && segment_sum_supported((int)X) && n_right_rows >= 0 && n_left_rows >= 0 &&
+                    (reinterpret_cast<uintptr_t>(left) & 15) == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(grad_left) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_right) & 15) == 0;
+  if (fast) {
+    // grad_left: one writer per row for kind 0 (left rows are edge rows) -> store / read-modify-write;
+    // shared compact rows (kind 2) -> atomics on zeroed rows
+    const idx_t* lmap = kind == 2 ? map_a : nullptr;
+    const int mode = kind == 0 ? (accumulate ? 1 : 2) : 0;
+    if (!accumulate && mode == 0) HET_HIP(hipMemsetAsync(grad_left, 0, sizeof(float) * n_left_rows * X, s));
+    if (num_edges > 0) {
+      const unsigned nb = grid_for(num_edges * (X / 4));
+#define HET_IPL(MODEV) HET_HGT_LPR((int)(X / 4), hipLaunchKernelGGL((HET_rows_inner_product_bwd_left<LPR, MODEV>), dim3(nb), \
+                                   dim3(kBlock), 0, s, eids, lmap, row, num_edges, right, gradout, grad_left, (int)H, (int)D))
+      if (mode == 2) { HET_IPL(2); } else if (mode == 1) { HET_IPL(1); } else { HET_IPL(0); }
+#undef HET_IPL
+      HET_LAUNCH_CHECK("HET_rows_inner_product_bwd_left");
+    }
+    // grad_right[node] (+)= SUM over the edges whose right operand is node of gout[e,h] * left[lrow(e),h,:]
+    return launch_segment_sum(gr, left, grad_right, (int)X, gradout, s, (int)H, n_right_rows, accumulate);
+  }
+  if (!accumulate) {
+    HET_REQUIRE(n_left_rows >= 0 && n_right_rows >= 0, "%s: row counts needed to overwrite the gradients", op);
+    HET_HIP(hipMemsetAsync(grad_left, 0, sizeof(float) * n_left_rows * X, s));
+    HET_HIP(hipMemsetAsync(grad_right, 0, sizeof(float) * n_right_rows * X, s));
+  }
   if (num_edges == 0) return HET_OK;
   EdgeView v;
   v.E = num_edges; v.eids = eids; v.rel_ptrs = rel_ptrs; v.R = (int)num_rels;
-  hipLaunchKernelGGL(HET_edge_inner_product_bwd, dim3(grid_for(num_edges * H * D)), dim3(kBlock), 0, (hipStream_t)stream,
-                     v, (int)kind, map_a, map_b, col, row, left, right, gradout, grad_left, grad_right, (int)H, (int)D);
+  hipLaunchKernelGGL(HET_edge_inner_product_bwd, dim3(grid_for(num_edges * H * D)), dim3(kBlock), 0, s, v, (int)kind,
+                     map_a, map_b, col, row, left, right, gradout, grad_left, grad_right, (int)H, (int)D);
   HET_LAUNCH_CHECK("HET_edge_inner_product_bwd");
   return HET_OK;
 }
@@ -320,6 +586,21 @@ extern "C" int het_hgt_full_graph_hetero_attention_ops_coo(
               "%s: null data pointer", op);
   if (num_edges == 0) return HET_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (mfma_shape_supported((int)(H * dk), (int)(H * dout)) && rows_shape_ok(H, dout) &&
+      (reinterpret_cast<uintptr_t>(k) & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(inner) & 15) == 0) {
+    MfmaGemmArgs m;  // inner[eid, :] = k[row, :] . blockdiag(W[r])
+    m.A = k; m.a_ld = H * dk; m.gather = row; m.B = weights; m.b_rel_stride = H * dk * dout; m.b_headcat = 2;
+    m.headcat_d = (int)dout; m.blockdiag_k = (int)dk; m.C = inner; m.c_ld = H * dout; m.scatter = eids;
+    m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_edges; m.K = (int)(H * dk); m.X = (int)(H * dout);
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    const unsigned nb = grid_for(num_edges * (H * dout / 4));
+    HET_HGT_LPR((int)(H * dout / 4), hipLaunchKernelGGL(HET_rows_inner_product<LPR>, dim3(nb), dim3(kBlock), 0, s, eids,
+                                                         (const idx_t*)nullptr, col, num_edges, inner, q, score, (int)H,
+                                                         (int)dout));
+    HET_LAUNCH_CHECK("HET_rows_inner_product");
+    return HET_OK;
+  }
   SegGemmArgs g;  // inner[eid, h, :] = k[row, h, :] . W[r, h]
   g.A = k; g.a_ld = H * dk; g.a_head_stride = dk; g.gather = row;
   g.B = weights; g.b_rel_stride = H * dk * dout; g.b_head_stride = dk * dout;
@@ -338,7 +619,9 @@ extern "C" int het_hgt_full_graph_hetero_attention_ops_coo(
 extern "C" int het_backward_hgt_full_graph_hetero_attention_ops_coo(
     const int64_t* row, const int64_t* col, const int64_t* eids, const int64_t* rel_ptrs, int64_t num_rels,
     int64_t num_edges, float* grad_w, const float* weights_t, const float* k, const float* q, const float* inner,
-    const float* grad_score, float* grad_k, float* grad_q, int64_t H, int64_t dk, int64_t dout, het_stream stream) {
+    const float* grad_score, float* grad_k, float* grad_q, int64_t H, int64_t dk, int64_t dout,
+    const het_grouping* by_dst, const het_grouping* by_rel_src, int64_t n_q_rows, void* workspace,
+    int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_hgt_full_graph_hetero_attention_ops_coo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, 0)) return rc;
   HET_REQUIRE(H > 0 && dk > 0 && dout > 0 &&
@@ -346,6 +629,30 @@ extern "C" int het_backward_hgt_full_graph_hetero_attention_ops_coo(
               "%s: null data pointer", op);
   if (num_edges == 0) return HET_OK;
   hipStream_t s = (hipStream_t)stream;
+  const het_grouping *gd = by_dst, *gs = by_rel_src;
+  if (gd && gs && gd->R == 0 && gd->E == num_edges && gd->p0 && gs->R == (int)num_rels && gs->E == num_edges && gs->p0 &&
+      gs->p1 && rows_shape_ok(H, dout) && segment_sum_supported((int)(H * dout)) &&
+      mfma_shape_supported((int)(H * dout), (int)(H * dk)) && mfma_dw_supported((int)(H * dk), (int)(H * dout)) &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * gs->S * H * dout && n_q_rows >= 0 &&
+      (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(inner) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_q) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(grad_k) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0) {
+    // grad_q[dst] += SUM_{e into dst} gs[e,h] * inner[e,h,:]     (by_dst: payload0 = eids)
+    if (int rc = launch_segment_sum(gd, inner, grad_q, (int)(H * dout), grad_score, s, (int)H, n_q_rows, 1)) return rc;
+    // qs[(r,u)] = SUM over the out-edges of u in relation r of gs[e,h] * q[dst_e,h,:]   (payload0 = col, payload1 = eids)
+    float* qs = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(gs, q, qs, (int)(H * dout), grad_score, s, (int)H)) return rc;
+    MfmaGemmArgs m;  // grad_k[u] += qs[(r,u)] . blockdiag(Wt[r])
+    m.A = qs; m.a_ld = H * dout; m.B = weights_t; m.b_rel_stride = H * dout * dk; m.b_headcat = 2; m.headcat_d = (int)dk;
+    m.blockdiag_k = (int)dout; m.C = grad_k; m.c_ld = H * dk; m.scatter = gs->seg_key64; m.atomic = 1;
+    m.seg_ptrs = gs->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = gs->S; m.K = (int)(H * dout); m.X = (int)(H * dk);
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;  // grad_w[r,h] += k[u,h,:]^T (x) qs[(r,u),h,:]
+    w.A = k; w.a_ld = H * dk; w.gather = gs->seg_key64; w.G = qs; w.g_ld = H * dout; w.dW = grad_w;
+    w.dw_rel_stride = H * dk * dout; w.headcat = 2; w.headcat_d = (int)dout; w.blockdiag_k = (int)dk;
+    w.seg_ptrs = gs->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gs->S; w.K = (int)(H * dk); w.X = (int)(H * dout);
+    return launch_seg_dw_mfma(w, s);
+  }
   EdgeView v;
   v.E = num_edges; v.eids = eids; v.rel_ptrs = rel_ptrs; v.R = (int)num_rels;
   // grad_q[col, h, :] += gs * inner[eid, h, :]

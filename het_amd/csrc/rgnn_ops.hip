@@ -40,6 +40,16 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
     return launch_rowdot_fwd(q, s);
   }
+  if (!in1head && H > 1 && mfma_shape_supported((int)(H * K), (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
+    // per-head K x D products (HGT: 8 heads of 8 x 8) as ONE row GEMM with a block-diagonal weight: the
+    // kernel is bound by moving the [rows, H*K] / [rows, H*D] tensors, not by the (mostly zero) MFMA work
+    MfmaGemmArgs m;
+    m.A = x; m.a_ld = H * K; m.gather = gather_idx; m.B = weights; m.b_rel_stride = H * K * D; m.b_headcat = 2;
+    m.headcat_d = (int)D; m.blockdiag_k = (int)K; m.C = ret; m.c_ld = H * D; m.scatter = scatter;
+    m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * K); m.X = (int)(H * D);
+    return launch_seg_gemm_mfma(m, s);
+  }
   SegGemmArgs a;
   a.A = x; a.gather = gather_idx; a.B = weights; a.C = ret; a.scatter = scatter;
   a.seg_ptrs = rel_ptrs; a.num_segs = (int)num_rels; a.num_rows = num_rows; a.KA = (int)K;
@@ -90,6 +100,33 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     return launch_rowdot_bwd_dw(q, s);
   }
   const het_grouping* g = by_rel_gather;
+  if (!in1head && H > 1 && mfma_shape_supported((int)(H * D), (int)(H * K)) && mfma_dw_supported((int)(H * K), (int)(H * D)) &&
+      (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // per-head products as block-diagonal row GEMMs (see the forward)
+    const bool grouped = g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
+                         segment_sum_supported((int)(H * D)) && workspace &&
+                         workspace_bytes >= (int64_t)sizeof(float) * g->S * H * D &&
+                         (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    const float* G = gradout;
+    const idx_t *g_rows = scatter, *x_rows = gather_idx, *segs = rel_ptrs;
+    int64_t rows = num_rows;
+    if (grouped) {
+      float* gsum = static_cast<float*>(workspace);
+      if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s)) return rc;
+      G = gsum; g_rows = nullptr; x_rows = g->seg_key64; segs = g->seg_rel_ptr64; rows = g->S;
+    }
+    MfmaGemmArgs m;
+    m.A = G; m.a_ld = H * D; m.gather = g_rows; m.B = weights_t; m.b_rel_stride = H * D * K; m.b_headcat = 2;
+    m.headcat_d = (int)K; m.blockdiag_k = (int)D; m.C = grad_x; m.c_ld = H * K; m.scatter = x_rows; m.atomic = 1;
+    m.seg_ptrs = segs; m.num_segs = (int)num_rels; m.num_rows = rows; m.K = (int)(H * D); m.X = (int)(H * K);
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = x; w.a_ld = H * K; w.gather = x_rows; w.G = G; w.g_ld = H * D; w.g_gather = g_rows;
+    w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 2; w.headcat_d = (int)D; w.blockdiag_k = (int)K;
+    w.seg_ptrs = segs; w.num_segs = (int)num_rels; w.num_rows = rows; w.K = (int)(H * K); w.X = (int)(H * D);
+    return launch_seg_dw_mfma(w, s);
+  }
   if (in1head && g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
       mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
       segment_sum_supported((int)(H * D)) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H * D &&
@@ -241,11 +278,26 @@ extern "C" int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64
                                             const int64_t* col, int64_t num_rels, int64_t num_edges,
                                             int64_t num_nodes, const float* x, const float* weights,
                                             const float* norm, float* ret, int64_t K, int64_t D,
-                                            const het_grouping* by_rel_dst, het_stream stream) {
+                                            const het_grouping* by_rel_dst, void* workspace, int64_t workspace_bytes,
+                                            het_stream stream) {
   const char* op = "rgcn_layer1_separate_coo";
   HET_REQUIRE(num_rels > 0 && num_edges >= 0 && num_nodes >= 0 && K > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(rel_ptrs && (num_edges == 0 || (eids && row && col && x && weights && norm && ret)), "%s: null pointer", op);
-  (void)by_rel_dst;
+  const het_grouping* g = by_rel_dst;
+  if (g && g->R == (int)num_rels && g->E == num_edges && g->p0 && g->p1 && segment_sum_supported((int)K) &&
+      mfma_shape_supported((int)K, (int)D) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * K &&
+      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
+    // Edges that share (relation, destination) share weight and output row: sum their scaled source rows first
+    // (one gather pass over x), then one GEMM row per distinct (relation, destination) pair, added into ret.
+    hipStream_t s = (hipStream_t)stream;
+    float* ssum = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(g, x, ssum, (int)K, norm, s)) return rc;
+    MfmaGemmArgs m;
+    m.A = ssum; m.a_ld = K; m.B = weights; m.b_rel_stride = K * D; m.C = ret; m.c_ld = D; m.scatter = g->seg_key64;
+    m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)K; m.X = (int)D;
+    return launch_seg_gemm_mfma(m, s);
+  }
   SegGemmArgs a;
   a.A = x; a.a_ld = K; a.gather = row; a.row_scale = norm; a.scale_idx = eids;
   a.B = weights; a.b_rel_stride = K * D; a.C = ret; a.c_ld = D; a.scatter = col; a.atomic = 1;
@@ -258,14 +310,32 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
                                                      int64_t num_nodes, const float* x, const float* weights_t,
                                                      const float* norm, float* grad_norm, float* grad_x,
                                                      const float* gradout, float* grad_w, int64_t K, int64_t D,
-                                                     const het_grouping* by_rel_src, const het_grouping* by_rel_dst,
-                                                     het_stream stream) {
+                                                     const het_grouping* by_rel_src, void* workspace,
+                                                     int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgcn_layer1_separate_coo";
   HET_REQUIRE(num_rels > 0 && num_edges >= 0 && num_nodes >= 0 && K > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(rel_ptrs && (num_edges == 0 || (eids && row && col && x && weights_t && norm && grad_x && gradout && grad_w)),
               "%s: null pointer", op);
-  (void)grad_norm; (void)by_rel_src; (void)by_rel_dst;
+  (void)grad_norm;
   hipStream_t s = (hipStream_t)stream;
+  const het_grouping* g = by_rel_src;
+  if (g && g->R == (int)num_rels && g->E == num_edges && g->p0 && g->p1 && segment_sum_supported((int)D) &&
+      mfma_shape_supported((int)D, (int)K) && mfma_dw_supported((int)K, (int)D) && workspace &&
+      workspace_bytes >= (int64_t)sizeof(float) * g->S * D && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+    // gsum[(r,u)] = SUM over the out-edges of u in relation r of norm * gradout[dst]; then
+    //   grad_x[u] += gsum[(r,u)] . Wt[r]      and      grad_w[r] += x[u]^T (x) gsum[(r,u)]
+    float* gsum = static_cast<float*>(workspace);
+    if (int rc = launch_segment_sum(g, gradout, gsum, (int)D, norm, s)) return rc;
+    MfmaGemmArgs m;
+    m.A = gsum; m.a_ld = D; m.B = weights_t; m.b_rel_stride = D * K; m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64;
+    m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)D; m.X = (int)K;
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    MfmaDwArgs w;
+    w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = gsum; w.g_ld = D; w.dW = grad_w; w.dw_rel_stride = K * D;
+    w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S; w.K = (int)K; w.X = (int)D;
+    return launch_seg_dw_mfma(w, s);
+  }
   SegGemmArgs a;  // grad_x[row] += (gradout[col] * norm) . Wt[r]
   a.A = gradout; a.a_ld = D; a.gather = col; a.row_scale = norm; a.scale_idx = eids;
   a.B = weights_t; a.b_rel_stride = D * K; a.C = grad_x; a.c_ld = K; a.scatter = row; a.atomic = 1;

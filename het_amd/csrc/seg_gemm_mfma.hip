@@ -35,9 +35,13 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   float* Ws = smem + (B_REGS ? 0 : K * X) + wave * WREG;      // wave-private: A tile [32][LDA], then C tile [32][LDC]
   const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
   auto b_elem = [&](int k, int n) -> float {
-    if (a.b_headcat) {
+    if (a.b_headcat == 1) {
       const int Dh = a.headcat_d, h = n / Dh, d = n - h * Dh;
       return Bm[(int64_t)h * K * Dh + (int64_t)k * Dh + d];
+    }
+    if (a.b_headcat == 2) {  // block diagonal: per-head [Kh x Dh] blocks, A and C rows are [H*Kh] / [H*Dh]
+      const int Dh = a.headcat_d, Kh = a.blockdiag_k, hk = k / Kh, hn = n / Dh;
+      return hk == hn ? Bm[((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (n - hn * Dh)] : 0.f;
     }
     return Bm[k * X + n];
   };
@@ -251,9 +255,13 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
           const float v = acc[kt][nt][e] + smem[o] + smem[NACC * 64 + o] + smem[2 * NACC * 64 + o];
           const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, nn = nt * 32 + col;
           int64_t off;
-          if (a.headcat) {
+          if (a.headcat == 1) {
             const int h = nn / Dh, d = nn - h * Dh;
             off = (int64_t)h * K * Dh + (int64_t)k * Dh + d;
+          } else if (a.headcat == 2) {  // keep the per-head diagonal blocks of the full product only
+            const int Kh = a.blockdiag_k, hk = k / Kh, hn = nn / Dh;
+            if (hk != hn) continue;
+            off = ((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (nn - hn * Dh);
           } else {
             off = (int64_t)k * X + nn;
           }

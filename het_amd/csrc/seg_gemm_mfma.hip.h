@@ -11,7 +11,8 @@ struct MfmaGemmArgs {
   const idx_t* scale_idx = nullptr;
   const float* B = nullptr;       // per segment: plain [K][X], or head-concatenated [Hc][K][Dh]
   int64_t b_rel_stride = 0;
-  int b_headcat = 0, headcat_d = 1;
+  int b_headcat = 0, headcat_d = 1;  // 0 plain [K][X]; 1 head-concatenated [Hc][K][Dh]; 2 block diagonal [H][Kh][Dh]
+  int blockdiag_k = 1;               // Kh for layout 2
   float* C = nullptr;             // [*, X]
   int64_t c_ld = 0;
   const idx_t* scatter = nullptr; // NULL: identity
@@ -52,7 +53,8 @@ struct MfmaDwArgs {
   const idx_t* g_gather = nullptr;
   float* dW = nullptr;
   int64_t dw_rel_stride = 0;
-  int headcat = 0, headcat_d = 1;
+  int headcat = 0, headcat_d = 1;    // 0 plain; 1 head-concatenated; 2 block diagonal (per-head Kh x Dh blocks)
+  int blockdiag_k = 1;
   const idx_t* seg_ptrs = nullptr;
   int num_segs = 0;
   int64_t num_rows = 0;

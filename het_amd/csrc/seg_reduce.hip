@@ -14,14 +14,17 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
                                                            const int32_t* __restrict__ seg_ptr, int64_t num_items,
                                                            const int32_t* __restrict__ p_row,
                                                            const int32_t* __restrict__ p_scale,
-                                                           const float* __restrict__ scale,
-                                                           const float* __restrict__ in, float* __restrict__ out) {
+                                                           const float* __restrict__ scale, int scale_heads,
+                                                           const float* __restrict__ in, float* __restrict__ out,
+                                                           const int32_t* __restrict__ out_row, int accumulate) {
   constexpr int EPW = 64 / LPR, X = LPR * 4;
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= num_items) return;
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
   const int slot = lane / LPR, x = (lane % LPR) * 4;
+  // per-row scale: one float per row (scale_heads == 0) or one per (row, head), heads of X/scale_heads floats
+  const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int U = 4;  // rows per lane group and step, loads issued in independent phases
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 #pragma unroll
       for (int u = 0; u < U; ++u) si[u] = p_scale[jc[u]];
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = scale[si[u]];
+      for (int u = 0; u < U; ++u) w[u] = scale[(int64_t)si[u] * sld + sh];
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) w[u] = 1.f;
@@ -61,8 +64,12 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
     acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
   }
   if (slot != 0) return;
-  float* p = out + (int64_t)seg * X + x;
+  float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + x;
   if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) {
+    if (accumulate) {  // the segment's only writer: plain read-modify-write
+      const float4 c = ld4(p);
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+    }
     st4(p, acc);
   } else {
     atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
@@ -73,13 +80,23 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 
 bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
 
-int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s) {
-  HET_REQUIRE(segment_sum_supported(X) && g->p0 && (!scale || g->p1), "segment sum: unsupported shape or grouping");
+int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
+                       int scale_heads, int64_t scatter_rows, int accumulate) {
+  HET_REQUIRE(segment_sum_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
+  HET_REQUIRE(scale_heads == 0 || (X % scale_heads == 0 && (X / scale_heads) % 4 == 0),
+              "segment sum: a head must cover whole float4 pieces");
+  // scatter_rows >= 0: out has that many rows and segment s lands in row seg_key[s] (rows without a
+  // segment read zero unless accumulating); otherwise out is dense [S, X]
+  const int32_t* out_row = scatter_rows >= 0 ? g->seg_key : nullptr;
+  if (!accumulate) {
+    if (scatter_rows >= 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * scatter_rows * X, s));
+    else if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+  }
   if (g->S == 0) return HET_OK;
-  if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+  const int32_t* p_scale = g->p1 ? g->p1 : g->p0;
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
 #define HET_SS(L) hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, \
-                                     g->item_end, g->seg_ptr, g->num_items, g->p0, g->p1, scale, in, out)
+                                     g->item_end, g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate)
   switch (X / 4) {
     case 1: HET_SS(1); break;
     case 2: HET_SS(2); break;

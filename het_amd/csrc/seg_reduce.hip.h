@@ -2,7 +2,11 @@
 #pragma once
 #include "grouping.hip.h"
 
-// row(j) = g->p0[j] (payload0 of the grouping); w(j) = scale[g->p1[j]] when scale != NULL, else 1.
+// row(j) = g->p0[j] (payload0 of the grouping); w(j) = scale[g->p1[j]] when scale != NULL, else 1; with
+// scale_heads = H > 0 the scale is per (row, head): scale[g->p1[j] * H + h] for the X/H floats of head h.
 // X floats per row, X/4 a power of two <= 64.  `out` has g->S rows and is fully overwritten.
 bool segment_sum_supported(int X);
-int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s);
+// scatter_rows >= 0: `out` has scatter_rows rows and segment s is written to row seg_key[s] instead of row s.
+// accumulate: add to `out` instead of overwriting it.  The scale index is payload1, or payload0 without one.
+int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
+                       int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0);

@@ -265,9 +265,13 @@ class HetGraph:
         return {k: o[k] for k in ("rel_types", "row_indices", "col_indices", "eids")}
 
     def get_out_csr(self):
+        if "out_csr" not in self.graph_data:
+            self.generate_csrs()
         return dict(self.graph_data["out_csr"])
 
     def get_in_csr(self):
+        if "transposed" not in self.graph_data:
+            self.generate_csrs()
         return dict(self.graph_data["transposed"])
 
     def get_original_node_type_offsets(self):

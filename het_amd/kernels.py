@@ -165,7 +165,7 @@ def matmul_backward(args_tensor_dict, IntKind, weights_transposed, node_feat, gr
          tuple(t for t in (rp, g, s) if t is not None))
     R, H, D, K = weights_transposed.shape
     grp, ws = None, None
-    if IntKind == 0 and InputNumHeadOneFlag and g.data_ptr() != s.data_ptr():
+    if IntKind == 0 and g.data_ptr() != s.data_ptr() and (InputNumHeadOneFlag or D > 1):
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
         if grp is not None:
             ws = torch.empty(max(1, grp.num_segments) * H * D, dtype=torch.float32, device=gradout.device)
@@ -406,10 +406,13 @@ def rgcn_layer1_separate_coo(separate_coo_relptrs, separate_coo_eids, separate_c
     _chk("rgcn_layer1_separate_coo", (node_feat_input, weights, edge_norm, node_feat_output),
          (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
     R, K, D = weights.shape
+    N = node_feat_output.shape[0]
+    g = _plan.get_grouping(separate_coo_relptrs, separate_coo_col_indices, N, separate_coo_row_indices, separate_coo_eids)
+    ws = None if g is None else torch.empty(max(1, g.num_segments) * K, dtype=torch.float32, device=weights.device)
     _call(node_feat_output, "het_rgcn_layer1_separate_coo", _p(separate_coo_relptrs), _p(separate_coo_eids),
-          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(),
-          node_feat_output.shape[0], _p(node_feat_input), _p(weights), _p(edge_norm), _p(node_feat_output), K, D, None,
-          _stream(node_feat_output))
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(), N,
+          _p(node_feat_input), _p(weights), _p(edge_norm), _p(node_feat_output), K, D, None if g is None else g.handle,
+          _p(ws), 0 if ws is None else ws.numel() * 4, _stream(node_feat_output))
 
 
 @_op("backward_rgcn_layer1_separate_coo(Tensor separate_coo_relptrs, Tensor separate_coo_eids, "
@@ -423,11 +426,15 @@ def backward_rgcn_layer1_separate_coo(separate_coo_relptrs, separate_coo_eids, s
          (node_feat_input, weights_transposed, edge_norm, delta_node_feat_input, delta_node_feat_output, delta_weights),
          (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
     R, D, K = weights_transposed.shape
+    N = delta_node_feat_output.shape[0]
+    g = _plan.get_grouping(separate_coo_relptrs, separate_coo_row_indices, node_feat_input.shape[0],
+                           separate_coo_col_indices, separate_coo_eids)
+    ws = None if g is None else torch.empty(max(1, g.num_segments) * D, dtype=torch.float32, device=delta_weights.device)
     _call(delta_weights, "het_backward_rgcn_layer1_separate_coo", _p(separate_coo_relptrs), _p(separate_coo_eids),
-          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(),
-          delta_node_feat_output.shape[0], _p(node_feat_input), _p(weights_transposed), _p(edge_norm),
-          _p(grad_edge_norm), _p(delta_node_feat_input), _p(delta_node_feat_output), _p(delta_weights), K, D, None, None,
-          _stream(delta_weights))
+          _p(separate_coo_row_indices), _p(separate_coo_col_indices), R, separate_coo_eids.numel(), N,
+          _p(node_feat_input), _p(weights_transposed), _p(edge_norm), _p(grad_edge_norm), _p(delta_node_feat_input),
+          _p(delta_node_feat_output), _p(delta_weights), K, D, None if g is None else g.handle, _p(ws),
+          0 if ws is None else ws.numel() * 4, _stream(delta_weights))
 
 
 def _rgcn_maps(d: Dict[str, Tensor], direct: bool):
@@ -522,12 +529,37 @@ def backward_inner_product_right_node_separatecoo(arg_tensor_dict, IntKind, sepa
          (left_side_data, right_node_vectors, gradout, grad_left_side_data, grad_right_node_vectors),
          (separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(t for t in (a, b) if t is not None))
+    inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices,
+                           separate_coo_col_indices, left_side_data, right_node_vectors, gradout, grad_left_side_data,
+                           grad_right_node_vectors, accumulate=True, checked=True)
+
+
+def inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices,
+                           separate_coo_col_indices, left_side_data, right_node_vectors, gradout, grad_left_side_data,
+                           grad_right_node_vectors, accumulate: bool, checked: bool = False):
+    a, b = _ip_maps(arg_tensor_dict, IntKind)
+    if not checked:
+        _chk("backward_inner_product_right_node_separatecoo",
+             (left_side_data, right_node_vectors, gradout, grad_left_side_data, grad_right_node_vectors),
+             (separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices)
+             + tuple(t for t in (a, b) if t is not None))
     H = gradout.shape[1]
     D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
+    g = None
+    if IntKind in (0, 2) and _plan.enabled:
+        if IntKind == 0:
+            lrow = separate_coo_eids
+        else:
+            key = ("iplrow", a.data_ptr(), a._version, separate_coo_eids.data_ptr())
+            hit = _derived.get(key)
+            lrow = hit[0] if hit is not None else a[separate_coo_eids].contiguous()
+            _derived[key] = (lrow, (a, separate_coo_eids))
+        g = _plan.get_grouping(None, separate_coo_row_indices, right_node_vectors.shape[0], lrow, separate_coo_eids)
     _call(gradout, "het_backward_inner_product_right_node_separatecoo", IntKind, _p(a), _p(b),
           _p(separate_coo_rel_ptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), _p(left_side_data), _p(right_node_vectors),
-          _p(gradout), _p(grad_left_side_data), _p(grad_right_node_vectors), H, D, _stream(gradout))
+          _p(gradout), _p(grad_left_side_data), _p(grad_right_node_vectors), H, D, int(accumulate),
+          None if g is None else g.handle, left_side_data.shape[0], right_node_vectors.shape[0], _stream(gradout))
 
 
 @_op("hgt_full_graph_edge_softmax_ops_separate_coo(Tensor row_indices, Tensor col_indices, Tensor eids, Tensor rel_ptrs, "
@@ -574,10 +606,13 @@ def hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(separate
     _chk("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", (inputs, weights, edge_norm, new_h),
          (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
     R, H, dk, dout = weights.shape
+    g = _plan.get_grouping(separate_coo_relptrs, separate_coo_col_indices, new_h.shape[0], separate_coo_row_indices,
+                           separate_coo_eids)
+    ws = None if g is None else torch.empty(max(1, g.num_segments) * H * dk, dtype=torch.float32, device=new_h.device)
     _call(new_h, "het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", _p(separate_coo_relptrs),
           _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices), R,
           separate_coo_eids.numel(), new_h.shape[0], _p(inputs), _p(weights), _p(edge_norm), _p(new_h), H, dk, dout,
-          _stream(new_h))
+          None if g is None else g.handle, _p(ws), 0 if ws is None else ws.numel() * 4, _stream(new_h))
 
 
 @_op("backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "
@@ -591,10 +626,14 @@ def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo
          (inputs, weights_transposed, edge_norm, new_h, grad_input, grad_weights, grad_edge_norm, gradout),
          (separate_coo_relptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices))
     R, H, dout, dk = weights_transposed.shape
+    g = _plan.get_grouping(separate_coo_relptrs, separate_coo_row_indices, inputs.shape[0], separate_coo_col_indices,
+                           separate_coo_eids)
+    ws = None if g is None else torch.empty(max(1, g.num_segments) * H * dout, dtype=torch.float32, device=gradout.device)
     _call(gradout, "het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
           _p(separate_coo_relptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           R, separate_coo_eids.numel(), new_h.shape[0], _p(inputs), _p(weights_transposed), _p(edge_norm), _p(new_h),
-          _p(grad_input), _p(grad_weights), _p(grad_edge_norm), _p(gradout), H, dk, dout, _stream(gradout))
+          _p(grad_input), _p(grad_weights), _p(grad_edge_norm), _p(gradout), H, dk, dout,
+          None if g is None else g.handle, _p(ws), 0 if ws is None else ws.numel() * 4, _stream(gradout))
 
 
 @_op("hgt_full_graph_hetero_attention_ops_coo(Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, "
@@ -633,11 +672,17 @@ def backward_hgt_full_graph_hetero_attention_ops_coo(incsr_row_ptrs, incsr_col_i
           attn_score_inner_product, grad_unnorm_attn_score, grad_k, grad_q),
          (separate_coo_row_indices, separate_coo_col_indices, separate_coo_eids, separate_coo_relptrs))
     R, H, dout, dk = attn_score_weight_transposed.shape
+    nq = applied_qlinear_node_features.shape[0]
+    gd = _plan.get_grouping(None, separate_coo_col_indices, nq, separate_coo_eids, None)
+    gs = _plan.get_grouping(separate_coo_relptrs, separate_coo_row_indices, applied_klinear_node_features.shape[0],
+                            separate_coo_col_indices, separate_coo_eids)
+    ws = None if gs is None else torch.empty(max(1, gs.num_segments) * H * dout, dtype=torch.float32, device=grad_k.device)
     _call(grad_k, "het_backward_hgt_full_graph_hetero_attention_ops_coo", _p(separate_coo_row_indices),
           _p(separate_coo_col_indices), _p(separate_coo_eids), _p(separate_coo_relptrs), R, separate_coo_eids.numel(),
           _p(grad_attn_weight), _p(attn_score_weight_transposed), _p(applied_klinear_node_features),
           _p(applied_qlinear_node_features), _p(attn_score_inner_product), _p(grad_unnorm_attn_score), _p(grad_k),
-          _p(grad_q), H, dk, dout, _stream(grad_k))
+          _p(grad_q), H, dk, dout, None if gd is None else gd.handle, None if gs is None else gs.handle, nq, _p(ws),
+          0 if ws is None else ws.numel() * 4, _stream(grad_k))
 
 
 REGISTERED_OPS = tuple(_registered)

@@ -201,7 +201,10 @@ int het_backward_relational_fused_gat_csr(const int64_t* out_row_ptrs, const int
 /* ------------------------------------------------------------------------
  * a7  rgcn_layer1_separate_coo            OpExport/RGCNOps.inc.h:84-138
  *   ret[col[i], :] += (x[row[i], :] * norm[eids[i]]) . W[r(i)]        W [R,K,D]
- *   by_rel_dst: optional grouping of the positions by (relation, col).
+ *   by_rel_dst: optional grouping of the positions by (relation, col):
+ *   het_grouping_create(rel_ptrs, R, col, E, N, payload0 = row, payload1 = eids, ...) with a workspace of
+ *   het_grouping_num_segments(g) * K floats; the backward takes the grouping by (relation, row) with
+ *   payload0 = col, payload1 = eids and num_segments * D floats.
  * a8  backward_rgcn_layer1_separate_coo   OpExport/RGCNOps.inc.h:368-467
  *   grad_x[row[i], :] += (gradout[col[i], :] * norm[eids[i]]) . Wt[r]   (intended direction)
  *   grad_w[r]         += (x[row[i], :] * norm[eids[i]])^T (x) gradout[col[i], :]
@@ -210,13 +213,14 @@ int het_backward_relational_fused_gat_csr(const int64_t* out_row_ptrs, const int
 int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
                                  const int64_t* col, int64_t num_rels, int64_t num_edges, int64_t num_nodes,
                                  const float* x, const float* weights, const float* norm, float* ret,
-                                 int64_t K, int64_t D, const het_grouping* by_rel_dst, het_stream stream);
+                                 int64_t K, int64_t D, const het_grouping* by_rel_dst, void* workspace,
+                                 int64_t workspace_bytes, het_stream stream);
 int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
                                           const int64_t* col, int64_t num_rels, int64_t num_edges,
                                           int64_t num_nodes, const float* x, const float* weights_t,
                                           const float* norm, float* grad_norm, float* grad_x,
                                           const float* gradout, float* grad_w, int64_t K, int64_t D,
-                                          const het_grouping* by_rel_src, const het_grouping* by_rel_dst,
+                                          const het_grouping* by_rel_src, void* workspace, int64_t workspace_bytes,
                                           het_stream stream);
 
 /* a9  rgcn_node_mean_aggregation_compact_as_of_node_separate_coo (+ backward)  RGCNOps.inc.h:24-82, 303-366
@@ -257,23 +261,30 @@ int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
  *   new_h[col[i],h,:] += (v[row[i],h,:] * a[eids[i],h]) . W[r,h]                      W [R,H,dk,dout]
  *   grad_v[row[i],h,:] += (gradout[col[i],h,:] * a) . Wt[r,h]     (intended direction)
  *   grad_w[r,h]        += (v[row[i],h,:] * a)^T (x) gradout[col[i],h,:]
- *   grad_a[eids[i],h]   = < gradout[col[i],h,:] . Wt[r,h], v[row[i],h,:] >            Wt [R,H,dout,dk] */
+ *   grad_a[eids[i],h]   = < gradout[col[i],h,:] . Wt[r,h], v[row[i],h,:] >            Wt [R,H,dout,dk]
+ *   Optional fast paths: by_rel_dst / by_rel_src are the groupings of rgcn_layer1 (by (relation, col) with
+ *   payload0 = row, payload1 = eids; by (relation, row) with payload0 = col, payload1 = eids) and a workspace of
+ *   num_segments * H * dk (forward) / num_segments * H * dout (backward) floats. */
 int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
     const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* v, const float* weights, const float* a, float* new_h,
-    int64_t H, int64_t dk, int64_t dout, het_stream stream);
+    int64_t H, int64_t dk, int64_t dout, const het_grouping* by_rel_dst, void* workspace, int64_t workspace_bytes,
+    het_stream stream);
 int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
     const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* v, const float* weights_t, const float* a, const float* new_h,
     float* grad_v, float* grad_w, float* grad_a, const float* gradout, int64_t H, int64_t dk, int64_t dout,
-    het_stream stream);
+    const het_grouping* by_rel_src, void* workspace, int64_t workspace_bytes, het_stream stream);
 
 /* a12  rgnn_inner_product_right_node_separatecoo (+ backward)    OpExport/RGNNOps.inc.h:609-658, 1131-1181
  *   out[eids[i],h] = < left[lrow(i),h,:], right[row[i],h,:] >                               (out overwritten)
  *   lrow(i) = eids[i] (kind 0) | row of (r(i), col[i]) in the unique list map_a = rel_ptrs, map_b = node ids
  *             (kind 1) | map_a[eids[i]] (kind 2, edata_idx_to_inverse_idx)
  *   grad_left[lrow(i),h,:] += gradout[eids[i],h] * right[row[i],h,:];   grad_right[row[i],h,:] += ... * left[lrow(i),h,:]
- *   (accumulating; the reference kernel stores without atomics) */
+ *   (accumulating; the reference kernel stores without atomics).  accumulate == 0: both
+ *   gradients are overwritten instead (n_left_rows / n_right_rows = their row counts).  by_right: optional
+ *   grouping of the positions by row (het_grouping_create(NULL, 0, row, E, n_right_rows, payload0 = lrow per
+ *   position, payload1 = eids)), used for kinds 0 and 2. */
 int het_rgnn_inner_product_right_node_separatecoo(int64_t kind, const int64_t* map_a, const int64_t* map_b,
                                                   const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
                                                   const int64_t* col, int64_t num_rels, int64_t num_edges,
@@ -284,12 +295,16 @@ int het_backward_inner_product_right_node_separatecoo(int64_t kind, const int64_
                                                       const int64_t* row, const int64_t* col, int64_t num_rels,
                                                       int64_t num_edges, const float* left, const float* right,
                                                       const float* gradout, float* grad_left, float* grad_right,
-                                                      int64_t H, int64_t D, het_stream stream);
+                                                      int64_t H, int64_t D, int accumulate,
+                                                      const het_grouping* by_right, int64_t n_left_rows,
+                                                      int64_t n_right_rows, het_stream stream);
 
 /*      hgt_full_graph_hetero_attention_ops_coo (+ backward)     OpExport/HGTOpsEdgeParallel.inc.h:95-158, 166-293
  *   inner[eids[i],h,:] = k[row[i],h,:] . W[r,h];   score[eids[i],h] = < inner[eids[i],h,:], q[col[i],h,:] >
  *   grad_q[col[i],h,:] += gs * inner[eids[i],h,:];  grad_k[row[i],h,:] += (gs * q[col[i],h,:]) . Wt[r,h];
- *   grad_w[r,h] += k[row[i],h,:]^T (x) (gs * q[col[i],h,:]),   gs = grad_score[eids[i],h] */
+ *   grad_w[r,h] += k[row[i],h,:]^T (x) (gs * q[col[i],h,:]),   gs = grad_score[eids[i],h]
+ *   Optional fast path: by_dst (by col, payload0 = eids), by_rel_src (by (relation, row), payload0 = col,
+ *   payload1 = eids), n_q_rows rows of q, workspace of by_rel_src segments * H * dout floats. */
 int het_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, const int64_t* col, const int64_t* eids,
                                                 const int64_t* rel_ptrs, int64_t num_rels, int64_t num_edges,
                                                 const float* k, const float* q, const float* weights, float* inner,
@@ -299,7 +314,9 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
                                                          float* grad_w, const float* weights_t, const float* k,
                                                          const float* q, const float* inner, const float* grad_score,
                                                          float* grad_k, float* grad_q, int64_t H, int64_t dk,
-                                                         int64_t dout, het_stream stream);
+                                                         int64_t dout, const het_grouping* by_dst,
+                                                         const het_grouping* by_rel_src, int64_t n_q_rows,
+                                                         void* workspace, int64_t workspace_bytes, het_stream stream);
 
 #ifdef __cplusplus
 }
