@@ -27,10 +27,11 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   idx_t rb, re;
   if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunkRows, blockIdx.x, r, rb, re)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // Small weights (K*X <= 64*64) live in registers: every lane keeps the KH*NT B-operand values it feeds
-  // to the MFMAs, so the MFMA loop issues back to back with no LDS read (and no barrier) in it.  Larger
-  // weights are staged once per workgroup in LDS.
-  constexpr bool B_REGS = KH * NT <= 64;
+  // The relation's weight is staged once per workgroup in LDS ([K][X], read conflict-free: 32 consecutive
+  // floats per lane half).
+  // (keeping small weights in registers instead was measured slower: 201 VGPRs, 2 waves per SIMD, 2.22 ms vs
+  //  2.08 ms with the weight in LDS at 3 waves per SIMD on the 64x64 forward projection of ogbn-mag)
+  constexpr bool B_REGS = false;
   float* Bs = smem;                                           // [K][X] (unused when B_REGS)
   float* Ws = smem + (B_REGS ? 0 : K * X) + wave * WREG;      // wave-private: A tile [32][LDA], then C tile [32][LDC]
   const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
@@ -63,72 +64,77 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   const int ra = lane / LPRA, ca = (lane % LPRA) * 4;  // A-load mapping
   const int rc = lane / LPRC, cc = (lane % LPRC) * 4;  // C-store mapping
 
-  // Loads are issued in phases of independent instructions (all row indices, then all rows) and are
-  // branch-free -- out-of-range rows are clamped to the last row and masked afterwards -- so that the
-  // compiler can keep a whole phase in flight instead of waiting after every dependent pair.
+  // Global loads are software-pipelined two tiles deep and issued in branch-free phases of independent
+  // instructions (out-of-range rows clamp to the last row and are masked afterwards):
+  //   iteration t:  wait rows(t) -> LDS;  issue rows(t+1) (their row ids arrived an iteration ago);
+  //                 issue row ids of tile t+2 (A gather list and C scatter list);  MFMAs(t);  stores(t)
+  // vmcnt counts loads and stores in issue order, so a wait for a load also waits for every older store:
+  // with this order everything consumed in iteration t+1 was requested BEFORE the stores of tile t, and
+  // no wait in the loop ever covers a store that was just issued.
   float4 areg[NITA];
-  auto load_tile = [&](idx_t wb) {
-    idx_t ar[NITA];
-    if (a.gather) {
+  int ar_next[NITA];    // A row ids of the next tile (32-bit: row counts < 2^31 are checked by the callers)
+  int crow_next[NITC];  // C row ids of the next tile, -1 = no row
+  // No branch inside the loop (the waitcnt pass is conservative at block boundaries): a missing gather /
+  // scatter list is read as seg_ptrs[0] (always valid) and the loaded value is discarded by a select.
+  const bool has_g = a.gather != nullptr, has_s = a.scatter != nullptr;
+  const idx_t* __restrict__ gp = has_g ? a.gather : a.seg_ptrs;
+  const idx_t* __restrict__ sp = has_s ? a.scatter : a.seg_ptrs;
+  // load_ids only ISSUES loads (raw 32-bit halves of the int64 ids, no arithmetic on them): the values are
+  // first touched one iteration later, so no wait for them is placed in front of the MFMAs.
+  auto load_ids = [&](idx_t wb, int (&ar)[NITA], int (&cr)[NITC]) {
 #pragma unroll
-      for (int it = 0; it < NITA; ++it) {
-        const idx_t i = wb + it * RPIA + ra;
-        ar[it] = a.gather[i < re ? i : re - 1];
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < NITA; ++it) {
-        const idx_t i = wb + it * RPIA + ra;
-        ar[it] = i < re ? i : re - 1;
-      }
+    for (int it = 0; it < NITA; ++it) {
+      const idx_t i = wb + it * RPIA + ra, ic = i < re ? i : re - 1;
+      ar[it] = reinterpret_cast<const int*>(gp + (has_g ? ic : 0))[0];
     }
+#pragma unroll
+    for (int it = 0; it < NITC; ++it) {
+      const idx_t i = wb + it * RPIC + rc, ic = i < re ? i : re - 1;
+      cr[it] = reinterpret_cast<const int*>(sp + (has_s ? ic : 0))[0];
+    }
+  };
+  // rows of the tile starting at wb, ids as loaded by load_ids for that tile
+  auto load_rows = [&](idx_t wb, const int (&ar)[NITA]) {
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+      const idx_t i = wb + it * RPIA + ra, ic = i < re ? i : re - 1;
 #ifdef HET_ABL_NOLOAD
-#pragma unroll
-    for (int it = 0; it < NITA; ++it) ar[it] = ra;
+      const int64_t r64 = ra;
+#else
+      const int64_t r64 = has_g ? (int64_t)ar[it] : (int64_t)ic;
 #endif
-#pragma unroll
-    for (int it = 0; it < NITA; ++it) areg[it] = *reinterpret_cast<const float4*>(a.A + ar[it] * a.a_ld + ca);
-    if (a.row_scale) {
-      idx_t si[NITA];
-#pragma unroll
-      for (int it = 0; it < NITA; ++it) {
-        const idx_t i = wb + it * RPIA + ra, ic = i < re ? i : re - 1;
-        si[it] = a.scale_idx ? a.scale_idx[ic] : ic;
-      }
-#pragma unroll
-      for (int it = 0; it < NITA; ++it) {
-        const float sc = a.row_scale[si[it]];
-        areg[it].x *= sc; areg[it].y *= sc; areg[it].z *= sc; areg[it].w *= sc;
-      }
+      areg[it] = *reinterpret_cast<const float4*>(a.A + r64 * a.a_ld + ca);
     }
-#pragma unroll
-    for (int it = 0; it < NITA; ++it)
-      if (wb + it * RPIA + ra >= re) areg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  idx_t wb = rb + wave * 32;
-  if (wb < re) load_tile(wb);
-  for (; wb < re; wb += 128) {
+  // One tile: rows(t) -> LDS, request tile t+1 / ids of t+2, MFMAs, epilogue.  The body is instantiated twice
+  // (first tile peeled, then the loop) so that both entries of the loop header see the same queue of pending
+  // memory operations [ids, rows, stores] and the compiler's counted waits stay exact.
+  int crow_cur[NITC];
+  auto tile = [&](idx_t wb) {
+    // Rows past the end of the segment (last tile only) are clamped to its last row everywhere, so that all
+    // lanes run the same unpredicated code (stores the compiler can count): when storing they recompute and
+    // rewrite that row's values (same bytes), when accumulating they add zeros to it.
 #pragma unroll
-    for (int it = 0; it < NITA; ++it)
-      *reinterpret_cast<float4*>(&Ws[(it * RPIA + ra) * LDA + ca]) = areg[it];
-    // C rows of this tile (needed in the epilogue) and the A rows of the next tile: both stay in
-    // flight while the MFMAs below run
-    idx_t crow[NITC];
-    if (a.scatter) {
-#pragma unroll
-      for (int it = 0; it < NITC; ++it) {
-        const idx_t i = wb + it * RPIC + rc;
-        crow[it] = a.scatter[i < re ? i : re - 1];
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < NITC; ++it) crow[it] = wb + it * RPIC + rc;
+    for (int it = 0; it < NITA; ++it) {
+      const bool in = !ATOMIC || wb + it * RPIA + ra < re;
+      *reinterpret_cast<float4*>(&Ws[(it * RPIA + ra) * LDA + ca]) = in ? areg[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    int crow[NITC];
 #pragma unroll
-    for (int it = 0; it < NITC; ++it)
-      if (wb + it * RPIC + rc >= re) crow[it] = -1;
-    if (wb + 128 < re) load_tile(wb + 128);
+    for (int it = 0; it < NITC; ++it) {
+      const idx_t i = wb + it * RPIC + rc, ic = i < re ? i : re - 1;
+      crow[it] = has_s ? crow_cur[it] : (int)ic;
+    }
+    // (ids beyond the segment clamp to its last row: always valid addresses, results never used)
+    int ar_cur[NITA];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) ar_cur[it] = ar_next[it];
+#pragma unroll
+    for (int it = 0; it < NITC; ++it) crow_cur[it] = crow_next[it];
+    load_ids(wb + 256, ar_next, crow_next);
+    load_rows(wb + 128, ar_cur);
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above the MFMAs
 
     float af[KH];
 #pragma unroll
@@ -146,27 +152,30 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float b = B_REGS ? breg[B_REGS ? s * NT + nt : 0] : Bs[(half * KH + s) * X + nt * 32 + row];
+#ifdef HET_ABL_NOMFMA  // diagnostic builds only (exp/mfma_bench.hip)
+        acc[nt][s & 15] += af[s] * b;
+#else
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b, acc[nt], 0, 0, 0);
+#endif
       }
     }
-    // Epilogue: transpose through the wave's LDS region so that every output row leaves as whole
-    // 16-byte pieces (X/4 lanes x float4 per row) instead of 32 row-strided dword stores.
-    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     if (ATOMIC) {
       // straight from the accumulators: one atomic instruction adds two 128-byte row segments, the shape
-      // float atomics run at full rate with (MI355X_MICROARCH.md, Global float atomics)
-      // C-row ids go through the wave's LDS region (all lanes of a store row group hold the same id)
+      // float atomics run at full rate with (MI355X_MICROARCH.md, Global float atomics); C-row ids go through
+      // the wave's LDS region (all lanes of a store row group hold the same id)
 #pragma unroll
-      for (int it = 0; it < NITC; ++it) reinterpret_cast<idx_t*>(Ws)[it * RPIC + rc] = crow[it];
+      for (int it = 0; it < NITC; ++it) reinterpret_cast<int*>(Ws)[it * RPIC + rc] = crow[it];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const idx_t cr = reinterpret_cast<const idx_t*>(Ws)[(reg & 3) + 8 * (reg >> 2) + 4 * half];
-        if (cr < 0) continue;
-        float* p = a.C + cr * a.c_ld + row;
+        const int cr = reinterpret_cast<const int*>(Ws)[(reg & 3) + 8 * (reg >> 2) + 4 * half];
+        float* p = a.C + (int64_t)cr * a.c_ld + row;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) atomicAdd(p + nt * 32, acc[nt][reg]);
       }
     } else {
+      // transpose through the wave's LDS region so that every output row leaves as whole 16-byte pieces
+      // (X/4 lanes x float4 per row) instead of 32 row-strided dword stores
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -175,14 +184,26 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
 #pragma unroll
       for (int it = 0; it < NITC; ++it) {
         const float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
-        if (crow[it] < 0) continue;
 #ifdef HET_ABL_NOSTORE
         if (a.num_rows < 0)
 #endif
-        *reinterpret_cast<float4*>(a.C + crow[it] * a.c_ld + cc) = v;
+        *reinterpret_cast<float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc) = v;
       }
     }
+  };
+
+  idx_t wb = rb + wave * 32;
+  if (wb >= re) return;
+  load_ids(wb, ar_next, crow_cur);
+  {
+    int ar0[NITA];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) ar0[it] = ar_next[it];
+    load_ids(wb + 128, ar_next, crow_next);
+    load_rows(wb, ar0);
   }
+  tile(wb);
+  for (wb += 128; wb < re; wb += 128) tile(wb);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------
@@ -286,7 +307,7 @@ int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
 template <int K, int NT>
 int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   constexpr int X = NT * 32, LDA = K + 4, LDC = X + 4;
-  constexpr bool B_REGS = (K / 2) * NT <= 64;
+  constexpr bool B_REGS = false;
   const size_t lds = sizeof(float) * ((B_REGS ? 0 : K * X) + 4 * 32 * (LDA > LDC ? LDA : LDC));
   const int64_t gx = ceil_div64(a.num_rows, kChunkRows) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
@@ -322,6 +343,7 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   HET_REQUIRE(mfma_shape_supported(a.K, a.X), "segment GEMM (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
   HET_REQUIRE(a.a_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "segment GEMM (MFMA): A rows must be 16-byte aligned");
   HET_REQUIRE(a.c_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0, "segment GEMM (MFMA): C rows must be 16-byte aligned");
+  HET_REQUIRE(!a.row_scale, "segment GEMM (MFMA): row scales are applied by the segment-sum pre-pass, not here");
   switch (a.K) {
     case 32: return launch_k<32>(a, s);
     case 64: return launch_k<64>(a, s);
