@@ -293,3 +293,114 @@ def test_cpu_tensors_are_rejected(K):
     e = torch.zeros(1, dtype=torch.int64)
     with pytest.raises((HetError, RuntimeError)):
         K.rgcn_layer1_separate_coo(torch.tensor([0, 1]), e, e, e, torch.randn(2, 4), torch.randn(1, 4, 4), torch.rand(1), torch.zeros(2, 4))
+
+
+# ---------------------------------------------------------------- HGT ops
+@pytest.mark.parametrize("H,dk", [(8, 8), (2, 16), (3, 5), (1, 4)])
+def test_hgt_edge_softmax_fwd_bwd(K, plan_mode, H, dk):
+    g = random_graph(seed=61, n=260, r=4, e=4000)
+    s = g.get_separate_coo_original()
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator().manual_seed(12)
+    score, mu = torch.randn(E, H, generator=gen), torch.rand(R, H, generator=gen) + 0.5
+    ga = torch.randn(E, H, generator=gen)
+    idx = (s["row_indices"], s["col_indices"], s["eids"], s["rel_ptrs"])
+    sm_r, m_r, a_r = torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64)
+    O.hgt_full_graph_edge_softmax_ops_separate_coo(*idx, to64(score), to64(mu), sm_r, m_r, a_r)
+    gs_r, gmu_r, tmp_r = torch.zeros(E, H, dtype=torch.float64), torch.zeros(R, H, dtype=torch.float64), torch.zeros(N, H, dtype=torch.float64)
+    O.backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(*idx, to64(score), a_r, to64(ga), to64(mu), gs_r, gmu_r, tmp_r)
+    didx = tuple(t.to(DEV) for t in idx)
+    sm, m, a = torch.full((N, H), 5.0, device=DEV), torch.empty(E, H, device=DEV), torch.empty(E, H, device=DEV)
+    K.hgt_full_graph_edge_softmax_ops_separate_coo(*didx, score.to(DEV), mu.to(DEV), sm, m, a)
+    assert_close(sm, sm_r, what="sum"); assert_close(m, m_r, what="m"); assert_close(a, a_r, what="a")
+    gs, gmu, tmp = torch.empty(E, H, device=DEV), torch.zeros(R, H, device=DEV), torch.empty(N, H, device=DEV)
+    K.backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(*didx, score.to(DEV), a, ga.to(DEV), mu.to(DEV), gs, gmu, tmp)
+    assert_close(gs, gs_r, what="grad_score"); assert_close(gmu, gmu_r, what="grad_mu")
+
+
+@pytest.mark.parametrize("H,dk", [(8, 8), (4, 16), (2, 6)])
+def test_hgt_fused_message_fwd_bwd(K, plan_mode, H, dk):
+    g = random_graph(seed=62, n=280, r=4, e=4500)
+    s = g.get_separate_coo_original()
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator().manual_seed(13)
+    v, W, a = torch.randn(N, H, dk, generator=gen), torch.randn(R, H, dk, dk, generator=gen) * 0.4, torch.rand(E, H, generator=gen)
+    go = torch.randn(N, H, dk, generator=gen)
+    idx = (s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"])
+    nh_r = torch.zeros(N, H, dk, dtype=torch.float64)
+    O.hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*idx, to64(v), to64(W), to64(a), nh_r)
+    gv_r, gW_r, ga_r = torch.zeros(N, H, dk, dtype=torch.float64), torch.zeros(R, H, dk, dk, dtype=torch.float64), torch.zeros(E, H, dtype=torch.float64)
+    O.backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*idx, to64(v), to64(W).transpose(2, 3).contiguous(), to64(a), nh_r, gv_r, gW_r, ga_r, to64(go))
+    didx = tuple(t.to(DEV) for t in idx)
+    nh = torch.zeros(N, H, dk, device=DEV)
+    K.hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*didx, v.to(DEV), W.to(DEV), a.to(DEV), nh)
+    assert_close(nh, nh_r, what="new_h")
+    gv, gW, ga = torch.zeros(N, H, dk, device=DEV), torch.zeros(R, H, dk, dk, device=DEV), torch.full((E, H), float("nan"), device=DEV)
+    K.backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*didx, v.to(DEV), W.transpose(2, 3).contiguous().to(DEV), a.to(DEV), nh, gv, gW, ga, go.to(DEV))
+    assert_close(gv, gv_r, what="grad_v"); assert_close(gW, gW_r, what="grad_W"); assert_close(ga, ga_r, what="grad_a")
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("H,dk", [(8, 8), (3, 5)])
+def test_inner_product_right_node(K, plan_mode, kind, H, dk):
+    g = random_graph(seed=63, n=240, r=3, e=3500, empty_rel=False)
+    s = g.get_separate_coo_original()
+    ss, ssi = g.get_separate_unique_node_indices_single_sided(), g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    nl = E if kind == 0 else int(ss["rel_ptrs_col"][-1])
+    d = {} if kind == 0 else ({"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+                              if kind == 1 else {"edata_idx_to_inverse_idx": ssi["inverse_indices_col"]})
+    gen = torch.Generator().manual_seed(14)
+    left, right, go = torch.randn(nl, H, dk, generator=gen), torch.randn(N, H, dk, generator=gen), torch.randn(E, H, generator=gen)
+    idx = (s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"])
+    out_r = torch.zeros(E, H, dtype=torch.float64)
+    O.rgnn_inner_product_right_node_separatecoo(d, kind, *idx, to64(left), to64(right), out_r)
+    gl_r, gr_r = torch.zeros(nl, H, dk, dtype=torch.float64), torch.zeros(N, H, dk, dtype=torch.float64)
+    O.backward_inner_product_right_node_separatecoo(d, kind, *idx, to64(left), to64(right), to64(go), gl_r, gr_r)
+    didx = tuple(t.to(DEV) for t in idx)
+    out = torch.full((E, H), float("nan"), device=DEV)
+    K.rgnn_inner_product_right_node_separatecoo(_dev(d), kind, *didx, left.to(DEV), right.to(DEV), out)
+    assert_close(out, out_r, what="out")
+    gl, gr = torch.zeros(nl, H, dk, device=DEV), torch.zeros(N, H, dk, device=DEV)
+    K.backward_inner_product_right_node_separatecoo(_dev(d), kind, *didx, left.to(DEV), right.to(DEV), go.to(DEV), gl, gr)
+    assert_close(gl, gl_r, what="grad_left"); assert_close(gr, gr_r, what="grad_right")
+
+
+@pytest.mark.parametrize("H,dk", [(8, 8), (2, 6)])
+def test_hgt_fused_attention(K, plan_mode, H, dk):
+    g = random_graph(seed=64, n=230, r=3, e=3200)
+    s = g.get_separate_coo_original()
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator().manual_seed(15)
+    k, q, W = torch.randn(N, H, dk, generator=gen), torch.randn(N, H, dk, generator=gen), torch.randn(R, H, dk, dk, generator=gen) * 0.4
+    gs = torch.randn(E, H, generator=gen)
+    idx = (s["row_indices"], s["col_indices"], s["eids"], s["rel_ptrs"])
+    inner_r, score_r = torch.zeros(E, H, dk, dtype=torch.float64), torch.zeros(E, H, dtype=torch.float64)
+    O.hgt_full_graph_hetero_attention_ops_coo(*idx, to64(k), to64(q), to64(W), inner_r, score_r)
+    gW_r, gk_r, gq_r = torch.zeros(R, H, dk, dk, dtype=torch.float64), torch.zeros(N, H, dk, dtype=torch.float64), torch.zeros(N, H, dk, dtype=torch.float64)
+    dummy = torch.zeros(0, dtype=torch.int64)
+    O.backward_hgt_full_graph_hetero_attention_ops_coo(dummy, dummy, dummy, dummy, *idx, gW_r, to64(W).transpose(2, 3).contiguous(), to64(k), to64(q), inner_r, to64(gs), gk_r, gq_r)
+    didx = tuple(t.to(DEV) for t in idx)
+    inner, score = torch.empty(E, H, dk, device=DEV), torch.empty(E, H, device=DEV)
+    K.hgt_full_graph_hetero_attention_ops_coo(*didx, k.to(DEV), q.to(DEV), W.to(DEV), inner, score)
+    assert_close(inner, inner_r, what="inner"); assert_close(score, score_r, what="score")
+    gW, gk, gq = torch.zeros(R, H, dk, dk, device=DEV), torch.zeros(N, H, dk, device=DEV), torch.zeros(N, H, dk, device=DEV)
+    dd = dummy.to(DEV)
+    K.backward_hgt_full_graph_hetero_attention_ops_coo(dd, dd, dd, dd, *didx, gW, W.transpose(2, 3).contiguous().to(DEV), k.to(DEV), q.to(DEV), inner, gs.to(DEV), gk, gq)
+    assert_close(gW, gW_r, what="grad_W"); assert_close(gk, gk_r, what="grad_k"); assert_close(gq, gq_r, what="grad_q")
+
+
+def test_gat_and_hgt_on_a_graph_without_edges(K):
+    """E = 0: outputs are zero-filled, nothing faults."""
+    z = torch.zeros(0, dtype=torch.int64, device=DEV)
+    rp = torch.zeros(3, dtype=torch.int64, device=DEV)
+    N, H, D = 7, 4, 16
+    sm, ex, ret = torch.full((N, H), 3.0, device=DEV), torch.zeros(0, H, device=DEV), torch.full((N, H, D), 3.0, device=DEV)
+    K.relational_fused_gat_separate_coo(z, rp, z, z, 0, {}, torch.zeros(0, H, D, device=DEV), torch.zeros(0, H, device=DEV),
+                                        torch.zeros(0, H, device=DEV), sm, ex, ret, 0.2)
+    assert float(sm.abs().sum()) == 0.0 and float(ret.abs().sum()) == 0.0
+    s2 = torch.full((N, H), 3.0, device=DEV)
+    K.hgt_full_graph_edge_softmax_ops_separate_coo(z, z, z, rp, torch.zeros(0, H, device=DEV), torch.ones(2, H, device=DEV), s2,
+                                                   torch.zeros(0, H, device=DEV), torch.zeros(0, H, device=DEV))
+    assert float(s2.abs().sum()) == 0.0
+    torch.cuda.synchronize()
