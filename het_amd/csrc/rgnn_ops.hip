@@ -40,6 +40,12 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
     return launch_rowdot_fwd(q, s);
   }
+  if (in1head && D == 1 && rowdot1h_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    RowDotArgs q;  // one x row against the H folded attention vectors of its relation
+    q.A = x; q.gather = gather_idx; q.W = weights; q.out = ret; q.scatter = scatter; q.seg_ptrs = rel_ptrs;
+    q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
+    return launch_rowdot1h_fwd(q, s);
+  }
   if (!in1head && H > 1 && mfma_shape_supported((int)(H * K), (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
     // per-head K x D products (HGT: 8 heads of 8 x 8) as ONE row GEMM with a block-diagonal weight: the
@@ -100,6 +106,24 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     return launch_rowdot_bwd_dw(q, s);
   }
   const het_grouping* g = by_rel_gather;
+  if (in1head && D == 1 && rowdot1h_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+    RowDotArgs q;
+    q.A = x; q.gather = gather_idx; q.W = weights_t; q.scatter = scatter; q.go = gradout; q.seg_ptrs = rel_ptrs;
+    q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
+    if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
+        segment_sum_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
+        (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+      // positions sharing (relation, x row) share both factors: sum their [H] gradients first
+      float* gsum = static_cast<float*>(workspace);
+      if (int rc = launch_segment_sum(g, gradout, gsum, (int)H, nullptr, s)) return rc;
+      q.gather = g->seg_key64; q.scatter = nullptr; q.go = gsum; q.seg_ptrs = g->seg_rel_ptr64; q.num_rows = g->S;
+    }
+    q.out = grad_x;
+    if (int rc = launch_rowdot1h_bwd_dx(q, s)) return rc;
+    q.out = grad_w;
+    return launch_rowdot1h_bwd_dw(q, s);
+  }
   if (!in1head && H > 1 && mfma_shape_supported((int)(H * D), (int)(H * K)) && mfma_dw_supported((int)(H * K), (int)(H * D)) &&
       (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(x) & 15) == 0) {

@@ -144,6 +144,127 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot_bwd_dw(RowDotArgs a, int ch
   }
 }
 
+// ---- one shared input head, H weight heads, D_out = 1 ----------------------------------------------------
+// A row of K floats is covered by LPR = K/4 lanes; every lane forms its 4-element partial dot product with each
+// of the H weight vectors and the LPR lanes combine them with xor-shuffles.
+template <int LPR, int H>
+__global__ __launch_bounds__(kBlock) void HET_rowdot1h_fwd(RowDotArgs a) {
+  constexpr int EPW = 64 / LPR, K = LPR * 4;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunk, blockIdx.x, r, rb, re)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4;
+  float4 w[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) w[h] = ld4(a.W + ((int64_t)r * H + h) * K + x);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld4(a.A + gi[u] * K + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float p[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) p[h] = v[u].x * w[h].x + v[u].y * w[h].y + v[u].z * w[h].z + v[u].w * w[h].w;
+#pragma unroll
+      for (int off = LPR >> 1; off > 0; off >>= 1)
+#pragma unroll
+        for (int h = 0; h < H; ++h) p[h] += __shfl_xor(p[h], off);
+      if (ok[u] && sub < H) {
+        float o = p[0];
+#pragma unroll
+        for (int h = 1; h < H; ++h) o = (sub == h) ? p[h] : o;
+        a.out[si[u] * H + sub] = o;
+      }
+    }
+  }
+}
+
+template <int LPR, int H>
+__global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dx(RowDotArgs a) {
+  constexpr int EPW = 64 / LPR, K = LPR * 4;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunk, blockIdx.x, r, rb, re)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  float4 w[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) w[h] = ld4(a.W + ((int64_t)r * H + h) * K + x);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float g[U][H];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int h = 0; h < H; ++h) g[u][h] = a.go[si[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        o.x = fmaf(g[u][h], w[h].x, o.x); o.y = fmaf(g[u][h], w[h].y, o.y);
+        o.z = fmaf(g[u][h], w[h].z, o.z); o.w = fmaf(g[u][h], w[h].w, o.w);
+      }
+      float* p = a.out + gi[u] * K + x;
+      atomicAdd(p + 0, o.x); atomicAdd(p + 1, o.y); atomicAdd(p + 2, o.z); atomicAdd(p + 3, o.w);
+    }
+  }
+}
+
+template <int LPR, int H>
+__global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dw(RowDotArgs a, int chunk) {
+  constexpr int EPW = 64 / LPR, K = LPR * 4;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, chunk, blockIdx.x, r, rb, re)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4;
+  float4 acc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ld4(a.A + gi[u] * K + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float gu = ok[u] ? a.go[si[u] * H + h] : 0.f;
+        acc[h].x = fmaf(gu, v[u].x, acc[h].x); acc[h].y = fmaf(gu, v[u].y, acc[h].y);
+        acc[h].z = fmaf(gu, v[u].z, acc[h].z); acc[h].w = fmaf(gu, v[u].w, acc[h].w);
+      }
+    }
+  }
+  __shared__ float4 part[4][64];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float4 t = acc[h];
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off);
+      t.z += __shfl_xor(t.z, off); t.w += __shfl_xor(t.w, off);
+    }
+    __syncthreads();
+    if (slot == 0) part[wave][sub] = t;
+    __syncthreads();
+    if (wave == 0 && slot == 0) {
+      float4 o = part[0][sub];
+      for (int wv = 1; wv < 4; ++wv) {
+        const float4 q = part[wv][sub];
+        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+      }
+      float* p = a.out + ((int64_t)r * H + h) * K + x;
+      atomicAdd(p + 0, o.x); atomicAdd(p + 1, o.y); atomicAdd(p + 2, o.z); atomicAdd(p + 3, o.w);
+    }
+  }
+}
+
 inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 #define HET_ROWDOT_DISPATCH(LPRV, CALL)                 \
@@ -192,5 +313,43 @@ int launch_rowdot_bwd_dw(const RowDotArgs& a, hipStream_t s) {
   dim3 grid((unsigned)(ceil_div64(a.num_rows, chunk) + a.num_segs)), block(kBlock);
   HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL(HET_rowdot_bwd_dw<LPR>, grid, block, 0, s, a, (int)chunk));
   HET_LAUNCH_CHECK("HET_rowdot_bwd_dw");
+  return HET_OK;
+}
+
+bool rowdot1h_supported(int H, int K) {
+  return (H == 1 || H == 2 || H == 4 || H == 8) && K >= 4 * H && is_pow2(K) && K / 4 <= 64;
+}
+
+#define HET_ROWDOT1H_DISPATCH(KERNEL, ...)                                                           \
+  switch (a.H) {                                                                                     \
+    case 1: HET_ROWDOT_DISPATCH(a.K / 4, hipLaunchKernelGGL((KERNEL<LPR, 1>), grid, block, 0, s, __VA_ARGS__)); break; \
+    case 2: HET_ROWDOT_DISPATCH(a.K / 4, hipLaunchKernelGGL((KERNEL<LPR, 2>), grid, block, 0, s, __VA_ARGS__)); break; \
+    case 4: HET_ROWDOT_DISPATCH(a.K / 4, hipLaunchKernelGGL((KERNEL<LPR, 4>), grid, block, 0, s, __VA_ARGS__)); break; \
+    default: HET_ROWDOT_DISPATCH(a.K / 4, hipLaunchKernelGGL((KERNEL<LPR, 8>), grid, block, 0, s, __VA_ARGS__)); break; \
+  }
+
+int launch_rowdot1h_fwd(const RowDotArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  dim3 grid((unsigned)(ceil_div64(a.num_rows, kChunk) + a.num_segs)), block(kBlock);
+  HET_ROWDOT1H_DISPATCH(HET_rowdot1h_fwd, a)
+  HET_LAUNCH_CHECK("HET_rowdot1h_fwd");
+  return HET_OK;
+}
+
+int launch_rowdot1h_bwd_dx(const RowDotArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  dim3 grid((unsigned)(ceil_div64(a.num_rows, kChunk) + a.num_segs)), block(kBlock);
+  HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dx, a)
+  HET_LAUNCH_CHECK("HET_rowdot1h_bwd_dx");
+  return HET_OK;
+}
+
+int launch_rowdot1h_bwd_dw(const RowDotArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  int64_t chunk = ceil_div64(a.num_rows, 2048);
+  if (chunk < 1024) chunk = 1024;
+  dim3 grid((unsigned)(ceil_div64(a.num_rows, chunk) + a.num_segs)), block(kBlock);
+  HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dw, a, (int)chunk)
+  HET_LAUNCH_CHECK("HET_rowdot1h_bwd_dw");
   return HET_OK;
 }

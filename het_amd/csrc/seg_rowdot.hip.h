@@ -22,3 +22,13 @@ bool rowdot_supported(int H, int K);
 int launch_rowdot_fwd(const RowDotArgs& a, hipStream_t s);
 int launch_rowdot_bwd_dx(const RowDotArgs& a, hipStream_t s);
 int launch_rowdot_bwd_dw(const RowDotArgs& a, hipStream_t s);
+
+// One input head shared by H weight heads, D_out = 1 (the reference's --multiply_among_weights_first_flag:
+// er = x[dst] . (W . attn_r), weight [R,H,K,1]):  out[s_i, h] = sum_k A[g_i, k] * W[r, h, k]
+//   bwd dX: grad_A[g_i, :] += sum_h go[s_i, h] * W[r, h, :]      (atomics: rows are shared between positions)
+//   bwd dW: dW[r, h, :]    += sum_i go[s_i, h] * A[g_i, :]
+// A rows are [*, K]; same RowDotArgs, H <= 8, K/4 a power of two <= 64.
+bool rowdot1h_supported(int H, int K);
+int launch_rowdot1h_fwd(const RowDotArgs& a, hipStream_t s);
+int launch_rowdot1h_bwd_dx(const RowDotArgs& a, hipStream_t s);
+int launch_rowdot1h_bwd_dw(const RowDotArgs& a, hipStream_t s);

@@ -41,6 +41,9 @@ SHAPES = [  # (H, K, D, in1head)
     (3, 7, 5, False),     # odd everything, per-head input
     (3, 7, 5, True),      # odd, shared input
     (8, 8, 8, False),     # HGT relation_att shape
+    (4, 64, 1, True),     # mulfirst: x . (W . attn) with one shared input head
+    (2, 16, 1, True),
+    (8, 32, 1, True),
 ]
 
 

@@ -29,7 +29,7 @@ def assert_close(actual, expected, rtol=2e-4, atol=2e-5, what=""):
     """fp32 HIP result vs fp64 oracle.  Tolerance: the reference states rtol 1e-3 between
     implementations (hrt/python/utils_lite/graphiler_bench.py:22-26); we hold 2e-4, with atol
     scaled to the magnitude of the expected tensor (sums over up to thousands of edges)."""
-    expected = expected.to(torch.float64)
+    expected = expected.detach().to(torch.float64)
     scale = float(expected.abs().max()) if expected.numel() else 1.0
     torch.testing.assert_close(actual.detach().cpu().double(), expected, rtol=rtol, atol=atol * max(1.0, scale),
                                msg=lambda m: f"{what}: {m}")
