@@ -13,6 +13,7 @@ __all__ = [
     "relational_fused_gat_csr", "relational_fused_gat_separate_coo",
     "relational_fused_gat_compact_as_of_node_separate_coo_dual_unique_node_list",
     "relational_fused_gat_compact_as_of_node_separate_coo_single_sided",
+    "relational_fused_gat_separate_coo_with_attn_l", "relational_fused_gat_separate_coo_with_attn_l_ok",
 ]
 
 
@@ -74,6 +75,58 @@ class _FusedGatSeparateCOO(th.autograd.Function):
         _k.fused_gat_backward(eids, rel_ptrs, row, col, ctx.kind, ctx.bwd_dict, feat_src, el, er, s, exp, ret,
                               gradout.contiguous(), grad_feat_src, grad_el, grad_er, ctx.slope, exp_sorted)
         return None, None, None, None, None, None, None, grad_feat_src, grad_el, grad_er, None, None, None, None
+
+
+class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
+    """el = <feat_src, attn_l[r]> (the D_out = 1 segment GEMM of RGAT/models.py:288-296) and the fused GAT op under
+    ONE autograd node, so that the two gradients that meet in feat_src are written by one store: the GAT backward
+    kernel adds grad_el * attn_l[r] while it writes a * gradout[dst] (include/het_amd.h: fold_attn_l).  Same
+    values as RgnnRelationalMatmul + RelationalFusedGatSeparateCOO; saves the separate gradient tensor, its
+    read-modify-write pass and the autograd accumulation over [E,H,D]."""
+
+    @staticmethod
+    def forward(ctx, eids, rel_ptrs, row, col, feat_src, attn_l, er, s, exp, ret, slope):
+        E, H = eids.numel(), attn_l.shape[1]
+        by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+        el = th.empty((E, H), dtype=feat_src.dtype, device=feat_src.device)
+        K.rgnn_relational_matmul(by_eid, 0, attn_l.unsqueeze(-1), feat_src, el, False)
+        exp_sorted = th.empty_like(exp)
+        used = _k.fused_gat_forward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, slope, exp_sorted)
+        if not used:
+            raise RuntimeError("relational_fused_gat_separate_coo_with_attn_l needs the destination-grouped kernels")
+        ctx.save_for_backward(eids, rel_ptrs, row, col, feat_src, attn_l, el, er, s, exp, ret, exp_sorted)
+        ctx.slope = slope
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        eids, rel_ptrs, row, col, feat_src, attn_l, el, er, s, exp, ret, exp_sorted = ctx.saved_tensors
+        grad_el, grad_feat_src = th.empty_like(el), th.empty_like(feat_src)
+        _k.fused_gat_backward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, gradout.contiguous(),
+                              grad_feat_src, grad_el, grad_el, ctx.slope, exp_sorted, fold_attn_l=attn_l)
+        by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+        grad_attn_l = th.empty_like(attn_l)
+        _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat_src, grad_el, None, grad_attn_l.unsqueeze(-1), False,
+                           accumulate=False)
+        return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None
+
+
+def relational_fused_gat_separate_coo_with_attn_l_ok(g, feat, attn_l, negative_slope):
+    """Whether the fused node applies: kind 0 shapes of the destination-grouped kernels, slope >= 0."""
+    H = attn_l.shape[1]
+    D = attn_l.shape[2]
+    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat.is_cuda
+            and g.get_num_edges() > 0)
+
+
+def relational_fused_gat_separate_coo_with_attn_l(g, feat, attn_l, er, negative_slope):
+    d = g.get_separate_coo_original()
+    exp = er.new_empty(er.shape)
+    s = er.new_empty([g.get_num_nodes()] + list(er.size()[1:]))
+    ret = th.empty([g.get_num_nodes()] + list(feat.size()[1:]), dtype=feat.dtype, device=feat.device)
+    return _FusedGatSeparateCOOWithAttnL.apply(d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"],
+                                               feat.contiguous(), attn_l.contiguous(), er.contiguous(), s, exp, ret,
+                                               negative_slope)
 
 
 class RelationalFusedGatSeparateCOO:

@@ -135,12 +135,16 @@ __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t*
 // SORTED: exp is read from the by_dst-ordered copy the forward wrote (a coalesced stream) and the
 // leaky-ReLU branch is recovered from it (slope >= 0: z > 0 <=> exp(leaky(z)) > 1), so el / er are
 // not touched at all.
-template <int LPR, bool SORTED>
+// FOLD: the caller formed el[e,h] = <feat[e,h,:], fold_w[r,h,:]> (r = relation of the edge's position) and wants
+// the gradient through that product added here: grad_feat[e,h,:] += grad_el[e,h] * fold_w[r,h,:].  Saves the
+// separate read-modify-write pass over the [E,H,D] gradient.
+template <int LPR, bool SORTED, bool FOLD>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
     const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
-    float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope) {
+    float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope,
+    const int32_t* __restrict__ perm, const idx_t* __restrict__ rel_ptrs, int R, const float* __restrict__ fold_w) {
   constexpr int EPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -184,15 +188,39 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 #pragma unroll
       for (int u = 0; u < U; ++u) dl[u] = (zl[u] + zr[u]) > 0.f ? 1.f : slope;
     }
+    float4 w[U];
+    if (FOLD) {
+      int pos[U], rl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) pos[u] = perm[jc[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int lo = 0, hi = R;  // relation of the position: rel_ptrs[lo] <= pos < rel_ptrs[lo + 1]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (rel_ptrs[mid] <= pos[u]) lo = mid; else hi = mid;
+        }
+        rl[u] = lo;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = ld4(fold_w + rl[u] * X + x);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = j0 + u * EPW < e;  // uniform within the LPR lanes of a slot (shuffles below stay inside it)
       const float a = ex[u] * sinv;
-      if (ok) st4(grad_feat + eid[u] * X + x, make_float4(a * g.x, a * g.y, a * g.z, a * g.w));
       float tt = g.x * (f[u].x - r.x) + g.y * (f[u].y - r.y) + g.z * (f[u].z - r.z) + g.w * (f[u].w - r.w);
       for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
+      tt *= a * dl[u];  // every lane of the head holds the edge's grad_el
+      if (ok) {
+        float4 o = make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
+        if (FOLD) {
+          o.x = fmaf(tt, w[u].x, o.x); o.y = fmaf(tt, w[u].y, o.y);
+          o.z = fmaf(tt, w[u].z, o.z); o.w = fmaf(tt, w[u].w, o.w);
+        }
+        st4(grad_feat + eid[u] * X + x, o);
+      }
       if (ok && (sub & (DL - 1)) == 0) {
-        tt *= a * dl[u];
         grad_el[eid[u] * H + h] = tt;
         if (grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
       }
@@ -347,26 +375,35 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   return HET_OK;
 }
 
+bool gat_backward_fold_supported(const het_grouping* g, const EdgeView& v, const RowMaps& m, int H, int D) {
+  return g && m.kind == HET_KIND_DISABLED && grouped_shape_ok(H, D) && g->p0 && g->perm && g->E == v.E && g->R == 0;
+}
+
 int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
-                         float* grad_er, int H, int D, float slope, hipStream_t s) {
-  if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0)
+                         float* grad_er, int H, int D, float slope, const float* fold_w, hipStream_t s) {
+  if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0) {
+    HET_REQUIRE(!fold_w, "backward_relational_fused_gat_separate_coo: fold_attn_l needs the destination-grouped path");
     return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
+  }
   if (v.E == 0) return HET_OK;
   const int64_t X = (int64_t)H * D;
   Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
-  if (exp_sorted && slope >= 0.f) {
-    HET_DISPATCH_LPR((int)(X / 4),
-                     hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
-                                        feat, el, er, sum, exp_sorted, ret, gradout, grad_feat, grad_el, grad_er, H, D,
-                                        slope));
+  const bool sorted = exp_sorted && slope >= 0.f;
+  const float* ex = sorted ? exp_sorted : exp;
+#define HET_GAT_BWD(SORTED, FOLD)                                                                                    \
+  HET_DISPATCH_LPR((int)(X / 4),                                                                                     \
+                   hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, FOLD>), dim3(nb), dim3(kBlock), 0, s, it, \
+                                      g->p0, feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, D,  \
+                                      slope, g->perm, v.rel_ptrs, v.R, fold_w))
+  if (fold_w) {
+    if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
   } else {
-    HET_DISPATCH_LPR((int)(X / 4),
-                     hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, false>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
-                                        feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope));
+    if (sorted) { HET_GAT_BWD(true, false); } else { HET_GAT_BWD(false, false); }
   }
+#undef HET_GAT_BWD
   HET_LAUNCH_CHECK("HET_gat_backward_grouped");
   return HET_OK;
 }

@@ -78,7 +78,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
                                                    int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
-  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
+  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
   HET_REQUIRE(accumulate || num_x_rows >= 0, "%s: num_x_rows needed to overwrite grad_x", op);
@@ -87,11 +87,13 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
   const bool unique = kind == HET_KIND_DISABLED && gather_idx == scatter_idx;
   const bool rowdot = !in1head && D == 1 && rowdot_supported((int)H, (int)K) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  // grad_x == NULL: weight gradient only (a caller that folded the input gradient elsewhere); row-dot shape only
+  HET_REQUIRE(num_rows == 0 || grad_x || rowdot, "%s: grad_x may be NULL only for the per-head D == 1 shape", op);
   if (!accumulate) {  // "=" semantics: zero what the kernels below accumulate into
     HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
     // rows of x that no position gathers must read zero; with a unique row-dot list of all rows every
     // row is stored exactly once instead
-    if (!(rowdot && unique && num_rows == num_x_rows))
+    if (grad_x && !(rowdot && unique && num_rows == num_x_rows))
       HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_x_rows * (in1head ? K : H * K), s));
   }
   if (rowdot) {
@@ -101,7 +103,8 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     q.unique_rows = unique;
     q.overwrite = !accumulate && unique && num_rows == num_x_rows;
     q.out = grad_x;
-    if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
+    if (grad_x)
+      if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
     q.out = grad_w;
     return launch_rowdot_bwd_dw(q, s);
   }

@@ -101,7 +101,12 @@ class HET_RGATLayer(nn.Module):
             by_eid = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"],
                       "separate_coo_eids": s["eids"]}
             feat_src_per_edge = B.rgnn_relational_matmul(by_src, self.conv_weights, inputs, True, 0)
-            el = B.rgnn_relational_matmul(by_eid, self.attn_l.unsqueeze(-1), feat_src_per_edge, False, 0)
+            # el and the GAT op under one autograd node when the grouped kernels apply (same values; the two
+            # gradients of feat_src_per_edge are then written by one store)
+            fuse_el = self.gat_edge_parallel_flag and B.relational_fused_gat_separate_coo_with_attn_l_ok(
+                g, feat_src_per_edge, self.attn_l, self.leaky_relu_slope)
+            if not fuse_el:
+                el = B.rgnn_relational_matmul(by_eid, self.attn_l.unsqueeze(-1), feat_src_per_edge, False, 0)
             if self.multiply_among_weights_first_flag:
                 # one input head, [R,H,K,1] weight (the reference passes False here, models.py:310-326,
                 # which only works for num_heads == 1)
@@ -109,11 +114,15 @@ class HET_RGATLayer(nn.Module):
             else:
                 feat_dst_per_edge = B.rgnn_relational_matmul(by_dst, self.conv_weights, inputs, True, 0)
                 er = B.rgnn_relational_matmul(by_eid, self.attn_r.unsqueeze(-1), feat_dst_per_edge, False, 0)
-            el, er = el.view(-1, self.num_heads), er.view(-1, self.num_heads)
-            if self.gat_edge_parallel_flag:
+            er = er.view(-1, self.num_heads)
+            if fuse_el:
+                h = B.relational_fused_gat_separate_coo_with_attn_l(g, feat_src_per_edge, self.attn_l, er,
+                                                                    self.leaky_relu_slope)
+            elif self.gat_edge_parallel_flag:
+                el = el.view(-1, self.num_heads)
                 h = B.relational_fused_gat_separate_coo(g, feat_src_per_edge, el, er, self.leaky_relu_slope)
             else:
-                h = B.relational_fused_gat_csr(g, feat_src_per_edge, el, er, self.leaky_relu_slope)
+                h = B.relational_fused_gat_csr(g, feat_src_per_edge, el.view(-1, self.num_heads), er, self.leaky_relu_slope)
         h = h.view(-1, self.out_feat)  # models.py:377-385
         if self.self_loop:
             # the reference calls th.matmul here (models.py:378-379); same product through the segment GEMM

@@ -96,7 +96,8 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
  *   with it, `workspace` must hold het_grouping_num_segments(g) * H * D floats (16-byte aligned).
  *   accumulate != 0: "+=" into the caller's buffers as the reference does (its wrapper zero-fills them,
  *   rgnn_layers_and_funcs.py:52-55); accumulate == 0: grad_x and grad_w are overwritten, no pre-zeroing
- *   needed (saves a fill + a read-modify-write pass when every grad_x row has a single writer). */
+ *   needed (saves a fill + a read-modify-write pass when every grad_x row has a single writer).
+ *   grad_x may be NULL for the per-head D == 1 shape (attention vectors): weight gradient only. */
 int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                         int64_t num_x_rows /* rows of x and grad_x */,
@@ -163,7 +164,11 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   Compact kinds, optional fast path (slope >= 0): by_src_row = het_grouping_create(NULL, 0, srow, E,
  *   n_src_rows, payload0 = eids, payload1 = col) over the feat row of every position, by_dst_row likewise
  *   over the er row (payload0 = eids), workspace of (N*2H + E*H) floats; grad_feat / grad_el / grad_er are
- *   then overwritten.  n_src_rows / n_dst_rows: rows of feat/el and of er. */
+ *   then overwritten.  n_src_rows / n_dst_rows: rows of feat/el and of er.
+ *   fold_attn_l (extension, NULL = the reference op): [R,H,D]; for a caller that formed
+ *   el[e,h] = <feat[e,h,:], fold_attn_l[r,h,:]> (RGAT/models.py:288-296) the gradient through that product,
+ *   grad_el[e,h] * fold_attn_l[r,h,:], is added into grad_feat by the same store -- kind 0 with by_dst only
+ *   (error otherwise); replaces a read-modify-write pass over the [E,H,D] gradient. */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
@@ -177,7 +182,7 @@ int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const in
                                                    const het_grouping* by_dst, const het_grouping* by_src_row,
                                                    const het_grouping* by_dst_row, int64_t n_src_rows,
                                                    int64_t n_dst_rows, void* workspace, int64_t workspace_bytes,
-                                                   het_stream stream);
+                                                   const float* fold_attn_l, het_stream stream);
 
 /* a6  relational_fused_gat_csr / backward_relational_fused_gat_csr   RGATOps.inc.h:251-277, 430-460
  *   forward over the in-CSR (rows = dst, col_indices = src); backward over the out-CSR

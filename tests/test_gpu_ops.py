@@ -407,3 +407,37 @@ def test_gat_and_hgt_on_a_graph_without_edges(K):
                                                    torch.zeros(0, H, device=DEV), torch.zeros(0, H, device=DEV))
     assert float(s2.abs().sum()) == 0.0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("H,D", [(4, 16), (1, 64), (2, 8)])
+def test_fused_gat_with_folded_attn_l(H, D):
+    """el = <feat, attn_l[r]> + GAT under one autograd node (fold_attn_l of include/het_amd.h) against the unfused
+    composition of the two reference-named functions, on a graph whose relations are interleaved (eids != arange)."""
+    import het_amd.backend as B
+    g = random_graph(seed=77, n=300, r=4, e=5000, empty_rel=False)
+    s = g.get_separate_coo_original()
+    assert not torch.equal(s["eids"], torch.arange(s["eids"].numel()))
+    E, R = g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator().manual_seed(5)
+    feat = (0.5 * torch.randn(E, H, D, generator=gen)).to(DEV)
+    attn = (0.5 * torch.randn(R, H, D, generator=gen)).to(DEV)
+    er = (0.5 * torch.randn(E, H, generator=gen)).to(DEV)
+    go = torch.randn(g.get_num_nodes(), H, D, generator=gen).to(DEV)
+    g.to_(DEV)
+    sd = g.get_separate_coo_original()
+    by_eid = {"separate_coo_rel_ptrs": sd["rel_ptrs"], "separate_coo_node_indices": sd["eids"],
+              "separate_coo_eids": sd["eids"]}
+    outs = []
+    for fused in (False, True):
+        f, a, r = (t.clone().requires_grad_(True) for t in (feat, attn, er))
+        if fused:
+            assert B.relational_fused_gat_separate_coo_with_attn_l_ok(g, f, a, 0.2)
+            out = B.relational_fused_gat_separate_coo_with_attn_l(g, f, a, r, 0.2)
+        else:
+            el = B.rgnn_relational_matmul(by_eid, a.unsqueeze(-1), f, False, 0).view(E, H)
+            out = B.relational_fused_gat_separate_coo(g, f, el, r, 0.2)
+        out.backward(go)
+        outs.append((out.detach(), f.grad, a.grad, r.grad))
+    g.cpu_()
+    for name, u, v in zip(("out", "grad_feat", "grad_attn_l", "grad_er"), outs[0], outs[1]):
+        assert_close(v, u.cpu(), what=name)

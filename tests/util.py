@@ -13,12 +13,32 @@ def to64(t):
     return t.detach().cpu().double()
 
 
-def random_graph(seed=0, n=257, r=5, e=3001, empty_rel=True):
+def random_graph(seed=0, n=257, r=5, e=3001, empty_rel=True, shuffle=True):
     coo = make_random(n, r, e, seed=seed)
     if empty_rel and r > 2:  # leave one relation empty, one tiny
         coo.rel[coo.rel == 1] = 0
         coo.rel = torch.sort(coo.rel).values
-    return HetGraph.from_integrated_coo(coo)
+    g = HetGraph.from_integrated_coo(coo)
+    if shuffle:
+        permute_eids(g, seed + 1000)
+    return g
+
+
+def permute_eids(g, seed):
+    """HetGraph canonicalises eids to arange(E) in separate-COO order, as the reference does; the ops accept any
+    edge numbering, so renumber every layout's eids with one random permutation (edge data row != position)."""
+    E = g.get_num_edges()
+    pi = torch.randperm(E, generator=torch.Generator().manual_seed(seed))
+
+    def walk(d):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v)
+            elif k == "eids":
+                d[k] = pi[v]
+
+    walk(g.graph_data)
+    g._plans.clear()
 
 
 def mag_graph(scale=2e-3):
