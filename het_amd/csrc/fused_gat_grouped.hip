@@ -37,6 +37,9 @@ struct Items {
   int64_t n;
 };
 
+// Wave per work item: the 64/LPR lane groups take the item's edges round-robin, U edges per group and step; the
+// ids of the next step are fetched while the current rows are in flight (one dependent round trip per step).
+// (A lane group per item was measured slower here: in-edge lists are skewed and a 256-edge item then runs serially.)
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, const int32_t* __restrict__ p_eid,
                                                                      const int32_t* __restrict__ p_srow,
@@ -44,42 +47,45 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
                                                                      const float* __restrict__ exp,
                                                                      float* __restrict__ sum, float* __restrict__ ret,
                                                                      float* __restrict__ exp_sorted, int H, int D) {
-  constexpr int EPW = 64 / LPR;
+  constexpr int EPW = 64 / LPR, U = 4;
   const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
-  const int64_t v = it.seg_key[seg];
-  const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
   const int64_t X = (int64_t)H * D;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float ssum = 0.f;
-  // U edges per lane group and step; the three dependent load phases (edge id -> exp, feat row) are each
-  // issued for all U edges before the first use, indices clamped (branch-free) and masked afterwards
-  constexpr int U = 4;
+  int jn[U];
+  int64_t eidn[U], srown[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) jn[u] = b + slot + u * EPW < e ? b + slot + u * EPW : e - 1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
+  if (p_srow) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
+  }
+  const int64_t v = it.seg_key[seg];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     int jc[U];
-    int64_t eid[U], srow[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * EPW;
-      jc[u] = j < e ? j : e - 1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) eid[u] = p_eid[jc[u]];
-    if (p_srow) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) srow[u] = p_srow[jc[u]];
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) srow[u] = eid[u];
-    }
     float w[U];
     float4 f[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = exp[eid[u] * H + h];
+    for (int u = 0; u < U; ++u) jc[u] = jn[u];
 #pragma unroll
-    for (int u = 0; u < U; ++u) f[u] = ld4(feat + srow[u] * X + x);
+    for (int u = 0; u < U; ++u) w[u] = exp[eidn[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + (p_srow ? srown[u] : eidn[u]) * X + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
+    if (p_srow) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = j0 + u * EPW < e;
@@ -101,7 +107,6 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
     ssum += __shfl_xor(ssum, off);
   }
   if (slot != 0) return;
-  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
@@ -135,46 +140,48 @@ __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t*
 // SORTED: exp is read from the by_dst-ordered copy the forward wrote (a coalesced stream) and the
 // leaky-ReLU branch is recovered from it (slope >= 0: z > 0 <=> exp(leaky(z)) > 1), so el / er are
 // not touched at all.
-// FOLD: the caller formed el[e,h] = <feat[e,h,:], fold_w[r,h,:]> (r = relation of the edge's position) and wants
-// the gradient through that product added here: grad_feat[e,h,:] += grad_el[e,h] * fold_w[r,h,:].  Saves the
-// separate read-modify-write pass over the [E,H,D] gradient.
+// FOLD: the caller formed el[e,h] = <feat[e,h,:], fold_w[r,h,:]> (r = relation of the edge's position, carried as
+// payload1 of the grouping) and wants the gradient through that product added here:
+// grad_feat[e,h,:] += grad_el[e,h] * fold_w[r,h,:].  Saves the separate read-modify-write pass over the [E,H,D]
+// gradient.  Wave per item with id prefetch, like the forward.
 template <int LPR, bool SORTED, bool FOLD>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
     const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
     float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope,
-    const int32_t* __restrict__ perm, const idx_t* __restrict__ rel_ptrs, int R, const float* __restrict__ fold_w) {
-  constexpr int EPW = 64 / LPR;
+    const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w) {
+  constexpr int EPW = 64 / LPR, U = 2;  // (U = 4 measured slower)
   const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
-  const int64_t v = it.seg_key[seg];
-  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
   const int64_t X = (int64_t)H * D;
+  int jn[U], reln[U];
+  int64_t eidn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) jn[u] = b + slot + u * EPW < e ? b + slot + u * EPW : e - 1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
+  if (FOLD) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) reln[u] = p_rel[jn[u]];
+  }
+  const int64_t v = it.seg_key[seg];
   const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
   const float sinv = 1.f / sum[v * H + h];
-  constexpr int U = 2;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    int jc[U];
     int64_t eid[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * EPW;
-      jc[u] = j < e ? j : e - 1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) eid[u] = p_eid[jc[u]];
     float ex[U], dl[U];
-    float4 f[U];
+    float4 f[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) eid[u] = eidn[u];
     if (SORTED) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) ex[u] = exp[(int64_t)jc[u] * H + h];
+      for (int u = 0; u < U; ++u) ex[u] = exp[(int64_t)jn[u] * H + h];
 #pragma unroll
       for (int u = 0; u < U; ++u) f[u] = ld4(feat + eid[u] * X + x);
-#pragma unroll
-      for (int u = 0; u < U; ++u) dl[u] = ex[u] > 1.f ? 1.f : slope;
     } else {
       float zl[U], zr[U];
 #pragma unroll
@@ -188,22 +195,22 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 #pragma unroll
       for (int u = 0; u < U; ++u) dl[u] = (zl[u] + zr[u]) > 0.f ? 1.f : slope;
     }
-    float4 w[U];
     if (FOLD) {
-      int pos[U], rl[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) pos[u] = perm[jc[u]];
+      for (int u = 0; u < U; ++u) w[u] = ld4(fold_w + reln[u] * X + x);
+    }
+    // ids of the next step (clamped: the last step re-reads its own)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int lo = 0, hi = R;  // relation of the position: rel_ptrs[lo] <= pos < rel_ptrs[lo + 1]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (rel_ptrs[mid] <= pos[u]) lo = mid; else hi = mid;
-        }
-        rl[u] = lo;
-      }
+    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1;
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = ld4(fold_w + rl[u] * X + x);
+    for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
+    if (FOLD) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) reln[u] = p_rel[jn[u]];
+    }
+    if (SORTED) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) dl[u] = ex[u] > 1.f ? 1.f : slope;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -265,21 +272,21 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_grouped(
   const int64_t u = it.seg_key[seg];
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
   const int64_t X = (int64_t)H * D;
+  int jn[U];
+  int64_t eidn[U], dstn[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) jn[q] = b + slot + q * EPW < e ? b + slot + q * EPW : e - 1;
+#pragma unroll
+  for (int q = 0; q < U; ++q) eidn[q] = p_eid[jn[q]];
+#pragma unroll
+  for (int q = 0; q < U; ++q) dstn[q] = p_dst[jn[q]];
   const float4 f = ld4(feat + u * X + x);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float acc_el = 0.f;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    int jc[U];
     int64_t eid[U], dst[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int j = j0 + q * EPW;
-      jc[q] = j < e ? j : e - 1;
-    }
-#pragma unroll
-    for (int q = 0; q < U; ++q) eid[q] = p_eid[jc[q]];
-#pragma unroll
-    for (int q = 0; q < U; ++q) dst[q] = p_dst[jc[q]];
+    for (int q = 0; q < U; ++q) { eid[q] = eidn[q]; dst[q] = dstn[q]; }
     float ex[U], sinv[U], gr[U];
     float4 g[U];
 #pragma unroll
@@ -290,6 +297,13 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_grouped(
     for (int q = 0; q < U; ++q) gr[q] = pack[dst[q] * 2 * H + H + h];
 #pragma unroll
     for (int q = 0; q < U; ++q) g[q] = ld4(gradout + dst[q] * X + x);
+    // ids of the next step, fetched while this step's rows are in flight (clamped at the end)
+#pragma unroll
+    for (int q = 0; q < U; ++q) jn[q] = j0 + (U + q) * EPW < e ? j0 + (U + q) * EPW : e - 1;
+#pragma unroll
+    for (int q = 0; q < U; ++q) eidn[q] = p_eid[jn[q]];
+#pragma unroll
+    for (int q = 0; q < U; ++q) dstn[q] = p_dst[jn[q]];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const bool ok = j0 + q * EPW < e;  // uniform within a lane group
@@ -376,7 +390,7 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
 }
 
 bool gat_backward_fold_supported(const het_grouping* g, const EdgeView& v, const RowMaps& m, int H, int D) {
-  return g && m.kind == HET_KIND_DISABLED && grouped_shape_ok(H, D) && g->p0 && g->perm && g->E == v.E && g->R == 0;
+  return g && m.kind == HET_KIND_DISABLED && grouped_shape_ok(H, D) && g->p0 && g->p1 && g->E == v.E && g->R == 0;
 }
 
 int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
@@ -390,6 +404,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   if (v.E == 0) return HET_OK;
   const int64_t X = (int64_t)H * D;
   Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
+  HET_REQUIRE(!fold_w || g->p1, "backward_relational_fused_gat_separate_coo: fold_attn_l needs payload1 = relation");
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
   const bool sorted = exp_sorted && slope >= 0.f;
   const float* ex = sorted ? exp_sorted : exp;
@@ -397,7 +412,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   HET_DISPATCH_LPR((int)(X / 4),                                                                                     \
                    hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, FOLD>), dim3(nb), dim3(kBlock), 0, s, it, \
                                       g->p0, feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, D,  \
-                                      slope, g->perm, v.rel_ptrs, v.R, fold_w))
+                                      slope, g->p1, fold_w))
   if (fold_w) {
     if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
   } else {

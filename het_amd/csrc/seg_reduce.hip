@@ -1,4 +1,4 @@
-// Wave-per-work-item segmented sum of gathered rows (no atomics except for split hub segments).
+// Segmented sum of gathered rows, one lane group per work item (no atomics except for split hub segments).
 #include "seg_reduce.hip.h"
 
 namespace {
@@ -7,66 +7,70 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// Slot-per-item: the LPR lanes of a slot own one work item each, so a wave runs 64/LPR items side by side.
+// Short segments (a few rows) then keep every lane group busy, the per-item prologue (item record -> ids -> rows) is
+// shared by 64/LPR items, and the row ids of the next step are fetched while the current rows are in flight, which
+// leaves one dependent round trip per step.  No cross-slot reduction is needed.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restrict__ item_seg,
-                                                           const int32_t* __restrict__ item_begin,
-                                                           const int32_t* __restrict__ item_end,
-                                                           const int32_t* __restrict__ seg_ptr, int64_t num_items,
-                                                           const int32_t* __restrict__ p_row,
-                                                           const int32_t* __restrict__ p_scale,
-                                                           const float* __restrict__ scale, int scale_heads,
-                                                           const float* __restrict__ in, float* __restrict__ out,
-                                                           const int32_t* __restrict__ out_row, int accumulate) {
-  constexpr int EPW = 64 / LPR, X = LPR * 4;
+                                                                 const int32_t* __restrict__ item_begin,
+                                                                 const int32_t* __restrict__ item_end,
+                                                                 const int32_t* __restrict__ seg_ptr, int64_t num_items,
+                                                                 const int32_t* __restrict__ p_row,
+                                                                 const int32_t* __restrict__ p_scale,
+                                                                 const float* __restrict__ scale, int scale_heads,
+                                                                 const float* __restrict__ in, float* __restrict__ out,
+                                                                 const int32_t* __restrict__ out_row, int accumulate) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  const int64_t item = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
   if (item >= num_items) return;
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
-  const int slot = lane / LPR, x = (lane % LPR) * 4;
-  // per-row scale: one float per row (scale_heads == 0) or one per (row, head), heads of X/scale_heads floats
   const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int U = 4;  // rows per lane group and step, loads issued in independent phases
-  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    int jc[U];
-    int64_t row[U];
+  int jn[U];
+  int64_t rown[U];
+  int sin[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) jn[u] = b + u < e ? b + u : e - 1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) rown[u] = p_row[jn[u]];
+  if (scale) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
+  }
+  for (int j0 = b; j0 < e; j0 += U) {
     float w[U];
     float4 f[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * EPW;
-      jc[u] = j < e ? j : e - 1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) row[u] = p_row[jc[u]];
     if (scale) {
-      int si[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) si[u] = p_scale[jc[u]];
-#pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = scale[(int64_t)si[u] * sld + sh];
+      for (int u = 0; u < U; ++u) w[u] = scale[(int64_t)sin[u] * sld + sh];
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) w[u] = 1.f;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) f[u] = ld4(in + row[u] * X + x);
+    for (int u = 0; u < U; ++u) f[u] = ld4(in + rown[u] * X + x);
+    // ids of the next step (clamped: the last step re-reads its own ids)
+#pragma unroll
+    for (int u = 0; u < U; ++u) jn[u] = j0 + U + u < e ? j0 + U + u : e - 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) rown[u] = p_row[jn[u]];
+    if (scale) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float wu = (j0 + u * EPW < e) ? w[u] : 0.f;
+      const float wu = (j0 + u < e) ? w[u] : 0.f;
       acc.x = fmaf(wu, f[u].x, acc.x); acc.y = fmaf(wu, f[u].y, acc.y);
       acc.z = fmaf(wu, f[u].z, acc.z); acc.w = fmaf(wu, f[u].w, acc.w);
     }
   }
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
-    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
-  }
-  if (slot != 0) return;
   float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + x;
   if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) {
-    if (accumulate) {  // the segment's only writer: plain read-modify-write
+    if (accumulate) {
       const float4 c = ld4(p);
       acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
     }
@@ -94,9 +98,10 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   }
   if (g->S == 0) return HET_OK;
   const int32_t* p_scale = g->p1 ? g->p1 : g->p0;
-  const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
-#define HET_SS(L) hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, \
-                                     g->item_end, g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate)
+  const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+#define HET_SS(L)                                                                                                   \
+  hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \
+                     g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate)
   switch (X / 4) {
     case 1: HET_SS(1); break;
     case 2: HET_SS(2); break;

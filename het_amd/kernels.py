@@ -277,11 +277,28 @@ def _dst_rows_by_position(kind, maps, rel_ptrs, col, eids):
     return drow
 
 
+def _rel_by_position(rel_ptrs, num_positions):
+    """Relation of every edge position of the separate COO (cached per graph)."""
+    key = ("rel", rel_ptrs.data_ptr(), rel_ptrs._version, num_positions)
+    hit = _derived.get(key)
+    if hit is not None:
+        return hit[0]
+    R = rel_ptrs.numel() - 1
+    rel = torch.repeat_interleave(torch.arange(R, device=rel_ptrs.device), rel_ptrs[1:] - rel_ptrs[:-1],
+                                  output_size=num_positions).contiguous()
+    if len(_derived) > 16:
+        _derived.clear()
+    _derived[key] = (rel, (rel_ptrs,))
+    return rel
+
+
 def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
+    """Positions grouped by destination; payload0 = edge id, payload1 = feat row (compact kinds) or the relation
+    of the position (kind 0; read by the fold_attn_l backward)."""
     if not _plan.enabled:
         return None
-    srow = None if kind == 0 else _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
-    return _plan.get_grouping(None, col, num_nodes, eids, srow)
+    p1 = _rel_by_position(rel_ptrs, eids.numel()) if kind == 0 else _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
+    return _plan.get_grouping(None, col, num_nodes, eids, p1)
 
 
 @_op("relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "

@@ -168,7 +168,8 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   fold_attn_l (extension, NULL = the reference op): [R,H,D]; for a caller that formed
  *   el[e,h] = <feat[e,h,:], fold_attn_l[r,h,:]> (RGAT/models.py:288-296) the gradient through that product,
  *   grad_el[e,h] * fold_attn_l[r,h,:], is added into grad_feat by the same store -- kind 0 with by_dst only
- *   (error otherwise); replaces a read-modify-write pass over the [E,H,D] gradient. */
+ *   (error otherwise; by_dst must then carry payload1 = relation of every position); replaces a
+ *   read-modify-write pass over the [E,H,D] gradient. */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
