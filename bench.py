@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs at 2.4 GHz)
 
 
 def parse():
@@ -200,14 +201,16 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    bwd_name = "het_backward_relational_fused_gat_separate_coo"
+    bwd_name, mm_name = "het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul"
     HK.event_timers[bwd_name] = []
+    HK.event_timers[mm_name] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     ev = HK.event_timers.pop(bwd_name)
+    ev_mm = HK.event_timers.pop(mm_name)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -216,25 +219,41 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = E_global / (dt / args.steps) / 1e6
 
-    def pmc_traffic(kernel):
-        """HBM bytes per launch from the committed PMC passes of this same command (profiles/): rocprofv3 cannot
-        run inside the timed process.  None when no profile matches this workload."""
-        path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_default.json")
-        if args.scale != 1.0 or args.variant != "default" or world != 1 or not os.path.exists(path):
+    def pmc(kernel, field):
+        """Per-launch PMC figure from the committed counter passes of this same command (profiles/r01/, written by
+        profiles/tools/collect.sh): rocprofv3 cannot run inside the timed process.  None when no profile matches
+        this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
+        path = os.path.join(ROOT, "profiles", "r01", "default_pmc.json")
+        if args.scale != 1.0 or args.variant != "default" or world != 1 or args.model != "rgat" or not os.path.exists(path):
             return None
-        rec = json.load(open(path))["kernels"].get(kernel)
-        return None if rec is None else rec["hbm_bytes_per_launch"]
+        recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in json.load(open(path))["kernels"].items()
+                if k.startswith(kernel) and field in v]
+        return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel (E rows)
 
     roofline = None
     if ev and not args.variant.startswith("compact") and args.model == "rgat":
-        k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        k_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
         nbytes = gat_bwd_bytes(E_local, N_local, H, X)
         ach = nbytes / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "HET_gat_backward_grouped (backward_relational_fused_gat_separate_coo, kind 0)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy_6.29TBs": round(ach / HBM_COPY_GBS, 4),
-                    "traffic": pmc_traffic("HET_gat_backward_grouped"),
+                    "traffic": pmc("HET_gat_backward_grouped", "hbm_bytes_per_launch"),
                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes}
+    # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the per-edge
+    # projection launches of rgnn_relational_matmul (num_rows = E, D > 1), HIP events on the launch stream
+    roofline_gemm = None
+    proj = [(a, b) for a, b, c in ev_mm if int(c[5]) == E_local and int(c[11]) > 1]
+    if proj and args.model == "rgat":
+        g_ms = sum(a.elapsed_time(b) for a, b in proj) / len(proj)
+        flops = 2.0 * E_local * K * X
+        tf = flops / (g_ms * 1e-3) / 1e12
+        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, E rows, K=X=%d)" % K,
+                         "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
+                         "launches_per_step": len(proj) // max(1, args.steps),
+                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false>", "mfma_busy_frac"),
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false>", "hbm_bytes_per_launch")}
 
     if rank == 0:
         out = {
@@ -247,6 +266,7 @@ def main():
                        "edge_order": args.edge_order, "scale": args.scale,
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
             "roofline": roofline,
+            "roofline_segment_gemm": roofline_gemm,
         }
         if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
             out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)

@@ -56,7 +56,7 @@ def _op(schema: str):
     return deco
 
 
-# Optional per-entry-point device timing (bench.py): name -> list of (start, end) events recorded on
+# Optional per-entry-point device timing (bench.py): name -> list of (start, end, args) with events recorded on
 # the stream the kernels are launched on.  Empty = no overhead.
 event_timers: Dict[str, list] = {}
 
@@ -71,7 +71,7 @@ def _call(dev_tensor: Tensor, cname: str, *args):
         a.record()
         _lib.call(cname, *args)
         b.record()
-        rec.append((a, b))
+        rec.append((a, b, args))
 
 
 # ------------------------------------------------------------------------------------
