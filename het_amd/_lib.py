@@ -17,6 +17,7 @@ P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
     "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_rgnn_relational_matmul_attn_dot": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, P],
     "het_backward_rgnn_relational_matmul": [I64, P, I64, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P, P, I64, P],
     "het_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, I64, I64, I64, INT, P],
     "het_backward_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P],

@@ -85,11 +85,12 @@ class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
     read-modify-write pass and the autograd accumulation over [E,H,D]."""
 
     @staticmethod
-    def forward(ctx, eids, rel_ptrs, row, col, feat_src, attn_l, er, s, exp, ret, slope):
+    def forward(ctx, eids, rel_ptrs, row, col, feat_src, attn_l, er, s, exp, ret, slope, el):
         E, H = eids.numel(), attn_l.shape[1]
-        by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
-        el = th.empty((E, H), dtype=feat_src.dtype, device=feat_src.device)
-        K.rgnn_relational_matmul(by_eid, 0, attn_l.unsqueeze(-1), feat_src, el, False)
+        if el is None:  # else: el = <feat_src, attn_l[r]> as produced by rgnn_relational_matmul_with_attn_dot(folded=True)
+            by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+            el = th.empty((E, H), dtype=feat_src.dtype, device=feat_src.device)
+            K.rgnn_relational_matmul(by_eid, 0, attn_l.unsqueeze(-1), feat_src, el, False)
         exp_sorted = th.empty_like(exp)
         used = _k.fused_gat_forward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, slope, exp_sorted)
         if not used:
@@ -108,7 +109,7 @@ class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
         grad_attn_l = th.empty_like(attn_l)
         _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat_src, grad_el, None, grad_attn_l.unsqueeze(-1), False,
                            accumulate=False)
-        return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None
+        return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None, None
 
 
 def relational_fused_gat_separate_coo_with_attn_l_ok(g, feat, attn_l, negative_slope):
@@ -119,14 +120,14 @@ def relational_fused_gat_separate_coo_with_attn_l_ok(g, feat, attn_l, negative_s
             and g.get_num_edges() > 0)
 
 
-def relational_fused_gat_separate_coo_with_attn_l(g, feat, attn_l, er, negative_slope):
+def relational_fused_gat_separate_coo_with_attn_l(g, feat, attn_l, er, negative_slope, el=None):
     d = g.get_separate_coo_original()
     exp = er.new_empty(er.shape)
     s = er.new_empty([g.get_num_nodes()] + list(er.size()[1:]))
     ret = th.empty([g.get_num_nodes()] + list(feat.size()[1:]), dtype=feat.dtype, device=feat.device)
     return _FusedGatSeparateCOOWithAttnL.apply(d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"],
                                                feat.contiguous(), attn_l.contiguous(), er.contiguous(), s, exp, ret,
-                                               negative_slope)
+                                               negative_slope, None if el is None else el.detach())
 
 
 class RelationalFusedGatSeparateCOO:

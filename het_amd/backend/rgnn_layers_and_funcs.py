@@ -12,6 +12,7 @@ from ..kernels import K
 __all__ = [
     "RgnnRelationalMatmul", "RgnnRelationalMatmulNoScatterGatherList", "RgnnRelationalMatmulCompactAsOfNode",
     "rgnn_relational_matmul", "rgnn_relational_matmul_no_scatter_gather_list",
+    "rgnn_relational_matmul_with_attn_dot", "rgnn_relational_matmul_with_attn_dot_ok",
 ]
 
 
@@ -40,6 +41,71 @@ class RgnnRelationalMatmul(th.autograd.Function):
             0, th.transpose(weights, 2, 3).contiguous(), inputs, gradout.contiguous(), grad_input, grad_weight,
             ctx.input_num_head_one_flag, accumulate=False)
         return None, None, None, grad_weight, grad_input, None, None
+
+
+class _RgnnRelationalMatmulWithAttnDot(th.autograd.Function):
+    """Per-edge projection (RgnnRelationalMatmul, one input head, kind 0) that also returns the attention term
+    dot[e, h] = <feat[e, h, :], attn[r, h, :]> from the GEMM epilogue (RGAT/models.py:288-296 forms it with a second
+    segment GEMM over the tensor just written).  ``folded``: the caller hands ``dot`` and ``attn`` to
+    relational_fused_gat_separate_coo_with_attn_l, whose backward delivers the gradients through the dot product
+    (into grad feat and grad attn) itself -- ``dot`` is then marked non-differentiable here."""
+
+    @staticmethod
+    def forward(ctx, relptrs, node_indices, eids, weights, inputs, attn, folded):
+        E, H, D = node_indices.numel(), weights.size(1), weights.size(3)
+        ret = th.empty((E, H, D), dtype=weights.dtype, device=weights.device)
+        dot = th.empty((E, H), dtype=weights.dtype, device=weights.device)
+        d = {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids}
+        _k.matmul_attn_dot(d, 0, weights, inputs, ret, attn, dot)
+        ctx.folded = folded
+        ctx.set_materialize_grads(False)  # an unused output's gradient stays None (no [E,H,D] zero tensor)
+        if folded:
+            ctx.save_for_backward(relptrs, node_indices, eids, weights, inputs)
+            ctx.mark_non_differentiable(dot)
+        else:
+            ctx.save_for_backward(relptrs, node_indices, eids, weights, inputs, attn, ret)
+        return ret, dot
+
+    @staticmethod
+    def backward(ctx, grad_ret, grad_dot):
+        if ctx.folded or grad_dot is None:
+            relptrs, node_indices, eids, weights, inputs = ctx.saved_tensors[:5]
+            grad_attn = None
+            if grad_ret is None:
+                return None, None, None, None, None, None, None
+            gradout = grad_ret.contiguous()
+        else:
+            relptrs, node_indices, eids, weights, inputs, attn, ret = ctx.saved_tensors
+            # gradient through dot = <ret, attn>: grad_ret += grad_dot (x) attn[r]; grad_attn[r] = SUM grad_dot * ret
+            by_eid = {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+            grad_attn = th.empty_like(attn)
+            gd = grad_dot.contiguous()
+            if grad_ret is None:
+                gradout = th.empty_like(ret)
+                _k.matmul_backward(by_eid, 0, attn.unsqueeze(2), ret, gd, gradout, grad_attn.unsqueeze(-1), False,
+                                   accumulate=False)
+            else:
+                gradout = grad_ret.contiguous().clone()
+                grad_attn.zero_()
+                _k.matmul_backward(by_eid, 0, attn.unsqueeze(2), ret, gd, gradout, grad_attn.unsqueeze(-1), False,
+                                   accumulate=True)
+        grad_weight = th.empty_like(weights, memory_format=th.contiguous_format)
+        grad_input = th.empty_like(inputs, memory_format=th.contiguous_format)
+        _k.matmul_backward(
+            {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids},
+            0, th.transpose(weights, 2, 3).contiguous(), inputs, gradout, grad_input, grad_weight, True, accumulate=False)
+        return None, None, None, grad_weight, grad_input, grad_attn, None
+
+
+def rgnn_relational_matmul_with_attn_dot_ok(weights, inputs):
+    return inputs.is_cuda and inputs.dim() == 2 and _k.matmul_attn_dot_ok(weights.size(1), weights.size(2), weights.size(3))
+
+
+def rgnn_relational_matmul_with_attn_dot(arg_tensor_dict, weights, inputs, attn, folded=False):
+    """(feat [E,H,D], dot [E,H]) for the separate COO lists of ``arg_tensor_dict`` (kind 0)."""
+    return _RgnnRelationalMatmulWithAttnDot.apply(
+        arg_tensor_dict["separate_coo_rel_ptrs"], arg_tensor_dict["separate_coo_node_indices"],
+        arg_tensor_dict["separate_coo_eids"], weights.contiguous(), inputs.contiguous(), attn.contiguous(), folded)
 
 
 class RgnnRelationalMatmulNoScatterGatherList(th.autograd.Function):

@@ -68,6 +68,27 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
   return launch_seg_gemm(a, s);
 }
 
+extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                                                   const int64_t* gather_idx, const int64_t* scatter_idx,
+                                                   int64_t num_rows, const float* weights, const float* x, float* ret,
+                                                   const float* dot_w, float* dot_out, int64_t H, int64_t K, int64_t D,
+                                                   het_stream stream) {
+  const char* op = "rgnn_relational_matmul_attn_dot";
+  if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
+  HET_REQUIRE(num_rows == 0 || (weights && x && ret && dot_w && dot_out), "%s: null data pointer", op);
+  if (!(mfma_fwd_supported((int)K, (int)(H * D)) && D >= 4 && (D & (D - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(dot_w) & 15) == 0)) {
+    het_set_error("%s: only the MFMA shapes (K, H*D in {32, 64, 128}, D a power of two >= 4, 16-byte aligned rows)", op);
+    return HET_ERR_UNSUPPORTED;
+  }
+  MfmaGemmArgs a;
+  a.A = x; a.a_ld = K; a.gather = gather_idx; a.B = weights; a.b_rel_stride = H * K * D; a.b_headcat = 1; a.headcat_d = (int)D;
+  a.C = ret; a.c_ld = H * D; a.scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx; a.seg_ptrs = rel_ptrs;
+  a.num_segs = (int)num_rels; a.num_rows = num_rows; a.K = (int)K; a.X = (int)(H * D);
+  a.dot_w = dot_w; a.dot_out = dot_out;
+  return launch_seg_gemm_mfma(a, (hipStream_t)stream);
+}
+
 extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                                    const int64_t* gather_idx, const int64_t* scatter_idx,
                                                    int64_t num_rows, int64_t num_x_rows, const float* weights_t,

@@ -16,7 +16,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kChunkRows = 2048;  // rows of one relation per workgroup (16 tiles per wave)
 
-template <int K, int NT, bool ATOMIC>
+// DOT (plain stores only): additionally dot_out[cs(i), h] = < C row (h, :), dot_w[r, h, :] > from the row pieces the
+// epilogue already holds -- the attention-vector product of RGAT without re-reading the tensor just written.
+template <int K, int NT, bool ATOMIC, bool DOT = false>
 __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   constexpr int X = NT * 32, KH = K / 2;
   constexpr int LDA = K + 4, LPRA = K / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;  // A tile: rows per load instr
@@ -63,6 +65,9 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   const int row = lane & 31, half = lane >> 5;
   const int ra = lane / LPRA, ca = (lane % LPRA) * 4;  // A-load mapping
   const int rc = lane / LPRC, cc = (lane % LPRC) * 4;  // C-store mapping
+  float4 dotw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (DOT) dotw = *reinterpret_cast<const float4*>(a.dot_w + (int64_t)r * X + cc);
+  const int dot_dl = DOT ? a.headcat_d >> 2 : 1, dot_h = DOT ? cc / a.headcat_d : 0, dot_H = DOT ? X / a.headcat_d : 1;
 
   // Global loads are software-pipelined two tiles deep and issued in branch-free phases of independent
   // instructions (out-of-range rows clamp to the last row and are masked afterwards):
@@ -188,6 +193,12 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
         if (a.num_rows < 0)
 #endif
         *reinterpret_cast<float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc) = v;
+        if (DOT) {
+          float p = v.x * dotw.x + v.y * dotw.y + v.z * dotw.z + v.w * dotw.w;
+          for (int off = dot_dl >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
+          // all lanes of a head store the same value to the same word (no lane predicate: see the store note above)
+          a.dot_out[(int64_t)crow[it] * dot_H + dot_h] = p;
+        }
       }
     }
   };
@@ -312,7 +323,10 @@ int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   const int64_t gx = ceil_div64(a.num_rows, kChunkRows) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
   dim3 grid((unsigned)gx), block(256);
-  if (a.atomic) {
+  if (a.dot_w) {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a);
+  } else if (a.atomic) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, true>), grid, block, lds, s, a);
   } else {
@@ -344,6 +358,12 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   HET_REQUIRE(a.a_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "segment GEMM (MFMA): A rows must be 16-byte aligned");
   HET_REQUIRE(a.c_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0, "segment GEMM (MFMA): C rows must be 16-byte aligned");
   HET_REQUIRE(!a.row_scale, "segment GEMM (MFMA): row scales are applied by the segment-sum pre-pass, not here");
+  if (a.dot_w) {
+    const int Dh = a.headcat_d;
+    HET_REQUIRE(a.dot_out && !a.atomic && a.b_headcat == 1 && Dh >= 4 && (Dh & (Dh - 1)) == 0 && a.X % Dh == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.dot_w) & 15) == 0,
+                "segment GEMM (MFMA): the dot epilogue needs plain stores, head-concatenated weights and a power-of-two D >= 4");
+  }
   switch (a.K) {
     case 32: return launch_k<32>(a, s);
     case 64: return launch_k<64>(a, s);

@@ -21,6 +21,9 @@ struct MfmaGemmArgs {
   int num_segs = 0;
   int64_t num_rows = 0;
   int K = 0, X = 0;
+  // optional epilogue (plain stores, b_headcat == 1): dot_out[cs(i), h] = < C[cs(i), h, :], dot_w[r, h, :] >
+  const float* dot_w = nullptr;  // [num_segs, X]
+  float* dot_out = nullptr;      // [*, X / headcat_d]
 };
 
 bool mfma_shape_supported(int K, int X);

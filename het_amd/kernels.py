@@ -149,6 +149,20 @@ def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, I
           _p(ret), H, K, D, int(InputNumHeadOneFlag), _stream(ret))
 
 
+def matmul_attn_dot_ok(H: int, K: int, D: int) -> bool:
+    """Shapes het_rgnn_relational_matmul_attn_dot covers (the MFMA forward with the dot epilogue)."""
+    return K in (32, 64, 128) and H * D in (32, 64, 128) and D >= 4 and D & (D - 1) == 0
+
+
+def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, dot_out):
+    """rgnn_relational_matmul (one input head) that also writes dot_out[row, h] = <ret[row, h, :], dot_w[r, h, :]>."""
+    rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
+    _chk("rgnn_relational_matmul_attn_dot", (weights, node_feat, ret, dot_w, dot_out), tuple(t for t in (rp, g, s) if t is not None))
+    R, H, K, D = weights.shape
+    _call(ret, "het_rgnn_relational_matmul_attn_dot", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
+          _p(ret), _p(dot_w), _p(dot_out), H, K, D, _stream(ret))
+
+
 @_op("backward_rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights_transposed, "
      "Tensor node_feat, Tensor gradout, Tensor(a!) grad_node_feat, Tensor(b!) grad_weights, bool InputNumHeadOneFlag) -> ()")
 def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat,

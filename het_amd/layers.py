@@ -100,24 +100,33 @@ class HET_RGATLayer(nn.Module):
                       "separate_coo_eids": s["eids"]}
             by_eid = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"],
                       "separate_coo_eids": s["eids"]}
-            feat_src_per_edge = B.rgnn_relational_matmul(by_src, self.conv_weights, inputs, True, 0)
-            # el and the GAT op under one autograd node when the grouped kernels apply (same values; the two
-            # gradients of feat_src_per_edge are then written by one store)
-            fuse_el = self.gat_edge_parallel_flag and B.relational_fused_gat_separate_coo_with_attn_l_ok(
-                g, feat_src_per_edge, self.attn_l, self.leaky_relu_slope)
-            if not fuse_el:
-                el = B.rgnn_relational_matmul(by_eid, self.attn_l.unsqueeze(-1), feat_src_per_edge, False, 0)
+            # Same values as the reference's op sequence, fewer passes over the [E,H,D] tensors where the shapes
+            # allow: the attention terms el / er come out of the projection GEMM's epilogue (dot_ok), and el and the
+            # GAT op share one autograd node (fuse_el) so the two gradients of feat_src_per_edge are written by one store
+            dot_ok = B.rgnn_relational_matmul_with_attn_dot_ok(self.conv_weights, inputs)
+            fuse_el = self.gat_edge_parallel_flag and inputs.is_cuda and B.relational_fused_gat_separate_coo_with_attn_l_ok(
+                g, inputs, self.attn_l, self.leaky_relu_slope)
+            el = None
+            if dot_ok:
+                feat_src_per_edge, el = B.rgnn_relational_matmul_with_attn_dot(by_src, self.conv_weights, inputs,
+                                                                               self.attn_l, folded=fuse_el)
+            else:
+                feat_src_per_edge = B.rgnn_relational_matmul(by_src, self.conv_weights, inputs, True, 0)
+                if not fuse_el:
+                    el = B.rgnn_relational_matmul(by_eid, self.attn_l.unsqueeze(-1), feat_src_per_edge, False, 0)
             if self.multiply_among_weights_first_flag:
                 # one input head, [R,H,K,1] weight (the reference passes False here, models.py:310-326,
                 # which only works for num_heads == 1)
                 er = B.rgnn_relational_matmul(by_dst, self._w_attn_r(), inputs, True, 0)
+            elif dot_ok:
+                _, er = B.rgnn_relational_matmul_with_attn_dot(by_dst, self.conv_weights, inputs, self.attn_r)
             else:
                 feat_dst_per_edge = B.rgnn_relational_matmul(by_dst, self.conv_weights, inputs, True, 0)
                 er = B.rgnn_relational_matmul(by_eid, self.attn_r.unsqueeze(-1), feat_dst_per_edge, False, 0)
             er = er.view(-1, self.num_heads)
             if fuse_el:
                 h = B.relational_fused_gat_separate_coo_with_attn_l(g, feat_src_per_edge, self.attn_l, er,
-                                                                    self.leaky_relu_slope)
+                                                                    self.leaky_relu_slope, el=el)
             elif self.gat_edge_parallel_flag:
                 el = el.view(-1, self.num_heads)
                 h = B.relational_fused_gat_separate_coo(g, feat_src_per_edge, el, er, self.leaky_relu_slope)

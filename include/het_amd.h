@@ -88,6 +88,16 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
                                const float* weights, const float* x, float* ret,
                                int64_t H, int64_t K, int64_t D, int in1head, het_stream stream);
 
+/* a1 + the attention-vector product of RGAT in the GEMM epilogue (extension; RGAT/models.py:288-296 computes
+ * el = <feat, attn_l[r]> with a second, D_out = 1 segment GEMM that re-reads the [rows,H,D] tensor just written):
+ *   ret as het_rgnn_relational_matmul with in1head = 1, and
+ *   dot_out[scatter_idx[i], h] = < ret[scatter_idx[i], h, :], dot_w[r, h, :] >       dot_w [R,H,D], dot_out [*,H]
+ * MFMA shapes only (K and H*D in {32, 64, 128}, D a power of two >= 4): HET_ERR_UNSUPPORTED otherwise. */
+int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
+                                        const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+                                        const float* weights, const float* x, float* ret, const float* dot_w,
+                                        float* dot_out, int64_t H, int64_t K, int64_t D, het_stream stream);
+
 /* a2  backward_rgnn_relational_matmul   OpExport/RGNNOps.inc.h:946-1010
  *   grad_x[gather_idx[i], (h), :] += gradout[scatter_idx[i], h, :] . Wt[r, h]   (heads summed iff in1head)
  *   grad_w[r, h]                  += x[gather_idx[i], (h), :]^T (x) gradout[scatter_idx[i], h, :]

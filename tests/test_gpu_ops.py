@@ -441,3 +441,51 @@ def test_fused_gat_with_folded_attn_l(H, D):
     g.cpu_()
     for name, u, v in zip(("out", "grad_feat", "grad_attn_l", "grad_er"), outs[0], outs[1]):
         assert_close(v, u.cpu(), what=name)
+
+
+@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (1, 32, 32), (2, 64, 64), (8, 128, 4)])
+def test_matmul_with_attn_dot_epilogue(H, Kd, D):
+    """het_rgnn_relational_matmul_attn_dot (projection + attention term from the GEMM epilogue) against the oracle's
+    two ops, and the autograd node against the unfused composition (feat used, feat unused)."""
+    import het_amd.backend as B
+    g = random_graph(seed=91, n=300, r=4, e=5000)
+    s = g.get_separate_coo_original()
+    E, R, N = g.get_num_edges(), g.get_num_rels(), g.get_num_nodes()
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(N, Kd, generator=gen)
+    W = 0.2 * torch.randn(R, H, Kd, D, generator=gen)
+    attn = torch.randn(R, H, D, generator=gen)
+    by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"],
+              "separate_coo_eids": s["eids"]}
+    by_eid = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"], "separate_coo_eids": s["eids"]}
+    feat_ref = torch.zeros(E, H, D, dtype=torch.float64)
+    O.rgnn_relational_matmul(by_src, 0, to64(W), to64(x), feat_ref, True)
+    dot_ref = torch.zeros(E, H, 1, dtype=torch.float64)
+    O.rgnn_relational_matmul(by_eid, 0, to64(attn).unsqueeze(-1), feat_ref, dot_ref, False)
+    assert B.rgnn_relational_matmul_with_attn_dot_ok(W, x.to(DEV))
+    go_f = torch.randn(E, H, D, generator=gen).to(DEV)
+    go_d = torch.randn(E, H, generator=gen).to(DEV)
+    res = {}
+    for mode in ("fused", "plain"):
+        xd, Wd, ad = (t.to(DEV).requires_grad_(True) for t in (x, W, attn))
+        if mode == "fused":
+            feat, dot = B.rgnn_relational_matmul_with_attn_dot(_dev(by_src), Wd, xd, ad)
+        else:
+            feat = B.rgnn_relational_matmul(_dev(by_src), Wd, xd, True, 0)
+            dot = B.rgnn_relational_matmul(_dev(by_eid), ad.unsqueeze(-1), feat, False, 0).view(E, H)
+        ((feat * go_f).sum() + (dot * go_d).sum()).backward()
+        res[mode] = (feat.detach(), dot.detach(), xd.grad, Wd.grad, ad.grad)
+        xd2, Wd2, ad2 = (t.to(DEV).requires_grad_(True) for t in (x, W, attn))
+        if mode == "fused":  # projection output unused: only the attention term carries gradient
+            _, dot2 = B.rgnn_relational_matmul_with_attn_dot(_dev(by_src), Wd2, xd2, ad2)
+        else:
+            f2 = B.rgnn_relational_matmul(_dev(by_src), Wd2, xd2, True, 0)
+            dot2 = B.rgnn_relational_matmul(_dev(by_eid), ad2.unsqueeze(-1), f2, False, 0).view(E, H)
+        (dot2 * go_d).sum().backward()
+        res[mode + "_dot_only"] = (xd2.grad, Wd2.grad, ad2.grad)
+    assert_close(res["fused"][0], feat_ref, what="feat")
+    assert_close(res["fused"][1], dot_ref.view(E, H), what="dot")
+    for name, u, v in zip(("grad_x", "grad_W", "grad_attn"), res["plain"][2:], res["fused"][2:]):
+        assert_close(v, u.cpu(), what=name)
+    for name, u, v in zip(("grad_x", "grad_W", "grad_attn"), res["plain_dot_only"], res["fused_dot_only"]):
+        assert_close(v, u.cpu(), what=name + " (dot only)")
