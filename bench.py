@@ -35,7 +35,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--scale", type=float, default=1.0, help="shrink the mag-like graph (1.0 = full ogbn-mag size)")
-    p.add_argument("--heads", type=int, default=4)
+    p.add_argument("--heads", type=int, default=None, help="default: 4 (RGAT, BASELINE.json configs[2]); 8 for --model hgt (configs[3])")
     p.add_argument("--feat", type=int, default=64)
     p.add_argument("--variant", default="default", choices=["default", "compact", "compact_mulfirst", "mulfirst"],
                    help="reference layer flags: default = per-edge projections (the reference's default flags); "
@@ -46,7 +46,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
     p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.heads is None:
+        a.heads = 8 if a.model == "hgt" else 4
+    return a
 
 
 def layer_flags(variant):

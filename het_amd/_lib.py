@@ -29,8 +29,8 @@ _SIGNATURES = {
     "het_backward_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P, I64, P],
     "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P],
     "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, INT, P],
-    "het_hgt_full_graph_edge_softmax_ops_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, P],
-    "het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, P],
+    "het_hgt_full_graph_edge_softmax_ops_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, P, P],
+    "het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, P, P],
     "het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, I64, P, P, I64, P],
     "het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, P, I64, I64, I64, P, P, I64, P],
     "het_rgnn_inner_product_right_node_separatecoo": [I64, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, P],

@@ -51,6 +51,119 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_normalize(const idx_t*
   }
 }
 
+// Destination-grouped softmax (by_dst: payload0 = edge id, payload1 = relation of the position): one wave per work
+// item, H/4 lanes x float4 per edge.  Pass 1 forms m = exp(score * mu[r]) and the item's head sums; when the item is
+// a whole destination (all but hub nodes) pass 2 writes a = m / sum from the same, still cached, scores.  No float
+// atomics except for split hub destinations, which are normalised by HET_hgt_softmax_normalize_split.
+__device__ __forceinline__ float4 hgt_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void hgt_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_grouped(
+    const int32_t* __restrict__ item_seg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ item_end,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_key, int64_t num_items,
+    const int32_t* __restrict__ p_eid, const int32_t* __restrict__ p_rel, const float* __restrict__ score,
+    const float* __restrict__ mu, float* __restrict__ sum, float* __restrict__ m, float* __restrict__ a) {
+  constexpr int EPW = 64 / LPR, H = LPR * 4, U = 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= num_items) return;
+  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int64_t eid[U];
+    int rl[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * EPW;
+      ok[u] = j < e;
+      const int jc = ok[u] ? j : e - 1;
+      eid[u] = p_eid[jc];
+      rl[u] = p_rel[jc];
+    }
+    float4 sc[U], mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sc[u] = hgt_ld4(score + eid[u] * H + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) mv[u] = hgt_ld4(mu + (int64_t)rl[u] * H + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 v = make_float4(expf(sc[u].x * mv[u].x), expf(sc[u].y * mv[u].y), expf(sc[u].z * mv[u].z),
+                                   expf(sc[u].w * mv[u].w));
+      if (ok[u]) {
+        hgt_st4(m + eid[u] * H + x, v);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  const int64_t v = seg_key[seg];
+  if (!(b == seg_ptr[seg] && e == seg_ptr[seg + 1])) {  // hub destination: partial sums, normalised afterwards
+    if (slot == 0) {
+      float* p = sum + v * H + x;
+      atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
+    }
+    return;
+  }
+  if (slot == 0) hgt_st4(sum + v * H + x, acc);
+  const float4 inv = make_float4(1.f / acc.x, 1.f / acc.y, 1.f / acc.z, 1.f / acc.w);
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int64_t eid[U];
+    int rl[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * EPW;
+      ok[u] = j < e;
+      const int jc = ok[u] ? j : e - 1;
+      eid[u] = p_eid[jc];
+      rl[u] = p_rel[jc];
+    }
+    float4 sc[U], mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sc[u] = hgt_ld4(score + eid[u] * H + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) mv[u] = hgt_ld4(mu + (int64_t)rl[u] * H + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u])
+        hgt_st4(a + eid[u] * H + x, make_float4(expf(sc[u].x * mv[u].x) * inv.x, expf(sc[u].y * mv[u].y) * inv.y,
+                                                expf(sc[u].z * mv[u].z) * inv.z, expf(sc[u].w * mv[u].w) * inv.w));
+  }
+}
+
+// a = m / sum for the edges of the split (hub) destinations: one wave per work item, items of whole segments
+// (already normalised by the kernel above) leave at once
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_normalize_split(
+    const int32_t* __restrict__ item_seg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ item_end,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_key, int64_t num_items,
+    const int32_t* __restrict__ p_eid, const float* __restrict__ sum, const float* __restrict__ m, float* __restrict__ a) {
+  constexpr int EPW = 64 / LPR, H = LPR * 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= num_items) return;
+  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
+  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) return;
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  const float4 sv = hgt_ld4(sum + (int64_t)seg_key[seg] * H + x);
+  for (int j = b + slot; j < e; j += EPW) {
+    const int64_t eid = p_eid[j];
+    const float4 mv = hgt_ld4(m + eid * H + x);
+    hgt_st4(a + eid * H + x, make_float4(mv.x / sv.x, mv.y / sv.y, mv.z / sv.z, mv.w / sv.w));
+  }
+}
+
+inline bool softmax_grouped_ok(const het_grouping* g, int64_t E, int64_t H) {
+  return g && g->R == 0 && g->E == E && g->p0 && g->p1 && H % 4 == 0 && H <= 256 && ((H / 4) & (H / 4 - 1)) == 0;
+}
+
 // tmp[dst,h] += a * grad_a
 __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_bwd_stage0(const idx_t* __restrict__ col,
                                                                       const idx_t* __restrict__ eids, int64_t E,
@@ -362,13 +475,30 @@ int check_edges(const char* op, const idx_t* row, const idx_t* col, const idx_t*
 extern "C" int het_hgt_full_graph_edge_softmax_ops_separate_coo(
     const int64_t* row, const int64_t* col, const int64_t* eids, const int64_t* rel_ptrs, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* score, const float* mu, float* sum, float* m, float* a, int64_t H,
-    het_stream stream) {
+    const het_grouping* by_dst, het_stream stream) {
   const char* op = "hgt_full_graph_edge_softmax_ops_separate_coo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, num_nodes)) return rc;
   HET_REQUIRE(H > 0 && sum && (num_edges == 0 || (score && mu && m && a)), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));
   if (num_edges == 0) return HET_OK;
+  if (softmax_grouped_ok(by_dst, num_edges, H) && ((reinterpret_cast<uintptr_t>(score) | reinterpret_cast<uintptr_t>(mu) |
+                                                     reinterpret_cast<uintptr_t>(sum) | reinterpret_cast<uintptr_t>(m) |
+                                                     reinterpret_cast<uintptr_t>(a)) & 15) == 0) {
+    const het_grouping* g = by_dst;
+    const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
+    HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, g->item_seg,
+                                                 g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items, g->p0,
+                                                 g->p1, score, mu, sum, m, a));
+    HET_LAUNCH_CHECK("HET_hgt_softmax_grouped");
+    if (g->num_split > 0) {
+      HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_normalize_split<LPR>, dim3(nb), dim3(kBlock), 0, s,
+                                                   g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key,
+                                                   g->num_items, g->p0, sum, m, a));
+      HET_LAUNCH_CHECK("HET_hgt_softmax_normalize_split");
+    }
+    return HET_OK;
+  }
   hipLaunchKernelGGL(HET_hgt_softmax_exp_sum, dim3(grid_for(num_edges * H)), dim3(kBlock), 0, s, col, eids, rel_ptrs,
                      (int)num_rels, num_edges, score, mu, sum, m, (int)H);
   HET_LAUNCH_CHECK("HET_hgt_softmax_exp_sum");
@@ -381,17 +511,24 @@ extern "C" int het_hgt_full_graph_edge_softmax_ops_separate_coo(
 extern "C" int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
     const int64_t* row, const int64_t* col, const int64_t* eids, const int64_t* rel_ptrs, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* score, const float* a, const float* grad_a, const float* mu,
-    float* grad_score, float* grad_mu, float* tmp, int64_t H, het_stream stream) {
+    float* grad_score, float* grad_mu, float* tmp, int64_t H, const het_grouping* by_dst, het_stream stream) {
   const char* op = "backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, num_nodes)) return rc;
   HET_REQUIRE(H > 0 && H <= kMaxLdsHeads && tmp && (num_edges == 0 || (score && a && grad_a && mu && grad_score && grad_mu)),
               "%s: null data pointer or too many heads", op);
   hipStream_t s = (hipStream_t)stream;
-  HET_HIP(hipMemsetAsync(tmp, 0, sizeof(float) * num_nodes * H, s));
+  if (num_edges > 0 && softmax_grouped_ok(by_dst, num_edges, H) && segment_sum_supported((int)H) &&
+      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(grad_a) | reinterpret_cast<uintptr_t>(tmp)) & 15) == 0) {
+    // tmp[dst, :] = SUM over the in-edges of a[eid, :] * grad_a[eid, :]: a segmented sum instead of E*H float atomics
+    if (int rc = launch_segment_sum(by_dst, grad_a, tmp, (int)H, a, s, (int)H, num_nodes, 0, 1)) return rc;
+  } else {
+    HET_HIP(hipMemsetAsync(tmp, 0, sizeof(float) * num_nodes * H, s));
+    if (num_edges == 0) return HET_OK;
+    hipLaunchKernelGGL(HET_hgt_softmax_bwd_stage0, dim3(grid_for(num_edges * H)), dim3(kBlock), 0, s, col, eids, num_edges,
+                       a, grad_a, tmp, (int)H);
+    HET_LAUNCH_CHECK("HET_hgt_softmax_bwd_stage0");
+  }
   if (num_edges == 0) return HET_OK;
-  hipLaunchKernelGGL(HET_hgt_softmax_bwd_stage0, dim3(grid_for(num_edges * H)), dim3(kBlock), 0, s, col, eids, num_edges,
-                     a, grad_a, tmp, (int)H);
-  HET_LAUNCH_CHECK("HET_hgt_softmax_bwd_stage0");
   int64_t chunk = ceil_div64(num_edges, 4096);
   if (chunk < 256) chunk = 256;
   hipLaunchKernelGGL(HET_hgt_softmax_bwd_stage1, dim3((unsigned)(ceil_div64(num_edges, chunk) + num_rels)), dim3(kBlock),

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   const int64_t item = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
   if (item >= num_items) return;
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
-  const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
+  // scale_heads == X: one scale per element (a float4 per lane); else one per (row, head) or per row
+  const bool ew = scale_heads == X;
+  const int sld = scale_heads ? scale_heads : 1, sh = ew ? x : (scale_heads ? x / (X / scale_heads) : 0);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int jn[U];
   int64_t rown[U];
@@ -41,14 +43,20 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
     for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
   }
   for (int j0 = b; j0 < e; j0 += U) {
-    float w[U];
+    float4 w[U];
     float4 f[U];
-    if (scale) {
+    if (scale && ew) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = scale[(int64_t)sin[u] * sld + sh];
+      for (int u = 0; u < U; ++u) w[u] = ld4(scale + (int64_t)sin[u] * sld + sh);
+    } else if (scale) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float t = scale[(int64_t)sin[u] * sld + sh];
+        w[u] = make_float4(t, t, t, t);
+      }
     } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = 1.f;
+      for (int u = 0; u < U; ++u) w[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(in + rown[u] * X + x);
@@ -63,9 +71,9 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float wu = (j0 + u < e) ? w[u] : 0.f;
-      acc.x = fmaf(wu, f[u].x, acc.x); acc.y = fmaf(wu, f[u].y, acc.y);
-      acc.z = fmaf(wu, f[u].z, acc.z); acc.w = fmaf(wu, f[u].w, acc.w);
+      const float ok = (j0 + u < e) ? 1.f : 0.f;
+      acc.x = fmaf(ok * w[u].x, f[u].x, acc.x); acc.y = fmaf(ok * w[u].y, f[u].y, acc.y);
+      acc.z = fmaf(ok * w[u].z, f[u].z, acc.z); acc.w = fmaf(ok * w[u].w, f[u].w, acc.w);
     }
   }
   float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + x;
@@ -85,10 +93,10 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
 
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
-                       int scale_heads, int64_t scatter_rows, int accumulate) {
+                       int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0) {
   HET_REQUIRE(segment_sum_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
-  HET_REQUIRE(scale_heads == 0 || (X % scale_heads == 0 && (X / scale_heads) % 4 == 0),
-              "segment sum: a head must cover whole float4 pieces");
+  HET_REQUIRE(scale_heads == 0 || scale_heads == X || (X % scale_heads == 0 && (X / scale_heads) % 4 == 0),
+              "segment sum: a head must cover whole float4 pieces (or scale_heads == X: one scale per element)");
   // scatter_rows >= 0: out has that many rows and segment s lands in row seg_key[s] (rows without a
   // segment read zero unless accumulating); otherwise out is dense [S, X]
   const int32_t* out_row = scatter_rows >= 0 ? g->seg_key : nullptr;
@@ -97,7 +105,7 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
     else if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
   }
   if (g->S == 0) return HET_OK;
-  const int32_t* p_scale = g->p1 ? g->p1 : g->p0;
+  const int32_t* p_scale = (g->p1 && !scale_by_p0) ? g->p1 : g->p0;
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
 #define HET_SS(L)                                                                                                   \
   hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \

@@ -7,6 +7,8 @@
 // X floats per row, X/4 a power of two <= 64.  `out` has g->S rows and is fully overwritten.
 bool segment_sum_supported(int X);
 // scatter_rows >= 0: `out` has scatter_rows rows and segment s is written to row seg_key[s] instead of row s.
-// accumulate: add to `out` instead of overwriting it.  The scale index is payload1, or payload0 without one.
+// accumulate: add to `out` instead of overwriting it.  The scale index is payload1, or payload0 without one
+// (scale_by_p0: payload0 even when the grouping carries a payload1).  scale_heads == X: one scale per element,
+// i.e. out[s, :] = SUM scale[idx(j), :] * in[row(j), :].
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
-                       int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0);
+                       int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0, int scale_by_p0 = 0);

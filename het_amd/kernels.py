@@ -605,10 +605,13 @@ def hgt_full_graph_edge_softmax_ops_separate_coo(row_indices, col_indices, eids,
          (unnormalized_attn_score, mu, edgesoftmax_sum_per_node, mu_softmax_applied_unnormalized_attn_score,
           normalized_attn_score), (row_indices, col_indices, eids, rel_ptrs))
     H = mu.shape[1]
+    N = edgesoftmax_sum_per_node.shape[0]
+    g = _by_dst(0, None, rel_ptrs, row_indices, col_indices, eids, N) if H % 4 == 0 and eids.numel() > 0 else None
     _call(mu, "het_hgt_full_graph_edge_softmax_ops_separate_coo", _p(row_indices), _p(col_indices), _p(eids),
-          _p(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(), edgesoftmax_sum_per_node.shape[0],
+          _p(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(), N,
           _p(unnormalized_attn_score), _p(mu), _p(edgesoftmax_sum_per_node),
-          _p(mu_softmax_applied_unnormalized_attn_score), _p(normalized_attn_score), H, _stream(mu))
+          _p(mu_softmax_applied_unnormalized_attn_score), _p(normalized_attn_score), H,
+          None if g is None else g.handle, _stream(mu))
 
 
 @_op("backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(Tensor row_indices, Tensor col_indices, "
@@ -622,11 +625,13 @@ def backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
          (unnormalized_attn_score, normalized_attn_score, grad_normalized_attn_score, mu, grad_unnormalized_attn_score,
           grad_mu, sum_incoming_edges_product_softmax_score), (row_indices, col_indices, eids, rel_ptrs))
     H = mu.shape[1]
+    N = sum_incoming_edges_product_softmax_score.shape[0]
+    g = _by_dst(0, None, rel_ptrs, row_indices, col_indices, eids, N) if H % 4 == 0 and eids.numel() > 0 else None
     _call(mu, "het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo", _p(row_indices),
           _p(col_indices), _p(eids), _p(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(),
-          sum_incoming_edges_product_softmax_score.shape[0], _p(unnormalized_attn_score), _p(normalized_attn_score),
+          N, _p(unnormalized_attn_score), _p(normalized_attn_score),
           _p(grad_normalized_attn_score), _p(mu), _p(grad_unnormalized_attn_score), _p(grad_mu),
-          _p(sum_incoming_edges_product_softmax_score), H, _stream(mu))
+          _p(sum_incoming_edges_product_softmax_score), H, None if g is None else g.handle, _stream(mu))
 
 
 @_op("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "

@@ -262,15 +262,18 @@ int het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
  *      backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo   HGTOps.inc.h:597-648
  *   tmp[col[i],h] = SUM_i a*grad_a;  c = (grad_a - tmp[col[i],h]) * a
  *   grad_score[eids[i],h] = c * mu[r,h];  grad_mu[r,h] += c * score[eids[i],h]      
+ *   by_dst (optional, H % 4 == 0): het_grouping_create(NULL, 0, col, E, N, payload0 = eids, payload1 = relation of
+ *   every position) -- the denominators / tmp become segmented sums instead of E*H float atomics.
  * ------------------------------------------------------------------------ */
 int het_hgt_full_graph_edge_softmax_ops_separate_coo(const int64_t* row, const int64_t* col, const int64_t* eids,
                                                      const int64_t* rel_ptrs, int64_t num_rels, int64_t num_edges,
                                                      int64_t num_nodes, const float* score, const float* mu,
-                                                     float* sum, float* m, float* a, int64_t H, het_stream stream);
+                                                     float* sum, float* m, float* a, int64_t H,
+                                                     const het_grouping* by_dst, het_stream stream);
 int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
     const int64_t* row, const int64_t* col, const int64_t* eids, const int64_t* rel_ptrs, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* score, const float* a, const float* grad_a, const float* mu,
-    float* grad_score, float* grad_mu, float* tmp, int64_t H, het_stream stream);
+    float* grad_score, float* grad_mu, float* tmp, int64_t H, const het_grouping* by_dst, het_stream stream);
 
 /* a11  hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo (+ backward)
  *      OpExport/HGTOpsEdgeParallel.inc.h:33-88, 295-369

@@ -299,9 +299,22 @@ def test_cpu_tensors_are_rejected(K):
 
 
 # ---------------------------------------------------------------- HGT ops
-@pytest.mark.parametrize("H,dk", [(8, 8), (2, 16), (3, 5), (1, 4)])
-def test_hgt_edge_softmax_fwd_bwd(K, plan_mode, H, dk):
-    g = random_graph(seed=61, n=260, r=4, e=4000)
+def _hub_graph(seed, N=500, E=6000, R=3):
+    """One destination with half of all edges (its segment is split over several work items), many without any."""
+    from het_amd.graph import HetGraph
+    from het_amd.synth import IntegratedCOO
+    gen = torch.Generator().manual_seed(seed)
+    col = torch.randint(0, 40, (E,), generator=gen)
+    col[: E // 2] = 7
+    row = torch.randint(0, N, (E,), generator=gen)
+    rel = torch.sort(torch.randint(0, R, (E,), generator=gen)).values
+    return HetGraph.from_integrated_coo(IntegratedCOO(N, R, torch.tensor([0, N]), row, col, rel, torch.randperm(E, generator=gen)))
+
+
+@pytest.mark.parametrize("H,dk,hub", [(8, 8, False), (8, 8, True), (4, 8, True), (16, 4, False), (2, 16, False), (3, 5, False),
+                                      (1, 4, False)])
+def test_hgt_edge_softmax_fwd_bwd(K, plan_mode, H, dk, hub):
+    g = _hub_graph(9) if hub else random_graph(seed=61, n=260, r=4, e=4000)
     s = g.get_separate_coo_original()
     N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
     gen = torch.Generator().manual_seed(12)
