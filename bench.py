@@ -162,6 +162,7 @@ def main():
     X = K
     torch.manual_seed(0)
     use_dist = world > 1 or os.environ.get("HET_FORCE_DIST") == "1"
+    layout_ms = None
     if use_dist:
         from het_amd.dist import DistRGAT
         runner = DistRGAT(coo, K, X, H, dev, **layer_flags(args.variant))
@@ -170,7 +171,11 @@ def main():
     else:
         for f in ("row", "col", "rel", "eids", "node_type_offsets"):
             setattr(coo, f, getattr(coo, f).to(dev))
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
         g = HetGraph.from_integrated_coo(coo, full=args.variant.startswith("compact") or args.model == "hgt")
+        torch.cuda.synchronize()
+        layout_ms = (time.perf_counter() - t_l) * 1e3  # device-side builders (layouts.hip); outside the timed region
         extra = ()
         if args.model == "rgat":
             layer = HET_RGATLayer(K, X, g.get_num_rels(), H, self_loop=True, dropout=0.0, **layer_flags(args.variant)).to(dev)
@@ -267,6 +272,7 @@ def main():
             "config": {"workload": f"{args.model.upper()} layer fwd+bwd, ogbn-mag-shaped synthetic graph (N={N_global}, E={E_global}, R=4), "
                                    f"feat={K}, heads={H}, self_loop, no optimizer step, layer flags: {args.variant}",
                        "edge_order": args.edge_order, "scale": args.scale,
+                       "layout_build_ms": None if layout_ms is None else round(layout_ms, 1),
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
             "roofline": roofline,
             "roofline_segment_gemm": roofline_gemm,

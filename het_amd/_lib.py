@@ -16,6 +16,10 @@ P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 # name -> argtypes, in the order of include/het_amd.h
 _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
+    "het_layout_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
+    "het_layout_coo_to_csr": [P, P, P, P, I64, I64, P, P, P, P, P],
+    "het_layout_transpose_csr": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
+    "het_layout_unique_rel_nodes": [P, I64, P, P, I64, I64, P, P, P, P, P],
     "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rgnn_relational_matmul_attn_dot": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, P],
     "het_backward_rgnn_relational_matmul": [I64, P, I64, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P, P, I64, P],

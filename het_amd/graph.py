@@ -16,8 +16,11 @@ Layouts:
               lists + inverse indices (hrt/python/utils_lite/
               mydgl_graph_methods.py:10-157)
 
-All builders are vectorised torch code and run on whatever device the tensors
-live on (the reference's run on CPU with Python loops).
+Builders: on GPU tensors the native device-side builders of libhet_amd.so
+(het_amd/csrc/layouts.hip: one hipCUB radix sort + gather / boundary / run-length
+kernels per conversion); on CPU tensors the same conversions as vectorised torch
+code (the reference's run on CPU with C++ vector-of-vector bucketing and Python
+loops).  Both produce the reference builders' results exactly (tests/golden).
 """
 from __future__ import annotations
 
@@ -25,9 +28,26 @@ from typing import Dict, Optional
 
 import torch
 
+import ctypes as _C
+
+from . import _lib
 from .synth import IntegratedCOO
 
 _I64 = torch.int64
+
+
+def _p(t):
+    return None if t is None else _C.c_void_p(t.data_ptr())
+
+
+def _native(name, ref, *args):
+    """Call a het_layout_* entry point on the device / current stream of ``ref``."""
+    with torch.cuda.device(ref.device):
+        _lib.call(name, *args, _C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream))
+
+
+def _c64(t):
+    return t.to(_I64).contiguous()
 
 
 def _stable_argsort(x: torch.Tensor) -> torch.Tensor:
@@ -45,6 +65,13 @@ def coo_to_csr(row, col, rel, eids, num_rows: int):
     """Integrated COO -> CSR over ``row`` (stable, so ties keep COO order;
     reference: hrt/python/utils_lite/sparse_matrix_converters.py:6-39, which
     uses an unstable argsort)."""
+    if row.is_cuda:
+        row, col, rel, eids = _c64(row), _c64(col), _c64(rel), _c64(eids)
+        E = row.numel()
+        ptrs = torch.empty(num_rows + 1, dtype=_I64, device=row.device)
+        c, r, e = torch.empty_like(col), torch.empty_like(rel), torch.empty_like(eids)
+        _native("het_layout_coo_to_csr", row, _p(row), _p(col), _p(rel), _p(eids), E, num_rows, _p(ptrs), _p(c), _p(r), _p(e))
+        return ptrs, c, r, e
     o = _stable_argsort(row)
     return _ptrs_from_sorted(row[o], num_rows), col[o], rel[o], eids[o]
 
@@ -60,8 +87,16 @@ def transpose_csr(row_ptrs, col_indices, eids, rel_types):
     """CSR -> CSR of the transposed adjacency (reference op ``transpose_csr``,
     hrt/include/DGLHackKernel/OpExport/DataConverters.inc.h:283-344; restated
     in hrt/python/testing/adjacency_manipulation.py:72-107)."""
-    rows = csr_to_coo_rows(row_ptrs)
     n = max(int(row_ptrs.numel() - 1), int(col_indices.max().item()) + 1 if col_indices.numel() else 0)
+    if row_ptrs.is_cuda:
+        row_ptrs, col_indices, eids, rel_types = _c64(row_ptrs), _c64(col_indices), _c64(eids), _c64(rel_types)
+        E = col_indices.numel()
+        ptrs = torch.empty(n + 1, dtype=_I64, device=row_ptrs.device)
+        c, e, r = torch.empty_like(col_indices), torch.empty_like(eids), torch.empty_like(rel_types)
+        _native("het_layout_transpose_csr", row_ptrs, _p(row_ptrs), _p(col_indices), _p(eids), _p(rel_types),
+                row_ptrs.numel() - 1, E, n, _p(ptrs), _p(c), _p(e), _p(r))
+        return ptrs, c, e, r
+    rows = csr_to_coo_rows(row_ptrs)
     ptrs, c, r, e = coo_to_csr(col_indices, rows, rel_types, eids, n)
     return ptrs, c, e, r
 
@@ -70,6 +105,14 @@ def integrated_coo_to_separate_coo(row, col, rel, eids, num_rels: int):
     """Bucket edges by relation, each bucket sorted by eid (reference:
     ``convert_integrated_coo_to_separate_coo`` hrt/include/MyHyb/MyHyb.h:1047-1096
     followed by ``sort_coo_by_etype_eids_torch_tensors``)."""
+    if row.is_cuda:
+        row, col, rel, eids = _c64(row), _c64(col), _c64(rel), _c64(eids)
+        E = row.numel()
+        rp = torch.empty(num_rels + 1, dtype=_I64, device=row.device)
+        r, c, e = torch.empty_like(row), torch.empty_like(col), torch.empty_like(eids)
+        bound = int(eids.max().item()) + 1 if E else 1
+        _native("het_layout_separate_coo", row, _p(row), _p(col), _p(rel), _p(eids), E, num_rels, bound, _p(rp), _p(r), _p(c), _p(e))
+        return rp, r, c, e
     o = _stable_argsort(eids)
     o = o[_stable_argsort(rel[o])]
     return _ptrs_from_sorted(rel[o], num_rels), row[o], col[o], eids[o]
@@ -79,12 +122,30 @@ def _unique_per_relation(rel_ptrs: torch.Tensor, nodes: torch.Tensor, num_nodes:
     """Sorted unique node ids inside every relation bucket, concatenated.
     Returns (node_indices[U], rel_ptrs_u[R+1], inverse[len(nodes)])."""
     R = rel_ptrs.numel() - 1
+    if nodes.is_cuda:
+        return _unique_rel_nodes_native(rel_ptrs, nodes, None, num_nodes)
     rel_of = torch.repeat_interleave(
         torch.arange(R, dtype=_I64, device=nodes.device), rel_ptrs[1:] - rel_ptrs[:-1]
     )
     key = rel_of * int(num_nodes) + nodes
     uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
     return uniq % int(num_nodes), _ptrs_from_sorted(uniq // int(num_nodes), R), inv
+
+
+def _unique_rel_nodes_native(rel_ptrs, nodes_a, nodes_b, num_nodes: int):
+    """(node_indices[U], rel_ptrs_u[R+1], inverse) through het_layout_unique_rel_nodes; with ``nodes_b`` the dual
+    list over both arrays, inverse in the reference's per-relation [rows..., cols...] order."""
+    rel_ptrs, nodes_a = _c64(rel_ptrs), _c64(nodes_a)
+    nodes_b = None if nodes_b is None else _c64(nodes_b)
+    R, E = rel_ptrs.numel() - 1, nodes_a.numel()
+    total = E * (2 if nodes_b is not None else 1)
+    out_nodes = torch.empty(max(total, 1), dtype=_I64, device=nodes_a.device)
+    out_ptrs = torch.empty(R + 1, dtype=_I64, device=nodes_a.device)
+    inv = torch.empty(total, dtype=_I64, device=nodes_a.device)
+    count = _C.c_int64(0)
+    _native("het_layout_unique_rel_nodes", nodes_a, _p(rel_ptrs), R, _p(nodes_a), _p(nodes_b), E, int(num_nodes),
+            _p(out_nodes), _p(out_ptrs), _p(inv), _C.byref(count))
+    return out_nodes[: count.value].clone(), out_ptrs, inv
 
 
 class HetGraph:
@@ -222,6 +283,13 @@ class HetGraph:
         E = s["row_indices"].numel()
         # per relation: unique(concat(rows, cols))  (mydgl_graph_methods.py:104-157)
         R = self._num_rels
+        if s["row_indices"].is_cuda:
+            nodes, ptrs, inv = _unique_rel_nodes_native(s["rel_ptrs"], s["row_indices"], s["col_indices"], self._num_nodes)
+            d = {"node_indices": nodes, "rel_ptrs": ptrs}
+            if produce_inverse_idx:
+                d["inverse_indices"] = inv
+            self.graph_data["separate"]["unique_node_indices"] = d
+            return
         rel_of = torch.repeat_interleave(torch.arange(R, dtype=_I64, device=s["rel_ptrs"].device),
                                          s["rel_ptrs"][1:] - s["rel_ptrs"][:-1])
         key = torch.cat([rel_of * self._num_nodes + s["row_indices"], rel_of * self._num_nodes + s["col_indices"]])

@@ -104,12 +104,10 @@ def convert_integrated_csr_to_separate_coo(row_ptrs, col_indices, rel_types, eid
 
 
 def _separate_csr(rows, cols, rels, eids, num_rows, num_rels):
-    o = torch.sort(rels * num_rows + rows, stable=True).indices
-    counts = torch.bincount(rels[o] * num_rows + rows[o], minlength=num_rows * num_rels)
-    row_ptrs = torch.zeros(num_rows * num_rels + 1, dtype=torch.int64, device=rows.device)
-    torch.cumsum(counts, 0, out=row_ptrs[1:])
+    # a CSR over the composite row (relation, row): stable, so a row keeps its edges in input order
+    row_ptrs, c, _, e = _graph.coo_to_csr(rels * num_rows + rows, cols, rels, eids, num_rows * num_rels)
     rel_ptrs = row_ptrs[::num_rows].contiguous()
-    return [rel_ptrs, row_ptrs, cols[o], eids[o]]
+    return [rel_ptrs, row_ptrs, c, e]
 
 
 @_op("convert_integrated_csr_to_separate_csr(Tensor row_ptrs, Tensor col_indices, Tensor rel_types, Tensor eids) -> Tensor[]")

@@ -337,6 +337,32 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
                                                          const het_grouping* by_rel_src, int64_t n_q_rows,
                                                          void* workspace, int64_t workspace_bytes, het_stream stream);
 
+/* ------------------------------------------------------------------------
+ * Layout builders (the step before the path).  Device-side replacements of the reference's CPU
+ * converters: torch.ops.torch_hrt.convert_integrated_{coo,csr}_to_separate_{coo,csr} / transpose_csr
+ * (OpExport/DataConverters.inc.h:10-344 over MyHyb/MyHyb.h:1047-1150) and the Python unique-list builders
+ * (hrt/python/utils_lite/mydgl_graph_methods.py:10-157).  int64 device arrays in and out, outputs caller-allocated;
+ * one stable radix sort per call; the call returns after the stream has drained (temporaries are freed).
+ * ------------------------------------------------------------------------ */
+/* edges bucketed by relation (out_rel_ptrs [R+1]), inside a bucket sorted by eid (< eid_bound), ties in input order */
+int het_layout_separate_coo(const int64_t* row, const int64_t* col, const int64_t* rel, const int64_t* eids,
+                            int64_t num_edges, int64_t num_rels, int64_t eid_bound, int64_t* out_rel_ptrs,
+                            int64_t* out_row, int64_t* out_col, int64_t* out_eids, het_stream stream);
+/* integrated COO -> CSR over `row` (stable); out_row_ptrs [num_rows+1] */
+int het_layout_coo_to_csr(const int64_t* row, const int64_t* col, const int64_t* rel, const int64_t* eids,
+                          int64_t num_edges, int64_t num_rows, int64_t* out_row_ptrs, int64_t* out_col, int64_t* out_rel,
+                          int64_t* out_eids, het_stream stream);
+/* transpose_csr: rows of the result are the columns of the input; out_row_ptrs [num_cols+1] */
+int het_layout_transpose_csr(const int64_t* row_ptrs, const int64_t* col, const int64_t* eids, const int64_t* rel,
+                             int64_t num_rows, int64_t num_edges, int64_t num_cols, int64_t* out_row_ptrs, int64_t* out_col,
+                             int64_t* out_eids, int64_t* out_rel, het_stream stream);
+/* sorted unique (relation, node) pairs of a relation-bucketed list: out_nodes (capacity E, or 2E with nodes_b),
+ * out_rel_ptrs [R+1], out_inverse (optional; [E], or [2E] for the dual list in the reference's order: per relation the
+ * entries of nodes_a then those of nodes_b), *out_count (host) = number of pairs */
+int het_layout_unique_rel_nodes(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* nodes_a, const int64_t* nodes_b,
+                                int64_t num_edges, int64_t num_nodes, int64_t* out_nodes, int64_t* out_rel_ptrs,
+                                int64_t* out_inverse, int64_t* out_count, het_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
