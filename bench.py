@@ -263,6 +263,19 @@ def main():
                          "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false>", "mfma_busy_frac"),
                          "traffic": pmc("HET_seg_gemm_mfma<64, 2, false>", "hbm_bytes_per_launch")}
 
+    # per-entry-point device time, from a few extra steps after the timed region (HIP events around every C-ABI call)
+    per_op = None
+    if world == 1 and not use_dist:
+        HK.event_timers["*"] = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        acc = {}
+        for a, b, name in HK.event_timers.pop("*"):
+            acc[name] = acc.get(name, 0.0) + a.elapsed_time(b) / 3
+        per_op = {k[4:]: round(v, 3) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}
+        per_op["(sum of C-ABI calls)"] = round(sum(acc.values()), 3)
+
     if rank == 0:
         out = {
             "metric": f"million edges/s (fwd+bwd) {args.model.upper()} layer, ogbn-mag feat=64",
@@ -276,6 +289,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
             "roofline": roofline,
             "roofline_segment_gemm": roofline_gemm,
+            "per_op_ms": per_op,
         }
         if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
             out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)

@@ -65,6 +65,15 @@ def _call(dev_tensor: Tensor, cname: str, *args):
     with torch.cuda.device(dev_tensor.device):
         rec = event_timers.get(cname)
         if rec is None:
+            rec = event_timers.get("*")  # wildcard: time every entry point (bench.py's per-op breakdown)
+            if rec is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                _lib.call(cname, *args)
+                b.record()
+                rec.append((a, b, cname))
+                return
+        if rec is None:
             _lib.call(cname, *args)
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

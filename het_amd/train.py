@@ -1,0 +1,224 @@
+"""Benchmark driver with the reference's flag names and timing protocol, without DGL.
+
+Mirrors hrt/python/RGNNUtils/RGNNUtils.py (arguments :575-679, training loop :199-433: 5 warm-up steps, forward
+and backward(+optimizer.step()) between event pairs, epochs < 3 dropped, of the rest the first quarter dropped,
+arithmetic mean, JSON log) and the model stacks of hrt/python/RGAT/models.py:387-512, RGCN/RGCN.py:353-405,
+HGT/models.py:246-347.  Datasets: the reference loads DGL/OGB graphs; neither is installable here, so ``-d`` picks a
+synthetic graph of the same shape (het_amd/synth.py) or ``--edges_npy`` a ``[3, E]`` (src, dst, etype) array.
+
+    python -m het_amd.train --model rgat -d mag --full_graph_training --num_layers 1 --n_infeat 64 \\
+        --num_classes 64 --num_heads 4 --compact_as_of_node_flag --compact_direct_indexing_flag
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .graph import HetGraph
+from .layers import HET_EglRelGraphConv_EdgeParallel, HET_HGTLayerHetero, HET_RelGraphEmbed, HET_RGATLayer
+from .synth import IntegratedCOO, make_aifb_like, make_mag_like
+
+
+class HET_RGATModel(nn.Module):
+    """hrt/python/RGAT/models.py:387-512: ``num_hidden_layers`` h2h layers + one h2o layer."""
+
+    def __init__(self, num_etypes, h_dim, out_dim, num_heads, num_hidden_layers=1, dropout=0.5, use_self_loop=True,
+                 last_layer_act=False, compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
+                 multiply_among_weights_first_flag=False, gat_edge_parallel_flag=True):
+        super().__init__()
+        flags = dict(compact_as_of_node_flag=compact_as_of_node_flag, compact_direct_indexing_flag=compact_direct_indexing_flag,
+                     multiply_among_weights_first_flag=multiply_among_weights_first_flag,
+                     gat_edge_parallel_flag=gat_edge_parallel_flag, self_loop=use_self_loop)
+        self.layers = nn.ModuleList(
+            [HET_RGATLayer(h_dim, h_dim, num_etypes, num_heads, activation=F.relu, dropout=dropout, **flags)
+             for _ in range(num_hidden_layers)])
+        last_heads = num_heads if num_hidden_layers == 0 else 1  # models.py:469-472
+        self.layers.append(HET_RGATLayer(h_dim, out_dim, num_etypes, last_heads,
+                                         activation=F.relu if last_layer_act else None, **flags))
+
+    def forward(self, g, h):
+        for layer in self.layers:
+            h = layer(g, h)
+        return h
+
+
+class HET_RGCNModel(nn.Module):
+    """hrt/python/RGCN/RGCN.py:353-405 (full-graph, edge-parallel separate-COO layers)."""
+
+    def __init__(self, num_rels, h_dim, out_dim, num_layers=1, num_bases=-1, dropout=0.0, compact_as_of_node_flag=False,
+                 compact_direct_indexing_flag=False):
+        super().__init__()
+        dims = [h_dim] * num_layers + [out_dim]
+        self.layers = nn.ModuleList(
+            [HET_EglRelGraphConv_EdgeParallel(dims[i], dims[i + 1], num_rels, num_bases,
+                                              activation=F.relu if i + 1 < num_layers else None, dropout=dropout,
+                                              compact_as_of_node_flag=compact_as_of_node_flag,
+                                              compact_direct_indexing_flag=compact_direct_indexing_flag)
+             for i in range(num_layers)])
+
+    def forward(self, g, h, norm):
+        for layer in self.layers:
+            h = layer(g, h, norm)
+        return h
+
+
+class HET_HGTModel(nn.Module):
+    """hrt/python/HGT/models.py:246-347 (stack of HET_HGTLayerHetero)."""
+
+    def __init__(self, num_ntypes, num_rels, h_dim, out_dim, num_heads, num_layers=1, dropout=0.2):
+        super().__init__()
+        dims = [h_dim] * num_layers + [out_dim]
+        self.layers = nn.ModuleList([HET_HGTLayerHetero(num_ntypes, num_rels, dims[i], dims[i + 1], num_heads=num_heads,
+                                                        dropout=dropout) for i in range(num_layers)])
+
+    def forward(self, g, h):
+        for layer in self.layers:
+            h = layer(g, h)
+        return h
+
+
+def add_generic_RGNN_args(p: argparse.ArgumentParser, default_logfilename: str):
+    """The reference's generic flags (RGNNUtils.py:575-679), same names and defaults."""
+    p.add_argument("--logfile_enabled", action="store_true", help="enable logging to json")
+    p.add_argument("--logfilename", type=str, default=default_logfilename)
+    p.add_argument("-d", "--dataset", type=str, default="mag", help="mag | aifb (synthetic graphs of those shapes)")
+    p.add_argument("--n_infeat", type=int, default=64)
+    p.add_argument("--sparse_format", type=str, default="csr")
+    p.add_argument("--sort_by_src", action="store_true")
+    p.add_argument("--sort_by_etype", action="store_true")
+    p.add_argument("--no_reindex_eid", action="store_true")
+    p.add_argument("--num_classes", type=int, default=8)
+    p.add_argument("--use_real_labels_and_features", action="store_true")
+    p.add_argument("--compact_direct_indexing_flag", action="store_true", default=False)
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--num_heads", type=int, default=1)
+    p.add_argument("-e", "--n_epochs", type=int, default=10)
+    p.add_argument("--fanout", type=int, nargs="+", default=[25, 20])
+    p.add_argument("--batch_size", type=int, default=1024)
+    p.add_argument("--full_graph_training", action="store_true")
+    p.add_argument("--num_layers", type=int, default=1)
+    p.add_argument("--compact_as_of_node_flag", action="store_true")
+    p.add_argument("--no_warm_up", action="store_true")
+    p.add_argument("--runs", type=int, default=1)
+    p.add_argument("--dropout", type=float, default=0.5)
+    # model-specific flags of RGAT/train_dgl.py:20-40, HGT/train.py
+    p.add_argument("--multiply_among_weights_first_flag", action="store_true")
+    p.add_argument("--gat_edge_parallel_flag", action="store_true", default=True)
+    p.add_argument("--n_bases", type=int, default=-1)
+    # ours
+    p.add_argument("--model", default="rgat", choices=["rgat", "rgcn", "hgt"])
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the synthetic graph")
+    p.add_argument("--edges_npy", type=str, default=None, help="[3, E] int array (src, dst, etype) instead of -d")
+    p.add_argument("--seed", type=int, default=0)
+
+
+def load_graph(args) -> IntegratedCOO:
+    if args.edges_npy:
+        a = th.from_numpy(np.load(args.edges_npy).astype(np.int64))
+        n, r = int(a[:2].max()) + 1, int(a[2].max()) + 1
+        o = th.sort(a[2], stable=True).indices
+        return IntegratedCOO(n, r, th.tensor([0, n]), a[0][o].contiguous(), a[1][o].contiguous(), a[2][o].contiguous(),
+                             th.arange(a.shape[1]))
+    if args.dataset in ("mag", "ogbn-mag"):
+        return make_mag_like(scale=args.scale)
+    if args.dataset == "aifb":
+        return make_aifb_like()
+    raise SystemExit(f"dataset {args.dataset!r}: only the synthetic 'mag' / 'aifb' shapes or --edges_npy are available (no DGL/OGB)")
+
+
+def aggregate_times(ms):
+    """RGNNUtils.py:336-345, 364-384: drop epochs < 3, then the first quarter of what is left; arithmetic mean."""
+    kept = ms[3:] if len(ms) > 3 else ms
+    kept = kept[len(kept) // 4:]
+    return float(sum(kept) / len(kept)) if kept else float("nan")
+
+
+def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=()):
+    def one_step(timed):
+        optimizer.zero_grad()
+        node_embed = node_embed_layer()
+        th.cuda.synchronize()
+        ev = [th.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        logits = model(g, node_embed, *extra)
+        ev[1].record()
+        loss = F.nll_loss(logits.log_softmax(dim=-1), labels)
+        ev[2].record()
+        loss.backward()
+        optimizer.step()  # the reference times the optimizer inside "backward" (RGNNUtils.py:304-311)
+        ev[3].record()
+        th.cuda.synchronize()
+        return (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), float(loss.detach())) if timed else None
+
+    model.train()
+    node_embed_layer.train()
+    if not args.no_warm_up:
+        for _ in range(5):
+            one_step(False)
+    fwd, bwd, losses = [], [], []
+    for epoch in range(args.n_epochs):
+        f, b, l = one_step(True)
+        fwd.append(f); bwd.append(b); losses.append(l)
+        print(f"Epoch {epoch:02d} | forward {f:.3f} ms | backward {b:.3f} ms | loss {l:.4f}")
+    return fwd, bwd, losses
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="HET RGAT / RGCN / HGT benchmark driver on het_amd (MI355X)")
+    add_generic_RGNN_args(p, "het_amd_train.json")
+    args = p.parse_args(argv)
+    if not args.full_graph_training:
+        print("note: mini-batch sampling needs DGL samplers (SURVEY.md 8f rank 4); running full-graph training", file=sys.stderr)
+    dev = th.device("cuda")
+    th.manual_seed(args.seed)
+    coo = load_graph(args)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    t0 = time.perf_counter()
+    g = HetGraph.from_integrated_coo(coo, full=True)
+    th.cuda.synchronize()
+    layout_ms = (time.perf_counter() - t0) * 1e3
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    print("Graph stats: ", E, N, R)
+    embed = HET_RelGraphEmbed(N, args.n_infeat).to(dev)
+    extra = ()
+    if args.model == "rgat":
+        model = HET_RGATModel(R, args.n_infeat, args.num_classes, args.num_heads, num_hidden_layers=args.num_layers - 1,
+                              dropout=args.dropout, use_self_loop=True,
+                              compact_as_of_node_flag=args.compact_as_of_node_flag,
+                              compact_direct_indexing_flag=args.compact_direct_indexing_flag,
+                              multiply_among_weights_first_flag=args.multiply_among_weights_first_flag,
+                              gat_edge_parallel_flag=args.gat_edge_parallel_flag)
+    elif args.model == "rgcn":
+        model = HET_RGCNModel(R, args.n_infeat, args.num_classes, num_layers=args.num_layers, num_bases=args.n_bases,
+                              dropout=args.dropout, compact_as_of_node_flag=args.compact_as_of_node_flag,
+                              compact_direct_indexing_flag=args.compact_direct_indexing_flag)
+        extra = (th.rand(E, 1, device=dev),)  # edge norm as RGCN.py:527-530
+    else:
+        model = HET_HGTModel(g.get_num_ntypes(), R, args.n_infeat, args.num_classes, args.num_heads,
+                             num_layers=args.num_layers, dropout=args.dropout)
+    model = model.to(dev)
+    labels = th.randint(0, args.num_classes, (N,), device=dev)  # random labels as train_dgl.py:132-148
+    optimizer = th.optim.Adam(list(model.parameters()) + list(embed.parameters()), lr=args.lr)
+    fwd, bwd, losses = HET_RGNN_train(g, model, embed, optimizer, labels, args, extra)
+    res = {"model": args.model, "dataset": args.edges_npy or args.dataset, "num_nodes": N, "num_edges": E, "num_rels": R,
+           "mean_forward_ms": round(aggregate_times(fwd), 4), "mean_backward_ms": round(aggregate_times(bwd), 4),
+           "layout_build_ms": round(layout_ms, 1), "final_loss": losses[-1] if losses else None,
+           "peak_memory_GB": round(th.cuda.max_memory_allocated() / 2**30, 3), "args": vars(args)}
+    res["million_edges_per_s"] = round(E / ((res["mean_forward_ms"] + res["mean_backward_ms"]) * 1e-3) / 1e6, 2)
+    print(json.dumps(res))
+    if args.logfile_enabled:
+        with open(args.logfilename, "a") as f:
+            f.write(json.dumps(res) + "\n")
+    return res
+
+
+if __name__ == "__main__":
+    main()
