@@ -241,28 +241,62 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[kt][nt][e] = 0.f;
-#pragma unroll 2
-  for (idx_t i0 = wb; i0 < we; i0 += 2) {
-    const idx_t i = i0 + half;
-    float av[KT], gv[NT];
-    if (i < we) {
-      const idx_t ar = a.gather ? a.gather[i] : i, gr = a.g_gather ? a.g_gather[i] : i;
-      const float sc = a.row_scale ? a.row_scale[a.scale_idx ? a.scale_idx[i] : i] : 1.f;
+  // Rows are consumed in batches of SB two-row MFMA steps with a two-deep, branch-free software pipeline (the same
+  // scheme as the GEMM kernel above): iteration b issues the row loads of batch b+1 (their ids arrived one batch
+  // ago) and the id loads of batch b+2, then runs the MFMAs of batch b.  Out-of-range rows clamp to the last row
+  // (valid addresses) and enter the product as zeros.
+  if (wb < we) {
+    constexpr int SB = 8;
+    const bool has_g = a.gather != nullptr, has_gg = a.g_gather != nullptr;
+    const idx_t* __restrict__ gp = has_g ? a.gather : a.seg_ptrs;
+    const idx_t* __restrict__ ggp = has_gg ? a.g_gather : a.seg_ptrs;
+    int ar[2][SB], gr[2][SB];
+    float av[2][SB][KT], gv[2][SB][NT];
+    auto load_ids = [&](idx_t base, int (&A)[SB], int (&G)[SB]) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) av[kt] = a.A[ar * a.a_ld + kt * 32 + col] * sc;
+      for (int st = 0; st < SB; ++st) {
+        const idx_t i = base + 2 * st + half, ic = i < we ? i : we - 1;
+        const int va = reinterpret_cast<const int*>(gp + (has_g ? ic : 0))[0];
+        const int vg = reinterpret_cast<const int*>(ggp + (has_gg ? ic : 0))[0];
+        A[st] = has_g ? va : (int)ic;
+        G[st] = has_gg ? vg : (int)ic;
+      }
+    };
+    auto load_rows = [&](const int (&A)[SB], const int (&G)[SB], float (&AV)[SB][KT], float (&GV)[SB][NT]) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) gv[nt] = a.G[gr * a.g_ld + nt * 32 + col];
-    } else {
+      for (int st = 0; st < SB; ++st) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) av[kt] = 0.f;
+        for (int kt = 0; kt < KT; ++kt) AV[st][kt] = a.A[(int64_t)A[st] * a.a_ld + kt * 32 + col];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) gv[nt] = 0.f;
+        for (int nt = 0; nt < NT; ++nt) GV[st][nt] = a.G[(int64_t)G[st] * a.g_ld + nt * 32 + col];
+      }
+    };
+    auto mma = [&](idx_t base, const float (&AV)[SB][KT], const float (&GV)[SB][NT]) {
+#pragma unroll
+      for (int st = 0; st < SB; ++st) {
+        const bool in = base + 2 * st + half < we;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const float x = in ? AV[st][kt] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, GV[st][nt], acc[kt][nt], 0, 0, 0);
+        }
+      }
+    };
+    load_ids(wb, ar[0], gr[0]);
+    load_ids(wb + 2 * SB, ar[1], gr[1]);
+    load_rows(ar[0], gr[0], av[0], gv[0]);
+    for (idx_t b = wb; b < we; b += 4 * SB) {
+      load_rows(ar[1], gr[1], av[1], gv[1]);
+      load_ids(b + 4 * SB, ar[0], gr[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b, av[0], gv[0]);
+      load_rows(ar[0], gr[0], av[0], gv[0]);
+      load_ids(b + 6 * SB, ar[1], gr[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b + 2 * SB, av[1], gv[1]);
     }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[kt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kt], gv[nt], acc[kt][nt], 0, 0, 0);
   }
   constexpr int NACC = KT * NT * 16;
   if (wave > 0) {
@@ -305,7 +339,9 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
 template <int KT, int NT>
 int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * 3 * KT * NT * 16 * 64;
-  int64_t chunk = ceil_div64(a.num_rows, 1024);  // about 1024 workgroups
+  HET_REQUIRE(!a.row_scale, "segment dW (MFMA): row scales are applied by the segment-sum pre-pass, not here");
+  // 48 KiB of LDS per workgroup -> 3 resident per CU, 768 on the chip: aim for about 4 rounds of them
+  int64_t chunk = ceil_div64(a.num_rows, 3072);
   if (chunk < 512) chunk = 512;
   chunk = (chunk + 7) & ~7ll;
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
