@@ -38,7 +38,7 @@ _SIGNATURES = {
     "het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, I64, P, P, I64, P],
     "het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, P, I64, I64, I64, P, P, I64, P],
     "het_rgnn_inner_product_right_node_separatecoo": [I64, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, P],
-    "het_backward_inner_product_right_node_separatecoo": [I64, P, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, INT, P, I64, I64, P],
+    "het_backward_inner_product_right_node_separatecoo": [I64, P, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, INT, P, P, I64, I64, P],
     "het_hgt_full_graph_hetero_attention_ops_coo": [P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, P],
     "het_backward_hgt_full_graph_hetero_attention_ops_coo": [P, P, P, P, I64, I64, P, P, P, P, P, P, P, P, I64, I64, I64, P, P, I64, P, I64, P],
 }

@@ -668,7 +668,8 @@ extern "C" int het_backward_inner_product_right_node_separatecoo(
     int64_t kind, const int64_t* map_a, const int64_t* map_b, const int64_t* rel_ptrs, const int64_t* eids,
     const int64_t* row, const int64_t* col, int64_t num_rels, int64_t num_edges, const float* left, const float* right,
     const float* gradout, float* grad_left, float* grad_right, int64_t H, int64_t D, int accumulate,
-    const het_grouping* by_right, int64_t n_left_rows, int64_t n_right_rows, het_stream stream) {
+    const het_grouping* by_right, const het_grouping* by_left, int64_t n_left_rows, int64_t n_right_rows,
+    het_stream stream) {
   const char* op = "backward_inner_product_right_node_separatecoo";
   if (int rc = check_edges(op, row, col, eids, rel_ptrs, num_rels, num_edges, 0)) return rc;
   HET_REQUIRE(kind == 0 || kind == 1 || kind == 2, "%s: unsupported CompactAsOfNodeKind %lld", op, (long long)kind);
@@ -687,8 +688,15 @@ extern "C" int het_backward_inner_product_right_node_separatecoo(
     // shared compact rows (kind 2) -> atomics on zeroed rows
     const idx_t* lmap = kind == 2 ? map_a : nullptr;
     const int mode = kind == 0 ? (accumulate ? 1 : 2) : 0;
-    if (!accumulate && mode == 0) HET_HIP(hipMemsetAsync(grad_left, 0, sizeof(float) * n_left_rows * X, s));
-    if (num_edges > 0) {
+    const bool left_grouped = mode == 0 && by_left && by_left->R == 0 && by_left->E == num_edges && by_left->p0 && by_left->p1;
+    if (left_grouped) {
+      // shared (compact) left rows: grad_left[row] (+)= SUM over its edges of gout[e,h] * right[ridx[e],h,:]
+      // (payload0 = right row, payload1 = edge id) -- no float atomics
+      if (int rc = launch_segment_sum(by_left, right, grad_left, (int)X, gradout, s, (int)H, n_left_rows, accumulate)) return rc;
+    } else if (!accumulate && mode == 0) {
+      HET_HIP(hipMemsetAsync(grad_left, 0, sizeof(float) * n_left_rows * X, s));
+    }
+    if (num_edges > 0 && !left_grouped) {
       const unsigned nb = grid_for(num_edges * (X / 4));
 #define HET_IPL(MODEV) HET_HGT_LPR((int)(X / 4), hipLaunchKernelGGL((HET_rows_inner_product_bwd_left<LPR, MODEV>), dim3(nb), \
                                    dim3(kBlock), 0, s, eids, lmap, row, num_edges, right, gradout, grad_left, (int)H, (int)D))

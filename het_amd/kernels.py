@@ -537,6 +537,28 @@ def _ip_maps(d: Dict[str, Tensor], kind: int):
     raise _lib.HetError(f"rgnn_inner_product_right_node: CompactAsOfNodeKind {kind} not supported")
 
 
+def _ip_direct(d: Dict[str, Tensor], kind: int, rel_ptrs, col, eids):
+    """(kind, map_a, map_b) as handed to the C entry points: the binary-search kind 1 is turned into the direct-index
+    kind 2 once per graph (left row of every edge id; cached), which is what the fast row kernels read."""
+    a, b = _ip_maps(d, kind)
+    if kind != 1 or not _plan.enabled or eids.numel() == 0:
+        return kind, a, b
+    key = ("ipmap", a.data_ptr(), a._version, b.data_ptr(), col.data_ptr(), eids.data_ptr())
+    hit = _derived.get(key)
+    if hit is None:
+        R = rel_ptrs.numel() - 1
+        bound = int(max(int(col.max().item()), int(b.max().item()))) + 1
+        rel_e = _rel_by_position(rel_ptrs, eids.numel())
+        rel_u = torch.repeat_interleave(torch.arange(R, device=col.device), a[1:] - a[:-1])
+        lrow = torch.searchsorted(rel_u * bound + b, rel_e * bound + col)
+        m = torch.empty(int(eids.max().item()) + 1, dtype=torch.int64, device=col.device)
+        m[eids] = lrow
+        if len(_derived) > 16:
+            _derived.clear()
+        hit = _derived[key] = (m, (a, b, col, eids))
+    return 2, hit[0], None
+
+
 @_op("rgnn_inner_product_right_node_separatecoo(Dict(str, Tensor) arg_tensor_dict, int IntKind, "
      "Tensor separate_coo_rel_ptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
      "Tensor separate_coo_col_indices, Tensor left_side_data, Tensor right_node_vectors, "
@@ -548,6 +570,7 @@ def rgnn_inner_product_right_node_separatecoo(arg_tensor_dict, IntKind, separate
     _chk("rgnn_inner_product_right_node_separatecoo", (left_side_data, right_node_vectors, edge_inner_product),
          (separate_coo_rel_ptrs, separate_coo_eids, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(t for t in (a, b) if t is not None))
+    IntKind, a, b = _ip_direct(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
     H = edge_inner_product.shape[1]
     D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
     _call(edge_inner_product, "het_rgnn_inner_product_right_node_separatecoo", IntKind, _p(a), _p(b),
@@ -585,7 +608,8 @@ def inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, sepa
              + tuple(t for t in (a, b) if t is not None))
     H = gradout.shape[1]
     D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
-    g = None
+    IntKind, a, b = _ip_direct(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
+    g = gl = None
     if IntKind in (0, 2) and _plan.enabled:
         if IntKind == 0:
             lrow = separate_coo_eids
@@ -594,12 +618,15 @@ def inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, sepa
             hit = _derived.get(key)
             lrow = hit[0] if hit is not None else a[separate_coo_eids].contiguous()
             _derived[key] = (lrow, (a, separate_coo_eids))
+            # compact left rows are shared by many edges: their gradient is a segmented sum over the edges of a row
+            gl = _plan.get_grouping(None, lrow, left_side_data.shape[0], separate_coo_row_indices, separate_coo_eids)
         g = _plan.get_grouping(None, separate_coo_row_indices, right_node_vectors.shape[0], lrow, separate_coo_eids)
     _call(gradout, "het_backward_inner_product_right_node_separatecoo", IntKind, _p(a), _p(b),
           _p(separate_coo_rel_ptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), _p(left_side_data), _p(right_node_vectors),
           _p(gradout), _p(grad_left_side_data), _p(grad_right_node_vectors), H, D, int(accumulate),
-          None if g is None else g.handle, left_side_data.shape[0], right_node_vectors.shape[0], _stream(gradout))
+          None if g is None else g.handle, None if gl is None else gl.handle, left_side_data.shape[0],
+          right_node_vectors.shape[0], _stream(gradout))
 
 
 @_op("hgt_full_graph_edge_softmax_ops_separate_coo(Tensor row_indices, Tensor col_indices, Tensor eids, Tensor rel_ptrs, "

@@ -303,7 +303,9 @@ int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate
  *   (accumulating; the reference kernel stores without atomics).  accumulate == 0: both
  *   gradients are overwritten instead (n_left_rows / n_right_rows = their row counts).  by_right: optional
  *   grouping of the positions by row (het_grouping_create(NULL, 0, row, E, n_right_rows, payload0 = lrow per
- *   position, payload1 = eids)), used for kinds 0 and 2. */
+ *   position, payload1 = eids)), used for kinds 0 and 2.  by_left (kind 2): grouping of the positions by lrow
+ *   (payload0 = row, payload1 = eids): the gradient of a shared compact row becomes a segmented sum instead of
+ *   float atomics.  (A caller holding kind-1 lists can precompute lrow per edge id once and call with kind 2.) */
 int het_rgnn_inner_product_right_node_separatecoo(int64_t kind, const int64_t* map_a, const int64_t* map_b,
                                                   const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row,
                                                   const int64_t* col, int64_t num_rels, int64_t num_edges,
@@ -315,8 +317,8 @@ int het_backward_inner_product_right_node_separatecoo(int64_t kind, const int64_
                                                       int64_t num_edges, const float* left, const float* right,
                                                       const float* gradout, float* grad_left, float* grad_right,
                                                       int64_t H, int64_t D, int accumulate,
-                                                      const het_grouping* by_right, int64_t n_left_rows,
-                                                      int64_t n_right_rows, het_stream stream);
+                                                      const het_grouping* by_right, const het_grouping* by_left,
+                                                      int64_t n_left_rows, int64_t n_right_rows, het_stream stream);
 
 /*      hgt_full_graph_hetero_attention_ops_coo (+ backward)     OpExport/HGTOpsEdgeParallel.inc.h:95-158, 166-293
  *   inner[eids[i],h,:] = k[row[i],h,:] . W[r,h];   score[eids[i],h] = < inner[eids[i],h,:], q[col[i],h,:] >
