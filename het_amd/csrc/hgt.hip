@@ -51,20 +51,21 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_normalize(const idx_t*
   }
 }
 
-// Destination-grouped softmax (by_dst: payload0 = edge id, payload1 = relation of the position): one wave per work
-// item, H/4 lanes x float4 per edge.  Pass 1 forms m = exp(score * mu[r]) and the item's head sums; when the item is
-// a whole destination (all but hub nodes) pass 2 writes a = m / sum from the same, still cached, scores.  No float
-// atomics except for split hub destinations, which are normalised by HET_hgt_softmax_normalize_split.
+// Softmax on the destination grouping (by_dst: payload0 = edge id, payload1 = relation of the position), two kernels
+// and no E*H float atomics:
+//   HET_hgt_softmax_sum_grouped   sum[dst, :] = SUM over the in-edges of exp(score[eid, :] * mu[r, :])
+//                                 (wave per work item, H/4 lanes x float4 per edge; atomics only for split hub segments)
+//   HET_hgt_softmax_finish        edge order, streaming: m = exp(score * mu[r]), a = m / sum[dst]
 __device__ __forceinline__ float4 hgt_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void hgt_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_grouped(
+__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_sum_grouped(
     const int32_t* __restrict__ item_seg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ item_end,
     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_key, int64_t num_items,
     const int32_t* __restrict__ p_eid, const int32_t* __restrict__ p_rel, const float* __restrict__ score,
-    const float* __restrict__ mu, float* __restrict__ sum, float* __restrict__ m, float* __restrict__ a) {
-  constexpr int EPW = 64 / LPR, H = LPR * 4, U = 2;
+    const float* __restrict__ mu, float* __restrict__ sum) {
+  constexpr int EPW = 64 / LPR, H = LPR * 4, U = 4;
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= num_items) return;
@@ -74,12 +75,9 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_grouped(
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     int64_t eid[U];
     int rl[U];
-    bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * EPW;
-      ok[u] = j < e;
-      const int jc = ok[u] ? j : e - 1;
+      const int j = j0 + u * EPW, jc = j < e ? j : e - 1;
       eid[u] = p_eid[jc];
       rl[u] = p_rel[jc];
     }
@@ -90,12 +88,9 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_grouped(
     for (int u = 0; u < U; ++u) mv[u] = hgt_ld4(mu + (int64_t)rl[u] * H + x);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float4 v = make_float4(expf(sc[u].x * mv[u].x), expf(sc[u].y * mv[u].y), expf(sc[u].z * mv[u].z),
-                                   expf(sc[u].w * mv[u].w));
-      if (ok[u]) {
-        hgt_st4(m + eid[u] * H + x, v);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
+      const float ok = j0 + u * EPW < e ? 1.f : 0.f;
+      acc.x += ok * expf(sc[u].x * mv[u].x); acc.y += ok * expf(sc[u].y * mv[u].y);
+      acc.z += ok * expf(sc[u].z * mv[u].z); acc.w += ok * expf(sc[u].w * mv[u].w);
     }
   }
 #pragma unroll
@@ -103,60 +98,35 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_grouped(
     acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
     acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
   }
-  const int64_t v = seg_key[seg];
-  if (!(b == seg_ptr[seg] && e == seg_ptr[seg + 1])) {  // hub destination: partial sums, normalised afterwards
-    if (slot == 0) {
-      float* p = sum + v * H + x;
-      atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
-    }
-    return;
-  }
-  if (slot == 0) hgt_st4(sum + v * H + x, acc);
-  const float4 inv = make_float4(1.f / acc.x, 1.f / acc.y, 1.f / acc.z, 1.f / acc.w);
-  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    int64_t eid[U];
-    int rl[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * EPW;
-      ok[u] = j < e;
-      const int jc = ok[u] ? j : e - 1;
-      eid[u] = p_eid[jc];
-      rl[u] = p_rel[jc];
-    }
-    float4 sc[U], mv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) sc[u] = hgt_ld4(score + eid[u] * H + x);
-#pragma unroll
-    for (int u = 0; u < U; ++u) mv[u] = hgt_ld4(mu + (int64_t)rl[u] * H + x);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u])
-        hgt_st4(a + eid[u] * H + x, make_float4(expf(sc[u].x * mv[u].x) * inv.x, expf(sc[u].y * mv[u].y) * inv.y,
-                                                expf(sc[u].z * mv[u].z) * inv.z, expf(sc[u].w * mv[u].w) * inv.w));
+  if (slot != 0) return;
+  float* p = sum + (int64_t)seg_key[seg] * H + x;
+  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) {
+    hgt_st4(p, acc);
+  } else {  // hub destination split over several items (sum is zero-filled by the caller)
+    atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
   }
 }
 
-// a = m / sum for the edges of the split (hub) destinations: one wave per work item, items of whole segments
-// (already normalised by the kernel above) leave at once
+// one workgroup = a chunk of edges of ONE relation; a lane owns 4 consecutive heads of an edge
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_normalize_split(
-    const int32_t* __restrict__ item_seg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ item_end,
-    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_key, int64_t num_items,
-    const int32_t* __restrict__ p_eid, const float* __restrict__ sum, const float* __restrict__ m, float* __restrict__ a) {
-  constexpr int EPW = 64 / LPR, H = LPR * 4;
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (item >= num_items) return;
-  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
-  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) return;
-  const int slot = lane / LPR, x = (lane % LPR) * 4;
-  const float4 sv = hgt_ld4(sum + (int64_t)seg_key[seg] * H + x);
-  for (int j = b + slot; j < e; j += EPW) {
-    const int64_t eid = p_eid[j];
-    const float4 mv = hgt_ld4(m + eid * H + x);
-    hgt_st4(a + eid * H + x, make_float4(mv.x / sv.x, mv.y / sv.y, mv.z / sv.z, mv.w / sv.w));
+__global__ __launch_bounds__(kBlock) void HET_hgt_softmax_finish(const idx_t* __restrict__ col, const idx_t* __restrict__ eids,
+                                                                  const idx_t* __restrict__ rel_ptrs, int R, int chunk,
+                                                                  const float* __restrict__ score,
+                                                                  const float* __restrict__ mu,
+                                                                  const float* __restrict__ sum, float* __restrict__ m,
+                                                                  float* __restrict__ a) {
+  constexpr int H = LPR * 4, EPB = kBlock / LPR;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(rel_ptrs, R, chunk, blockIdx.x, r, rb, re)) return;
+  const int slot = threadIdx.x / LPR, x = (threadIdx.x % LPR) * 4;
+  const float4 mv = hgt_ld4(mu + (int64_t)r * H + x);
+  for (idx_t i = rb + slot; i < re; i += EPB) {
+    const idx_t eid = eids[i], dst = col[i];
+    const float4 sc = hgt_ld4(score + eid * H + x), sv = hgt_ld4(sum + dst * H + x);
+    const float4 v = make_float4(expf(sc.x * mv.x), expf(sc.y * mv.y), expf(sc.z * mv.z), expf(sc.w * mv.w));
+    hgt_st4(m + eid * H + x, v);
+    hgt_st4(a + eid * H + x, make_float4(v.x / sv.x, v.y / sv.y, v.z / sv.z, v.w / sv.w));
   }
 }
 
@@ -199,14 +169,31 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_softmax_bwd_stage1(const idx_t
   for (int h = threadIdx.x; h < H; h += kBlock) part[h] = 0.f;
   __syncthreads();
   const int64_t total = (re - rb) * H;
-  for (int64_t t = threadIdx.x; t < total; t += kBlock) {
-    const idx_t i = rb + t / H;
-    const int h = (int)(t % H);
-    const idx_t eid = eids[i];
-    const float av = a[eid * H + h];
-    const float c = (grad_a[eid * H + h] - tmp[col[i] * H + h]) * av;
-    grad_score[eid * H + h] = c * mu[r * H + h];
-    atomicAdd(&part[h], c * score[eid * H + h]);
+  if (kBlock % H == 0) {
+    // a thread keeps its head for the whole chunk (t % H == threadIdx.x % H): accumulate in a register,
+    // one LDS atomic per thread at the end
+    const int h = threadIdx.x % H;
+    const float muv = mu[r * H + h];
+    float acc = 0.f;
+    for (int64_t t = threadIdx.x; t < total; t += kBlock) {
+      const idx_t i = rb + t / H;
+      const idx_t eid = eids[i];
+      const float av = a[eid * H + h];
+      const float c = (grad_a[eid * H + h] - tmp[col[i] * H + h]) * av;
+      grad_score[eid * H + h] = c * muv;
+      acc = fmaf(c, score[eid * H + h], acc);
+    }
+    atomicAdd(&part[h], acc);
+  } else {
+    for (int64_t t = threadIdx.x; t < total; t += kBlock) {
+      const idx_t i = rb + t / H;
+      const int h = (int)(t % H);
+      const idx_t eid = eids[i];
+      const float av = a[eid * H + h];
+      const float c = (grad_a[eid * H + h] - tmp[col[i] * H + h]) * av;
+      grad_score[eid * H + h] = c * mu[r * H + h];
+      atomicAdd(&part[h], c * score[eid * H + h]);
+    }
   }
   __syncthreads();
   for (int h = threadIdx.x; h < H; h += kBlock) atomicAdd(&grad_mu[(int64_t)r * H + h], part[h]);
@@ -487,16 +474,15 @@ extern "C" int het_hgt_full_graph_edge_softmax_ops_separate_coo(
                                                      reinterpret_cast<uintptr_t>(a)) & 15) == 0) {
     const het_grouping* g = by_dst;
     const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
-    HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, g->item_seg,
+    HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_sum_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, g->item_seg,
                                                  g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items, g->p0,
-                                                 g->p1, score, mu, sum, m, a));
-    HET_LAUNCH_CHECK("HET_hgt_softmax_grouped");
-    if (g->num_split > 0) {
-      HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_normalize_split<LPR>, dim3(nb), dim3(kBlock), 0, s,
-                                                   g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key,
-                                                   g->num_items, g->p0, sum, m, a));
-      HET_LAUNCH_CHECK("HET_hgt_softmax_normalize_split");
-    }
+                                                 g->p1, score, mu, sum));
+    HET_LAUNCH_CHECK("HET_hgt_softmax_sum_grouped");
+    const int64_t chunk = 2048;
+    const unsigned nf = (unsigned)(ceil_div64(num_edges, chunk) + num_rels);
+    HET_HGT_LPR((int)(H / 4), hipLaunchKernelGGL(HET_hgt_softmax_finish<LPR>, dim3(nf), dim3(kBlock), 0, s, col, eids, rel_ptrs,
+                                                 (int)num_rels, (int)chunk, score, mu, sum, m, a));
+    HET_LAUNCH_CHECK("HET_hgt_softmax_finish");
     return HET_OK;
   }
   hipLaunchKernelGGL(HET_hgt_softmax_exp_sum, dim3(grid_for(num_edges * H)), dim3(kBlock), 0, s, col, eids, rel_ptrs,
