@@ -50,11 +50,12 @@ def _worker(rank, world, port, kind, outdir):
         gen = torch.Generator().manual_seed(2)
         x_full = torch.randn(coo.num_nodes, K, generator=gen, dtype=torch.float64)
         go_full = torch.randn(coo.num_nodes, H * D, generator=gen, dtype=torch.float64)
-        x_own = x_full[lo:hi].clone().requires_grad_(True)
+        mine = dl.plan.node_order[lo:hi]  # original ids of the nodes this rank owns
+        x_own = x_full[mine].clone().requires_grad_(True)
         out = dl.forward(x_own)
-        out.backward(go_full[lo:hi])
+        out.backward(go_full[mine])
         dl.reduce_param_grads()
-        torch.save({"lo": lo, "hi": hi, "out": out.detach(), "gx": x_own.grad, "gW": p["W"].grad, "gal": p["al"].grad,
+        torch.save({"lo": lo, "hi": hi, "mine": mine, "sent": sum(dl.plan.send_counts), "out": out.detach(), "gx": x_own.grad, "gW": p["W"].grad, "gal": p["al"].grad,
                     "glw": p["lw"].grad, "n_halo": dl.plan.n_halo, "edges": dl.plan.num_local_edges,
                     "cut": dl.plan.edge_cut}, os.path.join(outdir, f"r{rank}.pt"))
     finally:
@@ -83,9 +84,10 @@ def test_partitioned_layer_matches_single_process(kind, world):
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == coo.num_nodes
     for a, b in zip(parts[:-1], parts[1:]):
         assert a["hi"] == b["lo"]
+    assert torch.equal(torch.sort(torch.cat([q["mine"] for q in parts])).values, torch.arange(coo.num_nodes))
     for q in parts:
-        torch.testing.assert_close(q["out"], ref.detach()[q["lo"]:q["hi"]])
-        torch.testing.assert_close(q["gx"], x.grad[q["lo"]:q["hi"]])
+        torch.testing.assert_close(q["out"], ref.detach()[q["mine"]])
+        torch.testing.assert_close(q["gx"], x.grad[q["mine"]])
         # after the all-reduce every rank holds the full weight gradients
         torch.testing.assert_close(q["gW"], p["W"].grad)
         torch.testing.assert_close(q["gal"], p["al"].grad)
@@ -103,3 +105,16 @@ def test_partition_bounds_balance_in_edges():
         # a single hub destination can exceed the ideal share; otherwise within 25 %
         hub = torch.bincount(coo.col).max().item()
         assert float(cnt.max()) <= coo.num_edges / world * 1.25 + hub
+
+
+def test_source_only_nodes_are_dealt_out_evenly():
+    """ogbn-mag's authors have no in-edges: their ownership (hence the rows a rank must send) is balanced."""
+    from het_amd.dist import build_plan
+    coo = make_mag_like(scale=5e-3)
+    world = 4
+    plans = [build_plan(coo, r, world) for r in range(world)]
+    sent = torch.tensor([float(sum(p.send_counts)) for p in plans])
+    assert float(sent.max()) <= 1.6 * float(sent.mean())
+    assert sum(p.num_local_edges for p in plans) == coo.num_edges
+    order = plans[0].node_order
+    assert torch.equal(torch.sort(order).values, torch.arange(coo.num_nodes))
