@@ -1,0 +1,97 @@
+"""Mini-batch (sampled block) path: neighbour sampling and per-batch layout regeneration on the GPU.
+
+The reference reaches mini-batch training only through DGL's samplers (``MultiLayerNeighborSampler`` /
+``DataLoader``, hrt/python/RGNNUtils/RGNNUtils.py:164-196) and converts every sampled block to its own layouts on the
+CPU (hrt/python/utils/mydglgraph_converters.py:18-71).  Here both steps run on the device: uniform sampling of at most
+``fanout`` in-edges per destination with vectorised torch ops over the in-CSR, then ``HetGraph.from_integrated_coo``
+on the block (the native builders of layouts.hip), so that the same ops and layers run on the block unchanged.
+
+A block follows DGL's convention: its destination nodes are the first ``num_dst`` of its nodes; a layer's output rows
+``[:num_dst]`` are the inputs of the next block.  (RGAT / RGCN layers; HGT needs type-contiguous node ids, which a
+block does not have.)
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Optional
+
+import torch
+
+from .graph import HetGraph
+from .synth import IntegratedCOO
+
+
+@dataclasses.dataclass
+class Block:
+    graph: HetGraph            # layouts of the sampled bipartite-style subgraph, local node ids
+    nodes: torch.Tensor        # [num_nodes] global id of every local node; the first num_dst are the destinations
+    num_dst: int
+    edge_ids: torch.Tensor     # [E_block] global edge id of every block edge, in the block's separate-COO order
+
+
+class NeighborSampler:
+    """Uniform in-neighbour sampling without replacement, ``fanouts[l]`` edges per destination for layer l
+    (-1 or 0: all in-edges), as dgl.dataloading.MultiLayerNeighborSampler does for the reference."""
+
+    def __init__(self, g: HetGraph, fanouts: List[int], seed: int = 0):
+        t = g.get_in_csr()  # rows = destinations, col_indices = sources
+        self.ptr, self.src, self.rel, self.eid = t["row_ptrs"], t["col_indices"], t["rel_types"], t["eids"]
+        self.num_nodes, self.num_rels = g.get_num_nodes(), g.get_num_rels()
+        self.fanouts = list(fanouts)
+        self.dev = self.ptr.device
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed)
+        self._map = torch.full((self.num_nodes,), -1, dtype=torch.int64, device=self.dev)
+
+    def _sample_in_edges(self, dst: torch.Tensor, fanout: int):
+        deg = self.ptr[dst + 1] - self.ptr[dst]
+        total = int(deg.sum())
+        B = dst.numel()
+        first = torch.cumsum(deg, 0) - deg
+        owner = torch.repeat_interleave(torch.arange(B, device=self.dev), deg, output_size=total)
+        within = torch.arange(total, device=self.dev) - first[owner]
+        pos = self.ptr[dst][owner] + within
+        if fanout > 0 and total > 0 and int(deg.max()) > fanout:
+            r = torch.rand(total, device=self.dev, generator=self.gen, dtype=torch.float64)
+            order = torch.sort(owner.to(torch.float64) + r).indices  # groups stay contiguous, random order inside
+            keep = order[within < fanout]                            # the first `fanout` of every group
+            keep = torch.sort(keep).values                           # back to CSR order (deterministic layouts)
+            pos, owner = pos[keep], owner[keep]
+        return pos, owner
+
+    def sample_block(self, dst: torch.Tensor, fanout: int) -> Block:
+        pos, owner = self._sample_in_edges(dst, fanout)
+        src_g = self.src[pos]
+        B = dst.numel()
+        m = self._map
+        m[dst] = torch.arange(B, device=self.dev)
+        extra = torch.unique(src_g[m[src_g] < 0])
+        m[extra] = B + torch.arange(extra.numel(), device=self.dev)
+        nodes = torch.cat([dst, extra])
+        rel = self.rel[pos]
+        o = torch.sort(rel, stable=True).indices  # relation-major, as the integrated COO of a graph is stored
+        coo = IntegratedCOO(int(nodes.numel()), self.num_rels, torch.tensor([0, int(nodes.numel())], device=self.dev),
+                            m[src_g][o].contiguous(), owner[o].contiguous(), rel[o].contiguous(),
+                            torch.arange(pos.numel(), device=self.dev))
+        m[nodes] = -1  # reset the scratch map
+        return Block(HetGraph.from_integrated_coo(coo, full=True), nodes, B, self.eid[pos][o].contiguous())
+
+    def sample_blocks(self, seeds: torch.Tensor) -> List[Block]:
+        """Blocks in layer order (first layer first); blocks[-1].nodes[:num_dst] == seeds and
+        blocks[l].nodes[:blocks[l].num_dst] == blocks[l+1].nodes."""
+        blocks: List[Block] = []
+        dst = seeds
+        for fanout in reversed(self.fanouts):
+            b = self.sample_block(dst, fanout)
+            blocks.insert(0, b)
+            dst = b.nodes
+        return blocks
+
+
+def run_blocks(layers, blocks: List[Block], h: torch.Tensor, edge_data: Optional[torch.Tensor] = None):
+    """``h`` = features of blocks[0].nodes.  Applies layer l to block l and keeps the destination rows.
+    ``edge_data`` (e.g. RGCN's norm, indexed by global edge id) is gathered per block."""
+    for layer, b in zip(layers, blocks):
+        extra = () if edge_data is None else (edge_data[b.edge_ids],)
+        h = layer(b.graph, h, *extra)[: b.num_dst]
+    return h

@@ -140,16 +140,32 @@ def aggregate_times(ms):
     return float(sum(kept) / len(kept)) if kept else float("nan")
 
 
-def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=()):
+def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=(), batches=None):
+    """``batches``: None for full-graph training, else a callable returning (blocks, seeds) per step -- the sampled
+    mini-batch path (het_amd/sampling.py); sampling + per-batch layout building is timed separately."""
+    from .sampling import run_blocks
+    prep_ms = []
+
     def one_step(timed):
         optimizer.zero_grad()
         node_embed = node_embed_layer()
+        cur_labels = labels
+        if batches is not None:
+            th.cuda.synchronize()
+            t0 = time.perf_counter()
+            blocks, seeds = batches()
+            th.cuda.synchronize()
+            prep_ms.append((time.perf_counter() - t0) * 1e3)
+            node_embed, cur_labels = node_embed[blocks[0].nodes], labels[seeds]
         th.cuda.synchronize()
         ev = [th.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        logits = model(g, node_embed, *extra)
+        if batches is None:
+            logits = model(g, node_embed, *extra)
+        else:
+            logits = run_blocks(model.layers, blocks, node_embed, extra[0] if extra else None)
         ev[1].record()
-        loss = F.nll_loss(logits.log_softmax(dim=-1), labels)
+        loss = F.nll_loss(logits.log_softmax(dim=-1), cur_labels)
         ev[2].record()
         loss.backward()
         optimizer.step()  # the reference times the optimizer inside "backward" (RGNNUtils.py:304-311)
@@ -167,6 +183,7 @@ def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=()
         f, b, l = one_step(True)
         fwd.append(f); bwd.append(b); losses.append(l)
         print(f"Epoch {epoch:02d} | forward {f:.3f} ms | backward {b:.3f} ms | loss {l:.4f}")
+    HET_RGNN_train.last_prep_ms = prep_ms
     return fwd, bwd, losses
 
 
@@ -174,8 +191,8 @@ def main(argv=None):
     p = argparse.ArgumentParser(description="HET RGAT / RGCN / HGT benchmark driver on het_amd (MI355X)")
     add_generic_RGNN_args(p, "het_amd_train.json")
     args = p.parse_args(argv)
-    if not args.full_graph_training:
-        print("note: mini-batch sampling needs DGL samplers (SURVEY.md 8f rank 4); running full-graph training", file=sys.stderr)
+    if not args.full_graph_training and args.model == "hgt":
+        raise SystemExit("mini-batch blocks have no type-contiguous node ids: HGT runs with --full_graph_training only")
     dev = th.device("cuda")
     th.manual_seed(args.seed)
     coo = load_graph(args)
@@ -207,10 +224,23 @@ def main(argv=None):
     model = model.to(dev)
     labels = th.randint(0, args.num_classes, (N,), device=dev)  # random labels as train_dgl.py:132-148
     optimizer = th.optim.Adam(list(model.parameters()) + list(embed.parameters()), lr=args.lr)
-    fwd, bwd, losses = HET_RGNN_train(g, model, embed, optimizer, labels, args, extra)
+    batches = None
+    if not args.full_graph_training:  # sampled blocks, one batch of --batch_size seeds per step ("epoch" = one step here)
+        from .sampling import NeighborSampler
+        fan = list(args.fanout)[: args.num_layers] + [args.fanout[-1]] * max(0, args.num_layers - len(args.fanout))
+        sampler = NeighborSampler(g, fan, seed=args.seed)
+        gen = th.Generator(device=dev)
+        gen.manual_seed(args.seed)
+
+        def batches():
+            seeds = th.randperm(N, device=dev, generator=gen)[: args.batch_size]
+            return sampler.sample_blocks(seeds), seeds
+    fwd, bwd, losses = HET_RGNN_train(g, model, embed, optimizer, labels, args, extra, batches)
     res = {"model": args.model, "dataset": args.edges_npy or args.dataset, "num_nodes": N, "num_edges": E, "num_rels": R,
            "mean_forward_ms": round(aggregate_times(fwd), 4), "mean_backward_ms": round(aggregate_times(bwd), 4),
            "layout_build_ms": round(layout_ms, 1), "final_loss": losses[-1] if losses else None,
+           "minibatch_sample_and_layout_ms": (round(aggregate_times(HET_RGNN_train.last_prep_ms), 3)
+                                              if HET_RGNN_train.last_prep_ms else None),
            "peak_memory_GB": round(th.cuda.max_memory_allocated() / 2**30, 3), "args": vars(args)}
     res["million_edges_per_s"] = round(E / ((res["mean_forward_ms"] + res["mean_backward_ms"]) * 1e-3) / 1e6, 2)
     print(json.dumps(res))
