@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
 // add per element and workgroup.
 template <int KT, int NT>
 __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) {
-  constexpr int K = KT * 32, X = NT * 32;
+  // blockIdx.y selects a (KT*32) x (NT*32) block of the K x X product when K or X exceed 64 (each block re-reads its
+  // column slices of the A and G rows)
+  const int Kf = a.K, Xf = a.X, nbn = Xf / (NT * 32);
+  const int kbase = ((int)blockIdx.y / nbn) * KT * 32, nbase = ((int)blockIdx.y % nbn) * NT * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][KT*NT*16][64] partials of waves 1..3
   int r;
   idx_t rb, re;
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
 #pragma unroll
       for (int st = 0; st < SB; ++st) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) AV[st][kt] = a.A[(int64_t)A[st] * a.a_ld + kt * 32 + col];
+        for (int kt = 0; kt < KT; ++kt) AV[st][kt] = a.A[(int64_t)A[st] * a.a_ld + kbase + kt * 32 + col];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) GV[st][nt] = a.G[(int64_t)G[st] * a.g_ld + nt * 32 + col];
+        for (int nt = 0; nt < NT; ++nt) GV[st][nt] = a.G[(int64_t)G[st] * a.g_ld + nbase + nt * 32 + col];
       }
     };
     auto mma = [&](idx_t base, const float (&AV)[SB][KT], const float (&GV)[SB][NT]) {
@@ -319,17 +322,17 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
         for (int e = 0; e < 16; ++e) {
           const int o = ((kt * NT + nt) * 16 + e) * 64 + lane;
           const float v = acc[kt][nt][e] + smem[o] + smem[NACC * 64 + o] + smem[2 * NACC * 64 + o];
-          const int k = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, nn = nt * 32 + col;
+          const int k = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, nn = nbase + nt * 32 + col;
           int64_t off;
           if (a.headcat == 1) {
             const int h = nn / Dh, d = nn - h * Dh;
-            off = (int64_t)h * K * Dh + (int64_t)k * Dh + d;
+            off = (int64_t)h * Kf * Dh + (int64_t)k * Dh + d;
           } else if (a.headcat == 2) {  // keep the per-head diagonal blocks of the full product only
             const int Kh = a.blockdiag_k, hk = k / Kh, hn = nn / Dh;
             if (hk != hn) continue;
             off = ((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (nn - hn * Dh);
           } else {
-            off = (int64_t)k * X + nn;
+            off = (int64_t)k * Xf + nn;
           }
           atomicAdd(out + off, v);
         }
@@ -345,8 +348,9 @@ int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
   if (chunk < 512) chunk = 512;
   chunk = (chunk + 7) & ~7ll;
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
+  const unsigned gy = (unsigned)((a.K / (KT * 32)) * (a.X / (NT * 32)));
   HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx), dim3(256), lds, s, a, (int)chunk);
+  hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx, gy), dim3(256), lds, s, a, (int)chunk);
   HET_LAUNCH_CHECK("HET_seg_dw_mfma");
   return HET_OK;
 }
@@ -407,11 +411,12 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   }
 }
 
-bool mfma_dw_supported(int K, int X) { return (K == 32 || K == 64) && (X == 32 || X == 64); }
+bool mfma_dw_supported(int K, int X) { return (K == 32 || K == 64 || K == 128) && (X == 32 || X == 64 || X == 128); }
 
 int launch_seg_dw_mfma(const MfmaDwArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   HET_REQUIRE(mfma_dw_supported(a.K, a.X), "segment dW (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
+  // 64-wide blocks of the product per workgroup; K or X = 128 are covered by 2 (or 4) blocks along blockIdx.y
   if (a.K == 32) return a.X == 32 ? launch_dw_kx<1, 1>(a, s) : launch_dw_kx<1, 2>(a, s);
   return a.X == 32 ? launch_dw_kx<2, 1>(a, s) : launch_dw_kx<2, 2>(a, s);
 }

@@ -44,6 +44,9 @@ SHAPES = [  # (H, K, D, in1head)
     (4, 64, 1, True),     # mulfirst: x . (W . attn) with one shared input head
     (2, 16, 1, True),
     (8, 32, 1, True),
+    (4, 128, 32, True),   # feat = 128 (BASELINE.json configs[4]): K = X = 128, dW in 64-wide blocks
+    (1, 128, 64, True),
+    (2, 32, 64, True),    # X = 128 from K = 32
 ]
 
 
