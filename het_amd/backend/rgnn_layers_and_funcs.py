@@ -81,6 +81,16 @@ class _RgnnRelationalMatmulWithAttnDot(th.autograd.Function):
             grad_attn = th.empty_like(attn)
             gd = grad_dot.contiguous()
             if grad_ret is None:
+                # only the attention term was used: its gradient through the projection is rank one per head, so the
+                # (relation, node) sums run over the [E,H] gradient (include/het_amd.h: ..._attn_dot_only)
+                grad_weight = th.empty_like(weights, memory_format=th.contiguous_format)
+                grad_input = th.empty_like(inputs, memory_format=th.contiguous_format)
+                d = {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids}
+                if _k.matmul_attn_dot_only_backward(d, th.transpose(weights, 2, 3).contiguous(), inputs, attn, gd,
+                                                    grad_input, grad_weight):
+                    _k.matmul_backward(by_eid, 0, attn.unsqueeze(2), ret, gd, None, grad_attn.unsqueeze(-1), False,
+                                       accumulate=False)
+                    return None, None, None, grad_weight, grad_input, grad_attn, None
                 gradout = th.empty_like(ret)
                 _k.matmul_backward(by_eid, 0, attn.unsqueeze(2), ret, gd, gradout, grad_attn.unsqueeze(-1), False,
                                    accumulate=False)

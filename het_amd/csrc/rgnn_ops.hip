@@ -89,6 +89,72 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
   return launch_seg_gemm_mfma(a, (hipStream_t)stream);
 }
 
+namespace {
+// G[s, h, :] = gs[s, h] * attn[r(s), h, :] for the S (relation, node) segments of a grouping (r from seg_rel_ptr)
+__global__ __launch_bounds__(256) void HET_expand_rank1(const float* __restrict__ gs, const float* __restrict__ attn,
+                                                        const idx_t* __restrict__ seg_rel_ptr, int R, int64_t S, int H, int D,
+                                                        float* __restrict__ G) {
+  const int64_t X4 = (int64_t)H * D / 4, total = S * X4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t sidx = t / X4;
+    const int x = (int)(t - sidx * X4) * 4, h = x / D;
+    const int r = find_segment(seg_rel_ptr, R, sidx);
+    const float g = gs[sidx * H + h];
+    const float4 a = *reinterpret_cast<const float4*>(attn + (int64_t)r * H * D + x);
+    *reinterpret_cast<float4*>(G + sidx * (int64_t)H * D + x) = make_float4(g * a.x, g * a.y, g * a.z, g * a.w);
+  }
+}
+}  // namespace
+
+// Backward of het_rgnn_relational_matmul_attn_dot for a caller that used ONLY dot_out: the gradient of the projection
+// output is then grad_dot (x) dot_w[r] -- rank one per head -- so rows sharing (relation, gather_idx) are summed over the
+// [rows, H] gradient (not over an [rows, H, D] tensor that would first have to be written and read back):
+//   gs[(r,v), h] = SUM grad_dot[scatter_idx[i], h];  G[(r,v), h, :] = gs * dot_w[r, h, :]
+//   grad_x[v] (+)= G . Wt[r];   grad_w[r] (+)= x[v]^T (x) G
+extern "C" int het_backward_rgnn_relational_matmul_attn_dot_only(
+    const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
+    int64_t num_x_rows, const float* weights_t, const float* x, const float* dot_w, const float* grad_dot, float* grad_x,
+    float* grad_w, int64_t H, int64_t K, int64_t D, int accumulate, const het_grouping* by_rel_gather, void* workspace,
+    int64_t workspace_bytes, het_stream stream) {
+  const char* op = "backward_rgnn_relational_matmul_attn_dot_only";
+  if (int rc = check_matmul(op, HET_KIND_DISABLED, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
+  HET_REQUIRE(num_rows == 0 || (weights_t && x && dot_w && grad_dot && grad_x && grad_w), "%s: null data pointer", op);
+  const het_grouping* g = by_rel_gather;
+  const int64_t X = H * D;
+  if (!(g && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_sum_supported((int)H) && (D % 4) == 0 &&
+        mfma_shape_supported((int)X, (int)K) && mfma_dw_supported((int)K, (int)X) && workspace &&
+        workspace_bytes >= (int64_t)sizeof(float) * g->S * (H + X) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(grad_dot) & 15) == 0 && (reinterpret_cast<uintptr_t>(dot_w) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0)) {
+    het_set_error("%s: needs the (relation, gather_idx) grouping, a workspace of S*(H + H*D) floats and MFMA shapes", op);
+    return HET_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
+    HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_x_rows * K, s));
+  }
+  if (num_rows == 0) return HET_OK;
+  float* gs = static_cast<float*>(workspace);
+  float* G = gs + ((g->S * H + 3) / 4) * 4;
+  if (int rc = launch_segment_sum(g, grad_dot, gs, (int)H, nullptr, s)) return rc;
+  const int64_t total = g->S * (X / 4);
+  int64_t nb = ceil_div64(total, 256);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(HET_expand_rank1, dim3((unsigned)nb), dim3(256), 0, s, gs, dot_w, g->seg_rel_ptr64, (int)num_rels, g->S,
+                     (int)H, (int)D, G);
+  HET_LAUNCH_CHECK("HET_expand_rank1");
+  MfmaGemmArgs m;
+  m.A = G; m.a_ld = X; m.B = weights_t; m.b_rel_stride = X * K; m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64; m.atomic = 1;
+  m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)X; m.X = (int)K;
+  if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+  MfmaDwArgs w;
+  w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = G; w.g_ld = X; w.dW = grad_w; w.dw_rel_stride = H * K * D;
+  w.headcat = 1; w.headcat_d = (int)D; w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S;
+  w.K = (int)K; w.X = (int)X;
+  return launch_seg_dw_mfma(w, s);
+}
+
 extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                                    const int64_t* gather_idx, const int64_t* scatter_idx,
                                                    int64_t num_rows, int64_t num_x_rows, const float* weights_t,

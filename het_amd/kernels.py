@@ -170,6 +170,25 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
           _p(ret), _p(dot_w), _p(dot_out), H, K, D, _stream(ret))
 
 
+def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights):
+    """Backward of matmul_attn_dot when only dot_out was used (see include/het_amd.h); returns False when the fast
+    path does not apply (no grouping / shape), leaving the outputs untouched."""
+    rp, g, s = _matmul_lists(args_tensor_dict, 0)
+    R, H, D, K = weights_transposed.shape
+    if not (_plan.enabled and H >= 4 and H & (H - 1) == 0 and D % 4 == 0 and g.numel() > 0):
+        return False
+    grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
+    if grp is None:
+        return False
+    _chk("backward_rgnn_relational_matmul_attn_dot_only", (weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights), (rp, g, s))
+    S = max(1, grp.num_segments)
+    ws = torch.empty(((S * H + 3) // 4) * 4 + S * H * D, dtype=torch.float32, device=grad_dot.device)
+    _call(grad_dot, "het_backward_rgnn_relational_matmul_attn_dot_only", _p(rp), R, _p(g), _p(s), g.numel(), node_feat.shape[0],
+          _p(weights_transposed), _p(node_feat), _p(dot_w), _p(grad_dot), _p(grad_node_feat), _p(grad_weights), H, K, D, 0,
+          grp.handle, _p(ws), ws.numel() * 4, _stream(grad_dot))
+    return True
+
+
 @_op("backward_rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights_transposed, "
      "Tensor node_feat, Tensor gradout, Tensor(a!) grad_node_feat, Tensor(b!) grad_weights, bool InputNumHeadOneFlag) -> ()")
 def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat,
