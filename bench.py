@@ -160,6 +160,7 @@ def main():
     E_global, N_global = coo.num_edges, coo.num_nodes
     H, K = args.heads, args.feat
     X = K
+    g_rels = coo.num_rels
     torch.manual_seed(0)
     use_dist = world > 1 or os.environ.get("HET_FORCE_DIST") == "1"
     layout_ms = None
@@ -242,12 +243,19 @@ def main():
     if ev and not args.variant.startswith("compact") and args.model == "rgat":
         k_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
         nbytes = gat_bwd_bytes(E_local, N_local, H, X)
+        parts = {"a5 backward_relational_fused_gat_separate_coo": nbytes}
+        if args.variant in ("default", "mulfirst") and g_rels <= 8:
+            # the launch also performs the weight gradient of el = <feat, attn_l> (a2 with D_out = 1: reads feat [E,X] and
+            # grad_el [E,H], index lists at 8 B), fused into the same pass over feat (fold_attn_l / grad_fold_attn_l)
+            parts["a2 weight gradient of el = <feat, attn_l> (D_out = 1), fused into the same launch"] = E_local * (4 * X + 4 * H + 16)
+            nbytes += E_local * (4 * X + 4 * H + 16)
         ach = nbytes / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "HET_gat_backward_grouped (backward_relational_fused_gat_separate_coo, kind 0)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy_6.29TBs": round(ach / HBM_COPY_GBS, 4),
                     "traffic": pmc("HET_gat_backward_grouped", "hbm_bytes_per_launch"),
-                    "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes}
+                    "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes, "algorithmic_bytes_by_op": parts,
+                    "frac_a5_bytes_only": round(parts["a5 backward_relational_fused_gat_separate_coo"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the per-edge
     # projection launches of rgnn_relational_matmul (num_rows = E, D > 1), HIP events on the launch stream
     roofline_gemm = None

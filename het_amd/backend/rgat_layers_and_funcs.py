@@ -103,12 +103,18 @@ class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
     def backward(ctx, gradout):
         eids, rel_ptrs, row, col, feat_src, attn_l, el, er, s, exp, ret, exp_sorted = ctx.saved_tensors
         grad_el, grad_feat_src = th.empty_like(el), th.empty_like(feat_src)
-        _k.fused_gat_backward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, gradout.contiguous(),
-                              grad_feat_src, grad_el, grad_el, ctx.slope, exp_sorted, fold_attn_l=attn_l)
-        by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
-        grad_attn_l = th.empty_like(attn_l)
-        _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat_src, grad_el, None, grad_attn_l.unsqueeze(-1), False,
-                           accumulate=False)
+        if attn_l.shape[0] <= 8:  # the weight gradient of the folded product from the same pass (R <= 8 in registers)
+            grad_attn_l = th.zeros_like(attn_l)
+            _k.fused_gat_backward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, gradout.contiguous(),
+                                  grad_feat_src, grad_el, grad_el, ctx.slope, exp_sorted, fold_attn_l=attn_l,
+                                  grad_fold_attn_l=grad_attn_l)
+        else:
+            _k.fused_gat_backward(eids, rel_ptrs, row, col, 0, {}, feat_src, el, er, s, exp, ret, gradout.contiguous(),
+                                  grad_feat_src, grad_el, grad_el, ctx.slope, exp_sorted, fold_attn_l=attn_l)
+            by_eid = {"separate_coo_rel_ptrs": rel_ptrs, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+            grad_attn_l = th.empty_like(attn_l)
+            _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat_src, grad_el, None, grad_attn_l.unsqueeze(-1), False,
+                               accumulate=False)
         return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None, None
 
 

@@ -10,6 +10,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kFoldRelMax = 8;  // relations the fused weight gradient of the folded GAT backward keeps in registers
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -144,20 +145,27 @@ __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t*
 // payload1 of the grouping) and wants the gradient through that product added here:
 // grad_feat[e,h,:] += grad_el[e,h] * fold_w[r,h,:].  Saves the separate read-modify-write pass over the [E,H,D]
 // gradient.  Wave per item with id prefetch, like the forward.
-template <int LPR, bool SORTED, bool FOLD>
+// DW (with FOLD): also accumulates grad_fold_w[r,h,:] += SUM grad_el[e,h] * feat[e,h,:] -- the weight gradient of the
+// folded product, from the feat rows this kernel reads anyway -- in per-relation registers (R <= kFoldRelMax); the grid
+// is then a fixed number of workgroups striding over the items, each flushing once through LDS with R*X atomics.
+template <int LPR, bool SORTED, bool FOLD, int RMAX = 0>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
     const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
     float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope,
-    const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w) {
+    const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w, float* __restrict__ grad_fold_w, int R) {
   constexpr int EPW = 64 / LPR, U = 2;  // same-box A/B: U = 1 3.89 ms, 2 3.76 ms, 4 3.82 ms
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
-  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (item >= it.n) return;
-  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   const int64_t X = (int64_t)H * D;
+  constexpr bool DW = RMAX > 0;
+  float4 accw[DW ? RMAX : 1];
+#pragma unroll
+  for (int q = 0; q < (DW ? RMAX : 1); ++q) accw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < it.n;
+       item += (int64_t)gridDim.x * (kBlock / 64)) {
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   int jn[U], reln[U];
   int64_t eidn[U];
 #pragma unroll
@@ -195,9 +203,12 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 #pragma unroll
       for (int u = 0; u < U; ++u) dl[u] = (zl[u] + zr[u]) > 0.f ? 1.f : slope;
     }
+    int rlc[U];
     if (FOLD) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) w[u] = ld4(fold_w + reln[u] * X + x);
+      for (int u = 0; u < U; ++u) rlc[u] = reln[u];
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = ld4(fold_w + rlc[u] * X + x);
     }
     // ids of the next step (clamped: the last step re-reads its own)
 #pragma unroll
@@ -230,6 +241,41 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
       if (ok && (sub & (DL - 1)) == 0) {
         grad_el[eid[u] * H + h] = tt;
         if (grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
+      }
+      if (DW) {
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+          const float sel = (ok && rlc[u] == q) ? tt : 0.f;
+          accw[q].x = fmaf(sel, f[u].x, accw[q].x); accw[q].y = fmaf(sel, f[u].y, accw[q].y);
+          accw[q].z = fmaf(sel, f[u].z, accw[q].z); accw[q].w = fmaf(sel, f[u].w, accw[q].w);
+        }
+      }
+    }
+  }
+  }  // items
+  if (DW) {
+    __shared__ float4 part[kBlock / 64][DW ? RMAX : 1][64];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      float4 t = accw[q];
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {
+        t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off);
+        t.z += __shfl_xor(t.z, off); t.w += __shfl_xor(t.w, off);
+      }
+      part[wave][q][lane] = t;
+    }
+    __syncthreads();
+    if (wave == 0 && slot == 0) {
+      for (int q = 0; q < R && q < RMAX; ++q) {
+        float4 t = part[0][q][lane];
+        for (int wv = 1; wv < kBlock / 64; ++wv) {
+          const float4 o = part[wv][q][lane];
+          t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        float* p = grad_fold_w + (int64_t)q * X + x;
+        atomicAdd(p + 0, t.x); atomicAdd(p + 1, t.y); atomicAdd(p + 2, t.z); atomicAdd(p + 3, t.w);
       }
     }
   }
@@ -396,7 +442,9 @@ bool gat_backward_fold_supported(const het_grouping* g, const EdgeView& v, const
 int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
-                         float* grad_er, int H, int D, float slope, const float* fold_w, hipStream_t s) {
+                         float* grad_er, int H, int D, float slope, const float* fold_w, float* grad_fold_w,
+                         hipStream_t s) {
+  HET_REQUIRE(!grad_fold_w || (fold_w && v.R <= kFoldRelMax), "backward_relational_fused_gat_separate_coo: grad_fold_attn_l needs fold_attn_l and at most %d relations", kFoldRelMax);
   if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0) {
     HET_REQUIRE(!fold_w, "backward_relational_fused_gat_separate_coo: fold_attn_l needs the destination-grouped path");
     return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
@@ -412,8 +460,22 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   HET_DISPATCH_LPR((int)(X / 4),                                                                                     \
                    hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, FOLD>), dim3(nb), dim3(kBlock), 0, s, it, \
                                       g->p0, feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, D,  \
-                                      slope, g->p1, fold_w))
-  if (fold_w) {
+                                      slope, g->p1, fold_w, (float*)nullptr, v.R))
+  if (grad_fold_w) {
+    // fixed grid striding over the items: every workgroup flushes R*X atomics once
+    const unsigned nbw = nb < 4096u ? nb : 4096u;
+#define HET_GAT_BWD_DW(SORTED, RM)                                                                                    \
+  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM>), dim3(nbw),       \
+                                                    dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \
+                                                    grad_feat, grad_el, grad_er, H, D, slope, g->p1, fold_w,            \
+                                                    grad_fold_w, v.R))
+    if (v.R <= 4) {
+      if (sorted) { HET_GAT_BWD_DW(true, 4); } else { HET_GAT_BWD_DW(false, 4); }
+    } else {
+      if (sorted) { HET_GAT_BWD_DW(true, 8); } else { HET_GAT_BWD_DW(false, 8); }
+    }
+#undef HET_GAT_BWD_DW
+  } else if (fold_w) {
     if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
   } else {
     if (sorted) { HET_GAT_BWD(true, false); } else { HET_GAT_BWD(false, false); }

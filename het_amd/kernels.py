@@ -392,7 +392,7 @@ def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_r
 
 def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                        IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
-                       grad_er, slope, exp_sorted, fold_attn_l=None):
+                       grad_er, slope, exp_sorted, fold_attn_l=None, grad_fold_attn_l=None):
     """fold_attn_l [R,H,D]: also add grad_el[e,h] * fold_attn_l[r,h,:] into grad_feat_src (see include/het_amd.h)."""
     name = "backward_relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, True)
@@ -416,7 +416,8 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
           None if g is None else _p(exp_sorted), _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D,
           float(slope), None if g is None else g.handle, None if gs is None else gs.handle,
           None if gd is None else gd.handle, feat_src.shape[0], er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
-          None if fold_attn_l is None else _p(fold_attn_l), _stream(ret))
+          None if fold_attn_l is None else _p(fold_attn_l), None if grad_fold_attn_l is None else _p(grad_fold_attn_l),
+          _stream(ret))
 
 
 @_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "

@@ -425,12 +425,12 @@ def test_gat_and_hgt_on_a_graph_without_edges(K):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("H,D", [(4, 16), (1, 64), (2, 8)])
-def test_fused_gat_with_folded_attn_l(H, D):
+@pytest.mark.parametrize("H,D,nrel", [(4, 16, 4), (1, 64, 4), (2, 8, 4), (4, 16, 11)])
+def test_fused_gat_with_folded_attn_l(H, D, nrel):
     """el = <feat, attn_l[r]> + GAT under one autograd node (fold_attn_l of include/het_amd.h) against the unfused
     composition of the two reference-named functions, on a graph whose relations are interleaved (eids != arange)."""
     import het_amd.backend as B
-    g = random_graph(seed=77, n=300, r=4, e=5000, empty_rel=False)
+    g = random_graph(seed=77, n=300, r=nrel, e=5000, empty_rel=False)  # > 8 relations: separate weight-gradient pass
     s = g.get_separate_coo_original()
     assert not torch.equal(s["eids"], torch.arange(s["eids"].numel()))
     E, R = g.get_num_edges(), g.get_num_rels()
