@@ -210,9 +210,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    bwd_name, mm_name = "het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul"
-    HK.event_timers[bwd_name] = []
-    HK.event_timers[mm_name] = []
+    bwd_name, mm_name, mmd_name = ("het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul",
+                                   "het_rgnn_relational_matmul_attn_dot")
+    for nm in (bwd_name, mm_name, mmd_name):
+        HK.event_timers[nm] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -220,6 +221,7 @@ def main():
     dt = time.perf_counter() - t0
     ev = HK.event_timers.pop(bwd_name)
     ev_mm = HK.event_timers.pop(mm_name)
+    ev_mmd = HK.event_timers.pop(mmd_name)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -259,17 +261,19 @@ def main():
     # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the per-edge
     # projection launches of rgnn_relational_matmul (num_rows = E, D > 1), HIP events on the launch stream
     roofline_gemm = None
+    # (argument positions: include/het_amd.h -- num_rows is argument 5; D is 11 / 13)
     proj = [(a, b) for a, b, c in ev_mm if int(c[5]) == E_local and int(c[11]) > 1]
+    proj += [(a, b) for a, b, c in ev_mmd if int(c[5]) == E_local and int(c[13]) > 1]
     if proj and args.model == "rgat":
         g_ms = sum(a.elapsed_time(b) for a, b in proj) / len(proj)
         flops = 2.0 * E_local * K * X
         tf = flops / (g_ms * 1e-3) / 1e12
-        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, E rows, K=X=%d)" % K,
+        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul[_attn_dot], E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "launches_per_step": len(proj) // max(1, args.steps),
-                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false>", "mfma_busy_frac"),
-                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false>", "hbm_bytes_per_launch")}
+                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false", "mfma_busy_frac"),
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false", "hbm_bytes_per_launch")}
 
     # per-entry-point device time, from a few extra steps after the timed region (HIP events around every C-ABI call)
     per_op = None
