@@ -88,7 +88,7 @@ struct Scratch {  // frees device temporaries on every exit path
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;

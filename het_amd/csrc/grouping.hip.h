@@ -26,4 +26,5 @@ struct het_grouping {
   int32_t* split_seg = nullptr;  // [num_split] segments that own several items
   int32_t* p0 = nullptr;         // [E] payload0[perm[j]] or NULL
   int32_t* p1 = nullptr;         // [E] payload1[perm[j]] or NULL
+  mutable int32_t* seg_of_rank = nullptr;  // [E] segment of sorted rank j; built on first use (segment broadcast)
 };

@@ -72,7 +72,8 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
                                                    const int64_t* gather_idx, const int64_t* scatter_idx,
                                                    int64_t num_rows, const float* weights, const float* x, float* ret,
                                                    const float* dot_w, float* dot_out, int64_t H, int64_t K, int64_t D,
-                                                   het_stream stream) {
+                                                   const het_grouping* by_rel_gather, void* workspace,
+                                                   int64_t workspace_bytes, het_stream stream) {
   const char* op = "rgnn_relational_matmul_attn_dot";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights && x && ret && dot_w && dot_out), "%s: null data pointer", op);
@@ -82,10 +83,24 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
     return HET_ERR_UNSUPPORTED;
   }
   MfmaGemmArgs a;
-  a.A = x; a.a_ld = K; a.gather = gather_idx; a.B = weights; a.b_rel_stride = H * K * D; a.b_headcat = 1; a.headcat_d = (int)D;
-  a.C = ret; a.c_ld = H * D; a.scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx; a.seg_ptrs = rel_ptrs;
-  a.num_segs = (int)num_rels; a.num_rows = num_rows; a.K = (int)K; a.X = (int)(H * D);
-  a.dot_w = dot_w; a.dot_out = dot_out;
+  a.A = x; a.a_ld = K; a.B = weights; a.b_rel_stride = H * K * D; a.b_headcat = 1; a.headcat_d = (int)D;
+  a.K = (int)K; a.X = (int)(H * D); a.num_segs = (int)num_rels; a.dot_w = dot_w;
+  const het_grouping* g = by_rel_gather;
+  const int64_t X = H * D;
+  if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_sum_supported((int)X) &&
+      H <= X / 4 && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * (X + H) &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(ret) & 15) == 0 && num_rows > 0) {
+    // Rows that share (relation, gather_idx) are identical: project the S distinct rows once (dense, into the
+    // workspace), then duplicate every row to the positions of its segment -- same values as the per-position GEMM.
+    float* comp = static_cast<float*>(workspace);
+    float* comp_dot = comp + g->S * X;
+    a.gather = g->seg_key64; a.C = comp; a.c_ld = X; a.scatter = nullptr; a.seg_ptrs = g->seg_rel_ptr64; a.num_rows = g->S;
+    a.dot_out = comp_dot;
+    if (int rc = launch_seg_gemm_mfma(a, (hipStream_t)stream)) return rc;
+    return launch_segment_broadcast(g, comp, ret, (int)X, comp_dot, dot_out, (int)H, (hipStream_t)stream);
+  }
+  a.gather = gather_idx; a.C = ret; a.c_ld = X; a.scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
+  a.seg_ptrs = rel_ptrs; a.num_rows = num_rows; a.dot_out = dot_out;
   return launch_seg_gemm_mfma(a, (hipStream_t)stream);
 }
 

@@ -12,3 +12,7 @@ bool segment_sum_supported(int X);
 // i.e. out[s, :] = SUM scale[idx(j), :] * in[row(j), :].
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
                        int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0, int scale_by_p0 = 0);
+
+// out[p0[j], :] = in[s, :] for every sorted rank j of segment s; optionally a second, narrower pair (X2 <= X/4 floats)
+int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,
+                             int X2, hipStream_t s);

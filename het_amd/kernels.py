@@ -166,8 +166,14 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
     rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
     _chk("rgnn_relational_matmul_attn_dot", (weights, node_feat, ret, dot_w, dot_out), tuple(t for t in (rp, g, s) if t is not None))
     R, H, K, D = weights.shape
+    grp = ws = None
+    if IntKind == 0 and _plan.enabled and g.numel() > 0 and g.data_ptr() != s.data_ptr():
+        grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
+        if grp is not None:
+            ws = torch.empty(max(1, grp.num_segments) * (H * D + H), dtype=torch.float32, device=ret.device)
     _call(ret, "het_rgnn_relational_matmul_attn_dot", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
-          _p(ret), _p(dot_w), _p(dot_out), H, K, D, _stream(ret))
+          _p(ret), _p(dot_w), _p(dot_out), H, K, D, None if grp is None else grp.handle, _p(ws),
+          0 if ws is None else ws.numel() * 4, _stream(ret))
 
 
 def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights):
