@@ -13,6 +13,7 @@ __all__ = [
     "RgnnRelationalMatmul", "RgnnRelationalMatmulNoScatterGatherList", "RgnnRelationalMatmulCompactAsOfNode",
     "rgnn_relational_matmul", "rgnn_relational_matmul_no_scatter_gather_list",
     "rgnn_relational_matmul_with_attn_dot", "rgnn_relational_matmul_with_attn_dot_ok",
+    "rgnn_relational_matmul_attn_dot_only", "rgnn_relational_matmul_attn_dot_only_ok",
 ]
 
 
@@ -105,6 +106,44 @@ class _RgnnRelationalMatmulWithAttnDot(th.autograd.Function):
             {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids},
             0, th.transpose(weights, 2, 3).contiguous(), inputs, gradout, grad_input, grad_weight, True, accumulate=False)
         return None, None, None, grad_weight, grad_input, grad_attn, None
+
+
+class _RgnnRelationalMatmulAttnDotOnly(th.autograd.Function):
+    """dot[e, h] = <x[node(e)] . W[r, h], attn[r, h, :]> per edge WITHOUT the per-edge projection tensor: the S distinct
+    (relation, node) rows are projected once and kept ([S,H,D]), only their [S,H] dots are duplicated to the edges.
+    For RGAT's er under the default flags (RGAT/models.py:300-308), whose per-edge projection feeds nothing else.
+    Same values as RgnnRelationalMatmul + the D_out = 1 RgnnRelationalMatmul."""
+
+    @staticmethod
+    def forward(ctx, relptrs, node_indices, eids, weights, inputs, attn):
+        E, H = node_indices.numel(), weights.size(1)
+        dot = th.empty((E, H), dtype=weights.dtype, device=weights.device)
+        d = {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids}
+        comp = _k.matmul_attn_dot(d, 0, weights, inputs, None, attn, dot)
+        ctx.save_for_backward(relptrs, node_indices, eids, weights, inputs, attn, comp)
+        return dot
+
+    @staticmethod
+    def backward(ctx, grad_dot):
+        relptrs, node_indices, eids, weights, inputs, attn, comp = ctx.saved_tensors
+        d = {"separate_coo_rel_ptrs": relptrs, "separate_coo_node_indices": node_indices, "separate_coo_eids": eids}
+        grad_weight = th.empty_like(weights, memory_format=th.contiguous_format)
+        grad_input = th.empty_like(inputs, memory_format=th.contiguous_format)
+        grad_attn = th.empty_like(attn)
+        ok = _k.matmul_attn_dot_only_backward(d, th.transpose(weights, 2, 3).contiguous(), inputs, attn, grad_dot.contiguous(),
+                                              grad_input, grad_weight, comp_rows=comp, grad_dot_w=grad_attn)
+        assert ok, "the grouping of the forward pass is gone"
+        return None, None, None, grad_weight, grad_input, grad_attn
+
+
+def rgnn_relational_matmul_attn_dot_only_ok(arg_tensor_dict, weights, inputs):
+    return inputs.dim() == 2 and _k.matmul_attn_dot_only_ok(arg_tensor_dict, weights, inputs)
+
+
+def rgnn_relational_matmul_attn_dot_only(arg_tensor_dict, weights, inputs, attn):
+    return _RgnnRelationalMatmulAttnDotOnly.apply(
+        arg_tensor_dict["separate_coo_rel_ptrs"], arg_tensor_dict["separate_coo_node_indices"],
+        arg_tensor_dict["separate_coo_eids"], weights.contiguous(), inputs.contiguous(), attn.contiguous())
 
 
 def rgnn_relational_matmul_with_attn_dot_ok(weights, inputs):

@@ -73,10 +73,10 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
                                                    int64_t num_rows, const float* weights, const float* x, float* ret,
                                                    const float* dot_w, float* dot_out, int64_t H, int64_t K, int64_t D,
                                                    const het_grouping* by_rel_gather, void* workspace,
-                                                   int64_t workspace_bytes, het_stream stream) {
+                                                   int64_t workspace_bytes, float* comp_rows, het_stream stream) {
   const char* op = "rgnn_relational_matmul_attn_dot";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
-  HET_REQUIRE(num_rows == 0 || (weights && x && ret && dot_w && dot_out), "%s: null data pointer", op);
+  HET_REQUIRE(num_rows == 0 || (weights && x && dot_w && dot_out), "%s: null data pointer", op);
   if (!(mfma_fwd_supported((int)K, (int)(H * D)) && D >= 4 && (D & (D - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(dot_w) & 15) == 0)) {
     het_set_error("%s: only the MFMA shapes (K, H*D in {32, 64, 128}, D a power of two >= 4, 16-byte aligned rows)", op);
@@ -87,18 +87,24 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
   a.K = (int)K; a.X = (int)(H * D); a.num_segs = (int)num_rels; a.dot_w = dot_w;
   const het_grouping* g = by_rel_gather;
   const int64_t X = H * D;
+  const int64_t ws_need = g ? (int64_t)sizeof(float) * g->S * ((comp_rows ? 0 : X) + H) : 0;
   if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_sum_supported((int)X) &&
-      H <= X / 4 && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * (X + H) &&
-      (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(ret) & 15) == 0 && num_rows > 0) {
-    // Rows that share (relation, gather_idx) are identical: project the S distinct rows once (dense, into the
-    // workspace), then duplicate every row to the positions of its segment -- same values as the per-position GEMM.
-    float* comp = static_cast<float*>(workspace);
-    float* comp_dot = comp + g->S * X;
+      H <= X / 4 && workspace && workspace_bytes >= ws_need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(ret) & 15) == 0 && (reinterpret_cast<uintptr_t>(comp_rows) & 15) == 0 && num_rows > 0 &&
+      (ret || segment_sum_supported((int)H))) {
+    // Rows that share (relation, gather_idx) are identical: project the S distinct rows once (dense, into comp_rows
+    // or the workspace), then duplicate every row to the positions of its segment -- same values as the per-position
+    // GEMM.  ret == NULL: the caller wants the attention term only; just the [S,H] dots are duplicated.
+    float* ws = static_cast<float*>(workspace);
+    float* comp = comp_rows ? comp_rows : ws;
+    float* comp_dot = comp_rows ? ws : ws + g->S * X;
     a.gather = g->seg_key64; a.C = comp; a.c_ld = X; a.scatter = nullptr; a.seg_ptrs = g->seg_rel_ptr64; a.num_rows = g->S;
     a.dot_out = comp_dot;
     if (int rc = launch_seg_gemm_mfma(a, (hipStream_t)stream)) return rc;
+    if (!ret) return launch_segment_broadcast(g, comp_dot, dot_out, (int)H, nullptr, nullptr, 0, (hipStream_t)stream);
     return launch_segment_broadcast(g, comp, ret, (int)X, comp_dot, dot_out, (int)H, (hipStream_t)stream);
   }
+  HET_REQUIRE(ret && !comp_rows, "%s: ret == NULL / comp_rows need the (relation, gather_idx) grouping path", op);
   a.gather = gather_idx; a.C = ret; a.c_ld = X; a.scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
   a.seg_ptrs = rel_ptrs; a.num_rows = num_rows; a.dot_out = dot_out;
   return launch_seg_gemm_mfma(a, (hipStream_t)stream);
@@ -130,7 +136,7 @@ extern "C" int het_backward_rgnn_relational_matmul_attn_dot_only(
     const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
     int64_t num_x_rows, const float* weights_t, const float* x, const float* dot_w, const float* grad_dot, float* grad_x,
     float* grad_w, int64_t H, int64_t K, int64_t D, int accumulate, const het_grouping* by_rel_gather, void* workspace,
-    int64_t workspace_bytes, het_stream stream) {
+    int64_t workspace_bytes, const float* comp_rows, float* grad_dot_w, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul_attn_dot_only";
   if (int rc = check_matmul(op, HET_KIND_DISABLED, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights_t && x && dot_w && grad_dot && grad_x && grad_w), "%s: null data pointer", op);
@@ -153,6 +159,17 @@ extern "C" int het_backward_rgnn_relational_matmul_attn_dot_only(
   float* gs = static_cast<float*>(workspace);
   float* G = gs + ((g->S * H + 3) / 4) * 4;
   if (int rc = launch_segment_sum(g, grad_dot, gs, (int)H, nullptr, s)) return rc;
+  if (comp_rows && grad_dot_w) {
+    // grad_dot_w[r, h, :] (+)= SUM over the segments of r of gs[s, h] * comp_rows[s, h, :]  -- the weight gradient of
+    // the attention product from the S distinct projected rows of the forward instead of the E duplicated ones
+    HET_REQUIRE(rowdot_supported((int)H, (int)D) && (reinterpret_cast<uintptr_t>(comp_rows) & 15) == 0,
+                "%s: comp_rows path needs the row-dot shapes", op);
+    if (!accumulate) HET_HIP(hipMemsetAsync(grad_dot_w, 0, sizeof(float) * num_rels * X, s));
+    RowDotArgs q;
+    q.A = comp_rows; q.go = gs; q.out = grad_dot_w; q.seg_ptrs = g->seg_rel_ptr64; q.num_segs = (int)num_rels;
+    q.num_rows = g->S; q.H = (int)H; q.K = (int)D;
+    if (int rc = launch_rowdot_bwd_dw(q, s)) return rc;
+  }
   const int64_t total = g->S * (X / 4);
   int64_t nb = ceil_div64(total, 256);
   if (nb > 65536) nb = 65536;

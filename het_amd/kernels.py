@@ -161,22 +161,40 @@ def matmul_attn_dot_ok(H: int, K: int, D: int) -> bool:
     return K in (32, 64, 128) and H * D in (32, 64, 128) and D >= 4 and D & (D - 1) == 0
 
 
-def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, dot_out):
-    """rgnn_relational_matmul (one input head) that also writes dot_out[row, h] = <ret[row, h, :], dot_w[r, h, :]>."""
-    rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
-    _chk("rgnn_relational_matmul_attn_dot", (weights, node_feat, ret, dot_w, dot_out), tuple(t for t in (rp, g, s) if t is not None))
+def matmul_attn_dot_only_ok(args_tensor_dict, weights, node_feat) -> bool:
+    """Whether the attention term can be formed without materialising the per-edge projection (kind 0 lists)."""
     R, H, K, D = weights.shape
-    grp = ws = None
+    rp, g, s = _matmul_lists(args_tensor_dict, 0)
+    return (_plan.enabled and node_feat.is_cuda and matmul_attn_dot_ok(H, K, D) and H >= 4 and H & (H - 1) == 0 and H <= H * D // 4
+            and g.numel() > 0 and g.data_ptr() != s.data_ptr())
+
+
+def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, dot_out, keep_rows=False):
+    """rgnn_relational_matmul (one input head) that also writes dot_out[row, h] = <ret[row, h, :], dot_w[r, h, :]>.
+    ret None: only dot_out (needs matmul_attn_dot_only_ok).  keep_rows: also return the [S, H, D] distinct projected
+    rows of the (relation, node) grouping (None when that path is not taken)."""
+    rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
+    _chk("rgnn_relational_matmul_attn_dot", tuple(t for t in (weights, node_feat, ret, dot_w, dot_out) if t is not None),
+         tuple(t for t in (rp, g, s) if t is not None))
+    R, H, K, D = weights.shape
+    grp = ws = comp = None
     if IntKind == 0 and _plan.enabled and g.numel() > 0 and g.data_ptr() != s.data_ptr():
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
         if grp is not None:
-            ws = torch.empty(max(1, grp.num_segments) * (H * D + H), dtype=torch.float32, device=ret.device)
-    _call(ret, "het_rgnn_relational_matmul_attn_dot", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
+            S = max(1, grp.num_segments)
+            if keep_rows or ret is None:
+                comp = torch.empty((S, H, D), dtype=torch.float32, device=dot_out.device)
+            ws = torch.empty(S * ((0 if comp is not None else H * D) + H), dtype=torch.float32, device=dot_out.device)
+    if ret is None and grp is None:
+        raise _lib.HetError("rgnn_relational_matmul_attn_dot: ret=None needs the (relation, node) grouping")
+    _call(dot_out, "het_rgnn_relational_matmul_attn_dot", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
           _p(ret), _p(dot_w), _p(dot_out), H, K, D, None if grp is None else grp.handle, _p(ws),
-          0 if ws is None else ws.numel() * 4, _stream(ret))
+          0 if ws is None else ws.numel() * 4, _p(comp), _stream(dot_out))
+    return comp
 
 
-def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights):
+def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights,
+                                  comp_rows=None, grad_dot_w=None):
     """Backward of matmul_attn_dot when only dot_out was used (see include/het_amd.h); returns False when the fast
     path does not apply (no grouping / shape), leaving the outputs untouched."""
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
@@ -191,7 +209,7 @@ def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_fea
     ws = torch.empty(((S * H + 3) // 4) * 4 + S * H * D, dtype=torch.float32, device=grad_dot.device)
     _call(grad_dot, "het_backward_rgnn_relational_matmul_attn_dot_only", _p(rp), R, _p(g), _p(s), g.numel(), node_feat.shape[0],
           _p(weights_transposed), _p(node_feat), _p(dot_w), _p(grad_dot), _p(grad_node_feat), _p(grad_weights), H, K, D, 0,
-          grp.handle, _p(ws), ws.numel() * 4, _stream(grad_dot))
+          grp.handle, _p(ws), ws.numel() * 4, _p(comp_rows), _p(grad_dot_w), _stream(grad_dot))
     return True
 
 

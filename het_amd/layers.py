@@ -118,6 +118,9 @@ class HET_RGATLayer(nn.Module):
                 # one input head, [R,H,K,1] weight (the reference passes False here, models.py:310-326,
                 # which only works for num_heads == 1)
                 er = B.rgnn_relational_matmul(by_dst, self._w_attn_r(), inputs, True, 0)
+            elif dot_ok and B.rgnn_relational_matmul_attn_dot_only_ok(by_dst, self.conv_weights, inputs):
+                # the per-edge projection by destination feeds nothing but er: it is not materialised
+                er = B.rgnn_relational_matmul_attn_dot_only(by_dst, self.conv_weights, inputs, self.attn_r)
             elif dot_ok:
                 _, er = B.rgnn_relational_matmul_with_attn_dot(by_dst, self.conv_weights, inputs, self.attn_r)
             else:

@@ -95,26 +95,32 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
  * MFMA shapes only (K and H*D in {32, 64, 128}, D a power of two >= 4): HET_ERR_UNSUPPORTED otherwise.
  * by_rel_gather (optional, kind 0; the grouping of a2) + workspace of S*(H*D + H) floats: rows that share
  * (relation, gather_idx) are identical, so the GEMM runs on the S distinct rows and a broadcast kernel duplicates
- * them to their positions (same values; on ogbn-mag S = 3.7 M of E = 21.1 M rows by source). */
+ * them to their positions (same values; on ogbn-mag S = 3.7 M of E = 21.1 M rows by source).
+ * comp_rows (optional, [S, H*D]): receives the distinct rows (the workspace then needs S*H floats only).
+ * ret == NULL (grouping path only, H a power of two >= 4): the caller wants dot_out alone -- RGAT's er, whose
+ * per-edge projection no other op reads -- and the [E,H,D] tensor is never written. */
 int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                         const float* weights, const float* x, float* ret, const float* dot_w,
                                         float* dot_out, int64_t H, int64_t K, int64_t D,
                                         const het_grouping* by_rel_gather, void* workspace, int64_t workspace_bytes,
-                                        het_stream stream);
+                                        float* comp_rows, het_stream stream);
 
 /* backward of the above for a caller that used only dot_out (RGAT's er = <x[dst].W, attn_r>): the gradient of ret is
  * grad_dot (x) dot_w[r], rank one per head, so the (relation, gather_idx) segment sums are taken over the [rows,H]
  * gradient: gs = SUM grad_dot;  G = gs * dot_w[r];  grad_x[v] (+)= G . Wt[r];  grad_w[r] (+)= x[v]^T (x) G.
  * Needs by_rel_gather (as in a2) and a workspace of (S*H rounded up to 4) + S*H*D floats; HET_ERR_UNSUPPORTED otherwise.
- * (The gradient of dot_w is the plain D_out = 1 weight gradient: het_backward_rgnn_relational_matmul, grad_x = NULL.) */
+ * The gradient of dot_w: with comp_rows (the distinct rows kept from the forward) and grad_dot_w [R,H,D] it is formed
+ * here as SUM_s gs[s,h] * comp_rows[s,h,:]; otherwise it is the plain D_out = 1 weight gradient over the [E,H,D]
+ * tensor (het_backward_rgnn_relational_matmul with grad_x = NULL). */
 int het_backward_rgnn_relational_matmul_attn_dot_only(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
                                                       const int64_t* scatter_idx, int64_t num_rows, int64_t num_x_rows,
                                                       const float* weights_t, const float* x, const float* dot_w,
                                                       const float* grad_dot, float* grad_x, float* grad_w, int64_t H,
                                                       int64_t K, int64_t D, int accumulate,
                                                       const het_grouping* by_rel_gather, void* workspace,
-                                                      int64_t workspace_bytes, het_stream stream);
+                                                      int64_t workspace_bytes, const float* comp_rows,
+                                                      float* grad_dot_w, het_stream stream);
 
 /* a2  backward_rgnn_relational_matmul   OpExport/RGNNOps.inc.h:946-1010
  *   grad_x[gather_idx[i], (h), :] += gradout[scatter_idx[i], h, :] . Wt[r, h]   (heads summed iff in1head)

@@ -505,3 +505,32 @@ def test_matmul_with_attn_dot_epilogue(H, Kd, D):
         assert_close(v, u.cpu(), what=name)
     for name, u, v in zip(("grad_x", "grad_W", "grad_attn"), res["plain_dot_only"], res["fused_dot_only"]):
         assert_close(v, u.cpu(), what=name + " (dot only)")
+
+
+@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (8, 128, 4), (4, 32, 8)])
+def test_attn_dot_only_without_the_per_edge_projection(H, Kd, D):
+    """er[e,h] = <x[dst_e] . W[r,h], attn[r,h,:]> formed on the distinct (relation, node) rows and duplicated as [E,H]
+    only, against the two reference-named ops; values and all gradients."""
+    import het_amd.backend as B
+    g = random_graph(seed=93, n=260, r=4, e=4500)
+    s = g.get_separate_coo_original()
+    E, R, N = g.get_num_edges(), g.get_num_rels(), g.get_num_nodes()
+    gen = torch.Generator().manual_seed(8)
+    x, W, attn = torch.randn(N, Kd, generator=gen), 0.2 * torch.randn(R, H, Kd, D, generator=gen), torch.randn(R, H, D, generator=gen)
+    go = torch.randn(E, H, generator=gen).to(DEV)
+    by_dst = _dev({"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"],
+                   "separate_coo_eids": s["eids"]})
+    by_eid = _dev({"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"], "separate_coo_eids": s["eids"]})
+    res = []
+    for fused in (False, True):
+        xd, Wd, ad = (t.to(DEV).requires_grad_(True) for t in (x, W, attn))
+        if fused:
+            assert B.rgnn_relational_matmul_attn_dot_only_ok(by_dst, Wd, xd)
+            er = B.rgnn_relational_matmul_attn_dot_only(by_dst, Wd, xd, ad)
+        else:
+            f = B.rgnn_relational_matmul(by_dst, Wd, xd, True, 0)
+            er = B.rgnn_relational_matmul(by_eid, ad.unsqueeze(-1), f, False, 0).view(E, H)
+        (er * go).sum().backward()
+        res.append((er.detach(), xd.grad, Wd.grad, ad.grad))
+    for name, u, v in zip(("er", "grad_x", "grad_W", "grad_attn"), res[0], res[1]):
+        assert_close(v, u.cpu(), what=name)
