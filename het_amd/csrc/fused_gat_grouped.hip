@@ -284,19 +284,24 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 // ---- backward for the compact kinds (feat / el rows shared by all out-edges of a (relation, source)) ----
 // pack[v] = { 1/sum[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }: what an edge needs from its
 // destination besides the gradout row, in one 2H-float record.
+// Row-per-lane-group: X/4 lanes x float4 read the gradout and ret rows of a node coalesced, D/4-lane shuffle per head.
+template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_gat_dst_pack(const float* __restrict__ sum, const float* __restrict__ ret,
                                                             const float* __restrict__ gradout, float* __restrict__ pack,
                                                             int64_t N, int H, int D) {
-  const int64_t total = N * H, stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
-    const int64_t v = t / H;
-    const int h = (int)(t - v * H);
-    const float* g = gradout + t * D;
-    const float* r = ret + t * D;
-    float dot = 0.f;
-    for (int d = 0; d < D; ++d) dot = fmaf(g[d], r[d], dot);
-    pack[v * 2 * H + h] = 1.f / sum[t];
-    pack[v * 2 * H + H + h] = dot;
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t step = (int64_t)gridDim.x * (kBlock / 64) * EPW;
+  for (int64_t v0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * EPW; v0 < N; v0 += step) {
+    const int64_t v = v0 + slot < N ? v0 + slot : N - 1;  // past the end: the last node again (same bytes rewritten)
+    const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
+    float dot = g.x * r.x + g.y * r.y + g.z * r.z + g.w * r.w;
+    for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if ((sub & (DL - 1)) == 0) {
+      pack[v * 2 * H + h] = 1.f / sum[v * H + h];
+      pack[v * 2 * H + H + h] = dot;
+    }
   }
 }
 
@@ -494,7 +499,8 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
   const int64_t X = (int64_t)H * D;
   float* pack = workspace;               // [N, 2H]
   float* tbuf = workspace + v.N * 2 * H; // [E, H]
-  hipLaunchKernelGGL(HET_gat_dst_pack, dim3(grid_for(v.N * H)), dim3(kBlock), 0, s, sum, ret, gradout, pack, v.N, H, D);
+  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_gat_dst_pack<LPR>, dim3(grid_for(v.N * (X / 4))), dim3(kBlock), 0, s,
+                                                    sum, ret, gradout, pack, v.N, H, D));
   HET_LAUNCH_CHECK("HET_gat_dst_pack");
   // rows whose segment was split accumulate atomically: start them (all) from zero
   HET_HIP(hipMemsetAsync(grad_el, 0, sizeof(float) * n_src_rows * H, s));
