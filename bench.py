@@ -210,18 +210,14 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    bwd_name, mm_name, mmd_name = ("het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul",
-                                   "het_rgnn_relational_matmul_attn_dot")
-    for nm in (bwd_name, mm_name, mmd_name):
-        HK.event_timers[nm] = []
+    bwd_name, mm_name = "het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul"
+    HK.event_timers[bwd_name] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     ev = HK.event_timers.pop(bwd_name)
-    ev_mm = HK.event_timers.pop(mm_name)
-    ev_mmd = HK.event_timers.pop(mmd_name)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -258,22 +254,32 @@ def main():
                     "traffic": pmc("HET_gat_backward_grouped", "hbm_bytes_per_launch"),
                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes, "algorithmic_bytes_by_op": parts,
                     "frac_a5_bytes_only": round(parts["a5 backward_relational_fused_gat_separate_coo"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the per-edge
-    # projection launches of rgnn_relational_matmul (num_rows = E, D > 1), HIP events on the launch stream
+    # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the reference-named op
+    # rgnn_relational_matmul exactly as the reference calls it for the per-edge projection (kind 0, gather by source,
+    # E rows, one input head), launched a few times after the timed region, HIP events on the launch stream.
+    # (Inside the layer the same product runs on the distinct (relation, node) rows only, see DESIGN.md.)
     roofline_gemm = None
-    # (argument positions: include/het_amd.h -- num_rows is argument 5; D is 11 / 13)
-    proj = [(a, b) for a, b, c in ev_mm if int(c[5]) == E_local and int(c[11]) > 1]
-    proj += [(a, b) for a, b, c in ev_mmd if int(c[5]) == E_local and int(c[13]) > 1]
-    if proj and args.model == "rgat":
-        g_ms = sum(a.elapsed_time(b) for a, b in proj) / len(proj)
+    if args.model == "rgat" and world == 1 and not use_dist:
+        sc = g.get_separate_coo_original()
+        d_src = {"separate_coo_rel_ptrs": sc["rel_ptrs"], "separate_coo_node_indices": sc["row_indices"],
+                 "separate_coo_eids": sc["eids"]}
+        Wp = torch.randn(g.get_num_rels(), H, K, X // H, device=dev) * 0.1
+        retp = torch.empty(E_local, H, X // H, device=dev)
+        HK.event_timers[mm_name] = []
+        with torch.no_grad():
+            for _ in range(6):
+                HK.K.rgnn_relational_matmul(d_src, 0, Wp, embed.detach(), retp, True)
+        torch.cuda.synchronize()
+        proj = HK.event_timers.pop(mm_name)[1:]
+        g_ms = sum(a.elapsed_time(b) for a, b, _ in proj) / len(proj)
         flops = 2.0 * E_local * K * X
         tf = flops / (g_ms * 1e-3) / 1e12
-        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul[_attn_dot], E rows, K=X=%d)" % K,
+        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
-                         "launches_per_step": len(proj) // max(1, args.steps),
-                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false", "mfma_busy_frac"),
-                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false", "hbm_bytes_per_launch")}
+                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "mfma_busy_frac"),
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "hbm_bytes_per_launch")}
+        del Wp, retp
 
     # per-entry-point device time, from a few extra steps after the timed region (HIP events around every C-ABI call)
     per_op = None

@@ -34,7 +34,7 @@ st = sorted(glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recur
 if st:
     shutil.copy(st[-1], os.path.join(d, "kernel_stats.csv"))
     rows = list(csv.DictReader(open(st[-1])))
-    print("== kernel stats (13 steps: 3 warm-up + 10 timed; one-time grouping builds included) ==")
+    print("== kernel stats (16 steps: 3 warm-up + 10 timed + 3 for the per-op breakdown; one-time grouping and layout builds included) ==")
     for r in rows[:22]:
         print(f"{short(r['Name']):45s} calls={int(r['Calls']):5d} avg_ms={float(r['AverageNs'])/1e6:8.3f} "
               f"total_ms={float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):5.1f}%")
