@@ -180,7 +180,8 @@ extern "C" int het_relational_fused_gat_separate_coo(
   HET_REQUIRE(sum && ret && (num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && exp)),
               "%s: null pointer", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
-  if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
+  if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
+    if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
   EdgeView v;
   v.E = num_edges; v.N = num_nodes; v.eids = eids; v.src = row; v.dst = col; v.rel_ptrs = rel_ptrs; v.R = (int)num_rels;
   RowMaps m;
@@ -206,7 +207,8 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
                                  grad_feat && grad_el && grad_er),
               "%s: null pointer", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
-  if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
+  if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
+    if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
   EdgeView v;
   v.E = num_edges; v.N = num_nodes; v.eids = eids; v.src = row; v.dst = col; v.rel_ptrs = rel_ptrs; v.R = (int)num_rels;
   RowMaps m;

@@ -77,6 +77,7 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
   const char* op = "rgnn_relational_matmul_attn_dot";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights && x && dot_w && dot_out), "%s: null data pointer", op);
+  if (num_rows == 0) return HET_OK;
   if (!(mfma_fwd_supported((int)K, (int)(H * D)) && D >= 4 && (D & (D - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(dot_w) & 15) == 0)) {
     het_set_error("%s: only the MFMA shapes (K, H*D in {32, 64, 128}, D a power of two >= 4, 16-byte aligned rows)", op);

@@ -144,3 +144,36 @@ def test_train_driver_reference_flags(model, flags, tmp_path):
     assert res["final_loss"] < 4.3  # ln(64) = 4.16 at initialisation: finite and not diverging
     # (the edge softmax has no max-subtraction, as the reference's: large learning rates overflow exp -- SURVEY Q2)
     assert log.exists() and '"model"' in log.read_text()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_layer_on_degenerate_graphs(compact):
+    """No edges at all; one relation only; more than 8 relations (the fused weight gradient keeps 8 in registers)."""
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import IntegratedCOO, make_random
+    z = torch.zeros(0, dtype=torch.int64)
+    cases = [IntegratedCOO(50, 3, torch.tensor([0, 50]), z, z.clone(), z.clone(), z.clone()),
+             make_random(120, 1, 900, seed=5), make_random(150, 11, 2500, seed=6)]
+    for coo in cases:
+        g = HetGraph.from_integrated_coo(coo)
+        torch.manual_seed(2)
+        layer = HET_RGATLayer(64, 64, coo.num_rels, 4, self_loop=True, dropout=0.0, compact_as_of_node_flag=compact,
+                              compact_direct_indexing_flag=compact)
+        x, go = torch.randn(coo.num_nodes, 64), torch.randn(coo.num_nodes, 64)
+        s = g.get_separate_coo_original()
+        p64 = {k: v.detach().double().requires_grad_(True) for k, v in layer.named_parameters()}
+        x64 = x.double().requires_grad_(True)
+        ref = OL.rgat_layer(x64, p64["conv_weights"], p64["attn_l"], p64["attn_r"], s["rel_ptrs"], s["row_indices"],
+                            s["col_indices"], coo.num_nodes, 0.2, p64["loop_weight"], p64["h_bias"])
+        ref.backward(go.double())
+        g.to_(DEV)
+        layer = layer.to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        out = layer(g, xd)
+        out.backward(go.to(DEV))
+        assert_close(out, ref, what=f"out R={coo.num_rels} E={coo.num_edges}")
+        assert_close(xd.grad, x64.grad, what="grad_x")
+        for n, prm in layer.named_parameters():
+            if prm.grad is not None:
+                assert_close(prm.grad, p64[n].grad if p64[n].grad is not None else torch.zeros_like(p64[n]), what="grad_" + n)
