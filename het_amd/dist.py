@@ -150,9 +150,9 @@ class HaloExchange(torch.autograd.Function):
 
 
 class DistLayer:
-    """One layer sharded over the ranks of ``group``.  ``layer_fn(graph, x_local)`` computes the layer
+    """One layer sharded over the ranks of ``group``.  ``layer_fn(graph, x_local, n_own)`` computes the layer
     on the local graph (HET_RGATLayer on the GPU; the CPU oracle in the gloo tests) and returns
-    [n_local, X]; rows of owned nodes are kept.  ``params`` are replicated and their gradients
+    [n_local, X] or only its first n_own rows; rows of owned nodes are kept.  ``params`` are replicated and their gradients
     all-reduced after backward."""
 
     def __init__(self, coo: IntegratedCOO, layer_fn: Callable, params, group=None, full_layouts: bool = False):
@@ -165,7 +165,7 @@ class DistLayer:
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
         x_local = HaloExchange.apply(x_own, self.plan, self.group)
-        return self.layer_fn(self.graph, x_local)[: self.plan.n_own]
+        return self.layer_fn(self.graph, x_local, self.plan.n_own)[: self.plan.n_own]
 
     def reduce_param_grads(self):
         grads = [p.grad for p in self.params if p.grad is not None]
@@ -189,7 +189,7 @@ class DistRGAT:
         torch.manual_seed(0)  # same weights on every rank
         self.layer = HET_RGATLayer(in_feat, out_feat, coo.num_rels, heads, self_loop=True, dropout=0.0,
                                    **layer_flags).to(device)
-        self.dl = DistLayer(coo, lambda g, x: self.layer(g, x), self.layer.parameters(),
+        self.dl = DistLayer(coo, lambda g, x, n_own: self.layer(g, x, num_dst=n_own), self.layer.parameters(),
                             full_layouts=bool(layer_flags.get("compact_as_of_node_flag")))
         p = self.dl.plan
         self.embed = torch.nn.Parameter(torch.empty(p.n_own, in_feat, device=device))

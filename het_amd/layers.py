@@ -70,7 +70,9 @@ class HET_RGATLayer(nn.Module):
         return th.bmm(self.conv_weights.view(-1, self.in_feat, dk), self.attn_r.view(-1, dk, 1)).view(
             -1, self.num_heads, self.in_feat, 1)
 
-    def forward(self, g, inputs: th.Tensor):
+    def forward(self, g, inputs: th.Tensor, num_dst=None):
+        """``num_dst``: the destination nodes of ``g`` are its first ``num_dst`` nodes (a sampled block, or the owned
+        nodes of a partition followed by halo nodes): only their rows are returned and the self-loop runs on them only."""
         if self.compact_as_of_node_flag:  # models.py:152-263
             ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"],
@@ -136,15 +138,18 @@ class HET_RGATLayer(nn.Module):
             else:
                 h = B.relational_fused_gat_csr(g, feat_src_per_edge, el.view(-1, self.num_heads), er, self.leaky_relu_slope)
         h = h.view(-1, self.out_feat)  # models.py:377-385
+        loop_in = inputs
+        if num_dst is not None and num_dst < inputs.shape[0]:
+            h, loop_in = h[:num_dst], inputs[:num_dst]
         if self.self_loop:
             # the reference calls th.matmul here (models.py:378-379); same product through the segment GEMM
             # with a single segment (MFMA kernel instead of a generic BLAS pick for a 64-wide GEMM)
-            key = (inputs.shape[0], inputs.device)
+            key = (loop_in.shape[0], inputs.device)
             if getattr(self, "_loop_offs_key", None) != key:  # built once per (N, device): no per-step host sync
-                self._loop_offs = th.tensor([0, inputs.shape[0]], dtype=th.int64, device=inputs.device)
+                self._loop_offs = th.tensor([0, loop_in.shape[0]], dtype=th.int64, device=inputs.device)
                 self._loop_offs_key = key
             h = h + B.rgnn_relational_matmul_no_scatter_gather_list(
-                self._loop_offs, self.loop_weight.view(1, 1, self.in_feat, self.out_feat), inputs)
+                self._loop_offs, self.loop_weight.view(1, 1, self.in_feat, self.out_feat), loop_in)
         if self.bias:
             h = h + self.h_bias
         if self.activation:
@@ -173,7 +178,7 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
             self.h_bias = nn.Parameter(th.zeros(out_feat))
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, g, x, norm):
+    def forward(self, g, x, norm, num_dst=None):
         if self.num_bases < self.num_rels:  # basis decomposition, RGCN.py:286-301
             weight = th.matmul(self.w_comp, self.weight.view(self.num_bases, -1)).view(
                 self.num_rels, self.in_feat, self.out_feat)
@@ -188,6 +193,8 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
                 g, feat_compact.view(feat_compact.shape[0], -1), norm, self.compact_direct_indexing_flag)
         else:
             node_repr = B.rgcn_layer1_separate_coo(g, x, weight, norm)
+        if num_dst is not None and num_dst < node_repr.shape[0]:
+            node_repr = node_repr[:num_dst]
         if self.bias:
             node_repr = node_repr + self.h_bias
         if self.activation:

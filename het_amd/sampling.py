@@ -93,5 +93,5 @@ def run_blocks(layers, blocks: List[Block], h: torch.Tensor, edge_data: Optional
     ``edge_data`` (e.g. RGCN's norm, indexed by global edge id) is gathered per block."""
     for layer, b in zip(layers, blocks):
         extra = () if edge_data is None else (edge_data[b.edge_ids],)
-        h = layer(b.graph, h, *extra)[: b.num_dst]
+        h = layer(b.graph, h, *extra, num_dst=b.num_dst)  # destination rows only (self-loop, bias, activation on them)
     return h

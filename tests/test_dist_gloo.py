@@ -40,7 +40,7 @@ def _worker(rank, world, port, kind, outdir):
         H, K, D = 2, 8, 4
         p = _params(coo.num_rels, H, K, D)
 
-        def layer_fn(g, x):
+        def layer_fn(g, x, n_own):
             s = g.get_separate_coo_original()
             return OL.rgat_layer(x, p["W"], p["al"], p["ar"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
                                  g.get_num_nodes(), 0.2, p["lw"], p["b"])
