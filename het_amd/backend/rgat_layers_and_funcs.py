@@ -14,6 +14,7 @@ __all__ = [
     "relational_fused_gat_compact_as_of_node_separate_coo_dual_unique_node_list",
     "relational_fused_gat_compact_as_of_node_separate_coo_single_sided",
     "relational_fused_gat_separate_coo_with_attn_l", "relational_fused_gat_separate_coo_with_attn_l_ok",
+    "relational_fused_gat_compact_with_attn_l", "relational_fused_gat_compact_with_attn_l_ok",
 ]
 
 
@@ -116,6 +117,67 @@ class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
             _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat_src, grad_el, None, grad_attn_l.unsqueeze(-1), False,
                                accumulate=False)
         return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None, None
+
+
+class _FusedGatCompactWithAttnL(th.autograd.Function):
+    """The compact-as-of-node counterpart of _FusedGatSeparateCOOWithAttnL: el_compact = <feat_compact, attn_l[r]> over
+    the (relation, source) rows and the fused GAT op (kinds 3 / 4) under one autograd node; the gradient through el is
+    added to the gradient of feat_compact by the store of the GAT backward (fold_attn_l on compact rows)."""
+
+    @staticmethod
+    def forward(ctx, eids, rel_ptrs, row, col, kind, fwd_dict, bwd_dict, row_rel_ptrs, feat_compact, attn_l, er, s, exp,
+                ret, slope):
+        el = th.empty((feat_compact.shape[0], attn_l.shape[1]), dtype=feat_compact.dtype, device=feat_compact.device)
+        K.rgnn_relational_matmul_no_scatter_gather_list(row_rel_ptrs, attn_l.unsqueeze(-1), feat_compact, el)
+        _k.fused_gat_forward(eids, rel_ptrs, row, col, kind, fwd_dict, feat_compact, el, er, s, exp, ret, slope, None)
+        ctx.save_for_backward(eids, rel_ptrs, row, col, row_rel_ptrs, feat_compact, attn_l, el, er, s, exp, ret)
+        ctx.kind, ctx.bwd_dict, ctx.slope = kind, bwd_dict, slope
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        eids, rel_ptrs, row, col, row_rel_ptrs, feat, attn_l, el, er, s, exp, ret = ctx.saved_tensors
+        grad_el, grad_er = th.zeros_like(el), th.zeros_like(er)
+        grad_feat = th.zeros_like(feat)
+        _k.fused_gat_backward(eids, rel_ptrs, row, col, ctx.kind, ctx.bwd_dict, feat, el, er, s, exp, ret,
+                              gradout.contiguous(), grad_feat, grad_el, grad_er, ctx.slope, None, fold_attn_l=attn_l,
+                              fold_row_rel_ptrs=row_rel_ptrs)
+        grad_attn_l = th.empty_like(attn_l)
+        _k.matmul_no_scatter_gather_backward(row_rel_ptrs, attn_l.unsqueeze(2), feat, grad_el, None,
+                                             grad_attn_l.unsqueeze(-1), accumulate=False)
+        return (None,) * 8 + (grad_feat, grad_attn_l, grad_er, None, None, None, None)
+
+
+def relational_fused_gat_compact_with_attn_l_ok(g, feat_compact, attn_l, negative_slope):
+    """Shapes / state for which the compact GAT backward runs on its groupings (the fold lives there)."""
+    H, D = attn_l.shape[1], attn_l.shape[2]
+    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and H >= 4 and feat_compact.is_cuda
+            and g.get_num_edges() > 0)
+
+
+def relational_fused_gat_compact_with_attn_l(g, feat_compact, attn_l, er_compact, negative_slope, compact_direct_indexing_flag):
+    d = g.get_separate_coo_original()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    N = g.get_num_nodes()
+    exp = er_compact.new_empty([g.get_num_edges()] + list(er_compact.size()[1:]))
+    s = er_compact.new_empty([N] + list(er_compact.size()[1:]))
+    ret = th.empty([N] + list(feat_compact.size()[1:]), dtype=feat_compact.dtype, device=feat_compact.device)
+    if compact_direct_indexing_flag:
+        inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+        kind = 4
+        dd = {"edata_idx_to_inverse_idx_row": inv["inverse_indices_row"], "edata_idx_to_inverse_idx_col": inv["inverse_indices_col"]}
+        fwd = bwd = dd
+    else:
+        kind = 3
+        fwd = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_rel_ptrs_col": ss["rel_ptrs_col"],
+               "unique_srcs_and_dests_node_indices_row": ss["node_indices_row"],
+               "unique_srcs_and_dests_node_indices_col": ss["node_indices_col"]}
+        bwd = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_rel_col": ss["rel_ptrs_col"],
+               "unique_srcs_and_dests_node_indices_row": ss["node_indices_row"],
+               "unique_srcs_and_dests_node_indices_col": ss["node_indices_col"]}
+    return _FusedGatCompactWithAttnL.apply(d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"], kind, fwd, bwd,
+                                           ss["rel_ptrs_row"], feat_compact.contiguous(), attn_l.contiguous(),
+                                           er_compact.contiguous(), s, exp, ret, negative_slope)
 
 
 def relational_fused_gat_separate_coo_with_attn_l_ok(g, feat, attn_l, negative_slope):

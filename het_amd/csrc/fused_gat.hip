@@ -200,7 +200,8 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
     const float* sum, const float* exp, const float* ret, const float* exp_sorted, const float* gradout,
     float* grad_feat, float* grad_el, float* grad_er, int64_t H, int64_t D, double slope, const het_grouping* by_dst,
     const het_grouping* by_src_row, const het_grouping* by_dst_row, int64_t n_src_rows, int64_t n_dst_rows,
-    void* workspace, int64_t workspace_bytes, const float* fold_attn_l, float* grad_fold_attn_l, het_stream stream) {
+    void* workspace, int64_t workspace_bytes, const float* fold_attn_l, float* grad_fold_attn_l,
+    const int64_t* fold_row_rel_ptrs, het_stream stream) {
   const char* op = "backward_relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && sum && exp && ret && gradout &&
@@ -217,13 +218,15 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
   if (by_dst && kind == HET_KIND_DISABLED)
     return gat_backward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, gradout, grad_feat, grad_el,
                                 grad_er, (int)H, (int)D, (float)slope, fold_attn_l, grad_fold_attn_l, s);
-  HET_REQUIRE(!fold_attn_l && !grad_fold_attn_l, "%s: fold_attn_l needs kind 0 and the by_dst grouping", op);
+  HET_REQUIRE(!grad_fold_attn_l && (kind != HET_KIND_DISABLED || !fold_attn_l),
+              "%s: fold_attn_l needs the by_dst grouping (kind 0); grad_fold_attn_l is kind 0 only", op);
   if (kind != HET_KIND_DISABLED && workspace &&
       workspace_bytes >= (int64_t)sizeof(float) * (num_nodes * 2 * H + num_edges * H) &&
       gat_backward_compact_supported(by_src_row, by_dst_row, num_edges, n_dst_rows, (int)H, (int)D, (float)slope))
     return gat_backward_compact_grouped(by_src_row, by_dst_row, v, n_src_rows, n_dst_rows, feat, sum, exp, ret, gradout,
                                         grad_feat, grad_el, grad_er, static_cast<float*>(workspace), (int)H, (int)D,
-                                        (float)slope, s);
+                                        (float)slope, fold_attn_l, fold_row_rel_ptrs, s);
+  HET_REQUIRE(!fold_attn_l, "%s: fold_attn_l on compact rows needs the by_src_row / by_dst_row groupings", op);
   return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, (int)H, (int)D,
                            (float)slope, s);
 }

@@ -28,4 +28,4 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
                                  int64_t n_src_rows, int64_t n_dst_rows, const float* feat, const float* sum,
                                  const float* exp, const float* ret, const float* gradout, float* grad_feat,
                                  float* grad_el, float* grad_er, float* workspace, int H, int D, float slope,
-                                 hipStream_t s);
+                                 const float* fold_w, const idx_t* fold_row_rel_ptrs, hipStream_t s);

@@ -314,7 +314,8 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_grouped(
     Items it, const int32_t* __restrict__ p_eid, const int32_t* __restrict__ p_dst, const float* __restrict__ feat,
     const float* __restrict__ exp, const float* __restrict__ pack, const float* __restrict__ gradout,
-    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, int D, float slope) {
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, int D, float slope,
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
   constexpr int EPW = 64 / LPR, U = 1;  // same-box A/B on ogbn-mag: U = 1 2.22 ms, 2 2.29 ms, 4 3.00 ms
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -375,6 +376,11 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_grouped(
     acc_el += __shfl_xor(acc_el, off);
   }
   if (slot != 0) return;
+  if (fold_w) {  // el[u,h] = <feat[u,h,:], fold_w[r(u),h,:]>: its gradient joins grad_feat here (linear: also per split item)
+    const float4 w = ld4(fold_w + (int64_t)find_segment(fold_row_rel_ptrs, R, (idx_t)u) * X + x);
+    acc.x = fmaf(acc_el, w.x, acc.x); acc.y = fmaf(acc_el, w.y, acc.y);
+    acc.z = fmaf(acc_el, w.z, acc.z); acc.w = fmaf(acc_el, w.w, acc.w);
+  }
   float* gp = grad_feat + u * X + x;
   if (b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1]) {
     st4(gp, acc);
@@ -494,7 +500,8 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
                                  int64_t n_src_rows, int64_t n_dst_rows, const float* feat, const float* sum,
                                  const float* exp, const float* ret, const float* gradout, float* grad_feat,
                                  float* grad_el, float* grad_er, float* workspace, int H, int D, float slope,
-                                 hipStream_t s) {
+                                 const float* fold_w, const idx_t* fold_row_rel_ptrs, hipStream_t s) {
+  HET_REQUIRE(!fold_w || fold_row_rel_ptrs, "backward_relational_fused_gat_separate_coo: fold_attn_l on compact rows needs their relation pointers");
   if (v.E == 0) return HET_OK;
   const int64_t X = (int64_t)H * D;
   float* pack = workspace;               // [N, 2H]
@@ -511,7 +518,8 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_items, kBlock / 64);
   HET_DISPATCH_LPR((int)(X / 4),
                    hipLaunchKernelGGL(HET_gat_backward_src_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, by_srow->p0,
-                                      by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope));
+                                      by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,
+                                      fold_row_rel_ptrs, v.R));
   HET_LAUNCH_CHECK("HET_gat_backward_src_grouped");
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[eid, :]   (segments of by_drow are the er rows in order)
   return launch_segment_sum(by_drow, tbuf, grad_er, H, nullptr, s);

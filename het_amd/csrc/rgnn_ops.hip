@@ -365,18 +365,20 @@ extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
     int accumulate, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul_no_scatter_gather_list";
   HET_REQUIRE(num_types > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && offsets, "%s: bad arguments", op);
-  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_x && grad_w), "%s: null data pointer", op);
+  HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   // rows are their own gather list here: every grad_x row has exactly one writer (rows outside
   // [offsets[0], offsets[T]) have none: they are zeroed when overwriting)
   const bool rowdot = (x_per_head || H == 1) && D == 1 && rowdot_supported((int)H, (int)K) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
-  const bool mfma = !x_per_head && mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
+  const bool mfma = grad_x && !x_per_head && mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
                     (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  // grad_x == NULL: weight gradient only (per-head D == 1 shape, as in het_backward_rgnn_relational_matmul)
+  HET_REQUIRE(num_rows == 0 || grad_x || rowdot, "%s: grad_x may be NULL only for the per-head D == 1 shape", op);
   if (!accumulate) {
     HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_types * H * K * D, s));
     // (rows outside [offsets[0], offsets[T]) have no writer and must read zero)
-    HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_rows * (x_per_head ? H * K : K), s));
+    if (grad_x) HET_HIP(hipMemsetAsync(grad_x, 0, sizeof(float) * num_rows * (x_per_head ? H * K : K), s));
   }
   if (mfma) {
     MfmaGemmArgs m;  // grad_x[i] (+)= gradout[i] . Wt[t]; plain stores would do, atomics give "+=" on both paths
@@ -395,7 +397,8 @@ extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
     q.A = x; q.W = weights_t; q.go = gradout; q.seg_ptrs = offsets; q.num_segs = (int)num_types; q.num_rows = num_rows;
     q.H = (int)H; q.K = (int)K; q.unique_rows = 1;
     q.out = grad_x;
-    if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
+    if (grad_x)
+      if (int rc = launch_rowdot_bwd_dx(q, s)) return rc;
     q.out = grad_w;
     return launch_rowdot_bwd_dw(q, s);
   }

@@ -262,7 +262,7 @@ def backward_rgnn_relational_matmul_no_scatter_gather_list(ntype_offset_ptrs, we
 def matmul_no_scatter_gather_backward(ntype_offset_ptrs, weights_transposed, inputs, gradout, grad_input, grad_weights,
                                       accumulate: bool):
     _chk("backward_rgnn_relational_matmul_no_scatter_gather_list",
-         (weights_transposed, inputs, gradout, grad_input, grad_weights), (ntype_offset_ptrs,))
+         tuple(t for t in (weights_transposed, inputs, gradout, grad_input, grad_weights) if t is not None), (ntype_offset_ptrs,))
     T, H, D, K = weights_transposed.shape
     n = inputs.shape[0]
     per_head = int(H > 1 and inputs.numel() == n * H * K)
@@ -416,7 +416,7 @@ def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_r
 
 def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                        IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
-                       grad_er, slope, exp_sorted, fold_attn_l=None, grad_fold_attn_l=None):
+                       grad_er, slope, exp_sorted, fold_attn_l=None, grad_fold_attn_l=None, fold_row_rel_ptrs=None):
     """fold_attn_l [R,H,D]: also add grad_el[e,h] * fold_attn_l[r,h,:] into grad_feat_src (see include/het_amd.h)."""
     name = "backward_relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, True)
@@ -441,7 +441,7 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
           float(slope), None if g is None else g.handle, None if gs is None else gs.handle,
           None if gd is None else gd.handle, feat_src.shape[0], er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
           None if fold_attn_l is None else _p(fold_attn_l), None if grad_fold_attn_l is None else _p(grad_fold_attn_l),
-          _stream(ret))
+          None if fold_row_rel_ptrs is None else _p(fold_row_rel_ptrs), _stream(ret))
 
 
 @_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "

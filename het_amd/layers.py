@@ -80,8 +80,11 @@ class HET_RGATLayer(nn.Module):
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"],
                      "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
             feat_compact = B.rgnn_relational_matmul(d_row, self.conv_weights, inputs, True, 1)
-            el_compact = B.rgnn_relational_matmul_no_scatter_gather_list(
-                ss["rel_ptrs_row"], self.attn_l.unsqueeze(-1), feat_compact)
+            fuse_el = self.gat_edge_parallel_flag and B.relational_fused_gat_compact_with_attn_l_ok(
+                g, feat_compact, self.attn_l, self.leaky_relu_slope)
+            if not fuse_el:
+                el_compact = B.rgnn_relational_matmul_no_scatter_gather_list(
+                    ss["rel_ptrs_row"], self.attn_l.unsqueeze(-1), feat_compact)
             if self.multiply_among_weights_first_flag:
                 er_compact = B.rgnn_relational_matmul(d_col, self._w_attn_r(), inputs, True, 1)
             else:
@@ -90,10 +93,15 @@ class HET_RGATLayer(nn.Module):
                     ss["rel_ptrs_col"], self.attn_r.unsqueeze(-1), feat_compact_dst)
             if not self.gat_edge_parallel_flag:
                 raise NotImplementedError("single-sided unique node lists need the edge-parallel op (models.py:253-256)")
-            h = B.relational_fused_gat_compact_as_of_node_separate_coo_single_sided(
-                g, feat_compact, el_compact.view(el_compact.shape[0], self.num_heads),
-                er_compact.view(er_compact.shape[0], self.num_heads), self.leaky_relu_slope,
-                self.compact_direct_indexing_flag)
+            if fuse_el:  # el and the GAT op under one autograd node (same values, one gradient store for feat_compact)
+                h = B.relational_fused_gat_compact_with_attn_l(
+                    g, feat_compact, self.attn_l, er_compact.view(er_compact.shape[0], self.num_heads),
+                    self.leaky_relu_slope, self.compact_direct_indexing_flag)
+            else:
+                h = B.relational_fused_gat_compact_as_of_node_separate_coo_single_sided(
+                    g, feat_compact, el_compact.view(el_compact.shape[0], self.num_heads),
+                    er_compact.view(er_compact.shape[0], self.num_heads), self.leaky_relu_slope,
+                    self.compact_direct_indexing_flag)
         else:  # models.py:265-372
             s = g.get_separate_coo_original()
             by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"],

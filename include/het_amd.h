@@ -205,7 +205,9 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   (error otherwise; by_dst must then carry payload1 = relation of every position); replaces a
  *   read-modify-write pass over the [E,H,D] gradient.  grad_fold_attn_l (optional with fold_attn_l, R <= 8): [R,H,D],
  *   receives += SUM_e grad_el[e,h] * feat[e,h,:] per relation -- the weight gradient of that product, from the feat
- *   rows the kernel reads anyway (saves a pass over feat); the caller zero-fills it. */
+ *   rows the kernel reads anyway (saves a pass over feat); the caller zero-fills it.
+ *   Compact kinds with the by_src_row / by_dst_row groupings: fold_attn_l works on the compact rows
+ *   (el[u,h] = <feat[u,h,:], fold_attn_l[r(u),h,:]>), fold_row_rel_ptrs [R+1] = the rows' relation pointers. */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
@@ -220,7 +222,7 @@ int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const in
                                                    const het_grouping* by_dst_row, int64_t n_src_rows,
                                                    int64_t n_dst_rows, void* workspace, int64_t workspace_bytes,
                                                    const float* fold_attn_l, float* grad_fold_attn_l,
-                                                   het_stream stream);
+                                                   const int64_t* fold_row_rel_ptrs, het_stream stream);
 
 /* a6  relational_fused_gat_csr / backward_relational_fused_gat_csr   RGATOps.inc.h:251-277, 430-460
  *   forward over the in-CSR (rows = dst, col_indices = src); backward over the out-CSR
