@@ -16,6 +16,7 @@ P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 # name -> argtypes, in the order of include/het_amd.h
 _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
+    "het_rows_add_bias": [P, P, P, P, I64, I64, P],
     "het_layout_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
     "het_layout_coo_to_csr": [P, P, P, P, I64, I64, P, P, P, P, P],
     "het_layout_transpose_csr": [P, P, P, P, I64, I64, I64, P, P, P, P, P],

@@ -1,0 +1,177 @@
+"""The whole RGAT layer (RGAT/models.py:16-385) as ONE autograd node.
+
+Same ops, same values and gradients as the op-by-op composition in het_amd/layers.py (which follows the reference's
+model code and stays the fallback); what the single node buys is control over the backward pass: every consumer of the
+layer input accumulates its gradient into ONE buffer (self-loop first with plain stores, then the two projections with
+their atomic epilogues) and the weight gradients into one buffer, instead of autograd allocating a gradient per
+consumer and summing them with elementwise kernels; the output ``h + loop_message + h_bias`` is one pass.  On ogbn-mag
+this removes ~1 ms of elementwise adds and fills per step.
+
+Two dataflows, selected by the layer flags exactly as in the op-by-op path:
+  kind 0 (default flags)   per-edge projections; the fusions of het_amd/layers.py (distinct-row projection + broadcast,
+                           attention terms from the GEMM epilogue, er without its per-edge tensor, el folded into the GAT node)
+  compact (kinds 3 / 4)    projections on the unique (relation, node) rows, el folded into the compact GAT backward
+"""
+import torch as th
+
+from .. import kernels as _k
+from ..kernels import K
+
+
+_OFFS = {}
+
+
+def _lists(g):
+    s = g.get_separate_coo_original()
+    by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"], "separate_coo_eids": s["eids"]}
+    by_dst = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"], "separate_coo_eids": s["eids"]}
+    return s, by_src, by_dst
+
+
+def _compact_dicts(g, direct):
+    ss = g.get_separate_unique_node_indices_single_sided()
+    if direct:
+        inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+        d = {"edata_idx_to_inverse_idx_row": inv["inverse_indices_row"], "edata_idx_to_inverse_idx_col": inv["inverse_indices_col"]}
+        return ss, 4, d, d
+    fwd = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_rel_ptrs_col": ss["rel_ptrs_col"],
+           "unique_srcs_and_dests_node_indices_row": ss["node_indices_row"],
+           "unique_srcs_and_dests_node_indices_col": ss["node_indices_col"]}
+    bwd = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_rel_col": ss["rel_ptrs_col"],
+           "unique_srcs_and_dests_node_indices_row": ss["node_indices_row"],
+           "unique_srcs_and_dests_node_indices_col": ss["node_indices_col"]}
+    return ss, 3, fwd, bwd
+
+
+def rgat_layer_fused_ok(g, x, W, slope, compact):
+    """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
+    R, H, Kd, D = W.shape
+    if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0 and H >= 4
+            and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
+        return False
+    if compact:
+        return True
+    _, _, by_dst = _lists(g)
+    return _k.matmul_attn_dot_only_ok(by_dst, W, x)
+
+
+class RgatLayerFunction(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, compact, direct, slope, num_dst, x, W, attn_l, attn_r, loop_w, bias):
+        x, W, attn_l, attn_r = x.contiguous(), W.contiguous(), attn_l.contiguous(), attn_r.contiguous()
+        s, by_src, by_dst = _lists(g)
+        rp, row, col, eids = s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"]
+        E, N = eids.numel(), x.shape[0]
+        R, H, Kd, D = W.shape
+        X = H * D
+        new = lambda *shape: th.empty(shape, dtype=x.dtype, device=x.device)
+        sm, ex, ret = new(N, H), new(E, H), new(N, H, D)
+        if compact:
+            ss, kind, fwd, bwd = _compact_dicts(g, direct)
+            d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
+            d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+            featc = new(ss["node_indices_row"].numel(), H, D)
+            K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
+            elc = new(featc.shape[0], H)
+            K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc)
+            featd = new(ss["node_indices_col"].numel(), H, D)
+            K.rgnn_relational_matmul(d_col, 1, W, x, featd, True)
+            erc = new(featd.shape[0], H)
+            K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_col"], attn_r.unsqueeze(-1), featd, erc)
+            _k.fused_gat_forward(eids, rp, row, col, kind, fwd, featc, elc, erc, sm, ex, ret, slope, None)
+            saved = (featc, elc, featd, erc)
+            ctx.bwd_dict, ctx.kind = bwd, kind
+        else:
+            feat, el, er, exs = new(E, H, D), new(E, H), new(E, H), new(E, H)
+            _k.matmul_attn_dot(by_src, 0, W, x, feat, attn_l, el)
+            comp = _k.matmul_attn_dot(by_dst, 0, W, x, None, attn_r, er)
+            used = _k.fused_gat_forward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, slope, exs)
+            assert used and comp is not None
+            saved = (feat, el, er, exs, comp)
+        nd = N if num_dst is None else min(int(num_dst), N)
+        out = ret.view(N, X)[:nd]
+        loop = None
+        offs = None
+        if loop_w is not None:
+            loop_w = loop_w.contiguous()
+            offs = _OFFS.get((nd, x.device))  # built once per (rows, device): no per-step host-to-device copy
+            if offs is None:
+                if len(_OFFS) > 64:
+                    _OFFS.clear()
+                offs = _OFFS[(nd, x.device)] = th.tensor([0, nd], dtype=th.int64, device=x.device)
+            loop = new(nd, X)
+            K.rgnn_relational_matmul_no_scatter_gather_list(offs, loop_w.view(1, 1, Kd, X), x[:nd], loop)
+        h = _k.rows_add_bias(out, loop, None if bias is None else bias.contiguous()) if (loop is not None or bias is not None) else out.clone()
+        ctx.g, ctx.compact, ctx.slope, ctx.nd = g, compact, slope, nd
+        ctx.has_loop, ctx.has_bias = loop_w is not None, bias is not None
+        ctx.save_for_backward(x, W, attn_l, attn_r, loop_w if loop_w is not None else x.new_empty(0), offs if offs is not None else eids,
+                              sm, ex, ret, *saved)
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        x, W, attn_l, attn_r, loop_w, offs, sm, ex, ret, *saved = ctx.saved_tensors
+        g, nd, slope = ctx.g, ctx.nd, ctx.slope
+        s, by_src, by_dst = _lists(g)
+        rp, row, col, eids = s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"]
+        N, Kd = x.shape
+        R, H, _, D = W.shape
+        X = H * D
+        grad_h = grad_h.contiguous()
+        grad_bias = grad_h.sum(0) if ctx.has_bias else None
+        Wt = th.transpose(W, 2, 3).contiguous()
+        grad_W = th.zeros_like(W)
+        # one input-gradient buffer: the self-loop writes its rows with plain stores, the projections add to it
+        grad_loop = None
+        if ctx.has_loop:
+            grad_x = th.empty_like(x) if nd == N else th.zeros_like(x)
+            grad_loop = th.empty_like(loop_w)
+            _k.matmul_no_scatter_gather_backward(offs, loop_w.view(1, 1, Kd, X).transpose(2, 3).contiguous(), x[:nd], grad_h,
+                                                 grad_x[:nd], grad_loop.view(1, 1, Kd, X), accumulate=False)
+        else:
+            grad_x = th.zeros_like(x)
+        if nd == N:
+            go = grad_h.view(N, H, D)
+        else:  # rows of non-destination nodes receive no gradient
+            go = th.zeros((N, H, D), dtype=x.dtype, device=x.device)
+            go.view(N, X)[:nd] = grad_h
+        if ctx.compact:
+            featc, elc, featd, erc = saved
+            ss = g.get_separate_unique_node_indices_single_sided()
+            d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
+            d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+            # (the grouped compact backward overwrites all three: rgat_layer_fused_ok guarantees that path)
+            g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
+            _k.fused_gat_backward(eids, rp, row, col, ctx.kind, ctx.bwd_dict, featc, elc, erc, sm, ex, ret, go, g_featc, g_elc,
+                                  g_erc, slope, None, fold_attn_l=attn_l, fold_row_rel_ptrs=ss["rel_ptrs_row"])
+            grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
+            _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
+                                                 grad_attn_l.unsqueeze(-1), accumulate=False)
+            g_featd = th.empty_like(featd)
+            _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_col"], attn_r.unsqueeze(2), featd, g_erc, g_featd,
+                                                 grad_attn_r.unsqueeze(-1), accumulate=False)
+            _k.matmul_backward(d_row, 1, Wt, x, g_featc, grad_x, grad_W, True, accumulate=True)
+            _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
+        else:
+            feat, el, er, exs, comp = saved
+            g_feat, g_el = th.empty_like(feat), th.empty_like(el)
+            grad_attn_l = th.zeros_like(attn_l)
+            if R <= 8:
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el, g_el, slope, exs,
+                                      fold_attn_l=attn_l, grad_fold_attn_l=grad_attn_l)
+            else:
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el, g_el, slope, exs,
+                                      fold_attn_l=attn_l)
+                by_eid = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
+                _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat, g_el, None, grad_attn_l.unsqueeze(-1), False,
+                                   accumulate=False)
+            _k.matmul_backward(by_src, 0, Wt, x, g_feat, grad_x, grad_W, True, accumulate=True)
+            grad_attn_r = th.zeros_like(attn_r)
+            ok = _k.matmul_attn_dot_only_backward(by_dst, Wt, x, attn_r, g_el, grad_x, grad_W, comp_rows=comp,
+                                                  grad_dot_w=grad_attn_r, accumulate=True)
+            assert ok, "the grouping of the forward pass is gone"
+        return None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
+
+
+def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None):
+    return RgatLayerFunction.apply(g, bool(compact), bool(direct), float(slope), num_dst, x, W, attn_l, attn_r, loop_w, bias)

@@ -497,3 +497,38 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
   w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_edges; w.KA = (int)K; w.NB = (int)D;
   return launch_seg_dw(w, s);
 }
+
+// ---- layer epilogue: out[i, :] = a[i, :] (+ b[i, :]) (+ bias[:]) -- the "h + loop_message + h_bias" of the layers
+// (RGAT/models.py:377-383) as one pass instead of two elementwise adds
+namespace {
+__global__ __launch_bounds__(256) void HET_rows_add_bias(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int64_t total4, int X4) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(a)[t];
+    if (b) {
+      const float4 w = reinterpret_cast<const float4*>(b)[t];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if (bias) {
+      const float4 w = reinterpret_cast<const float4*>(bias)[t % X4];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    reinterpret_cast<float4*>(out)[t] = v;
+  }
+}
+}  // namespace
+
+extern "C" int het_rows_add_bias(const float* a, const float* b, const float* bias, float* out, int64_t num_rows, int64_t X,
+                                 het_stream stream) {
+  HET_REQUIRE(num_rows >= 0 && X > 0 && X % 4 == 0 && (num_rows == 0 || (a && out)), "rows_add_bias: bad arguments");
+  HET_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(bias) |
+                reinterpret_cast<uintptr_t>(out)) & 15) == 0, "rows_add_bias: 16-byte aligned pointers expected");
+  if (num_rows == 0) return HET_OK;
+  const int64_t total4 = num_rows * (X / 4);
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(HET_rows_add_bias, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, b, bias, out, total4, (int)(X / 4));
+  HET_LAUNCH_CHECK("HET_rows_add_bias");
+  return HET_OK;
+}

@@ -193,8 +193,16 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
     return comp
 
 
+def rows_add_bias(a, b=None, bias=None):
+    """out = a (+ b) (+ bias broadcast over rows) in one pass (include/het_amd.h: het_rows_add_bias)."""
+    _chk("rows_add_bias", tuple(t for t in (a, b, bias) if t is not None))
+    out = torch.empty_like(a)
+    _call(a, "het_rows_add_bias", _p(a), _p(b), _p(bias), _p(out), a.shape[0], a.numel() // max(1, a.shape[0]), _stream(a))
+    return out
+
+
 def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights,
-                                  comp_rows=None, grad_dot_w=None):
+                                  comp_rows=None, grad_dot_w=None, accumulate=False):
     """Backward of matmul_attn_dot when only dot_out was used (see include/het_amd.h); returns False when the fast
     path does not apply (no grouping / shape), leaving the outputs untouched."""
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
@@ -208,8 +216,8 @@ def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_fea
     S = max(1, grp.num_segments)
     ws = torch.empty(((S * H + 3) // 4) * 4 + S * H * D, dtype=torch.float32, device=grad_dot.device)
     _call(grad_dot, "het_backward_rgnn_relational_matmul_attn_dot_only", _p(rp), R, _p(g), _p(s), g.numel(), node_feat.shape[0],
-          _p(weights_transposed), _p(node_feat), _p(dot_w), _p(grad_dot), _p(grad_node_feat), _p(grad_weights), H, K, D, 0,
-          grp.handle, _p(ws), ws.numel() * 4, _p(comp_rows), _p(grad_dot_w), _stream(grad_dot))
+          _p(weights_transposed), _p(node_feat), _p(dot_w), _p(grad_dot), _p(grad_node_feat), _p(grad_weights), H, K, D,
+          int(accumulate), grp.handle, _p(ws), ws.numel() * 4, _p(comp_rows), _p(grad_dot_w), _stream(grad_dot))
     return True
 
 

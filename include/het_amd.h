@@ -368,6 +368,11 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
                                                          const het_grouping* by_rel_src, int64_t n_q_rows,
                                                          void* workspace, int64_t workspace_bytes, het_stream stream);
 
+/* layer epilogue (RGAT/models.py:377-383: h + loop_message + h_bias): out[i,:] = a[i,:] (+ b[i,:]) (+ bias[:]) in one
+ * pass; b and bias optional, X % 4 == 0 */
+int het_rows_add_bias(const float* a, const float* b, const float* bias, float* out, int64_t num_rows, int64_t X,
+                      het_stream stream);
+
 /* ------------------------------------------------------------------------
  * Layout builders (the step before the path).  Device-side replacements of the reference's CPU
  * converters: torch.ops.torch_hrt.convert_integrated_{coo,csr}_to_separate_{coo,csr} / transpose_csr
