@@ -5,3 +5,9 @@ from .rgnn_layers_and_funcs import *  # noqa: F401,F403
 from .rgat_layers_and_funcs import *  # noqa: F401,F403
 from .rgcn_layers_and_funcs import *  # noqa: F401,F403
 from .hgt_layers_and_funcs import *  # noqa: F401,F403
+
+
+def plan_enabled() -> bool:
+    """Whether the cached device-side groupings (het_amd/plan.py) are in use (the fast paths of the ops)."""
+    from .. import plan as _plan
+    return bool(_plan.enabled)

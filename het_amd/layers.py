@@ -260,14 +260,21 @@ class HET_HGTLayerHetero(nn.Module):
         k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.k_linears, h).view(-1, self.num_heads, self.d_k)
         q = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.q_linears, h).view(-1, self.num_heads, self.d_k)
         v = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.v_linears, h).view(-1, self.num_heads, self.d_k)
+        # The per-edge tensor q[dst] . relation_att[r] of the default flags (models.py:215-241) is read by the inner
+        # product only and its rows repeat for every edge of a (relation, destination) pair: when the graph carries the
+        # unique (relation, node) lists it is formed on those rows and indexed directly -- the reference's compact
+        # dataflow, same values -- instead of being written and re-read as an [E,H,dk] tensor.
+        has_lists = "unique_node_indices_single_sided" in getattr(G, "graph_data", {}).get("separate", {})
+        as_compact = self.compact_as_of_node_flag or (has_lists and h.is_cuda and B.plan_enabled())
+        direct = self.compact_direct_indexing_flag or not self.compact_as_of_node_flag
         if self.hgt_fused_attn_score_flag:  # models.py:172-175
             attn_score = B.hgt_full_graph_hetero_attention_ops_coo(G, self.relation_att, k, q)
-        elif self.compact_as_of_node_flag:  # models.py:177-214
+        elif as_compact:  # models.py:177-214
             ss = G.get_separate_unique_node_indices_single_sided()
             compact = B.rgnn_relational_matmul(
                 {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"],
                  "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}, self.relation_att, q, False, 1)
-            attn_score = B.rgnn_inner_product_right_node(G, compact, k, 2 if self.compact_direct_indexing_flag else 1, "_col")
+            attn_score = B.rgnn_inner_product_right_node(G, compact, k, 2 if direct else 1, "_col")
         else:  # models.py:215-241
             s = G.get_separate_coo_original()
             per_edge = B.rgnn_relational_matmul(
