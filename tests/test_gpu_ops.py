@@ -534,3 +534,13 @@ def test_attn_dot_only_without_the_per_edge_projection(H, Kd, D):
         res.append((er.detach(), xd.grad, Wd.grad, ad.grad))
     for name, u, v in zip(("er", "grad_x", "grad_W", "grad_attn"), res[0], res[1]):
         assert_close(v, u.cpu(), what=name)
+
+
+def test_rows_add_bias():
+    import het_amd.kernels as k
+    gen = torch.Generator().manual_seed(3)
+    a, b, bias = torch.randn(333, 64, generator=gen), torch.randn(333, 64, generator=gen), torch.randn(64, generator=gen)
+    for bb, cc in ((b, bias), (None, bias), (b, None)):
+        out = k.rows_add_bias(a.to(DEV), None if bb is None else bb.to(DEV), None if cc is None else cc.to(DEV))
+        ref = a + (0 if bb is None else bb) + (0 if cc is None else cc)
+        assert torch.equal(out.cpu(), ref)
