@@ -473,7 +473,9 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
                                       g->p0, feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, D,  \
                                       slope, g->p1, fold_w, (float*)nullptr, v.R))
   if (grad_fold_w) {
-    // fixed grid striding over the items: every workgroup flushes R*X atomics once
+    // fixed grid striding over the items: every workgroup flushes R*X atomics once (same-box A/B, exp/ab_bwd.sh:
+    // 2048 .. 16384 workgroups and U = 1 / 2 all within +-3 %; 1280 workgroups 25 % slower; one workgroup per 4 items
+    // 5x slower -- the atomics on the R*X words serialise)
     const unsigned nbw = nb < 4096u ? nb : 4096u;
 #define HET_GAT_BWD_DW(SORTED, RM)                                                                                    \
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM>), dim3(nbw),       \
