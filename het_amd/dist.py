@@ -126,6 +126,26 @@ def build_plan(coo: IntegratedCOO, rank: int, world: int) -> DistPlan:
                     coo.num_edges, int(cut.sum()))
 
 
+def _all_to_all(recv, send, recv_counts, send_counts, group):
+    """all_to_all_single; with the gloo backend (CPU tests, or several test ranks sharing one GPU) device tensors are
+    staged through the host, with nccl (= RCCL over xGMI) they go device to device."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), recv_counts, send_counts, group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, recv_counts, send_counts, group=group)
+
+
+def _all_reduce(t, group):
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 class HaloExchange(torch.autograd.Function):
     """x_own [n_own, K] -> [n_own + n_halo, K]: owned rows followed by the halo rows received from
     their owners.  Backward sends the halo gradients home and adds them to the owners' rows."""
@@ -135,7 +155,7 @@ class HaloExchange(torch.autograd.Function):
         ctx.plan, ctx.group = plan, group
         send = x_own.index_select(0, plan.send_idx).contiguous()
         recv = x_own.new_empty((plan.n_halo, x_own.shape[1]))
-        dist.all_to_all_single(recv, send, plan.recv_counts, plan.send_counts, group=group)
+        _all_to_all(recv, send, plan.recv_counts, plan.send_counts, group)
         return torch.cat([x_own, recv], 0)
 
     @staticmethod
@@ -144,7 +164,7 @@ class HaloExchange(torch.autograd.Function):
         g_own = grad[: plan.n_own].clone()
         g_halo = grad[plan.n_own:].contiguous()
         back = grad.new_empty((int(plan.send_idx.numel()), grad.shape[1]))
-        dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=ctx.group)
+        _all_to_all(back, g_halo, plan.send_counts, plan.recv_counts, ctx.group)
         g_own.index_add_(0, plan.send_idx, back)
         return g_own, None, None
 
@@ -172,7 +192,7 @@ class DistLayer:
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, group=self.group)
+        _all_reduce(flat, self.group)
         off = 0
         for g in grads:
             g.copy_(flat[off: off + g.numel()].view_as(g))

@@ -1,0 +1,78 @@
+"""The multi-rank path with the real HIP layer: two ranks (gloo rendezvous, both computing on the one GPU of the test
+box, halo rows staged through the host) against the single-process layer -- outputs, input and weight gradients.
+The 8-GPU runs of the driver use the same plan / halo / gradient code with the nccl (RCCL) backend."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, compact, outdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from het_amd.dist import DistRGAT
+        from het_amd.synth import make_mag_like
+        dev = torch.device("cuda", 0)
+        coo = make_mag_like(scale=4e-3)
+        flags = dict(compact_as_of_node_flag=compact, compact_direct_indexing_flag=compact)
+        runner = DistRGAT(coo, 64, 64, 4, dev, **flags)
+        plan = runner.dl.plan
+        lo, hi = int(plan.bounds[rank]), int(plan.bounds[rank + 1])
+        mine = plan.node_order[lo:hi].cpu()
+        gen = torch.Generator().manual_seed(2)
+        x_full = torch.randn(coo.num_nodes, 64, generator=gen)
+        go_full = torch.randn(coo.num_nodes, 64, generator=gen)
+        x_own = x_full[mine].to(dev).requires_grad_(True)
+        out = runner.dl.forward(x_own)
+        out.backward(go_full[mine].to(dev))
+        runner.dl.reduce_param_grads()
+        torch.save({"mine": mine, "out": out.detach().cpu(), "gx": x_own.grad.cpu(),
+                    "grads": {n: p.grad.cpu() for n, p in runner.layer.named_parameters()}},
+                   os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_two_ranks_on_one_gpu_match_single_process(compact):
+    import torch.multiprocessing as mp
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.start_processes(_worker, args=(world, _free_port(), compact, d), nprocs=world, join=True, start_method="spawn")
+        parts = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
+    dev = torch.device("cuda", 0)
+    coo = make_mag_like(scale=4e-3)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    g = HetGraph.from_integrated_coo(coo, full=True)
+    torch.manual_seed(0)  # DistRGAT seeds its replicated layer the same way
+    layer = HET_RGATLayer(64, 64, coo.num_rels, 4, self_loop=True, dropout=0.0, compact_as_of_node_flag=compact,
+                          compact_direct_indexing_flag=compact).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(coo.num_nodes, 64, generator=gen).to(dev).requires_grad_(True)
+    go = torch.randn(coo.num_nodes, 64, generator=gen).to(dev)
+    ref = layer(g, x)
+    ref.backward(go)
+    assert torch.equal(torch.sort(torch.cat([q["mine"] for q in parts])).values, torch.arange(coo.num_nodes))
+    for q in parts:
+        torch.testing.assert_close(q["out"], ref.detach().cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(q["gx"], x.grad.cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
+        for n, p in layer.named_parameters():
+            torch.testing.assert_close(q["grads"][n], p.grad.cpu(), rtol=5e-4, atol=1e-4)
