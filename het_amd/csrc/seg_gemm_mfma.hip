@@ -14,12 +14,18 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kChunkRows = 2048;  // rows of one relation per workgroup (16 tiles per wave)
+constexpr int kChunkRows = 2048;  // rows of one relation per workgroup at most (16 tiles per wave)
+// Smaller inputs (a rank's share of a partitioned graph, a sampled block) get smaller chunks so that the launch still
+// has ~2000 workgroups: 128 rows = one 32-row tile per wave is the floor.
+inline int chunk_rows_for(int64_t num_rows) {
+  int64_t c = ((num_rows / 2048) + 127) / 128 * 128;
+  return (int)(c < 128 ? 128 : (c > kChunkRows ? kChunkRows : c));
+}
 
 // DOT (plain stores only): additionally dot_out[cs(i), h] = < C row (h, :), dot_w[r, h, :] > from the row pieces the
 // epilogue already holds -- the attention-vector product of RGAT without re-reading the tensor just written.
 template <int K, int NT, bool ATOMIC, bool DOT = false>
-__global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
+__global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chunk_rows) {
   constexpr int X = NT * 32, KH = K / 2;
   constexpr int LDA = K + 4, LPRA = K / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;  // A tile: rows per load instr
   constexpr int LDC = X + 4, LPRC = X / 4, RPIC = 64 / LPRC, NITC = 32 / RPIC;  // C tile: rows per store instr
@@ -27,7 +33,7 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int r;
   idx_t rb, re;
-  if (!tile_to_relation(a.seg_ptrs, a.num_segs, kChunkRows, blockIdx.x, r, rb, re)) return;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, chunk_rows, blockIdx.x, r, rb, re)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // The relation's weight is staged once per workgroup in LDS ([K][X], read conflict-free: 32 consecutive
   // floats per lane half).
@@ -362,18 +368,19 @@ int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   constexpr int X = NT * 32, LDA = K + 4, LDC = X + 4;
   constexpr bool B_REGS = false;
   const size_t lds = sizeof(float) * ((B_REGS ? 0 : K * X) + 4 * 32 * (LDA > LDC ? LDA : LDC));
-  const int64_t gx = ceil_div64(a.num_rows, kChunkRows) + a.num_segs;
+  const int chunk = chunk_rows_for(a.num_rows);
+  const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
   dim3 grid((unsigned)gx), block(256);
   if (a.dot_w) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a, chunk);
   } else if (a.atomic) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, true>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, true>), grid, block, lds, s, a, chunk);
   } else {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false>), grid, block, lds, s, a, chunk);
   }
   HET_LAUNCH_CHECK("HET_seg_gemm_mfma");
   return HET_OK;

@@ -8,8 +8,8 @@ defines ops with the same names, argument order and argument meaning in the same
 namespace and implements them by calling the C ABI of include/het_amd.h on the
 current torch stream.  Tensor arguments are only unwrapped to device pointers
 here; all arithmetic happens in the HIP library.  CPU tensors are rejected for
-the compute ops (there is no CPU path); the five layout converters are torch
-index ops and run on either device.
+the compute ops (there is no CPU path); the five layout converters run the native
+device-side builders (csrc/layouts.hip) on GPU tensors and torch index ops on CPU tensors.
 """
 from __future__ import annotations
 
