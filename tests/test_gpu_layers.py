@@ -213,3 +213,24 @@ def test_layer_step_is_hip_graph_capturable():
     torch.cuda.synchronize()
     for p, r in zip(params, ref):
         torch.testing.assert_close(p.grad, r, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["atomics", "op_by_op"])
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_layer_fallback_paths(mode, compact, monkeypatch):
+    """The layer without its single-node fast path: (atomics) groupings disabled -- every op on its atomics kernels, the
+    reference's op sequence; (op_by_op) groupings on, single node off -- the fused ops of het_amd/layers.py."""
+    import het_amd.plan as plan
+    from het_amd.backend import rgat_fused_layer as FL
+    old = plan.enabled
+    try:
+        if mode == "atomics":
+            plan.enabled = False
+            plan.clear()
+        else:
+            monkeypatch.setattr(FL, "rgat_layer_fused_ok", lambda *a, **k: False)
+        _run_rgat(random_graph(seed=47, n=300, r=4, e=5000, shuffle=False), H=4, K=64, X=64, compact=compact, direct=compact,
+                  mulfirst=False)
+    finally:
+        plan.enabled = old
+        plan.clear()
