@@ -94,6 +94,13 @@ __device__ __forceinline__ bool tile_to_relation(const idx_t* __restrict__ rel_p
 }
 
 __device__ __forceinline__ float leaky_exp(float z, float slope) {
-  // gatLeakyReluExp, DGLHackKernel/GAT/FusedGAT.cu.h:23-26
-  return z > 0.f ? expf(z) : expf(slope * z);
+  // gatLeakyReluExp, DGLHackKernel/GAT/FusedGAT.cu.h:23-26.
+  // The grouped backward recovers the leaky-ReLU branch from the stored value (slope >= 0: z > 0 <=> exp(..) > 1).  For
+  // 0 < z < 6e-8 expf(z) rounds to exactly 1.0f; it is stored as the next float up (exp(z) = 1 + z lies between the two,
+  // so either is a correctly rounded neighbour) which keeps that equivalence exact.
+  if (z > 0.f) {
+    const float v = expf(z);
+    return v > 1.f ? v : 1.00000012f;
+  }
+  return expf(slope * z);
 }

@@ -234,3 +234,10 @@ def test_rgat_layer_fallback_paths(mode, compact, monkeypatch):
     finally:
         plan.enabled = old
         plan.clear()
+
+
+@pytest.mark.parametrize("H,K,X,compact", [(4, 128, 128, False), (8, 64, 64, False), (8, 32, 128, True), (16, 64, 64, True)])
+def test_rgat_layer_other_shapes_single_node(H, K, X, compact):
+    """feat = 128 (BASELINE.json configs[4]), 8 and 16 heads, K != X: the single-node layer on its other shapes."""
+    _run_rgat(random_graph(seed=48, n=260, r=3, e=4000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,
+              mulfirst=False)
