@@ -241,3 +241,11 @@ def test_rgat_layer_other_shapes_single_node(H, K, X, compact):
     """feat = 128 (BASELINE.json configs[4]), 8 and 16 heads, K != X: the single-node layer on its other shapes."""
     _run_rgat(random_graph(seed=48, n=260, r=3, e=4000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,
               mulfirst=False)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_layer_many_seeds(compact):
+    """Eight random graphs / parameter draws per flag set (different sizes, relation counts, hub patterns)."""
+    for seed in range(8):
+        g = random_graph(seed=100 + seed, n=120 + 37 * seed, r=2 + seed % 4, e=1500 + 700 * seed, shuffle=False)
+        _run_rgat(g, H=4, K=64, X=64, compact=compact, direct=compact and seed % 2 == 0, mulfirst=False, seed=seed)
