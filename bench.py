@@ -308,6 +308,7 @@ def main():
             "roofline": roofline,
             "roofline_segment_gemm": roofline_gemm,
             "per_op_ms": per_op,
+            "peak_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
         }
         if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
             out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)
