@@ -33,8 +33,8 @@ _SIGNATURES = {
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],
     "het_backward_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P, I64, P],
-    "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P],
-    "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, INT, P],
+    "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P, P],
+    "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, INT, P, I64, P],
     "het_hgt_full_graph_edge_softmax_ops_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, P, P],
     "het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, P, P],
     "het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, I64, P, P, I64, P],

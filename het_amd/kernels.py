@@ -546,10 +546,15 @@ def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate_coo_eids
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices, a)
          + ((b,) if b is not None else ()))
     N = ret.shape[0]
+    g = None
+    if _plan.enabled and separate_coo_eids.numel() > 0:
+        crow = _src_rows_by_position(4 if DirectIndexFlag else 3, (a, b, None, None), separate_coo_rel_ptrs,
+                                     separate_coo_row_indices, separate_coo_eids)
+        g = _plan.get_grouping(None, separate_coo_col_indices, N, crow, separate_coo_eids)
     _call(ret, "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", _p(separate_coo_eids),
           _p(separate_coo_rel_ptrs), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), N, _p(a), _p(b), _p(feat_src), _p(enorm), _p(ret),
-          ret.numel() // max(1, N), int(DirectIndexFlag), _stream(ret))
+          ret.numel() // max(1, N), int(DirectIndexFlag), None if g is None else g.handle, _stream(ret))
 
 
 @_op("backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(Tensor separate_coo_eids, "
@@ -566,10 +571,16 @@ def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices, a)
          + ((b,) if b is not None else ()))
     N = ret.shape[0]
+    g = None
+    if _plan.enabled and separate_coo_eids.numel() > 0:
+        crow = _src_rows_by_position(4 if DirectIndexFlag else 3, (a, b, None, None), separate_coo_rel_ptrs,
+                                     separate_coo_row_indices, separate_coo_eids)
+        g = _plan.get_grouping(None, crow, grad_feat_src.shape[0], separate_coo_col_indices, separate_coo_eids)
     _call(ret, "het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", _p(separate_coo_eids),
           _p(separate_coo_rel_ptrs), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           separate_coo_rel_ptrs.numel() - 1, separate_coo_eids.numel(), N, _p(a), _p(b), _p(feat_src), _p(enorm), _p(ret),
-          _p(gradout), _p(grad_feat_src), ret.numel() // max(1, N), int(DirectIndexFlag), _stream(ret))
+          _p(gradout), _p(grad_feat_src), ret.numel() // max(1, N), int(DirectIndexFlag),
+          None if g is None else g.handle, grad_feat_src.shape[0], _stream(ret))
 
 
 K = getattr(torch.ops, NAMESPACE)

@@ -272,16 +272,19 @@ int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64_t
  *   ret[col[i], :]        = SUM_i enorm[eids[i]] * feat[crow(i), :]            (ret overwritten)
  *   grad_feat[crow(i), :] += enorm[eids[i]] * gradout[col[i], :]
  *   crow(i) = map_a[eids[i]] if direct (inverse_indices_row), else the row of (r(i), row[i]) in the
- *   unique list map_a = rel_ptrs_row [R+1], map_b = node_indices_row  (intended mapping). */
+ *   unique list map_a = rel_ptrs_row [R+1], map_b = node_indices_row  (intended mapping).
+ *   Optional fast paths (X a power of two in 4..256): by_dst = het_grouping_create(NULL, 0, col, E, N, payload0 = crow
+ *   per position, payload1 = eids); by_src_row = het_grouping_create(NULL, 0, crow, E, n_src_rows, payload0 = col,
+ *   payload1 = eids): segmented sums instead of E*X float atomics. */
 int het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
     const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const int64_t* map_a, const int64_t* map_b, const float* feat,
-    const float* enorm, float* ret, int64_t X, int direct, het_stream stream);
+    const float* enorm, float* ret, int64_t X, int direct, const het_grouping* by_dst, het_stream stream);
 int het_backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(
     const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const int64_t* map_a, const int64_t* map_b, const float* feat,
     const float* enorm, const float* ret, const float* gradout, float* grad_feat, int64_t X, int direct,
-    het_stream stream);
+    const het_grouping* by_src_row, int64_t n_src_rows, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * a10  hgt_full_graph_edge_softmax_ops_separate_coo     OpExport/HGTOpsEdgeParallel.inc.h:18-31 -> HGTOps.inc.h:23-106
