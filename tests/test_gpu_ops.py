@@ -249,7 +249,7 @@ def test_gat_golden_exp_sum(K, golden_mag):
 
 # ---------------------------------------------------------------- RGCN
 @pytest.mark.parametrize("Kd,D", [(16, 16), (64, 64), (7, 3)])
-def test_rgcn_layer1(K, Kd, D):
+def test_rgcn_layer1(K, plan_mode, Kd, D):
     g = random_graph(seed=31)
     s = g.get_separate_coo_original()
     R, N, E = g.get_num_rels(), g.get_num_nodes(), g.get_num_edges()
@@ -273,7 +273,7 @@ def test_rgcn_layer1(K, Kd, D):
 
 
 @pytest.mark.parametrize("direct", [False, True])
-def test_rgcn_compact_aggregation(K, direct):
+def test_rgcn_compact_aggregation(K, plan_mode, direct):
     g = random_graph(seed=32)
     s = g.get_separate_coo_original()
     ss, ssi = g.get_separate_unique_node_indices_single_sided(), g.get_separate_unique_node_indices_single_sided_inverse_idx()
