@@ -349,6 +349,19 @@ def _dst_rows_by_position(kind, maps, rel_ptrs, col, eids):
     return drow
 
 
+def _csr_expanded_rows(row_ptrs, num_edges):
+    """(row id of every CSR position, a one-relation rel_ptrs [0, E]) -- cached per CSR."""
+    key = ("csr", row_ptrs.data_ptr(), row_ptrs._version, num_edges)
+    hit = _derived.get(key)
+    if hit is None:
+        rows = _graph.csr_to_coo_rows(row_ptrs).contiguous()
+        rp1 = torch.tensor([0, num_edges], dtype=torch.int64, device=row_ptrs.device)
+        if len(_derived) > 16:
+            _derived.clear()
+        hit = _derived[key] = ((rows, rp1), (row_ptrs,))
+    return hit[0]
+
+
 def _rel_by_position(rel_ptrs, num_positions):
     """Relation of every edge position of the separate COO (cached per graph)."""
     key = ("rel", rel_ptrs.data_ptr(), rel_ptrs._version, num_positions)
@@ -462,6 +475,12 @@ def relational_fused_gat_csr(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr
          (incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes))
     N, E, H = incsr_row_ptr.numel() - 1, incsr_eids.numel(), el.shape[1]
     D = ret.numel() // max(1, N * H)
+    if not CompactAsOfNodeFlag and _plan.enabled and E > 0 and gat_grouped_shape_ok(H, D):
+        # the in-CSR IS the edge list grouped by destination: same math as the separate-COO op on (eids, src, dst) in
+        # CSR order, served by the destination-grouped kernels instead of E*H*D float atomics
+        dst, rp1 = _csr_expanded_rows(incsr_row_ptr, E)
+        fused_gat_forward(incsr_eids, rp1, incsr_col_indices, dst, 0, {}, feat_src, el, er, sum, exp, ret, slope, None)
+        return
     _call(ret, "het_relational_fused_gat_csr", _p(incsr_row_ptr), _p(incsr_col_indices), _p(incsr_eids),
           _p(incsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),
           max(0, unique_srcs_and_dests_rel_ptrs.numel() - 1), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
@@ -480,6 +499,13 @@ def backward_relational_fused_gat_csr(outcsr_row_ptr, outcsr_col_indices, outcsr
          (outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes))
     N, E, H = outcsr_row_ptr.numel() - 1, outcsr_eids.numel(), el.shape[1]
     D = ret.numel() // max(1, N * H)
+    if not CompactAsOfNodeFlag and _plan.enabled and E > 0 and gat_grouped_shape_ok(H, D) and slope >= 0:
+        # out-CSR rows are the sources: (eids, src, dst) in CSR order through the destination-grouped backward (every
+        # gradient row of kind 0 belongs to one edge, so "+=" into the zero-filled buffers equals the stores it does)
+        src, rp1 = _csr_expanded_rows(outcsr_row_ptr, E)
+        fused_gat_backward(outcsr_eids, rp1, src, outcsr_col_indices, 0, {}, feat_src, el, er, sum, exp, ret, gradout,
+                           grad_feat_src, grad_el, grad_er, slope, None)
+        return
     _call(ret, "het_backward_relational_fused_gat_csr", _p(outcsr_row_ptr), _p(outcsr_col_indices), _p(outcsr_eids),
           _p(outcsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),
           max(0, unique_srcs_and_dests_rel_ptrs.numel() - 1), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),

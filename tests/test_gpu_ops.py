@@ -202,7 +202,7 @@ def test_fused_gat_hub_destination(K, plan_mode):
 
 
 @pytest.mark.parametrize("compact", [False, True])
-def test_fused_gat_csr(K, compact):
+def test_fused_gat_csr(K, plan_mode, compact):
     g = random_graph(seed=23, n=200, r=3, e=2500, empty_rel=False)
     i, o, u = g.get_in_csr(), g.get_out_csr(), g.get_separate_unique_node_indices()
     N, E, H, D, slope = g.get_num_nodes(), g.get_num_edges(), 2, 8, 0.2
