@@ -305,6 +305,28 @@ def _gat_maps(kind: int, d: Dict[str, Tensor], backward: bool):
 _derived: Dict[tuple, tuple] = {}
 
 
+def _gat_direct(kind, maps, rel_ptrs, row, col, eids):
+    """(kind, maps) as handed to the C entry points: the binary-search kinds 1 / 3 are turned into the direct-index
+    kind 4 once per graph (feat / er row of every edge id, cached) -- the maps the kernels read without searching."""
+    if kind not in (1, 3) or not _plan.enabled or eids.numel() == 0:
+        return kind, maps
+    key = ("gatmap", kind, maps[0].data_ptr(), maps[0]._version, maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
+           row.data_ptr(), col.data_ptr(), eids.data_ptr())
+    hit = _derived.get(key)
+    if hit is None:
+        srow = _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
+        drow = _dst_rows_by_position(kind, maps, rel_ptrs, col, eids)
+        n = int(eids.max().item()) + 1
+        mr = torch.empty(n, dtype=torch.int64, device=eids.device)
+        mc = torch.empty(n, dtype=torch.int64, device=eids.device)
+        mr[eids] = srow
+        mc[eids] = drow
+        if len(_derived) > 16:
+            _derived.clear()
+        hit = _derived[key] = ((mr, None, mc, None), (maps, row, col, eids))
+    return 4, hit[0]
+
+
 def _src_rows_by_position(kind, maps, rel_ptrs, row, eids):
     """feat row of every edge position for the compact kinds (cached per graph)."""
     ra, rb = maps[0], maps[1]
@@ -412,6 +434,8 @@ def fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row
     _chk(name, (feat_src, el, er, sum, exp, ret),
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(m for m in maps if m is not None))
+    IntKind, maps = _gat_direct(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                                separate_coo_eids)
     E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
     D = feat_src.numel() // (feat_src.shape[0] * H) if feat_src.numel() else ret.numel() // max(1, N * H)
     g = _by_dst(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
@@ -444,6 +468,8 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
     _chk(name, (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er),
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(m for m in maps if m is not None))
+    IntKind, maps = _gat_direct(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                                separate_coo_eids)
     E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
     D = ret.numel() // max(1, N * H)
     g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
