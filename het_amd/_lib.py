@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhet_amd.so")
+LIB_PATH = os.environ.get("HET_AMD_LIB") or os.path.join(_HERE, "libhet_amd.so")  # override: A/B of experiment builds
 
 P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 

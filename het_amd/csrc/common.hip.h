@@ -93,6 +93,21 @@ __device__ __forceinline__ bool tile_to_relation(const idx_t* __restrict__ rel_p
   return false;
 }
 
+// Non-temporal 16-byte accesses.  Same-box A/B (exp/README.md): they pay where a kernel SCATTERS whole rows of a
+// once-written [E, X] tensor in random order -- the RGAT backward's grad_feat stores: 4.12 ms plain, 3.36 ms with nt
+// stores, 3.21 ms with nt stores + nt loads of the once-read feat rows -- and they cost where rows are written in
+// (nearly) sequential order (segment broadcast: +0.4 ms per launch) or gathered by a pure read kernel (aggregation:
+// +0.4 ms; segment sum: +0.05 ms), so only the backward uses them.
+typedef float het_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const het_f4v t = __builtin_nontemporal_load(reinterpret_cast<const het_f4v*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  het_f4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<het_f4v*>(p));
+}
+
 __device__ __forceinline__ float leaky_exp(float z, float slope) {
   // gatLeakyReluExp, DGLHackKernel/GAT/FusedGAT.cu.h:23-26.
   // The grouped backward recovers the leaky-ReLU branch from the stored value (slope >= 0: z > 0 <=> exp(..) > 1).  For

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 #pragma unroll
       for (int u = 0; u < U; ++u) ex[u] = exp[(int64_t)jn[u] * H + h];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = ld4(feat + eid[u] * X + x);
+      for (int u = 0; u < U; ++u) f[u] = ld4_nt(feat + eid[u] * X + x);
     } else {
       float zl[U], zr[U];
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
 #pragma unroll
       for (int u = 0; u < U; ++u) zr[u] = er[eid[u] * H + h];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = ld4(feat + eid[u] * X + x);
+      for (int u = 0; u < U; ++u) f[u] = ld4_nt(feat + eid[u] * X + x);
 #pragma unroll
       for (int u = 0; u < U; ++u) dl[u] = (zl[u] + zr[u]) > 0.f ? 1.f : slope;
     }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
           o.x = fmaf(tt, w[u].x, o.x); o.y = fmaf(tt, w[u].y, o.y);
           o.z = fmaf(tt, w[u].z, o.z); o.w = fmaf(tt, w[u].w, o.w);
         }
-        st4(grad_feat + eid[u] * X + x, o);
+        st4_nt(grad_feat + eid[u] * X + x, o);
       }
       if (ok && (sub & (DL - 1)) == 0) {
         grad_el[eid[u] * H + h] = tt;

@@ -691,7 +691,8 @@ extern "C" int het_backward_inner_product_right_node_separatecoo(
       HET_LAUNCH_CHECK("HET_rows_inner_product_bwd_left");
     }
     // grad_right[node] (+)= SUM over the edges whose right operand is node of gout[e,h] * left[lrow(e),h,:]
-    return launch_segment_sum(gr, left, grad_right, (int)X, gradout, s, (int)H, n_right_rows, accumulate);
+    return launch_segment_sum(gr, left, grad_right, (int)X, gradout, s, (int)H, n_right_rows, accumulate, 0,
+                              /*nt_in*/ 0);
   }
   if (!accumulate) {
     HET_REQUIRE(n_left_rows >= 0 && n_right_rows >= 0, "%s: row counts needed to overwrite the gradients", op);
@@ -769,7 +770,7 @@ extern "C" int het_backward_hgt_full_graph_hetero_attention_ops_coo(
       (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_q) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(grad_k) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0) {
     // grad_q[dst] += SUM_{e into dst} gs[e,h] * inner[e,h,:]     (by_dst: payload0 = eids)
-    if (int rc = launch_segment_sum(gd, inner, grad_q, (int)(H * dout), grad_score, s, (int)H, n_q_rows, 1)) return rc;
+    if (int rc = launch_segment_sum(gd, inner, grad_q, (int)(H * dout), grad_score, s, (int)H, n_q_rows, 1, 0, /*nt_in=*/0)) return rc;
     // qs[(r,u)] = SUM over the out-edges of u in relation r of gs[e,h] * q[dst_e,h,:]   (payload0 = col, payload1 = eids)
     float* qs = static_cast<float*>(workspace);
     if (int rc = launch_segment_sum(gs, q, qs, (int)(H * dout), grad_score, s, (int)H)) return rc;

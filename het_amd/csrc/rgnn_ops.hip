@@ -260,7 +260,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     int64_t rows = num_rows;
     if (grouped) {
       float* gsum = static_cast<float*>(workspace);
-      if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s)) return rc;
+      if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s, 0, -1, 0, 0, /*nt_in=*/0)) return rc;
       G = gsum; g_rows = nullptr; x_rows = g->seg_key64; segs = g->seg_rel_ptr64; rows = g->S;
     }
     MfmaGemmArgs m;
@@ -281,7 +281,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     // Rows that share (relation, gather_idx) share x row and weight: by linearity sum their gradout rows
     // first (one pass over gradout), then run both GEMMs on the S distinct (relation, node) rows only.
     float* gsum = static_cast<float*>(workspace);
-    if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s)) return rc;
+    if (int rc = launch_segment_sum(g, gradout, gsum, (int)(H * D), nullptr, s, 0, -1, 0, 0, /*nt_in=*/0)) return rc;
     MfmaGemmArgs m;
     m.A = gsum; m.a_ld = H * D; m.B = weights_t; m.b_rel_stride = H * D * K;
     m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64; m.atomic = 1;

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
                                                                  const int32_t* __restrict__ p_scale,
                                                                  const float* __restrict__ scale, int scale_heads,
                                                                  const float* __restrict__ in, float* __restrict__ out,
-                                                                 const int32_t* __restrict__ out_row, int accumulate) {
+                                                                 const int32_t* __restrict__ out_row, int accumulate,
+                                                                 int nt_in) {
   constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4;
@@ -58,8 +59,13 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 #pragma unroll
       for (int u = 0; u < U; ++u) w[u] = make_float4(1.f, 1.f, 1.f, 1.f);
     }
+    if (nt_in) {  // `in` is a once-read [E, X] stream
 #pragma unroll
-    for (int u = 0; u < U; ++u) f[u] = ld4(in + rown[u] * X + x);
+      for (int u = 0; u < U; ++u) f[u] = ld4_nt(in + rown[u] * X + x);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = ld4(in + rown[u] * X + x);
+    }
     // ids of the next step (clamped: the last step re-reads its own ids)
 #pragma unroll
     for (int u = 0; u < U; ++u) jn[u] = j0 + U + u < e ? j0 + U + u : e - 1;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
 
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
-                       int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0) {
+                       int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0, int nt_in) {
   HET_REQUIRE(segment_sum_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
   HET_REQUIRE(scale_heads == 0 || scale_heads == X || (X % scale_heads == 0 && (X / scale_heads) % 4 == 0),
               "segment sum: a head must cover whole float4 pieces (or scale_heads == X: one scale per element)");
@@ -109,7 +115,7 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
 #define HET_SS(L)                                                                                                   \
   hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \
-                     g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate)
+                     g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, nt_in)
   switch (X / 4) {
     case 1: HET_SS(1); break;
     case 2: HET_SS(2); break;

@@ -11,7 +11,8 @@ bool segment_sum_supported(int X);
 // (scale_by_p0: payload0 even when the grouping carries a payload1).  scale_heads == X: one scale per element,
 // i.e. out[s, :] = SUM scale[idx(j), :] * in[row(j), :].
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
-                       int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0, int scale_by_p0 = 0);
+                       int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0, int scale_by_p0 = 0,
+                       int nt_in = 0);  // nt_in: `in` is read once (an [E, X] stream): non-temporal loads
 
 // out[p0[j], :] = in[s, :] for every sorted rank j of segment s; optionally a second, narrower pair (X2 <= X/4 floats)
 int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,
