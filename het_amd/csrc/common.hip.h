@@ -97,7 +97,8 @@ __device__ __forceinline__ bool tile_to_relation(const idx_t* __restrict__ rel_p
 // once-written [E, X] tensor in random order -- the RGAT backward's grad_feat stores: 4.12 ms plain, 3.36 ms with nt
 // stores, 3.21 ms with nt stores + nt loads of the once-read feat rows -- and they cost where rows are written in
 // (nearly) sequential order (segment broadcast: +0.4 ms per launch) or gathered by a pure read kernel (aggregation:
-// +0.4 ms; segment sum: +0.05 ms), so only the backward uses them.
+// +0.4 ms; segment sum: +0.05 ms) or where the scattered stores are 4..16 bytes (grad_el / tbuf / broadcast dots:
+// +0.1..0.25 ms per step), so only the backward's row accesses use them.
 typedef float het_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4_nt(const float* p) {
   const het_f4v t = __builtin_nontemporal_load(reinterpret_cast<const het_f4v*>(p));
