@@ -61,6 +61,14 @@ __global__ void HET_grouping_payload(const int32_t* __restrict__ perm, const idx
     dst[j] = (int32_t)src[perm[j]];
 }
 
+// d_flag[0] |= 1 when payload0 in sorted order is not 0, 1, 2, ... (rows of a segment then are not contiguous)
+__global__ void HET_grouping_p0_not_identity(const int32_t* __restrict__ p0, int64_t E, int32_t* __restrict__ d_flag) {
+  bool bad = false;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (int64_t)gridDim.x * blockDim.x)
+    bad |= p0[j] != (int32_t)j;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(d_flag, 1);
+}
+
 int bits_for(int64_t n) {  // bits to represent values in [0, n)
   int b = 1;
   while (b < 63 && (1ll << b) < n) ++b;
@@ -210,6 +218,12 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     GALLOC(p0, E);
     hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload0, E, g->p0);
     HET_LAUNCH_CHECK("HET_grouping_payload");
+    hipLaunchKernelGGL(HET_grouping_p0_not_identity, dim3(blocks_for(E)), dim3(256), 0, s, g->p0, E, d_scalars + 2);
+    HET_LAUNCH_CHECK("HET_grouping_p0_not_identity");
+    int32_t h_bad = 1;
+    HET_HIP(hipMemcpyAsync(&h_bad, d_scalars + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HET_HIP(hipStreamSynchronize(s));
+    g->p0_contiguous = h_bad == 0;
   }
   if (payload1 && E > 0) {
     GALLOC(p1, E);

@@ -26,5 +26,6 @@ struct het_grouping {
   int32_t* split_seg = nullptr;  // [num_split] segments that own several items
   int32_t* p0 = nullptr;         // [E] payload0[perm[j]] or NULL
   int32_t* p1 = nullptr;         // [E] payload1[perm[j]] or NULL
+  bool p0_contiguous = false;    // p0[j] == j for every rank: the list already was in (relation, key) order
   mutable int32_t* seg_of_rank = nullptr;  // [E] segment of sorted rank j; built on first use (segment broadcast)
 };

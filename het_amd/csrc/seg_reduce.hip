@@ -21,7 +21,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
                                                                  const float* __restrict__ scale, int scale_heads,
                                                                  const float* __restrict__ in, float* __restrict__ out,
                                                                  const int32_t* __restrict__ out_row, int accumulate,
-                                                                 int nt_in) {
+                                                                 int nt_in, int contig) {
   constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4;
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   int sin[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) jn[u] = b + u < e ? b + u : e - 1;
+  // contig: the rows of a segment are consecutive rows of `in` (the list was already sorted): no id loads
 #pragma unroll
-  for (int u = 0; u < U; ++u) rown[u] = p_row[jn[u]];
+  for (int u = 0; u < U; ++u) rown[u] = contig ? jn[u] : p_row[jn[u]];
   if (scale) {
 #pragma unroll
     for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) jn[u] = j0 + U + u < e ? j0 + U + u : e - 1;
 #pragma unroll
-    for (int u = 0; u < U; ++u) rown[u] = p_row[jn[u]];
+    for (int u = 0; u < U; ++u) rown[u] = contig ? jn[u] : p_row[jn[u]];
     if (scale) {
 #pragma unroll
       for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
@@ -113,9 +114,11 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   if (g->S == 0) return HET_OK;
   const int32_t* p_scale = (g->p1 && !scale_by_p0) ? g->p1 : g->p0;
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  const int contig = g->p0_contiguous;  // same box: 2.35 -> 2.25 ms for the a2 backward of C3
 #define HET_SS(L)                                                                                                   \
   hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \
-                     g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, nt_in)
+                     g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, nt_in,  \
+                     contig)
   switch (X / 4) {
     case 1: HET_SS(1); break;
     case 2: HET_SS(2); break;
