@@ -107,7 +107,10 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
     res = {"default": {"ms_per_step": round(default_ms, 4), "million_edges_per_s": round(default_value, 2)}}
     g = HetGraph.from_integrated_coo(coo, full=True)
     E, N = coo.num_edges, coo.num_nodes
-    for variant in ("compact",):
+    flag_names = {"compact": "--compact_as_of_node_flag --compact_direct_indexing_flag",
+                  "mulfirst": "--multiply_among_weights_first_flag",
+                  "compact_mulfirst": "--compact_as_of_node_flag --compact_direct_indexing_flag --multiply_among_weights_first_flag"}
+    for variant in ("compact", "mulfirst", "compact_mulfirst"):
         torch.manual_seed(0)
         layer = HET_RGATLayer(args.feat, args.feat, g.get_num_rels(), args.heads, self_loop=True, dropout=0.0,
                               **layer_flags(variant)).to(dev)
@@ -130,7 +133,7 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         res[variant] = {"ms_per_step": round(dt * 1e3, 4), "million_edges_per_s": round(E / dt / 1e6, 2),
-                        "flags": "--compact_as_of_node_flag --compact_direct_indexing_flag"}
+                        "flags": flag_names[variant]}
         del layer, embed, go
     return res
 

@@ -21,7 +21,7 @@ _SIGNATURES = {
     "het_layout_coo_to_csr": [P, P, P, P, I64, I64, P, P, P, P, P],
     "het_layout_transpose_csr": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
     "het_layout_unique_rel_nodes": [P, I64, P, P, I64, I64, P, P, P, P, P],
-    "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P, P, I64, P],
     "het_backward_rgnn_relational_matmul_attn_dot_only": [P, I64, P, P, I64, I64, P, P, P, P, P, P, I64, I64, I64, INT, P, P, I64, P, P, P],
     "het_rgnn_relational_matmul_attn_dot": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, P, P, I64, P, P],
     "het_backward_rgnn_relational_matmul": [I64, P, I64, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P, P, I64, P],

@@ -11,6 +11,8 @@ Two dataflows, selected by the layer flags exactly as in the op-by-op path:
   kind 0 (default flags)   per-edge projections; the fusions of het_amd/layers.py (distinct-row projection + broadcast,
                            attention terms from the GEMM epilogue, er without its per-edge tensor, el folded into the GAT node)
   compact (kinds 3 / 4)    projections on the unique (relation, node) rows, el folded into the compact GAT backward
+and, for either, ``mulfirst`` (--multiply_among_weights_first_flag, RGAT/models.py:300-326): er = x[dst] . (W . attn_r)
+as a row-dot product on the distinct (relation, destination) rows instead of a projection followed by a dot.
 """
 import torch as th
 
@@ -43,12 +45,14 @@ def _compact_dicts(g, direct):
     return ss, 3, fwd, bwd
 
 
-def rgat_layer_fused_ok(g, x, W, slope, compact):
+def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
     R, H, Kd, D = W.shape
     if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0 and H >= 4
             and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
         return False
+    if mulfirst:  # er = x[dst] . (W . attn_r): the one-head row-dot kernels (seg_rowdot.hip)
+        return H in (4, 8) and Kd >= 4 * H and Kd & (Kd - 1) == 0 and Kd <= 256
     if compact:
         return True
     _, _, by_dst = _lists(g)
@@ -57,7 +61,7 @@ def rgat_layer_fused_ok(g, x, W, slope, compact):
 
 class RgatLayerFunction(th.autograd.Function):
     @staticmethod
-    def forward(ctx, g, compact, direct, slope, num_dst, x, W, attn_l, attn_r, loop_w, bias):
+    def forward(ctx, g, compact, direct, mulfirst, slope, num_dst, x, W, attn_l, attn_r, loop_w, bias):
         x, W, attn_l, attn_r = x.contiguous(), W.contiguous(), attn_l.contiguous(), attn_r.contiguous()
         s, by_src, by_dst = _lists(g)
         rp, row, col, eids = s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"]
@@ -66,6 +70,9 @@ class RgatLayerFunction(th.autograd.Function):
         X = H * D
         new = lambda *shape: th.empty(shape, dtype=x.dtype, device=x.device)
         sm, ex, ret = new(N, H), new(E, H), new(N, H, D)
+        wa = None
+        if mulfirst:  # RGAT/models.py:300-326: the attention vector folded into the weight, [R,H,K,1]
+            wa = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd, 1)
         if compact:
             ss, kind, fwd, bwd = _compact_dicts(g, direct)
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
@@ -74,20 +81,29 @@ class RgatLayerFunction(th.autograd.Function):
             K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
             elc = new(featc.shape[0], H)
             K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc)
-            featd = new(ss["node_indices_col"].numel(), H, D)
-            K.rgnn_relational_matmul(d_col, 1, W, x, featd, True)
-            erc = new(featd.shape[0], H)
-            K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_col"], attn_r.unsqueeze(-1), featd, erc)
+            erc = new(ss["node_indices_col"].numel(), H)
+            if mulfirst:
+                K.rgnn_relational_matmul(d_col, 1, wa, x, erc.view(-1, H, 1), True)
+                saved = (featc, elc, erc)
+            else:
+                featd = new(erc.shape[0], H, D)
+                K.rgnn_relational_matmul(d_col, 1, W, x, featd, True)
+                K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_col"], attn_r.unsqueeze(-1), featd, erc)
+                saved = (featc, elc, featd, erc)
             _k.fused_gat_forward(eids, rp, row, col, kind, fwd, featc, elc, erc, sm, ex, ret, slope, None)
-            saved = (featc, elc, featd, erc)
             ctx.bwd_dict, ctx.kind = bwd, kind
         else:
             feat, el, er, exs = new(E, H, D), new(E, H), new(E, H), new(E, H)
             _k.matmul_attn_dot(by_src, 0, W, x, feat, attn_l, el)
-            comp = _k.matmul_attn_dot(by_dst, 0, W, x, None, attn_r, er)
+            if mulfirst:
+                K.rgnn_relational_matmul(by_dst, 0, wa, x, er.view(E, H, 1), True)
+                saved = (feat, el, er, exs)
+            else:
+                comp = _k.matmul_attn_dot(by_dst, 0, W, x, None, attn_r, er)
+                assert comp is not None
+                saved = (feat, el, er, exs, comp)
             used = _k.fused_gat_forward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, slope, exs)
-            assert used and comp is not None
-            saved = (feat, el, er, exs, comp)
+            assert used
         nd = N if num_dst is None else min(int(num_dst), N)
         out = ret.view(N, X)[:nd]
         loop = None
@@ -102,7 +118,7 @@ class RgatLayerFunction(th.autograd.Function):
             loop = new(nd, X)
             K.rgnn_relational_matmul_no_scatter_gather_list(offs, loop_w.view(1, 1, Kd, X), x[:nd], loop)
         h = _k.rows_add_bias(out, loop, None if bias is None else bias.contiguous()) if (loop is not None or bias is not None) else out.clone()
-        ctx.g, ctx.compact, ctx.slope, ctx.nd = g, compact, slope, nd
+        ctx.g, ctx.compact, ctx.mulfirst, ctx.slope, ctx.nd = g, compact, mulfirst, slope, nd
         ctx.has_loop, ctx.has_bias = loop_w is not None, bias is not None
         ctx.save_for_backward(x, W, attn_l, attn_r, loop_w if loop_w is not None else x.new_empty(0), offs if offs is not None else eids,
                               sm, ex, ret, *saved)
@@ -115,6 +131,7 @@ class RgatLayerFunction(th.autograd.Function):
         s, by_src, by_dst = _lists(g)
         rp, row, col, eids = s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"]
         N, Kd = x.shape
+        E = eids.numel()
         R, H, _, D = W.shape
         X = H * D
         grad_h = grad_h.contiguous()
@@ -135,8 +152,15 @@ class RgatLayerFunction(th.autograd.Function):
         else:  # rows of non-destination nodes receive no gradient
             go = th.zeros((N, H, D), dtype=x.dtype, device=x.device)
             go.view(N, X)[:nd] = grad_h
+        mulfirst = ctx.mulfirst
+        if mulfirst:
+            wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)  # [R,H,K,1] transposed(2,3): same memory
+            grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
         if ctx.compact:
-            featc, elc, featd, erc = saved
+            if mulfirst:
+                (featc, elc, erc), featd = saved, None
+            else:
+                featc, elc, featd, erc = saved
             ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
@@ -147,13 +171,16 @@ class RgatLayerFunction(th.autograd.Function):
             grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
             _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
                                                  grad_attn_l.unsqueeze(-1), accumulate=False)
-            g_featd = th.empty_like(featd)
-            _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_col"], attn_r.unsqueeze(2), featd, g_erc, g_featd,
-                                                 grad_attn_r.unsqueeze(-1), accumulate=False)
             _k.matmul_backward(d_row, 1, Wt, x, g_featc, grad_x, grad_W, True, accumulate=True)
-            _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
+            if mulfirst:
+                _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True)
+            else:
+                g_featd = th.empty_like(featd)
+                _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_col"], attn_r.unsqueeze(2), featd, g_erc, g_featd,
+                                                     grad_attn_r.unsqueeze(-1), accumulate=False)
+                _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
         else:
-            feat, el, er, exs, comp = saved
+            feat, el, er, exs = saved[:4]
             g_feat, g_el = th.empty_like(feat), th.empty_like(el)
             grad_attn_l = th.zeros_like(attn_l)
             if R <= 8:
@@ -166,12 +193,19 @@ class RgatLayerFunction(th.autograd.Function):
                 _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat, g_el, None, grad_attn_l.unsqueeze(-1), False,
                                    accumulate=False)
             _k.matmul_backward(by_src, 0, Wt, x, g_feat, grad_x, grad_W, True, accumulate=True)
-            grad_attn_r = th.zeros_like(attn_r)
-            ok = _k.matmul_attn_dot_only_backward(by_dst, Wt, x, attn_r, g_el, grad_x, grad_W, comp_rows=comp,
-                                                  grad_dot_w=grad_attn_r, accumulate=True)
-            assert ok, "the grouping of the forward pass is gone"
-        return None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
+            if mulfirst:
+                _k.matmul_backward(by_dst, 0, wa_t, x, g_el.view(E, H, 1), grad_x, grad_wa, True, accumulate=True)
+            else:
+                grad_attn_r = th.zeros_like(attn_r)
+                ok = _k.matmul_attn_dot_only_backward(by_dst, Wt, x, attn_r, g_el, grad_x, grad_W, comp_rows=saved[4],
+                                                      grad_dot_w=grad_attn_r, accumulate=True)
+                assert ok, "the grouping of the forward pass is gone"
+        if mulfirst:  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
+            grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))
+            grad_attn_r = (W * grad_wa).sum(2)
+        return None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
 
 
-def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None):
-    return RgatLayerFunction.apply(g, bool(compact), bool(direct), float(slope), num_dst, x, W, attn_l, attn_r, loop_w, bias)
+def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None, mulfirst=False):
+    return RgatLayerFunction.apply(g, bool(compact), bool(direct), bool(mulfirst), float(slope), num_dst, x, W, attn_l, attn_r,
+                                   loop_w, bias)

@@ -25,7 +25,8 @@ int check_matmul(const char* op, int64_t kind, const int64_t* rel_ptrs, int64_t 
 extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                           const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                           const float* weights, const float* x, float* ret, int64_t H, int64_t K,
-                                          int64_t D, int in1head, het_stream stream) {
+                                          int64_t D, int in1head, const het_grouping* by_rel_gather, void* workspace,
+                                          int64_t workspace_bytes, het_stream stream) {
   const char* op = "rgnn_relational_matmul";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
@@ -44,6 +45,16 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     RowDotArgs q;  // one x row against the H folded attention vectors of its relation
     q.A = x; q.gather = gather_idx; q.W = weights; q.out = ret; q.scatter = scatter; q.seg_ptrs = rel_ptrs;
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
+    const het_grouping* g = by_rel_gather;
+    if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 && g->S > 0 &&
+        segment_sum_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
+        (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
+      // positions sharing (relation, x row) hold the same [H] product: form the S distinct ones, then duplicate
+      float* dots = static_cast<float*>(workspace);
+      q.gather = g->seg_key64; q.scatter = nullptr; q.out = dots; q.seg_ptrs = g->seg_rel_ptr64; q.num_rows = g->S;
+      if (int rc = launch_rowdot1h_fwd(q, s)) return rc;
+      return launch_segment_broadcast(g, dots, ret, (int)H, nullptr, nullptr, 0, s);
+    }
     return launch_rowdot1h_fwd(q, s);
   }
   if (!in1head && H > 1 && mfma_shape_supported((int)(H * K), (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&

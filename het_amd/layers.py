@@ -74,14 +74,15 @@ class HET_RGATLayer(nn.Module):
     def forward(self, g, inputs: th.Tensor, num_dst=None):
         """``num_dst``: the destination nodes of ``g`` are its first ``num_dst`` nodes (a sampled block, or the owned
         nodes of a partition followed by halo nodes): only their rows are returned and the self-loop runs on them only."""
-        if (self.gat_edge_parallel_flag and not self.multiply_among_weights_first_flag and
-                FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag)):
+        if (self.gat_edge_parallel_flag and
+                FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
+                                       self.multiply_among_weights_first_flag)):
             # the whole layer as one autograd node (het_amd/backend/rgat_fused_layer.py): same ops and values as the
             # composition below, gradients of the shared input accumulated in place instead of summed by autograd
             h = FL.rgat_layer_fused(g, inputs, self.conv_weights, self.attn_l, self.attn_r,
                                     self.loop_weight if self.self_loop else None, self.h_bias if self.bias else None,
                                     self.leaky_relu_slope, self.compact_as_of_node_flag, self.compact_direct_indexing_flag,
-                                    num_dst)
+                                    num_dst, self.multiply_among_weights_first_flag)
             if self.activation:
                 h = self.activation(h)
             return self.dropout(h)

@@ -82,11 +82,17 @@ int64_t het_grouping_num_segments(const het_grouping* g);
  *   kind 1: ret[i, h, :] = x[gather_idx[i], (h), :] . W[r(i), h]   scatter_idx = NULL
  *           (dict keys unique_srcs_and_dests_rel_ptrs / unique_srcs_and_dests_node_indices)
  *   W [R,H,K,D]; x [*, K] if in1head else [*, H, K]; ret [*, H, D].
+ *   by_rel_gather (optional, kind 0: the grouping of a2 -- positions by (relation, gather_idx), payload0 =
+ *   scatter_idx) + workspace of S*H floats: with in1head and D == 1 (RGAT's --multiply_among_weights_first_flag:
+ *   er = x[dst] . (W.attn_r)) the S distinct (relation, x row) products are formed once and duplicated to their
+ *   positions -- same values.  NULL / 0: every position is computed on its own.
  * ------------------------------------------------------------------------ */
 int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                const float* weights, const float* x, float* ret,
-                               int64_t H, int64_t K, int64_t D, int in1head, het_stream stream);
+                               int64_t H, int64_t K, int64_t D, int in1head,
+                               const het_grouping* by_rel_gather, void* workspace, int64_t workspace_bytes,
+                               het_stream stream);
 
 /* a1 + the attention-vector product of RGAT in the GEMM epilogue (extension; RGAT/models.py:288-296 computes
  * el = <feat, attn_l[r]> with a second, D_out = 1 segment GEMM that re-reads the [rows,H,D] tensor just written):

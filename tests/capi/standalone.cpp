@@ -54,7 +54,7 @@ int main() {
   CK(hipMalloc((void**)&d_gw, sizeof(float) * R * H * K * D));
   hipStream_t s;
   CK(hipStreamCreate(&s));
-  HK(het_rgnn_relational_matmul(HET_KIND_DISABLED, d_rp, R, d_row, d_eids, E, d_W, d_x, d_ret, H, K, D, 1, s));
+  HK(het_rgnn_relational_matmul(HET_KIND_DISABLED, d_rp, R, d_row, d_eids, E, d_W, d_x, d_ret, H, K, D, 1, nullptr, nullptr, 0, s));
   // backward with the optional (relation, row) grouping: payload0 = the scatter list
   het_grouping* g = nullptr;
   HK(het_grouping_create(d_rp, R, d_row, E, N, d_eids, nullptr, s, &g));
@@ -75,7 +75,7 @@ int main() {
   const double e1 = worst(ret, ret_ref), e2 = worst(gx, gx_ref), e3 = worst(gw, gw_ref);
   printf("segments %lld  rel err: ret %.2e grad_x %.2e grad_w %.2e\n", (long long)S, e1, e2, e3);
   // argument validation comes back as an error code + message, not a fault
-  const int rc = het_rgnn_relational_matmul(7, d_rp, R, d_row, d_eids, E, d_W, d_x, d_ret, H, K, D, 1, s);
+  const int rc = het_rgnn_relational_matmul(7, d_rp, R, d_row, d_eids, E, d_W, d_x, d_ret, H, K, D, 1, nullptr, nullptr, 0, s);
   printf("bad kind -> rc %d (%s)\n", rc, het_last_error());
   het_grouping_destroy(g);
   const bool ok = e1 < 2e-4 && e2 < 2e-4 && e3 < 2e-4 && rc == HET_ERR_UNSUPPORTED;

@@ -57,9 +57,9 @@ def test_argument_validation_without_gpu():
     message instead of a kernel fault (the reference only has compiled-out asserts)."""
     from het_amd import _lib
     L = _lib.lib()
-    rc = L.het_rgnn_relational_matmul(0, None, 4, None, None, 10, None, None, None, 4, 64, 16, 1, None)
+    rc = L.het_rgnn_relational_matmul(0, None, 4, None, None, 10, None, None, None, 4, 64, 16, 1, None, None, 0, None)
     assert rc == 1 and b"null" in L.het_last_error()
-    rc = L.het_rgnn_relational_matmul(7, None, 4, None, None, 10, None, None, None, 4, 64, 16, 1, None)
+    rc = L.het_rgnn_relational_matmul(7, None, 4, None, None, 10, None, None, None, 4, 64, 16, 1, None, None, 0, None)
     assert rc == 3
     rc = L.het_relational_fused_gat_separate_coo(None, None, None, None, 4, 10, 5, 2, None, None, None, None, None, None,
                                                  None, None, None, None, None, 4, 16, 0.2, None, None)

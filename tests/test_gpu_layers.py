@@ -45,7 +45,7 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0)
 
 
 @pytest.mark.parametrize("compact,direct,mulfirst", [(False, False, False), (False, False, True), (True, False, False),
-                                                     (True, True, False), (True, True, True)])
+                                                     (True, True, False), (True, True, True), (True, False, True)])
 def test_rgat_layer_variants(compact, direct, mulfirst):
     _run_rgat(random_graph(seed=41, n=400, r=4, e=6000, shuffle=False), H=4, K=64, X=64, compact=compact, direct=direct, mulfirst=mulfirst)
 
@@ -234,6 +234,17 @@ def test_rgat_layer_fallback_paths(mode, compact, monkeypatch):
     finally:
         plan.enabled = old
         plan.clear()
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_mulfirst_op_by_op_and_heads8(compact, monkeypatch):
+    """--multiply_among_weights_first_flag outside the single-node layer (op-by-op composition: the row-dot forward on the
+    distinct (relation, destination) rows) and, inside it, with 8 heads."""
+    from het_amd.backend import rgat_fused_layer as FL
+    g = random_graph(seed=49, n=280, r=4, e=4500, shuffle=False)
+    _run_rgat(g, H=8, K=64, X=64, compact=compact, direct=compact, mulfirst=True)
+    monkeypatch.setattr(FL, "rgat_layer_fused_ok", lambda *a, **k: False)
+    _run_rgat(g, H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=True)
 
 
 @pytest.mark.parametrize("H,K,X,compact", [(4, 128, 128, False), (8, 64, 64, False), (8, 32, 128, True), (16, 64, 64, True)])
