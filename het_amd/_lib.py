@@ -16,6 +16,7 @@ P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 # name -> argtypes, in the order of include/het_amd.h
 _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
+    "het_grouping_rank_of_position": [P, P, P],
     "het_rows_add_bias": [P, P, P, P, I64, I64, P],
     "het_layout_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
     "het_layout_coo_to_csr": [P, P, P, P, I64, I64, P, P, P, P, P],
@@ -28,7 +29,7 @@ _SIGNATURES = {
     "het_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, I64, I64, I64, INT, P],
     "het_backward_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P],
     "het_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P],
-    "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P],
+    "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P, P],
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],

@@ -181,16 +181,21 @@ class RgatLayerFunction(th.autograd.Function):
                 _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
         else:
             feat, el, er, exs = saved[:4]
+            # the edges' grad_el (= grad_er) in the kernel's destination-grouped order: sequential stores, and the
+            # (relation, destination) sums of the er side read contiguous runs instead of scattered 16-byte pieces
+            rank = _k.gat_rank_of_position(rp, row, col, eids, N)
+            by_dst = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": col, "separate_coo_eids": rank}
             g_feat, g_el = th.empty_like(feat), th.empty_like(el)
             grad_attn_l = th.zeros_like(attn_l)
             if R <= 8:
-                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el, g_el, slope, exs,
-                                      fold_attn_l=attn_l, grad_fold_attn_l=grad_attn_l)
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, None, None, slope, exs,
+                                      fold_attn_l=attn_l, grad_fold_attn_l=grad_attn_l, grad_el_sorted=g_el)
             else:
-                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el, g_el, slope, exs,
-                                      fold_attn_l=attn_l)
+                g_el_e = th.empty_like(el)
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el_e, g_el_e, slope, exs,
+                                      fold_attn_l=attn_l, grad_el_sorted=g_el)
                 by_eid = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
-                _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat, g_el, None, grad_attn_l.unsqueeze(-1), False,
+                _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat, g_el_e, None, grad_attn_l.unsqueeze(-1), False,
                                    accumulate=False)
             _k.matmul_backward(by_src, 0, Wt, x, g_feat, grad_x, grad_W, True, accumulate=True)
             if mulfirst:

@@ -201,12 +201,13 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
     float* grad_feat, float* grad_el, float* grad_er, int64_t H, int64_t D, double slope, const het_grouping* by_dst,
     const het_grouping* by_src_row, const het_grouping* by_dst_row, int64_t n_src_rows, int64_t n_dst_rows,
     void* workspace, int64_t workspace_bytes, const float* fold_attn_l, float* grad_fold_attn_l,
-    const int64_t* fold_row_rel_ptrs, het_stream stream) {
+    const int64_t* fold_row_rel_ptrs, float* grad_el_sorted, het_stream stream) {
   const char* op = "backward_relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
   HET_REQUIRE(num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && sum && exp && ret && gradout &&
-                                 grad_feat && grad_el && grad_er),
+                                 grad_feat && ((grad_el && grad_er) || (grad_el_sorted && !grad_el && !grad_er))),
               "%s: null pointer", op);
+  HET_REQUIRE(!grad_el_sorted || (by_dst && kind == HET_KIND_DISABLED), "%s: grad_el_sorted needs kind 0 and the by_dst grouping", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
   if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
     if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
@@ -217,7 +218,7 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
   hipStream_t s = (hipStream_t)stream;
   if (by_dst && kind == HET_KIND_DISABLED)
     return gat_backward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, gradout, grad_feat, grad_el,
-                                grad_er, (int)H, (int)D, (float)slope, fold_attn_l, grad_fold_attn_l, s);
+                                grad_er, (int)H, (int)D, (float)slope, fold_attn_l, grad_fold_attn_l, grad_el_sorted, s);
   HET_REQUIRE(!grad_fold_attn_l && (kind != HET_KIND_DISABLED || !fold_attn_l),
               "%s: fold_attn_l needs the by_dst grouping (kind 0); grad_fold_attn_l is kind 0 only", op);
   if (kind != HET_KIND_DISABLED && workspace &&

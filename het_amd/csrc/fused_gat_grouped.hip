@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
     const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
     float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope,
-    const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w, float* __restrict__ grad_fold_w, int R) {
+    const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w, float* __restrict__ grad_fold_w, int R,
+    float* __restrict__ grad_el_sorted) {
   constexpr int EPW = 64 / LPR, U = 2;  // same-box A/B: U = 1 3.89 ms, 2 3.76 ms, 4 3.82 ms
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
@@ -239,8 +240,9 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
         st4_nt(grad_feat + eid[u] * X + x, o);
       }
       if (ok && (sub & (DL - 1)) == 0) {
-        grad_el[eid[u] * H + h] = tt;
-        if (grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
+        if (grad_el_sorted) grad_el_sorted[(int64_t)(j0 + u * EPW) * H + h] = tt;  // rank order: sequential
+        if (grad_el) grad_el[eid[u] * H + h] = tt;
+        if (grad_er && grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
       }
       if (DW) {
 #pragma unroll
@@ -454,10 +456,10 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
                          float* grad_er, int H, int D, float slope, const float* fold_w, float* grad_fold_w,
-                         hipStream_t s) {
+                         float* grad_el_sorted, hipStream_t s) {
   HET_REQUIRE(!grad_fold_w || (fold_w && v.R <= kFoldRelMax), "backward_relational_fused_gat_separate_coo: grad_fold_attn_l needs fold_attn_l and at most %d relations", kFoldRelMax);
   if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0) {
-    HET_REQUIRE(!fold_w, "backward_relational_fused_gat_separate_coo: fold_attn_l needs the destination-grouped path");
+    HET_REQUIRE(!fold_w && !grad_el_sorted, "backward_relational_fused_gat_separate_coo: fold_attn_l / grad_el_sorted need the destination-grouped path");
     return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
   }
   if (v.E == 0) return HET_OK;
@@ -471,7 +473,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   HET_DISPATCH_LPR((int)(X / 4),                                                                                     \
                    hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, FOLD>), dim3(nb), dim3(kBlock), 0, s, it, \
                                       g->p0, feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, D,  \
-                                      slope, g->p1, fold_w, (float*)nullptr, v.R))
+                                      slope, g->p1, fold_w, (float*)nullptr, v.R, grad_el_sorted))
   if (grad_fold_w) {
     // fixed grid striding over the items: every workgroup flushes R*X atomics once (same-box A/B, exp/ab_bwd.sh:
     // 2048 .. 16384 workgroups and U = 1 / 2 all within +-3 %; 1280 workgroups 25 % slower; one workgroup per 4 items
@@ -481,7 +483,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM>), dim3(nbw),       \
                                                     dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \
                                                     grad_feat, grad_el, grad_er, H, D, slope, g->p1, fold_w,            \
-                                                    grad_fold_w, v.R))
+                                                    grad_fold_w, v.R, grad_el_sorted))
     if (v.R <= 4) {
       if (sorted) { HET_GAT_BWD_DW(true, 4); } else { HET_GAT_BWD_DW(false, 4); }
     } else {

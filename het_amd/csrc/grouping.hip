@@ -69,6 +69,11 @@ __global__ void HET_grouping_p0_not_identity(const int32_t* __restrict__ p0, int
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(d_flag, 1);
 }
 
+__global__ void HET_grouping_rank_of_position(const int32_t* __restrict__ perm, int64_t E, idx_t* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (int64_t)gridDim.x * blockDim.x)
+    out[perm[j]] = j;
+}
+
 int bits_for(int64_t n) {  // bits to represent values in [0, n)
   int b = 1;
   while (b < 63 && (1ll << b) < n) ++b;
@@ -103,6 +108,14 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
 }
 
 extern "C" int64_t het_grouping_num_segments(const het_grouping* g) { return g ? g->S : -1; }
+
+extern "C" int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream) {
+  HET_REQUIRE(g && (g->E == 0 || (out && g->perm)), "het_grouping_rank_of_position: null argument");
+  if (g->E == 0) return HET_OK;
+  hipLaunchKernelGGL(HET_grouping_rank_of_position, dim3(blocks_for(g->E)), dim3(256), 0, (hipStream_t)stream, g->perm, g->E, out);
+  HET_LAUNCH_CHECK("HET_grouping_rank_of_position");
+  return HET_OK;
+}
 
 extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* keys,
                                    int64_t num_positions, int64_t key_bound, const int64_t* payload0,

@@ -468,11 +468,15 @@ def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_r
 
 def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                        IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
-                       grad_er, slope, exp_sorted, fold_attn_l=None, grad_fold_attn_l=None, fold_row_rel_ptrs=None):
-    """fold_attn_l [R,H,D]: also add grad_el[e,h] * fold_attn_l[r,h,:] into grad_feat_src (see include/het_amd.h)."""
+                       grad_er, slope, exp_sorted, fold_attn_l=None, grad_fold_attn_l=None, fold_row_rel_ptrs=None,
+                       grad_el_sorted=None):
+    """fold_attn_l [R,H,D]: also add grad_el[e,h] * fold_attn_l[r,h,:] into grad_feat_src (see include/het_amd.h).
+    grad_el_sorted [E,H] (kind 0): grad_el in destination-grouped order (gat_rank_of_position); grad_el / grad_er
+    may then be None."""
     name = "backward_relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, True)
-    _chk(name, (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er),
+    _chk(name, tuple(t for t in (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, grad_el_sorted)
+                     if t is not None),
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(m for m in maps if m is not None))
     IntKind, maps = _gat_direct(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
@@ -495,7 +499,21 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
           float(slope), None if g is None else g.handle, None if gs is None else gs.handle,
           None if gd is None else gd.handle, feat_src.shape[0], er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
           None if fold_attn_l is None else _p(fold_attn_l), None if grad_fold_attn_l is None else _p(grad_fold_attn_l),
-          None if fold_row_rel_ptrs is None else _p(fold_row_rel_ptrs), _stream(ret))
+          None if fold_row_rel_ptrs is None else _p(fold_row_rel_ptrs), _p(grad_el_sorted), _stream(ret))
+
+
+def gat_rank_of_position(rel_ptrs, row, col, eids, num_nodes):
+    """[E] int64: the rank of every separate-COO position in the destination-grouped order of the kind-0 GAT kernels
+    (row j of exp_sorted / grad_el_sorted belongs to the position whose rank is j).  None without groupings."""
+    g = _by_dst(0, (None, None, None, None), rel_ptrs, row, col, eids, num_nodes)
+    if g is None:
+        return None
+    r = getattr(g, "rank_of_position", None)
+    if r is None:
+        r = torch.empty(eids.numel(), dtype=torch.int64, device=eids.device)
+        _call(r, "het_grouping_rank_of_position", g.handle, _p(r), _stream(r))
+        g.rank_of_position = r  # lives (and is evicted) with the grouping
+    return r
 
 
 @_op("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "

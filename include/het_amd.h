@@ -74,6 +74,8 @@ int het_grouping_create(const int64_t* rel_ptrs /* [R+1] or NULL */, int64_t num
 void het_grouping_destroy(het_grouping* g);
 /* number of segments (distinct (relation, key) pairs) */
 int64_t het_grouping_num_segments(const het_grouping* g);
+/* out[i] = sorted rank of position i (the inverse of the grouping's permutation), [E] */
+int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * a1  rgnn_relational_matmul            OpExport/RGNNOps.inc.h:238-295
@@ -213,7 +215,10 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   receives += SUM_e grad_el[e,h] * feat[e,h,:] per relation -- the weight gradient of that product, from the feat
  *   rows the kernel reads anyway (saves a pass over feat); the caller zero-fills it.
  *   Compact kinds with the by_src_row / by_dst_row groupings: fold_attn_l works on the compact rows
- *   (el[u,h] = <feat[u,h,:], fold_attn_l[r(u),h,:]>), fold_row_rel_ptrs [R+1] = the rows' relation pointers. */
+ *   (el[u,h] = <feat[u,h,:], fold_attn_l[r(u),h,:]>), fold_row_rel_ptrs [R+1] = the rows' relation pointers.
+ *   grad_el_sorted (extension, kind 0 with by_dst only): [E,H], receives grad_el in by_dst order (row j = the edge at
+ *   sorted rank j, see het_grouping_rank_of_position) -- sequential 16-byte stores instead of scattered ones, and a
+ *   consumer that sums it by (relation, destination) reads contiguous runs.  grad_el / grad_er may then be NULL. */
 int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs,
                                                    const int64_t* row, const int64_t* col, int64_t num_rels,
                                                    int64_t num_edges, int64_t num_nodes, int64_t kind,
@@ -228,7 +233,8 @@ int het_backward_relational_fused_gat_separate_coo(const int64_t* eids, const in
                                                    const het_grouping* by_dst_row, int64_t n_src_rows,
                                                    int64_t n_dst_rows, void* workspace, int64_t workspace_bytes,
                                                    const float* fold_attn_l, float* grad_fold_attn_l,
-                                                   const int64_t* fold_row_rel_ptrs, het_stream stream);
+                                                   const int64_t* fold_row_rel_ptrs, float* grad_el_sorted,
+                                                   het_stream stream);
 
 /* a6  relational_fused_gat_csr / backward_relational_fused_gat_csr   RGATOps.inc.h:251-277, 430-460
  *   forward over the in-CSR (rows = dst, col_indices = src); backward over the out-CSR
