@@ -24,11 +24,11 @@ _SIGNATURES = {
     "het_layout_unique_rel_nodes": [P, I64, P, P, I64, I64, P, P, P, P, P],
     "het_rgnn_relational_matmul": [I64, P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P, P, I64, P],
     "het_backward_rgnn_relational_matmul_attn_dot_only": [P, I64, P, P, I64, I64, P, P, P, P, P, P, I64, I64, I64, INT, P, P, I64, P, P, P],
-    "het_rgnn_relational_matmul_attn_dot": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, P, P, I64, P, P],
+    "het_rgnn_relational_matmul_attn_dot": [I64, P, I64, P, P, I64, P, P, P, P, P, I64, I64, I64, P, P, I64, P, P, P],
     "het_backward_rgnn_relational_matmul": [I64, P, I64, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P, P, I64, P],
     "het_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, I64, I64, I64, INT, P],
     "het_backward_rgnn_relational_matmul_no_scatter_gather_list": [P, I64, I64, P, P, P, P, P, I64, I64, I64, INT, INT, P],
-    "het_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P],
+    "het_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, P],
     "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P, P],
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],

@@ -69,7 +69,7 @@ class RgatLayerFunction(th.autograd.Function):
         R, H, Kd, D = W.shape
         X = H * D
         new = lambda *shape: th.empty(shape, dtype=x.dtype, device=x.device)
-        sm, ex, ret = new(N, H), new(E, H), new(N, H, D)
+        sm, ret = new(N, H), new(N, H, D)
         wa = None
         if mulfirst:  # RGAT/models.py:300-326: the attention vector folded into the weight, [R,H,K,1]
             wa = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd, 1)
@@ -77,6 +77,7 @@ class RgatLayerFunction(th.autograd.Function):
             ss, kind, fwd, bwd = _compact_dicts(g, direct)
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+            ex = new(E, H)
             featc = new(ss["node_indices_row"].numel(), H, D)
             K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
             elc = new(featc.shape[0], H)
@@ -93,17 +94,23 @@ class RgatLayerFunction(th.autograd.Function):
             _k.fused_gat_forward(eids, rp, row, col, kind, fwd, featc, elc, erc, sm, ex, ret, slope, None)
             ctx.bwd_dict, ctx.kind = bwd, kind
         else:
-            feat, el, er, exs = new(E, H, D), new(E, H), new(E, H), new(E, H)
-            _k.matmul_attn_dot(by_src, 0, W, x, feat, attn_l, el)
+            # el / er are produced directly in the destination-grouped order of the GAT kernels (rank of every position):
+            # the aggregation pass forms exp from two coalesced streams, no exp pass, no per-edge 16-byte gathers
+            rank = _k.gat_rank_of_position(rp, row, col, eids, N)
+            by_dst_s = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": col, "separate_coo_eids": rank}
+            feat, el_s, er_s, exs = new(E, H, D), new(E, H), new(E, H), new(E, H)
+            _k.matmul_attn_dot(by_src, 0, W, x, feat, attn_l, el_s, dot_rows=rank)
             if mulfirst:
-                K.rgnn_relational_matmul(by_dst, 0, wa, x, er.view(E, H, 1), True)
-                saved = (feat, el, er, exs)
+                K.rgnn_relational_matmul(by_dst_s, 0, wa, x, er_s.view(E, H, 1), True)
+                saved = (feat, exs)
             else:
-                comp = _k.matmul_attn_dot(by_dst, 0, W, x, None, attn_r, er)
+                comp = _k.matmul_attn_dot(by_dst_s, 0, W, x, None, attn_r, er_s)
                 assert comp is not None
-                saved = (feat, el, er, exs, comp)
-            used = _k.fused_gat_forward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, slope, exs)
+                saved = (feat, exs, comp)
+            used = _k.fused_gat_forward(eids, rp, row, col, 0, {}, feat, None, None, sm, None, ret, slope, exs,
+                                        el_sorted=el_s, er_sorted=er_s)
             assert used
+            ex = x.new_empty(0)
         nd = N if num_dst is None else min(int(num_dst), N)
         out = ret.view(N, X)[:nd]
         loop = None
@@ -180,20 +187,20 @@ class RgatLayerFunction(th.autograd.Function):
                                                      grad_attn_r.unsqueeze(-1), accumulate=False)
                 _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
         else:
-            feat, el, er, exs = saved[:4]
+            feat, exs = saved[:2]
             # the edges' grad_el (= grad_er) in the kernel's destination-grouped order: sequential stores, and the
             # (relation, destination) sums of the er side read contiguous runs instead of scattered 16-byte pieces
             rank = _k.gat_rank_of_position(rp, row, col, eids, N)
             by_dst = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": col, "separate_coo_eids": rank}
-            g_feat, g_el = th.empty_like(feat), th.empty_like(el)
+            g_feat, g_el = th.empty_like(feat), th.empty_like(exs)
             grad_attn_l = th.zeros_like(attn_l)
             if R <= 8:
-                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, None, None, slope, exs,
-                                      fold_attn_l=attn_l, grad_fold_attn_l=grad_attn_l, grad_el_sorted=g_el)
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, None, None, sm, None, ret, go, g_feat, None, None, slope,
+                                      exs, fold_attn_l=attn_l, grad_fold_attn_l=grad_attn_l, grad_el_sorted=g_el)
             else:
-                g_el_e = th.empty_like(el)
-                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, el, er, sm, ex, ret, go, g_feat, g_el_e, g_el_e, slope, exs,
-                                      fold_attn_l=attn_l, grad_el_sorted=g_el)
+                g_el_e = th.empty_like(exs)
+                _k.fused_gat_backward(eids, rp, row, col, 0, {}, feat, None, None, sm, None, ret, go, g_feat, g_el_e, g_el_e, slope,
+                                      exs, fold_attn_l=attn_l, grad_el_sorted=g_el)
                 by_eid = {"separate_coo_rel_ptrs": rp, "separate_coo_node_indices": eids, "separate_coo_eids": eids}
                 _k.matmul_backward(by_eid, 0, attn_l.unsqueeze(2), feat, g_el_e, None, grad_attn_l.unsqueeze(-1), False,
                                    accumulate=False)
@@ -202,7 +209,7 @@ class RgatLayerFunction(th.autograd.Function):
                 _k.matmul_backward(by_dst, 0, wa_t, x, g_el.view(E, H, 1), grad_x, grad_wa, True, accumulate=True)
             else:
                 grad_attn_r = th.zeros_like(attn_r)
-                ok = _k.matmul_attn_dot_only_backward(by_dst, Wt, x, attn_r, g_el, grad_x, grad_W, comp_rows=saved[4],
+                ok = _k.matmul_attn_dot_only_backward(by_dst, Wt, x, attn_r, g_el, grad_x, grad_W, comp_rows=saved[2],
                                                       grad_dot_w=grad_attn_r, accumulate=True)
                 assert ok, "the grouping of the forward pass is gone"
         if mulfirst:  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]

@@ -174,10 +174,13 @@ extern "C" int het_relational_fused_gat_separate_coo(
     int64_t num_edges, int64_t num_nodes, int64_t kind, const int64_t* map_row_a, const int64_t* map_row_b,
     const int64_t* map_col_a, const int64_t* map_col_b, const float* feat, const float* el, const float* er,
     float* sum, float* exp, float* ret, float* exp_sorted, int64_t H, int64_t D, double slope,
-    const het_grouping* by_dst, het_stream stream) {
+    const het_grouping* by_dst, const float* el_sorted, const float* er_sorted, het_stream stream) {
   const char* op = "relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
-  HET_REQUIRE(sum && ret && (num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && exp)),
+  HET_REQUIRE(!el_sorted == !er_sorted, "%s: el_sorted and er_sorted come together", op);
+  HET_REQUIRE(!el_sorted || (by_dst && exp_sorted && kind == HET_KIND_DISABLED),
+              "%s: el_sorted / er_sorted need kind 0, the by_dst grouping and exp_sorted", op);
+  HET_REQUIRE(sum && ret && (num_edges == 0 || (eids && rel_ptrs && row && col && feat && (el_sorted || (el && er && exp)))),
               "%s: null pointer", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
   if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
@@ -189,7 +192,8 @@ extern "C" int het_relational_fused_gat_separate_coo(
   hipStream_t s = (hipStream_t)stream;
   HET_REQUIRE(!exp_sorted || by_dst, "%s: exp_sorted needs the by_dst grouping", op);
   if (by_dst)
-    return gat_forward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, (int)H, (int)D, (float)slope, s);
+    return gat_forward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, (int)H, (int)D, (float)slope,
+                               el_sorted, er_sorted, s);
   return gat_forward_edge(v, m, feat, el, er, sum, exp, ret, (int)H, (int)D, (float)slope, s);
 }
 
@@ -204,8 +208,10 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
     const int64_t* fold_row_rel_ptrs, float* grad_el_sorted, het_stream stream) {
   const char* op = "backward_relational_fused_gat_separate_coo";
   HET_REQUIRE(num_edges >= 0 && num_nodes >= 0 && num_rels >= 0 && H > 0 && D > 0, "%s: bad sizes", op);
-  HET_REQUIRE(num_edges == 0 || (eids && rel_ptrs && row && col && feat && el && er && sum && exp && ret && gradout &&
-                                 grad_feat && ((grad_el && grad_er) || (grad_el_sorted && !grad_el && !grad_er))),
+  // with exp_sorted on the destination-grouped kind-0 path el / er / exp are not read
+  const bool streams_only = exp_sorted && by_dst && kind == HET_KIND_DISABLED && slope >= 0;
+  HET_REQUIRE(num_edges == 0 || (eids && rel_ptrs && row && col && feat && ((el && er && exp) || streams_only) && sum && ret &&
+                                 gradout && grad_feat && ((grad_el && grad_er) || (grad_el_sorted && !grad_el && !grad_er))),
               "%s: null pointer", op);
   HET_REQUIRE(!grad_el_sorted || (by_dst && kind == HET_KIND_DISABLED), "%s: grad_el_sorted needs kind 0 and the by_dst grouping", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);

@@ -13,7 +13,7 @@ int gat_backward_edge(const EdgeView& v, const RowMaps& m, const float* feat, co
 // or the row maps do not fit.
 int gat_forward_grouped(const het_grouping* by_dst, const EdgeView& v, const RowMaps& m, const float* feat,
                         const float* el, const float* er, float* sum, float* exp, float* ret, float* exp_sorted,
-                        int H, int D, float slope, hipStream_t s);
+                        int H, int D, float slope, const float* el_sorted, const float* er_sorted, hipStream_t s);
 int gat_backward_grouped(const het_grouping* by_dst, const EdgeView& v, const RowMaps& m, const float* feat,
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,

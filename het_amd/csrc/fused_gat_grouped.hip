@@ -41,13 +41,19 @@ struct Items {
 // Wave per work item: the 64/LPR lane groups take the item's edges round-robin, U edges per group and step; the
 // ids of the next step are fetched while the current rows are in flight (one dependent round trip per step).
 // (A lane group per item was measured slower here: in-edge lists are skewed and a 256-edge item then runs serially.)
-template <int LPR>
+// EXPF: exp is formed here from el / er given in the grouping's order (two coalesced streams) instead of gathered by
+// edge id from a separate pass' output; exp_edge (edge order) is written only when the caller asks for it.
+template <int LPR, bool EXPF = false>
 __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, const int32_t* __restrict__ p_eid,
                                                                      const int32_t* __restrict__ p_srow,
                                                                      const float* __restrict__ feat,
                                                                      const float* __restrict__ exp,
                                                                      float* __restrict__ sum, float* __restrict__ ret,
-                                                                     float* __restrict__ exp_sorted, int H, int D) {
+                                                                     float* __restrict__ exp_sorted, int H, int D,
+                                                                     const float* __restrict__ el_sorted = nullptr,
+                                                                     const float* __restrict__ er_sorted = nullptr,
+                                                                     float* __restrict__ exp_edge = nullptr,
+                                                                     float slope = 0.f) {
   constexpr int EPW = 64 / LPR, U = 4;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
@@ -75,8 +81,19 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
     float4 f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) jc[u] = jn[u];
+    float zl[U], zr[U];
+    int64_t eidc[U];
+    if (EXPF) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = exp[eidn[u] * H + h];
+      for (int u = 0; u < U; ++u) zl[u] = el_sorted[(int64_t)jc[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) zr[u] = er_sorted[(int64_t)jc[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < U; ++u) eidc[u] = eidn[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = exp[eidn[u] * H + h];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (p_srow ? srown[u] : eidn[u]) * X + x);
 #pragma unroll
@@ -90,6 +107,10 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = j0 + u * EPW < e;
+      if (EXPF) {
+        w[u] = leaky_exp(zl[u] + zr[u], slope);
+        if (exp_edge && ok && x % D == 0) exp_edge[eidc[u] * H + h] = w[u];
+      }
       const float wu = ok ? w[u] : 0.f;
       if (exp_sorted && ok && x % D == 0) exp_sorted[(int64_t)jc[u] * H + h] = wu;
       acc.x = fmaf(wu, f[u].x, acc.x);
@@ -421,10 +442,10 @@ inline bool grouped_shape_ok(int H, int D) {
 
 int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
                         const float* el, const float* er, float* sum, float* exp, float* ret, float* exp_sorted,
-                        int H, int D, float slope, hipStream_t s) {
+                        int H, int D, float slope, const float* el_sorted, const float* er_sorted, hipStream_t s) {
   const bool have_rows = m.kind == HET_KIND_DISABLED || g->p1 != nullptr;
   if (!grouped_shape_ok(H, D) || !g->p0 || !have_rows || g->E != v.E || g->R != 0) {
-    HET_REQUIRE(!exp_sorted, "relational_fused_gat_separate_coo: exp_sorted needs a shape the grouped kernels cover");
+    HET_REQUIRE(!exp_sorted && !el_sorted, "relational_fused_gat_separate_coo: exp_sorted / el_sorted need a shape the grouped kernels cover");
     return gat_forward_edge(v, m, feat, el, er, sum, exp, ret, H, D, slope, s);
   }
   const int64_t X = (int64_t)H * D;
@@ -432,13 +453,19 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * v.N * H, s));
   HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * v.N * X, s));
   if (v.E == 0) return HET_OK;
-  hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
-  HET_LAUNCH_CHECK("HET_gat_exp_edge");
   Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
   const int32_t* srow = m.kind == HET_KIND_DISABLED ? nullptr : g->p1;
-  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_gat_aggregate_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
-                                                    g->p0, srow, feat, exp, sum, ret, exp_sorted, H, D));
+  if (el_sorted) {
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s,
+                                                      it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
+                                                      H, D, el_sorted, er_sorted, exp, slope));
+  } else {
+    hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
+    HET_LAUNCH_CHECK("HET_gat_exp_edge");
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, false>), dim3(nb), dim3(kBlock), 0, s,
+                                                      it, g->p0, srow, feat, exp, sum, ret, exp_sorted, H, D));
+  }
   HET_LAUNCH_CHECK("HET_gat_aggregate_grouped");
   if (g->num_split > 0) {
     hipLaunchKernelGGL(HET_gat_normalize_split, dim3(grid_for(g->num_split * X)), dim3(kBlock), 0, s, g->split_seg,
@@ -459,7 +486,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
                          float* grad_el_sorted, hipStream_t s) {
   HET_REQUIRE(!grad_fold_w || (fold_w && v.R <= kFoldRelMax), "backward_relational_fused_gat_separate_coo: grad_fold_attn_l needs fold_attn_l and at most %d relations", kFoldRelMax);
   if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0) {
-    HET_REQUIRE(!fold_w && !grad_el_sorted, "backward_relational_fused_gat_separate_coo: fold_attn_l / grad_el_sorted need the destination-grouped path");
+    HET_REQUIRE(!fold_w && !grad_el_sorted && (v.E == 0 || (el && er && exp)), "backward_relational_fused_gat_separate_coo: fold_attn_l / grad_el_sorted / NULL el, er, exp need the destination-grouped path");
     return gat_backward_edge(v, m, feat, el, er, sum, exp, ret, gradout, grad_feat, grad_el, grad_er, H, D, slope, s);
   }
   if (v.E == 0) return HET_OK;

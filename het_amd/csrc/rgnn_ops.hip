@@ -84,7 +84,8 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
                                                    int64_t num_rows, const float* weights, const float* x, float* ret,
                                                    const float* dot_w, float* dot_out, int64_t H, int64_t K, int64_t D,
                                                    const het_grouping* by_rel_gather, void* workspace,
-                                                   int64_t workspace_bytes, float* comp_rows, het_stream stream) {
+                                                   int64_t workspace_bytes, float* comp_rows,
+                                                   const het_grouping* dot_grouping, het_stream stream) {
   const char* op = "rgnn_relational_matmul_attn_dot";
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights && x && dot_w && dot_out), "%s: null data pointer", op);
@@ -113,13 +114,16 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
     a.gather = g->seg_key64; a.C = comp; a.c_ld = X; a.scatter = nullptr; a.seg_ptrs = g->seg_rel_ptr64; a.num_rows = g->S;
     a.dot_out = comp_dot;
     if (int rc = launch_seg_gemm_mfma(a, (hipStream_t)stream)) return rc;
-    if (!ret) return launch_segment_broadcast(g, comp_dot, dot_out, (int)H, nullptr, nullptr, 0, (hipStream_t)stream);
+    // dot_grouping: the same (relation, gather_idx) segments with another payload0 -- where the dots go
+    const het_grouping* gd = dot_grouping ? dot_grouping : g;
+    HET_REQUIRE(gd->S == g->S && gd->E == g->E && gd->p0, "%s: dot_grouping must group the same keys", op);
+    if (!ret) return launch_segment_broadcast(gd, comp_dot, dot_out, (int)H, nullptr, nullptr, 0, (hipStream_t)stream);
     // rows and dots as two launches: the 16-byte dot stores interleaved with the row stores of one launch cost more than
     // a second pass over the index streams (same-box A/B: 2.64 -> 2.43 ms for the two projections of a step)
     if (int rc = launch_segment_broadcast(g, comp, ret, (int)X, nullptr, nullptr, 0, (hipStream_t)stream)) return rc;
-    return launch_segment_broadcast(g, comp_dot, dot_out, (int)H, nullptr, nullptr, 0, (hipStream_t)stream);
+    return launch_segment_broadcast(gd, comp_dot, dot_out, (int)H, nullptr, nullptr, 0, (hipStream_t)stream);
   }
-  HET_REQUIRE(ret && !comp_rows, "%s: ret == NULL / comp_rows need the (relation, gather_idx) grouping path", op);
+  HET_REQUIRE(ret && !comp_rows && !dot_grouping, "%s: ret == NULL / comp_rows / dot_grouping need the (relation, gather_idx) grouping path", op);
   a.gather = gather_idx; a.C = ret; a.c_ld = X; a.scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
   a.seg_ptrs = rel_ptrs; a.num_rows = num_rows; a.dot_out = dot_out;
   return launch_seg_gemm_mfma(a, (hipStream_t)stream);

@@ -176,10 +176,11 @@ def matmul_attn_dot_only_ok(args_tensor_dict, weights, node_feat) -> bool:
             and g.numel() > 0 and g.data_ptr() != s.data_ptr())
 
 
-def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, dot_out, keep_rows=False):
+def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, dot_out, keep_rows=False, dot_rows=None):
     """rgnn_relational_matmul (one input head) that also writes dot_out[row, h] = <ret[row, h, :], dot_w[r, h, :]>.
     ret None: only dot_out (needs matmul_attn_dot_only_ok).  keep_rows: also return the [S, H, D] distinct projected
-    rows of the (relation, node) grouping (None when that path is not taken)."""
+    rows of the (relation, node) grouping (None when that path is not taken).  dot_rows [E] int64: the dot of
+    position i goes to dot_out[dot_rows[i]] instead of its separate_coo_eids row (grouping path only)."""
     rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
     _chk("rgnn_relational_matmul_attn_dot", tuple(t for t in (weights, node_feat, ret, dot_w, dot_out) if t is not None),
          tuple(t for t in (rp, g, s) if t is not None))
@@ -192,11 +193,12 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
             if keep_rows or ret is None:
                 comp = torch.empty((S, H, D), dtype=torch.float32, device=dot_out.device)
             ws = torch.empty(S * ((0 if comp is not None else H * D) + H), dtype=torch.float32, device=dot_out.device)
-    if ret is None and grp is None:
-        raise _lib.HetError("rgnn_relational_matmul_attn_dot: ret=None needs the (relation, node) grouping")
+    if (ret is None or dot_rows is not None) and grp is None:
+        raise _lib.HetError("rgnn_relational_matmul_attn_dot: ret=None / dot_rows need the (relation, node) grouping")
+    dgrp = None if dot_rows is None else _plan.get_grouping(rp, g, node_feat.shape[0], dot_rows, None)
     _call(dot_out, "het_rgnn_relational_matmul_attn_dot", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
           _p(ret), _p(dot_w), _p(dot_out), H, K, D, None if grp is None else grp.handle, _p(ws),
-          0 if ws is None else ws.numel() * 4, _p(comp), _stream(dot_out))
+          0 if ws is None else ws.numel() * 4, _p(comp), None if dgrp is None else dgrp.handle, _stream(dot_out))
     return comp
 
 
@@ -433,24 +435,27 @@ def gat_grouped_shape_ok(H: int, D: int) -> bool:
 
 
 def fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
-                      IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, exp_sorted):
+                      IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, exp_sorted, el_sorted=None,
+                      er_sorted=None):
     """relational_fused_gat_separate_coo plus the optional ``exp_sorted`` output ([E,H], exp in
-    destination-grouped order) that lets the backward stream instead of gather."""
+    destination-grouped order) that lets the backward stream instead of gather.  el_sorted / er_sorted (kind 0): the
+    attention terms already in that order (gat_rank_of_position); el, er, exp may then be None."""
     name = "relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, False)
-    _chk(name, (feat_src, el, er, sum, exp, ret),
+    _chk(name, tuple(t for t in (feat_src, el, er, sum, exp, ret, el_sorted, er_sorted) if t is not None),
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(m for m in maps if m is not None))
     IntKind, maps = _gat_direct(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                                 separate_coo_eids)
-    E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
+    E, N, H = separate_coo_eids.numel(), ret.shape[0], sum.shape[1]
     D = feat_src.numel() // (feat_src.shape[0] * H) if feat_src.numel() else ret.numel() // max(1, N * H)
     g = _by_dst(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                 separate_coo_eids, N)
     _call(ret, "het_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
           _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
-          None if g is None else _p(exp_sorted), H, D, float(slope), None if g is None else g.handle, _stream(ret))
+          None if g is None else _p(exp_sorted), H, D, float(slope), None if g is None else g.handle, _p(el_sorted),
+          _p(er_sorted), _stream(ret))
     return g is not None and exp_sorted is not None
 
 
@@ -475,13 +480,13 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
     may then be None."""
     name = "backward_relational_fused_gat_separate_coo"
     maps = _gat_maps(IntKind, args_tensor_dict, True)
-    _chk(name, tuple(t for t in (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, grad_el_sorted)
-                     if t is not None),
+    _chk(name, tuple(t for t in (feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, grad_el_sorted,
+                                 exp_sorted) if t is not None),
          (separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices)
          + tuple(m for m in maps if m is not None))
     IntKind, maps = _gat_direct(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                                 separate_coo_eids)
-    E, N, H = separate_coo_eids.numel(), ret.shape[0], el.shape[1]
+    E, N, H = separate_coo_eids.numel(), ret.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
     g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                 separate_coo_eids, N) if IntKind == 0 else None
@@ -497,7 +502,7 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
           None if g is None else _p(exp_sorted), _p(gradout), _p(grad_feat_src), _p(grad_el), _p(grad_er), H, D,
           float(slope), None if g is None else g.handle, None if gs is None else gs.handle,
-          None if gd is None else gd.handle, feat_src.shape[0], er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
+          None if gd is None else gd.handle, feat_src.shape[0], E if er is None else er.shape[0], _p(ws), 0 if ws is None else ws.numel() * 4,
           None if fold_attn_l is None else _p(fold_attn_l), None if grad_fold_attn_l is None else _p(grad_fold_attn_l),
           None if fold_row_rel_ptrs is None else _p(fold_row_rel_ptrs), _p(grad_el_sorted), _stream(ret))
 

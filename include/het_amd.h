@@ -106,13 +106,16 @@ int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t nu
  * them to their positions (same values; on ogbn-mag S = 3.7 M of E = 21.1 M rows by source).
  * comp_rows (optional, [S, H*D]): receives the distinct rows (the workspace then needs S*H floats only).
  * ret == NULL (grouping path only, H a power of two >= 4): the caller wants dot_out alone -- RGAT's er, whose
- * per-edge projection no other op reads -- and the [E,H,D] tensor is never written. */
+ * per-edge projection no other op reads -- and the [E,H,D] tensor is never written.
+ * dot_grouping (optional, grouping path only): a grouping of the same (relation, gather_idx) keys whose payload0 says
+ * where the dots of every position go (dot_out[payload0[i], h]) when that is not scatter_idx -- e.g. the rank of the
+ * edge in the destination-grouped order of a4, so that a4 reads el / er as coalesced streams. */
 int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                         const float* weights, const float* x, float* ret, const float* dot_w,
                                         float* dot_out, int64_t H, int64_t K, int64_t D,
                                         const het_grouping* by_rel_gather, void* workspace, int64_t workspace_bytes,
-                                        float* comp_rows, het_stream stream);
+                                        float* comp_rows, const het_grouping* dot_grouping, het_stream stream);
 
 /* backward of the above for a caller that used only dot_out (RGAT's er = <x[dst].W, attn_r>): the gradient of ret is
  * grad_dot (x) dot_w[r], rank one per head, so the (relation, gather_idx) segment sums are taken over the [rows,H]
@@ -183,6 +186,10 @@ int het_backward_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* of
  *   payload0 = eids, payload1 = NULL or the feat row of every position (srow), ...).
  *   exp_sorted (optional, [E,H], needs by_dst): a second copy of exp in the grouping's order, which the
  *   backward can stream instead of gathering exp / el / er by edge id.
+ *   el_sorted, er_sorted (extension, kind 0 with by_dst and exp_sorted; both or neither): [E,H], the attention terms
+ *   already in the grouping's order (row j = the edge at sorted rank j, het_grouping_rank_of_position).  The
+ *   aggregation pass then forms exp itself from two coalesced streams -- no separate exp pass, no per-edge 16-byte
+ *   gathers -- and writes exp_sorted; el, er may be NULL, exp (edge order) is written only if not NULL.
  * ------------------------------------------------------------------------ */
 int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* rel_ptrs, const int64_t* row,
                                           const int64_t* col, int64_t num_rels, int64_t num_edges,
@@ -192,7 +199,8 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
                                           const float* feat, const float* el, const float* er,
                                           float* sum, float* exp, float* ret, float* exp_sorted,
                                           int64_t H, int64_t D, double slope,
-                                          const het_grouping* by_dst, het_stream stream);
+                                          const het_grouping* by_dst, const float* el_sorted, const float* er_sorted,
+                                          het_stream stream);
 
 /* a5  backward_relational_fused_gat_separate_coo   OpExport/RGATOps.inc.h:465-551
  *   a = exp[eids[i],h] / sum[col[i],h]
@@ -202,7 +210,8 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   kind 0: every feat/el/er row belongs to one edge, so the three gradients are OVERWRITTEN (stores, no
  *   atomics, no pre-zeroing needed) and grad_er may alias grad_el (same values).  Other kinds: "+=".
  *   exp_sorted: optional copy of exp in by_dst order written by the forward (slope >= 0 required: the
- *   leaky-ReLU branch is then recovered from exp > 1).
+ *   leaky-ReLU branch is then recovered from exp > 1); with it (kind 0, by_dst) el, er and exp are not read and
+ *   may be NULL.
  *   Compact kinds, optional fast path (slope >= 0): by_src_row = het_grouping_create(NULL, 0, srow, E,
  *   n_src_rows, payload0 = eids, payload1 = col) over the feat row of every position, by_dst_row likewise
  *   over the er row (payload0 = eids), workspace of (N*2H + E*H) floats; grad_feat / grad_el / grad_er are

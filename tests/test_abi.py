@@ -62,7 +62,7 @@ def test_argument_validation_without_gpu():
     rc = L.het_rgnn_relational_matmul(7, None, 4, None, None, 10, None, None, None, 4, 64, 16, 1, None, None, 0, None)
     assert rc == 3
     rc = L.het_relational_fused_gat_separate_coo(None, None, None, None, 4, 10, 5, 2, None, None, None, None, None, None,
-                                                 None, None, None, None, None, 4, 16, 0.2, None, None)
+                                                 None, None, None, None, None, 4, 16, 0.2, None, None, None, None)
     assert rc != 0
 
 
