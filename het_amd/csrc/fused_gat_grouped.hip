@@ -456,6 +456,10 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   Items it{g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->seg_key, g->num_items};
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
   const int32_t* srow = m.kind == HET_KIND_DISABLED ? nullptr : g->p1;
+  // (a persistent variant -- a fixed grid of waves striding over the items, the next item's record and first ids
+  // prefetched during the current item's rows -- was 25-40 % slower at 2048..16384 workgroups, same box: the hardware's
+  // own workgroup turnover already overlaps the per-item prologues; the pass runs at the rate random 256-byte rows
+  // come out of HBM)
   if (el_sorted) {
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s,
                                                       it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
