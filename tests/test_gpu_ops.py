@@ -544,3 +544,84 @@ def test_rows_add_bias():
         out = k.rows_add_bias(a.to(DEV), None if bb is None else bb.to(DEV), None if cc is None else cc.to(DEV))
         ref = a + (0 if bb is None else bb) + (0 if cc is None else cc)
         assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("H,D,nrel", [(4, 16, 4), (8, 8, 3), (4, 16, 11)])
+def test_gat_rank_order_extensions(H, D, nrel):
+    """The kind-0 GAT ops with their attention terms in the destination-grouped ("rank") order of the kernels
+    (include/het_amd.h: el_sorted / er_sorted of a4, grad_el_sorted of a5, het_grouping_rank_of_position) against the
+    oracle on edge-order tensors, on a graph with interleaved relations, a hub destination and eids != arange."""
+    import het_amd.kernels as k
+    g = random_graph(seed=79, n=240, r=nrel, e=5000, empty_rel=False)
+    s = g.get_separate_coo_original()
+    E, N = g.get_num_edges(), g.get_num_nodes()
+    gen = torch.Generator().manual_seed(9)
+    feat, el, er = (0.5 * torch.randn(E, H, D, generator=gen), 0.5 * torch.randn(E, H, generator=gen),
+                    0.5 * torch.randn(E, H, generator=gen))
+    go = torch.randn(N, H, D, generator=gen)
+    f64, l64, r64, go64 = to64(feat), to64(el), to64(er), to64(go)
+    sm, ex, ret = torch.zeros(N, H, dtype=torch.float64), torch.zeros(E, H, dtype=torch.float64), torch.zeros(N, H, D, dtype=torch.float64)
+    O.relational_fused_gat_separate_coo(s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], 0, {}, f64, l64, r64, sm, ex, ret, 0.2)
+    gf, gl, gr = torch.zeros_like(f64), torch.zeros_like(l64), torch.zeros_like(r64)
+    O.backward_relational_fused_gat_separate_coo(s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"], 0, {}, f64, l64, r64,
+                                                 sm, ex, ret, go64, gf, gl, gr, 0.2)
+    d = _dev(s)
+    eids, rp, row, col = d["eids"], d["rel_ptrs"], d["row_indices"], d["col_indices"]
+    rank = k.gat_rank_of_position(rp, row, col, eids, N)
+    # rank is a permutation of the positions that sorts them by destination, stably
+    assert torch.equal(torch.sort(rank).values.cpu(), torch.arange(E))
+    inv = torch.empty_like(rank)
+    inv[rank] = torch.arange(E, device=DEV)
+    assert torch.equal(col[inv].cpu(), torch.sort(s["col_indices"], stable=True).values)
+    # tensors in rank order: row rank[i] holds the value of the edge at position i (edge id eids[i])
+    el_s, er_s = torch.empty(E, H, device=DEV), torch.empty(E, H, device=DEV)
+    el_s[rank], er_s[rank] = el.to(DEV)[eids], er.to(DEV)[eids]
+    new = lambda *shape: torch.empty(shape, device=DEV)
+    smd, retd, exs = new(N, H), new(N, H, D), new(E, H)
+    used = k.fused_gat_forward(eids, rp, row, col, 0, {}, feat.to(DEV), None, None, smd, None, retd, 0.2, exs, el_sorted=el_s, er_sorted=er_s)
+    assert used
+    assert_close(smd, sm, what="sum")
+    assert_close(retd, ret, what="ret")
+    exs_ref = torch.empty(E, H, dtype=torch.float64)
+    exs_ref[rank.cpu()] = ex[s["eids"]]
+    assert_close(exs, exs_ref, what="exp_sorted")
+    g_feat, g_el_s = new(E, H, D), new(E, H)
+    k.fused_gat_backward(eids, rp, row, col, 0, {}, feat.to(DEV), None, None, smd, None, retd, go.to(DEV), g_feat, None, None, 0.2, exs,
+                         grad_el_sorted=g_el_s)
+    assert_close(g_feat, gf, what="grad_feat")
+    gl_s_ref = torch.empty(E, H, dtype=torch.float64)
+    gl_s_ref[rank.cpu()] = gl[s["eids"]]
+    assert_close(g_el_s, gl_s_ref, what="grad_el_sorted")
+    assert_close(gl, gr, what="oracle grad_el == grad_er (kind 0)")
+
+
+@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (8, 64, 8)])
+def test_attn_dot_with_dot_rows(H, Kd, D):
+    """het_rgnn_relational_matmul_attn_dot with dot_grouping: the projected rows go to their edge-id rows, the attention
+    terms to caller-chosen rows (a permutation here); and the one-head row-dot forward on distinct rows (a1 with grouping)."""
+    import het_amd.kernels as k
+    g = random_graph(seed=95, n=260, r=4, e=4500)
+    s = g.get_separate_coo_original()
+    E, R, N = g.get_num_edges(), g.get_num_rels(), g.get_num_nodes()
+    gen = torch.Generator().manual_seed(10)
+    x, W, attn = torch.randn(N, Kd, generator=gen), 0.2 * torch.randn(R, H, Kd, D, generator=gen), torch.randn(R, H, D, generator=gen)
+    by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"], "separate_coo_eids": s["eids"]}
+    by_eid = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["eids"], "separate_coo_eids": s["eids"]}
+    feat_ref = torch.zeros(E, H, D, dtype=torch.float64)
+    O.rgnn_relational_matmul(by_src, 0, to64(W), to64(x), feat_ref, True)
+    dot_ref = torch.zeros(E, H, 1, dtype=torch.float64)
+    O.rgnn_relational_matmul(by_eid, 0, to64(attn).unsqueeze(-1), feat_ref, dot_ref, False)
+    perm = torch.randperm(E, generator=gen)
+    feat, dots = torch.empty(E, H, D, device=DEV), torch.empty(E, H, device=DEV)
+    k.matmul_attn_dot(_dev(by_src), 0, W.to(DEV), x.to(DEV), feat, attn.to(DEV), dots, dot_rows=perm.to(DEV))
+    assert_close(feat, feat_ref, what="feat")
+    ref = torch.empty(E, H, dtype=torch.float64)
+    ref[perm] = dot_ref.view(E, H)[s["eids"]]
+    assert_close(dots, ref, what="dots at dot_rows")
+    # a1, one shared input head, D_out = 1: same values with and without the (relation, node) grouping
+    wa = torch.randn(R, H, Kd, 1, generator=gen)
+    out_ref = torch.zeros(E, H, 1, dtype=torch.float64)
+    O.rgnn_relational_matmul(by_src, 0, to64(wa), to64(x), out_ref, True)
+    out = torch.empty(E, H, 1, device=DEV)
+    k.K.rgnn_relational_matmul(_dev(by_src), 0, wa.to(DEV), x.to(DEV), out, True)
+    assert_close(out, out_ref, what="row-dot on distinct rows")
