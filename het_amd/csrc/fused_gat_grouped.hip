@@ -427,6 +427,82 @@ inline bool grouped_shape_ok(int H, int D) {
   return is_pow2(D) && D >= 4 && is_pow2(X) && X / 4 <= 64;
 }
 
+// Lane group per work item (64/LPR items side by side in a wave): feat rows have few out-edges each (5.7 on average on
+// ogbn-mag by (relation, source)), so a wave per item leaves most lane groups idle.  Same math as the kernel above, no
+// cross-group reduction.
+template <int LPR, int U>
+__global__ __launch_bounds__(kBlock) void HET_gat_backward_src_slot(
+    Items it, const int32_t* __restrict__ p_eid, const int32_t* __restrict__ p_dst, const float* __restrict__ feat,
+    const float* __restrict__ exp, const float* __restrict__ pack, const float* __restrict__ gradout,
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, int D, float slope,
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t item = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t u = it.seg_key[seg];
+  const int64_t X = (int64_t)H * D;
+  int jn[U];
+  int64_t eidn[U], dstn[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) jn[q] = b + q < e ? b + q : e - 1;
+#pragma unroll
+  for (int q = 0; q < U; ++q) eidn[q] = p_eid[jn[q]];
+#pragma unroll
+  for (int q = 0; q < U; ++q) dstn[q] = p_dst[jn[q]];
+  const float4 f = ld4(feat + u * X + x);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc_el = 0.f;
+  for (int j0 = b; j0 < e; j0 += U) {
+    int64_t eid[U], dst[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) { eid[q] = eidn[q]; dst[q] = dstn[q]; }
+    float ex[U], sinv[U], gr[U];
+    float4 g[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) ex[q] = exp[eid[q] * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) sinv[q] = pack[dst[q] * 2 * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) gr[q] = pack[dst[q] * 2 * H + H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + dst[q] * X + x);
+#pragma unroll
+    for (int q = 0; q < U; ++q) jn[q] = j0 + U + q < e ? j0 + U + q : e - 1;
+#pragma unroll
+    for (int q = 0; q < U; ++q) eidn[q] = p_eid[jn[q]];
+#pragma unroll
+    for (int q = 0; q < U; ++q) dstn[q] = p_dst[jn[q]];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const bool ok = j0 + q < e;  // uniform within the lane group
+      const float a = ok ? ex[q] * sinv[q] : 0.f;
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float t = a * (ex[q] > 1.f ? 1.f : slope) * (dot - gr[q]);
+      if (ok && (sub & (DL - 1)) == 0) tbuf[eid[q] * H + h] = t;
+      acc_el += t;
+    }
+  }
+  if (fold_w) {
+    const float4 w = ld4(fold_w + (int64_t)find_segment(fold_row_rel_ptrs, R, (idx_t)u) * X + x);
+    acc.x = fmaf(acc_el, w.x, acc.x); acc.y = fmaf(acc_el, w.y, acc.y);
+    acc.z = fmaf(acc_el, w.z, acc.z); acc.w = fmaf(acc_el, w.w, acc.w);
+  }
+  float* gp = grad_feat + u * X + x;
+  if (b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1]) {
+    st4(gp, acc);
+    if ((sub & (DL - 1)) == 0) grad_el[u * H + h] = acc_el;
+  } else {
+    atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
+    if ((sub & (DL - 1)) == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+  }
+}
+
 }  // namespace
 
 #define HET_DISPATCH_LPR(LPRV, CALL)           \
@@ -550,12 +626,23 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
     HET_HIP(hipMemsetAsync(grad_feat, 0, sizeof(float) * n_src_rows * X, s));
   Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key,
            by_srow->num_items};
-  const unsigned nb = (unsigned)ceil_div64(by_srow->num_items, kBlock / 64);
-  HET_DISPATCH_LPR((int)(X / 4),
-                   hipLaunchKernelGGL(HET_gat_backward_src_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, by_srow->p0,
-                                      by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,
-                                      fold_row_rel_ptrs, v.R));
-  HET_LAUNCH_CHECK("HET_gat_backward_src_grouped");
+  if (by_srow->E < 16 * by_srow->num_items) {
+    // short segments (5.7 edges per (relation, source) row on ogbn-mag): a lane group per item, two edges in flight
+    // (same box: wave per item 3.4-3.5 ms for the whole op, lane group per item with U = 1 / 2 / 4: 3.7 / 3.1 / 3.65 ms)
+    const unsigned nbs = (unsigned)ceil_div64(by_srow->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+    HET_DISPATCH_LPR((int)(X / 4),
+                     hipLaunchKernelGGL((HET_gat_backward_src_slot<LPR, 2>), dim3(nbs), dim3(kBlock), 0, s, it, by_srow->p0,
+                                        by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,
+                                        fold_row_rel_ptrs, v.R));
+    HET_LAUNCH_CHECK("HET_gat_backward_src_slot");
+  } else {
+    const unsigned nb = (unsigned)ceil_div64(by_srow->num_items, kBlock / 64);
+    HET_DISPATCH_LPR((int)(X / 4),
+                     hipLaunchKernelGGL(HET_gat_backward_src_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, by_srow->p0,
+                                        by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,
+                                        fold_row_rel_ptrs, v.R));
+    HET_LAUNCH_CHECK("HET_gat_backward_src_grouped");
+  }
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[eid, :]   (segments of by_drow are the er rows in order)
   return launch_segment_sum(by_drow, tbuf, grad_er, H, nullptr, s);
 }

@@ -148,9 +148,11 @@ def _gat_case(g, kind, H, D, seed):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 3, 4])
-@pytest.mark.parametrize("H,D", [(4, 16), (1, 64), (3, 5), (8, 8), (2, 2)])
-def test_fused_gat_separate_coo(K, plan_mode, kind, H, D):
-    g = random_graph(seed=21, n=300, r=4, e=5000)
+@pytest.mark.parametrize("H,D,n", [(4, 16, 300), (1, 64, 300), (3, 5, 300), (8, 8, 300), (2, 2, 300), (4, 16, 24)])
+def test_fused_gat_separate_coo(K, plan_mode, kind, H, D, n):
+    # n = 24: ~50 edges per (relation, node) row, rows with several hundred -- the wave-per-item compact backward and
+    # its split (atomic) rows; n = 300: ~4 per row -- the lane-group-per-item one
+    g = random_graph(seed=21, n=n, r=4, e=5000)
     s, feat, el, er, go, df, db = _gat_case(g, kind, H, D, seed=9)
     N, E, slope = g.get_num_nodes(), g.get_num_edges(), 0.2
     idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
