@@ -43,6 +43,9 @@ struct Items {
 // (A lane group per item was measured slower here: in-edge lists are skewed and a 256-edge item then runs serially.)
 // EXPF: exp is formed here from el / er given in the grouping's order (two coalesced streams) instead of gathered by
 // edge id from a separate pass' output; exp_edge (edge order) is written only when the caller asks for it.
+// Occupancy (same-box A/B, ogbn-mag): 92 VGPRs = 5 waves/SIMD 1.73 ms; forced to 6 / 8 waves (the compiler then keeps
+// fewer rows in flight per wave) 2.21 / 2.92 ms; capped below 5 waves with dynamic LDS 2.0-3.3 ms: the pass is bound by
+// the bytes it keeps in flight and sits at the optimum of waves x rows per wave the register file allows.
 template <int LPR, bool EXPF = false>
 __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, const int32_t* __restrict__ p_eid,
                                                                      const int32_t* __restrict__ p_srow,
