@@ -9,7 +9,9 @@ this removes ~1 ms of elementwise adds and fills per step.
 
 Two dataflows, selected by the layer flags exactly as in the op-by-op path:
   kind 0 (default flags)   per-edge projections; the fusions of het_amd/layers.py (distinct-row projection + broadcast,
-                           attention terms from the GEMM epilogue, er without its per-edge tensor, el folded into the GAT node)
+                           attention terms from the GEMM epilogue, er without its per-edge tensor, el folded into the GAT
+                           node); the [E,H] tensors el, er, exp and grad_el are kept in the destination-grouped order of
+                           the GAT kernels (kernels.gat_rank_of_position), where those kernels stream them
   compact (kinds 3 / 4)    projections on the unique (relation, node) rows, el folded into the compact GAT backward
 and, for either, ``mulfirst`` (--multiply_among_weights_first_flag, RGAT/models.py:300-326): er = x[dst] . (W . attn_r)
 as a row-dot product on the distinct (relation, destination) rows instead of a projection followed by a dot.
