@@ -1,0 +1,77 @@
+"""What one rank of an N-way partition computes, timed on ONE GPU without the exchange: the layer on rank 0's local graph
+(owned destinations + halo sources), the pack / unpack kernels around the all-to-all, and the bytes it would move."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from het_amd.dist import build_plan
+from het_amd.graph import HetGraph
+from het_amd.layers import HET_RGATLayer
+from het_amd.synth import make_mag_like
+
+dev = torch.device("cuda")
+coo = make_mag_like(scale=float(os.environ.get("SCALE", "1.0")))
+for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+    setattr(coo, f, getattr(coo, f).to(dev))
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+import het_amd.dist as D
+ONLY = os.environ.get("ONLY")  # "world,rank": just that share (for rocprofv3)
+for world, beta in [(1, 0.0)] + [(w, b) for w in (2, 4, 8) for b in (0.0, 12.0)]:
+    D.NODE_WEIGHT = beta
+    rows = []
+    for rank in range(world):
+        if ONLY and (world, rank) != tuple(int(t) for t in ONLY.split(",")):
+            continue
+        p = build_plan(coo, rank, world)
+        g = HetGraph.from_integrated_coo(p.local, full=False)
+        torch.manual_seed(0)
+        layer = HET_RGATLayer(64, 64, coo.num_rels, 4, self_loop=True, dropout=0.0).to(dev)
+        x_own = torch.nn.Parameter(torch.randn(p.n_own, 64, device=dev) * 0.1)
+        halo = torch.randn(p.n_halo, 64, device=dev) * 0.1
+        go = torch.randn(p.n_own, 64, device=dev)
+
+        def step():
+            layer.zero_grad(set_to_none=True)
+            x_own.grad = None
+            send = x_own.index_select(0, p.send_idx)          # pack (what HaloExchange.forward does around the all-to-all)
+            x_local = torch.cat([x_own, halo], 0)
+            out = layer(g, x_local, num_dst=p.n_own)
+            out.backward(go)
+            back = torch.zeros(p.send_idx.numel(), 64, device=dev)
+            x_own.grad.index_add_(0, p.send_idx, back)          # unpack of the returned halo gradients
+            return send
+
+        ms = timeit(step)
+        if os.environ.get("PROFILE_RANK") and world == 8 and rank == 7 and beta > 0:
+            torch.cuda.synchronize()
+            from het_amd import kernels as _k
+            _k.event_timers["*"] = []
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            acc = {}
+            for a, b, name in _k.event_timers.pop("*"):
+                acc[name] = acc.get(name, 0.0) + a.elapsed_time(b) / 5
+            print("world 8 rank 7 per C-ABI call (ms):", {k: round(v, 3) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}, flush=True)
+        rows.append((rank, p.num_local_edges, p.n_own, p.n_halo, int(p.send_idx.numel()), ms))
+        del layer, g, p
+    if os.environ.get("VERBOSE"):
+        for r in rows:
+            print(f"world {world} rank {r[0]}: local edges {r[1]:>9} own {r[2]:>8} halo {r[3]:>8} sends {r[4]:>8} rows "
+                  f"({r[4] * 256 / 1e6:7.1f} MB out, {r[3] * 256 / 1e6:7.1f} MB in)  compute+pack {r[5]:.2f} ms", flush=True)
+    if not rows:
+        continue
+    ms = [r[5] for r in rows]
+    print(f"world {world} node_weight {beta}: compute+pack per rank min {min(ms):.2f} max {max(ms):.2f} ms; "
+          f"max rows sent {max(r[4] for r in rows)}, max halo {max(r[3] for r in rows)}; "
+          f"=> {coo.num_edges / max(ms) / 1e3:.0f} M edges/s before the exchange", flush=True)

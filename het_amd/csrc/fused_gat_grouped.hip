@@ -588,7 +588,11 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
     // fixed grid striding over the items: every workgroup flushes R*X atomics once (same-box A/B, exp/ab_bwd.sh:
     // 2048 .. 16384 workgroups and U = 1 / 2 all within +-3 %; 1280 workgroups 25 % slower; one workgroup per 4 items
     // 5x slower -- the atomics on the R*X words serialise)
-    const unsigned nbw = nb < 4096u ? nb : 4096u;
+    // ... and the flush is a fixed cost: the grid follows the item count (ogbn-mag: 0.9 M items -> 4096 workgroups; one
+    // rank's share of an 8-way partition, 0.3 M items -> 1400, 0.52 -> 0.4 ms there)
+    unsigned nbw = (unsigned)(g->num_items / 220 + 1);
+    nbw = nbw < 256u ? 256u : (nbw > 4096u ? 4096u : nbw);
+    nbw = nb < nbw ? nb : nbw;
 #define HET_GAT_BWD_DW(SORTED, RM)                                                                                    \
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM>), dim3(nbw),       \
                                                     dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \

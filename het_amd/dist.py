@@ -24,6 +24,7 @@ by owning rank, so the received buffer is already in halo order).
 from __future__ import annotations
 
 import dataclasses
+import os
 from typing import Callable, List
 
 import torch
@@ -33,13 +34,22 @@ from .graph import HetGraph
 from .synth import IntegratedCOO
 
 
-def partition_bounds(col: torch.Tensor, num_nodes: int, world: int) -> torch.Tensor:
-    """Node-id boundaries [world+1] of contiguous destination ranges with ~equal in-edge counts."""
+# Cost of owning a destination node, in edges: its self-loop / output / gradient rows are per-node work on top of the
+# per-edge work of its in-edges (exp/dist_rank_share.py: with edges alone the ranks that own many low-degree
+# destinations run 40 % longer than the ones that own few high-degree ones).
+NODE_WEIGHT = float(os.environ.get("HET_DIST_NODE_WEIGHT", "12"))  # sweep 0..64 on ogbn-mag: best 8..16 at 2, 4 and 8 ranks
+
+
+def partition_bounds(col: torch.Tensor, num_nodes: int, world: int, node_weight: float = None) -> torch.Tensor:
+    """Node-id boundaries [world+1] of contiguous destination ranges with ~equal cost = in-edges + node_weight per
+    destination (node_weight 0: equal in-edge counts)."""
+    node_weight = NODE_WEIGHT if node_weight is None else node_weight
     indeg = torch.bincount(col, minlength=num_nodes)
-    csum = torch.cumsum(indeg, 0)
-    total = int(csum[-1]) if num_nodes else 0
+    cost = indeg.to(torch.float64) + node_weight * (indeg > 0).to(torch.float64)
+    csum = torch.cumsum(cost, 0)
+    total = float(csum[-1]) if num_nodes else 0.0
     targets = torch.arange(1, world, device=col.device, dtype=torch.float64) * (total / world)
-    cuts = torch.searchsorted(csum.to(torch.float64), targets, right=False) + 1
+    cuts = torch.searchsorted(csum, targets, right=False) + 1
     b = torch.cat([torch.zeros(1, dtype=torch.int64, device=col.device), cuts.clamp(max=num_nodes),
                    torch.tensor([num_nodes], dtype=torch.int64, device=col.device)])
     return torch.cummax(b, 0).values

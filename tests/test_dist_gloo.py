@@ -94,17 +94,21 @@ def test_partitioned_layer_matches_single_process(kind, world):
         torch.testing.assert_close(q["glw"], p["lw"].grad)
 
 
-def test_partition_bounds_balance_in_edges():
+def test_partition_bounds_balance_cost():
+    """Destination ranges carry ~equal cost = in-edges + node_weight per destination (node_weight 0: in-edges alone)."""
     from het_amd.dist import partition_bounds
     coo = make_mag_like(scale=2e-3)
-    for world in (2, 4, 8):
-        b = partition_bounds(coo.col, coo.num_nodes, world)
-        assert b[0] == 0 and b[-1] == coo.num_nodes and bool((b[1:] >= b[:-1]).all())
-        owner = torch.searchsorted(b[1:].contiguous(), coo.col, right=True)
-        cnt = torch.bincount(owner, minlength=world).double()
-        # a single hub destination can exceed the ideal share; otherwise within 25 %
-        hub = torch.bincount(coo.col).max().item()
-        assert float(cnt.max()) <= coo.num_edges / world * 1.25 + hub
+    indeg = torch.bincount(coo.col, minlength=coo.num_nodes).double()
+    hub = indeg.max().item()
+    for node_weight in (0.0, 12.0):
+        cost = indeg + node_weight * (indeg > 0)
+        for world in (2, 4, 8):
+            b = partition_bounds(coo.col, coo.num_nodes, world, node_weight)
+            assert b[0] == 0 and b[-1] == coo.num_nodes and bool((b[1:] >= b[:-1]).all())
+            owner = torch.searchsorted(b[1:].contiguous(), torch.arange(coo.num_nodes), right=True).clamp(max=world - 1)
+            per_rank = torch.zeros(world, dtype=torch.float64).index_add_(0, owner, cost)
+            # a single hub destination can exceed the ideal share; otherwise within 25 %
+            assert float(per_rank.max()) <= float(cost.sum()) / world * 1.25 + hub + node_weight
 
 
 def test_source_only_nodes_are_dealt_out_evenly():
