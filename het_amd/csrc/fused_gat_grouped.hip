@@ -46,7 +46,9 @@ struct Items {
 // Occupancy (same-box A/B, ogbn-mag): 92 VGPRs = 5 waves/SIMD 1.73 ms; forced to 6 / 8 waves (the compiler then keeps
 // fewer rows in flight per wave) 2.21 / 2.92 ms; capped below 5 waves with dynamic LDS 2.0-3.3 ms: the pass is bound by
 // the bytes it keeps in flight and sits at the optimum of waves x rows per wave the register file allows.
-template <int LPR, bool EXPF = false>
+// SLOT: a lane group (not a wave) per work item, 64/LPR items side by side -- for graphs whose destinations have few
+// in-edges (a rank's share of a partition, a sampled block, AIFB: < 16 on average), where a wave per item idles.
+template <int LPR, bool EXPF = false, bool SLOT = false>
 __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, const int32_t* __restrict__ p_eid,
                                                                      const int32_t* __restrict__ p_srow,
                                                                      const float* __restrict__ feat,
@@ -58,9 +60,12 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
                                                                      float* __restrict__ exp_edge = nullptr,
                                                                      float slope = 0.f) {
   constexpr int EPW = 64 / LPR, U = 4;
+  constexpr int ST = SLOT ? 1 : EPW;  // rank stride between the edges of one lane group
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
-  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int j_off = SLOT ? 0 : slot;
+  const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t item = SLOT ? wave_id * EPW + slot : wave_id;
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   const int64_t X = (int64_t)H * D;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
   int jn[U];
   int64_t eidn[U], srown[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) jn[u] = b + slot + u * EPW < e ? b + slot + u * EPW : e - 1;
+  for (int u = 0; u < U; ++u) jn[u] = b + j_off + u * ST < e ? b + j_off + u * ST : e - 1;
 #pragma unroll
   for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
   if (p_srow) {
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
   }
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
-  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+  for (int j0 = b + j_off; j0 < e; j0 += ST * U) {
     int jc[U];
     float w[U];
     float4 f[U];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (p_srow ? srown[u] : eidn[u]) * X + x);
 #pragma unroll
-    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1;
+    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * ST < e ? j0 + (U + u) * ST : e - 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
     if (p_srow) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool ok = j0 + u * EPW < e;
+      const bool ok = j0 + u * ST < e;
       if (EXPF) {
         w[u] = leaky_exp(zl[u] + zr[u], slope);
         if (exp_edge && ok && x % D == 0) exp_edge[eidc[u] * H + h] = w[u];
@@ -123,15 +128,17 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
       ssum += wu;
     }
   }
+  if (!SLOT) {
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-    acc.x += __shfl_xor(acc.x, off);
-    acc.y += __shfl_xor(acc.y, off);
-    acc.z += __shfl_xor(acc.z, off);
-    acc.w += __shfl_xor(acc.w, off);
-    ssum += __shfl_xor(ssum, off);
+    for (int off = LPR; off < 64; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off);
+      acc.y += __shfl_xor(acc.y, off);
+      acc.z += __shfl_xor(acc.z, off);
+      acc.w += __shfl_xor(acc.w, off);
+      ssum += __shfl_xor(ssum, off);
+    }
+    if (slot != 0) return;
   }
-  if (slot != 0) return;
   float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t*
 // DW (with FOLD): also accumulates grad_fold_w[r,h,:] += SUM grad_el[e,h] * feat[e,h,:] -- the weight gradient of the
 // folded product, from the feat rows this kernel reads anyway -- in per-relation registers (R <= kFoldRelMax); the grid
 // is then a fixed number of workgroups striding over the items, each flushing once through LDS with R*X atomics.
-template <int LPR, bool SORTED, bool FOLD, int RMAX = 0>
+template <int LPR, bool SORTED, bool FOLD, int RMAX = 0, bool SLOT = false>
 __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
@@ -181,20 +188,23 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w, float* __restrict__ grad_fold_w, int R,
     float* __restrict__ grad_el_sorted) {
   constexpr int EPW = 64 / LPR, U = 2;  // same-box A/B: U = 1 3.89 ms, 2 3.76 ms, 4 3.82 ms
+  constexpr int ST = SLOT ? 1 : EPW;     // SLOT: a lane group per item (short in-edge lists), see the forward
+  constexpr int IPW = SLOT ? EPW : 1;    // items per wave and pass
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int j_off = SLOT ? 0 : slot;
   const int64_t X = (int64_t)H * D;
   constexpr bool DW = RMAX > 0;
   float4 accw[DW ? RMAX : 1];
 #pragma unroll
   for (int q = 0; q < (DW ? RMAX : 1); ++q) accw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < it.n;
-       item += (int64_t)gridDim.x * (kBlock / 64)) {
+  for (int64_t item = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * IPW + (SLOT ? slot : 0); item < it.n;
+       item += (int64_t)gridDim.x * (kBlock / 64) * IPW) {
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   int jn[U], reln[U];
   int64_t eidn[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) jn[u] = b + slot + u * EPW < e ? b + slot + u * EPW : e - 1;
+  for (int u = 0; u < U; ++u) jn[u] = b + j_off + u * ST < e ? b + j_off + u * ST : e - 1;
 #pragma unroll
   for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
   if (FOLD) {
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
   const int64_t v = it.seg_key[seg];
   const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
   const float sinv = 1.f / sum[v * H + h];
-  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+  for (int j0 = b + j_off; j0 < e; j0 += ST * U) {
     int64_t eid[U];
     float ex[U], dl[U];
     float4 f[U], w[U];
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     }
     // ids of the next step (clamped: the last step re-reads its own)
 #pragma unroll
-    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1;
+    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * ST < e ? j0 + (U + u) * ST : e - 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) eidn[u] = p_eid[jn[u]];
     if (FOLD) {
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool ok = j0 + u * EPW < e;  // uniform within the LPR lanes of a slot (shuffles below stay inside it)
+      const bool ok = j0 + u * ST < e;  // uniform within the LPR lanes of a slot (shuffles below stay inside it)
       const float a = ex[u] * sinv;
       float tt = g.x * (f[u].x - r.x) + g.y * (f[u].y - r.y) + g.z * (f[u].z - r.z) + g.w * (f[u].w - r.w);
       for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
         st4_nt(grad_feat + eid[u] * X + x, o);
       }
       if (ok && (sub & (DL - 1)) == 0) {
-        if (grad_el_sorted) grad_el_sorted[(int64_t)(j0 + u * EPW) * H + h] = tt;  // rank order: sequential
+        if (grad_el_sorted) grad_el_sorted[(int64_t)(j0 + u * ST) * H + h] = tt;  // rank order: sequential
         if (grad_el) grad_el[eid[u] * H + h] = tt;
         if (grad_er && grad_er != grad_el) grad_er[eid[u] * H + h] = tt;
       }
@@ -519,6 +529,11 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_slot(
     default: { constexpr int LPR = 64; CALL; break; } \
   }
 
+// Destinations with few in-edges on average: a lane group per item instead of a wave per item (layer path kernels).
+// Same-box A/B on one rank's share of an 8-way ogbn-mag partition (9 in-edges per destination): backward 0.528 -> 0.506 ms,
+// forward unchanged.
+static bool short_items(const het_grouping* g) { return g->E < 16 * g->num_items; }
+
 int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps& m, const float* feat,
                         const float* el, const float* er, float* sum, float* exp, float* ret, float* exp_sorted,
                         int H, int D, float slope, const float* el_sorted, const float* er_sorted, hipStream_t s) {
@@ -539,7 +554,12 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   // prefetched during the current item's rows -- was 25-40 % slower at 2048..16384 workgroups, same box: the hardware's
   // own workgroup turnover already overlaps the per-item prologues; the pass runs at the rate random 256-byte rows
   // come out of HBM)
-  if (el_sorted) {
+  if (el_sorted && short_items(g)) {
+    const unsigned nbs = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true, true>), dim3(nbs), dim3(kBlock), 0,
+                                                      s, it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
+                                                      H, D, el_sorted, er_sorted, exp, slope));
+  } else if (el_sorted) {
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s,
                                                       it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
                                                       H, D, el_sorted, er_sorted, exp, slope));
@@ -593,15 +613,20 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
     unsigned nbw = (unsigned)(g->num_items / 220 + 1);
     nbw = nbw < 256u ? 256u : (nbw > 4096u ? 4096u : nbw);
     nbw = nb < nbw ? nb : nbw;
-#define HET_GAT_BWD_DW(SORTED, RM)                                                                                    \
-  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM>), dim3(nbw),       \
+#define HET_GAT_BWD_DW(SORTED, RM, SLOT)                                                                                 \
+  HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM, SLOT>), dim3(nbw),    \
                                                     dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \
                                                     grad_feat, grad_el, grad_er, H, D, slope, g->p1, fold_w,            \
                                                     grad_fold_w, v.R, grad_el_sorted))
-    if (v.R <= 4) {
-      if (sorted) { HET_GAT_BWD_DW(true, 4); } else { HET_GAT_BWD_DW(false, 4); }
+    if (sorted && short_items(g)) {  // the layer path on a low-degree graph: lane group per item
+      const unsigned per_wg = (kBlock / 64) * (64 / (unsigned)(X / 4));
+      const unsigned nbs = (unsigned)ceil_div64(g->num_items, per_wg);
+      nbw = nbs < nbw ? nbs : nbw;
+      if (v.R <= 4) { HET_GAT_BWD_DW(true, 4, true); } else { HET_GAT_BWD_DW(true, 8, true); }
+    } else if (v.R <= 4) {
+      if (sorted) { HET_GAT_BWD_DW(true, 4, false); } else { HET_GAT_BWD_DW(false, 4, false); }
     } else {
-      if (sorted) { HET_GAT_BWD_DW(true, 8); } else { HET_GAT_BWD_DW(false, 8); }
+      if (sorted) { HET_GAT_BWD_DW(true, 8, false); } else { HET_GAT_BWD_DW(false, 8, false); }
     }
 #undef HET_GAT_BWD_DW
   } else if (fold_w) {
