@@ -224,7 +224,8 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
   hipStream_t s = (hipStream_t)stream;
   if (by_dst && kind == HET_KIND_DISABLED)
     return gat_backward_grouped(by_dst, v, m, feat, el, er, sum, exp, ret, exp_sorted, gradout, grad_feat, grad_el,
-                                grad_er, (int)H, (int)D, (float)slope, fold_attn_l, grad_fold_attn_l, grad_el_sorted, s);
+                                grad_er, (int)H, (int)D, (float)slope, fold_attn_l, grad_fold_attn_l, grad_el_sorted,
+                                static_cast<float*>(workspace), workspace_bytes, s);
   HET_REQUIRE(!grad_fold_attn_l && (kind != HET_KIND_DISABLED || !fold_attn_l),
               "%s: fold_attn_l needs the by_dst grouping (kind 0); grad_fold_attn_l is kind 0 only", op);
   if (kind != HET_KIND_DISABLED && workspace &&

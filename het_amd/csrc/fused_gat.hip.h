@@ -18,7 +18,7 @@ int gat_backward_grouped(const het_grouping* by_dst, const EdgeView& v, const Ro
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
                          float* grad_er, int H, int D, float slope, const float* fold_w, float* grad_fold_w,
-                         float* grad_el_sorted, hipStream_t s);
+                         float* grad_el_sorted, float* workspace, int64_t workspace_bytes, hipStream_t s);
 
 // Compact kinds (1/3/4): by_srow groups the positions by feat row (payload0 = eids, payload1 = col), by_drow by
 // er row (payload0 = eids).  workspace: N*2H + E*H floats.

@@ -11,6 +11,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kFoldRelMax = 8;  // relations the fused weight gradient of the folded GAT backward keeps in registers
+constexpr int kFoldReplicas = 64;  // copies of that [R,X] gradient the workgroups spread their final atomics over
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -153,6 +154,16 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
   }
 }
 
+// out[i] += SUM over the replicas of part[rep][i]   (i < n: the R*X weight-gradient words of the folded backward)
+__global__ __launch_bounds__(kBlock) void HET_gat_fold_w_reduce(const float* __restrict__ part, int replicas, int n,
+                                                                 float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.f;
+  for (int r = 0; r < replicas; ++r) t += part[(int64_t)r * n + i];
+  out[i] += t;
+}
+
 __global__ __launch_bounds__(kBlock) void HET_gat_normalize_split(const int32_t* __restrict__ split_seg,
                                                                    const int32_t* __restrict__ seg_key,
                                                                    int64_t num_split, const float* __restrict__ sum,
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
     const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
     float* __restrict__ grad_el, float* __restrict__ grad_er, int H, int D, float slope,
     const int32_t* __restrict__ p_rel, const float* __restrict__ fold_w, float* __restrict__ grad_fold_w, int R,
-    float* __restrict__ grad_el_sorted) {
+    float* __restrict__ grad_el_sorted, int replicas = 1) {
   constexpr int EPW = 64 / LPR, U = 2;  // same-box A/B: U = 1 3.89 ms, 2 3.76 ms, 4 3.82 ms
   constexpr int ST = SLOT ? 1 : EPW;     // SLOT: a lane group per item (short in-edge lists), see the forward
   constexpr int IPW = SLOT ? EPW : 1;    // items per wave and pass
@@ -310,7 +321,8 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
           const float4 o = part[wv][q][lane];
           t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
         }
-        float* p = grad_fold_w + (int64_t)q * X + x;
+        // replicas > 1: the workgroups spread their flushes over that many copies (summed by HET_gat_fold_w_reduce)
+        float* p = grad_fold_w + ((int64_t)(blockIdx.x % (unsigned)replicas) * R + q) * X + x;
         atomicAdd(p + 0, t.x); atomicAdd(p + 1, t.y); atomicAdd(p + 2, t.z); atomicAdd(p + 3, t.w);
       }
     }
@@ -586,7 +598,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
                          const float* el, const float* er, const float* sum, const float* exp, const float* ret,
                          const float* exp_sorted, const float* gradout, float* grad_feat, float* grad_el,
                          float* grad_er, int H, int D, float slope, const float* fold_w, float* grad_fold_w,
-                         float* grad_el_sorted, hipStream_t s) {
+                         float* grad_el_sorted, float* workspace, int64_t workspace_bytes, hipStream_t s) {
   HET_REQUIRE(!grad_fold_w || (fold_w && v.R <= kFoldRelMax), "backward_relational_fused_gat_separate_coo: grad_fold_attn_l needs fold_attn_l and at most %d relations", kFoldRelMax);
   if (m.kind != HET_KIND_DISABLED || !grouped_shape_ok(H, D) || !g->p0 || g->E != v.E || g->R != 0) {
     HET_REQUIRE(!fold_w && !grad_el_sorted && (v.E == 0 || (el && er && exp)), "backward_relational_fused_gat_separate_coo: fold_attn_l / grad_el_sorted / NULL el, er, exp need the destination-grouped path");
@@ -607,21 +619,25 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   if (grad_fold_w) {
     // fixed grid striding over the items: every workgroup flushes R*X atomics once (same-box A/B, exp/ab_bwd.sh:
     // 2048 .. 16384 workgroups and U = 1 / 2 all within +-3 %; 1280 workgroups 25 % slower; one workgroup per 4 items
-    // 5x slower -- the atomics on the R*X words serialise)
-    // ... and the flush is a fixed cost: the grid follows the item count (ogbn-mag: 0.9 M items -> 4096 workgroups; one
-    // rank's share of an 8-way partition, 0.3 M items -> 1400, 0.52 -> 0.4 ms there)
-    unsigned nbw = (unsigned)(g->num_items / 220 + 1);
-    nbw = nbw < 256u ? 256u : (nbw > 4096u ? 4096u : nbw);
-    nbw = nb < nbw ? nb : nbw;
+    // 5x slower -- the atomics on the R*X words serialise).  With the replicas below 1024 .. 16384 workgroups are within
+    // 5 % at 1/8 of the graph too (0.43 ms; 0.51 ms at 4096 and 1.6 ms at 16384 workgroups without them)
+    const unsigned nbw = nb < 4096u ? nb : 4096u;
+    // every workgroup ends with R*X atomic adds: onto kFoldReplicas copies in the workspace when the caller gave one
+    // (all workgroups of a small graph finish together and serialise on the R*X words otherwise)
+    const int n_w = v.R * (int)X;
+    int replicas = 1;
+    float* dw_out = grad_fold_w;
+    if (workspace && workspace_bytes >= (int64_t)sizeof(float) * kFoldReplicas * n_w) {
+      replicas = kFoldReplicas;
+      dw_out = workspace;
+      HET_HIP(hipMemsetAsync(dw_out, 0, sizeof(float) * replicas * n_w, s));
+    }
 #define HET_GAT_BWD_DW(SORTED, RM, SLOT)                                                                                 \
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM, SLOT>), dim3(nbw),    \
                                                     dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \
                                                     grad_feat, grad_el, grad_er, H, D, slope, g->p1, fold_w,            \
-                                                    grad_fold_w, v.R, grad_el_sorted))
+                                                    dw_out, v.R, grad_el_sorted, replicas))
     if (sorted && short_items(g)) {  // the layer path on a low-degree graph: lane group per item
-      const unsigned per_wg = (kBlock / 64) * (64 / (unsigned)(X / 4));
-      const unsigned nbs = (unsigned)ceil_div64(g->num_items, per_wg);
-      nbw = nbs < nbw ? nbs : nbw;
       if (v.R <= 4) { HET_GAT_BWD_DW(true, 4, true); } else { HET_GAT_BWD_DW(true, 8, true); }
     } else if (v.R <= 4) {
       if (sorted) { HET_GAT_BWD_DW(true, 4, false); } else { HET_GAT_BWD_DW(false, 4, false); }
@@ -629,6 +645,11 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
       if (sorted) { HET_GAT_BWD_DW(true, 8, false); } else { HET_GAT_BWD_DW(false, 8, false); }
     }
 #undef HET_GAT_BWD_DW
+    if (replicas > 1) {
+      HET_LAUNCH_CHECK("HET_gat_backward_grouped");
+      hipLaunchKernelGGL(HET_gat_fold_w_reduce, dim3((n_w + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dw_out, replicas, n_w,
+                         grad_fold_w);
+    }
   } else if (fold_w) {
     if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
   } else {

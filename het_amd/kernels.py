@@ -497,6 +497,8 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
         gs = _plan.get_grouping(None, srow, feat_src.shape[0], separate_coo_eids, separate_coo_col_indices)
         gd = _plan.get_grouping(None, drow, er.shape[0], separate_coo_eids, None)
         ws = torch.empty(N * 2 * H + E * H, dtype=torch.float32, device=ret.device)
+    if IntKind == 0 and g is not None and grad_fold_attn_l is not None:
+        ws = torch.empty(64 * grad_fold_attn_l.numel(), dtype=torch.float32, device=ret.device)  # replicas of the weight gradient
     _call(ret, "het_backward_relational_fused_gat_separate_coo", _p(separate_coo_eids), _p(separate_coo_rel_ptrs),
           _p(separate_coo_row_indices), _p(separate_coo_col_indices), separate_coo_rel_ptrs.numel() - 1, E, N, IntKind,
           _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(maps[3]), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),

@@ -222,7 +222,9 @@ int het_relational_fused_gat_separate_coo(const int64_t* eids, const int64_t* re
  *   (error otherwise; by_dst must then carry payload1 = relation of every position); replaces a
  *   read-modify-write pass over the [E,H,D] gradient.  grad_fold_attn_l (optional with fold_attn_l, R <= 8): [R,H,D],
  *   receives += SUM_e grad_el[e,h] * feat[e,h,:] per relation -- the weight gradient of that product, from the feat
- *   rows the kernel reads anyway (saves a pass over feat); the caller zero-fills it.
+ *   rows the kernel reads anyway (saves a pass over feat); the caller zero-fills it.  With a workspace of
+ *   64*R*H*D floats (kind 0) the workgroups spread their final atomic adds over 64 copies that a last tiny kernel
+ *   sums -- on small graphs all workgroups finish together and would serialise on the R*H*D words.
  *   Compact kinds with the by_src_row / by_dst_row groupings: fold_attn_l works on the compact rows
  *   (el[u,h] = <feat[u,h,:], fold_attn_l[r(u),h,:]>), fold_row_rel_ptrs [R+1] = the rows' relation pointers.
  *   grad_el_sorted (extension, kind 0 with by_dst only): [E,H], receives grad_el in by_dst order (row j = the edge at
