@@ -550,3 +550,47 @@ extern "C" int het_rows_add_bias(const float* a, const float* b, const float* bi
   HET_LAUNCH_CHECK("HET_rows_add_bias");
   return HET_OK;
 }
+
+// ---- halo pack / unpack of the multi-GPU path (het_amd/dist.py): rows of a [*, X] tensor gathered into a send buffer,
+// received gradient rows added back (several ranks may return a gradient for the same row: atomics, one lane per float
+// so that an instruction covers whole lines)
+namespace {
+__global__ __launch_bounds__(256) void HET_rows_gather(const float* __restrict__ x, const idx_t* __restrict__ idx, int64_t total4,
+                                                       int X4, float* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / X4;
+    const int c = (int)(t - i * X4);
+    reinterpret_cast<float4*>(out)[t] = reinterpret_cast<const float4*>(x)[idx[i] * X4 + c];
+  }
+}
+__global__ __launch_bounds__(256) void HET_rows_scatter_add(const float* __restrict__ src, const idx_t* __restrict__ idx,
+                                                            int64_t total, int X, float* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / X;
+    atomicAdd(out + idx[i] * X + (t - i * X), src[t]);
+  }
+}
+}  // namespace
+
+extern "C" int het_rows_gather(const float* x, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream) {
+  HET_REQUIRE(num_rows >= 0 && X > 0 && X % 4 == 0 && (num_rows == 0 || (x && idx && out)), "rows_gather: bad arguments");
+  HET_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "rows_gather: 16-byte aligned pointers expected");
+  if (num_rows == 0) return HET_OK;
+  const int64_t total4 = num_rows * (X / 4);
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(HET_rows_gather, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, idx, total4, (int)(X / 4), out);
+  HET_LAUNCH_CHECK("HET_rows_gather");
+  return HET_OK;
+}
+
+extern "C" int het_rows_scatter_add(const float* src, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream) {
+  HET_REQUIRE(num_rows >= 0 && X > 0 && (num_rows == 0 || (src && idx && out)), "rows_scatter_add: bad arguments");
+  if (num_rows == 0) return HET_OK;
+  const int64_t total = num_rows * X;
+  int64_t nb = ceil_div64(total, 256);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(HET_rows_scatter_add, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, idx, total, (int)X, out);
+  HET_LAUNCH_CHECK("HET_rows_scatter_add");
+  return HET_OK;
+}

@@ -156,6 +156,20 @@ def _all_reduce(t, group):
         dist.all_reduce(t, group=group)
 
 
+def _gather_rows(x, idx):
+    if x.is_cuda:  # the product path: HIP kernels behind the C ABI (fails loudly without the library)
+        from . import kernels
+        return kernels.rows_gather(x.contiguous(), idx)
+    return x.index_select(0, idx).contiguous()  # CPU (gloo tests with the oracle as the per-rank layer)
+
+
+def _scatter_add_rows(out, idx, src):
+    if out.is_cuda:
+        from . import kernels
+        return kernels.rows_scatter_add_(out, idx, src.contiguous())
+    return out.index_add_(0, idx, src)
+
+
 class HaloExchange(torch.autograd.Function):
     """x_own [n_own, K] -> [n_own + n_halo, K]: owned rows followed by the halo rows received from
     their owners.  Backward sends the halo gradients home and adds them to the owners' rows."""
@@ -163,10 +177,11 @@ class HaloExchange(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_own, plan: DistPlan, group):
         ctx.plan, ctx.group = plan, group
-        send = x_own.index_select(0, plan.send_idx).contiguous()
-        recv = x_own.new_empty((plan.n_halo, x_own.shape[1]))
-        _all_to_all(recv, send, plan.recv_counts, plan.send_counts, group)
-        return torch.cat([x_own, recv], 0)
+        send = _gather_rows(x_own, plan.send_idx)
+        x_local = x_own.new_empty((plan.n_own + plan.n_halo, x_own.shape[1]))
+        x_local[: plan.n_own].copy_(x_own)
+        _all_to_all(x_local[plan.n_own:], send, plan.recv_counts, plan.send_counts, group)  # straight into the halo rows
+        return x_local
 
     @staticmethod
     def backward(ctx, grad):
@@ -175,7 +190,7 @@ class HaloExchange(torch.autograd.Function):
         g_halo = grad[plan.n_own:].contiguous()
         back = grad.new_empty((int(plan.send_idx.numel()), grad.shape[1]))
         _all_to_all(back, g_halo, plan.send_counts, plan.recv_counts, ctx.group)
-        g_own.index_add_(0, plan.send_idx, back)
+        _scatter_add_rows(g_own, plan.send_idx, back)
         return g_own, None, None
 
 

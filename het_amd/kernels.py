@@ -210,6 +210,25 @@ def rows_add_bias(a, b=None, bias=None):
     return out
 
 
+def rows_gather(x, idx):
+    """out[i, :] = x[idx[i], :] (include/het_amd.h: het_rows_gather); torch.index_select off the GPU or for odd widths."""
+    if not (x.is_cuda and x.dim() == 2 and x.shape[1] % 4 == 0 and x.dtype == torch.float32 and x.is_contiguous()):
+        return x.index_select(0, idx)
+    _chk("rows_gather", (x,), (idx,))
+    out = torch.empty((idx.numel(), x.shape[1]), dtype=x.dtype, device=x.device)
+    _call(x, "het_rows_gather", _p(x), _p(idx), idx.numel(), x.shape[1], _p(out), _stream(x))
+    return out
+
+
+def rows_scatter_add_(out, idx, src):
+    """out[idx[i], :] += src[i, :] in place (het_rows_scatter_add); Tensor.index_add_ off the GPU."""
+    if not (out.is_cuda and out.dim() == 2 and out.dtype == torch.float32 and out.is_contiguous() and src.is_contiguous()):
+        return out.index_add_(0, idx, src)
+    _chk("rows_scatter_add", (out, src), (idx,))
+    _call(out, "het_rows_scatter_add", _p(src), _p(idx), idx.numel(), out.shape[1], _p(out), _stream(out))
+    return out
+
+
 def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_feat, dot_w, grad_dot, grad_node_feat, grad_weights,
                                   comp_rows=None, grad_dot_w=None, accumulate=False):
     """Backward of matmul_attn_dot when only dot_out was used (see include/het_amd.h); returns False when the fast

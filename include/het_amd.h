@@ -399,6 +399,13 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
 int het_rows_add_bias(const float* a, const float* b, const float* bias, float* out, int64_t num_rows, int64_t X,
                       het_stream stream);
 
+/* Halo pack / unpack of the multi-GPU path (no reference counterpart: het_amd/dist.py pushes the features of remote source
+ * nodes with an all-to-all before the forward and returns their gradients after the backward).
+ *   het_rows_gather:       out[i, :] = x[idx[i], :]        i in [0, num_rows)   (X % 4 == 0, 16-byte aligned rows)
+ *   het_rows_scatter_add:  out[idx[i], :] += src[i, :]     (atomic: idx may repeat) */
+int het_rows_gather(const float* x, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream);
+int het_rows_scatter_add(const float* src, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream);
+
 /* ------------------------------------------------------------------------
  * Layout builders (the step before the path).  Device-side replacements of the reference's CPU
  * converters: torch.ops.torch_hrt.convert_integrated_{coo,csr}_to_separate_{coo,csr} / transpose_csr

@@ -627,3 +627,19 @@ def test_attn_dot_with_dot_rows(H, Kd, D):
     out = torch.empty(E, H, 1, device=DEV)
     k.K.rgnn_relational_matmul(_dev(by_src), 0, wa.to(DEV), x.to(DEV), out, True)
     assert_close(out, out_ref, what="row-dot on distinct rows")
+
+
+def test_halo_pack_unpack_rows():
+    """het_rows_gather / het_rows_scatter_add (multi-GPU halo pack / unpack) against index_select / index_add_."""
+    import het_amd.kernels as k
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(500, 64, generator=gen)
+    idx = torch.randint(0, 500, (3000,), generator=gen)  # repeated rows
+    out = k.rows_gather(x.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), x.index_select(0, idx))
+    src = torch.randn(3000, 64, generator=gen)
+    acc = torch.randn(500, 64, generator=gen)
+    ref = acc.double().index_add_(0, idx, src.double())
+    got = k.rows_scatter_add_(acc.to(DEV), idx.to(DEV), src.to(DEV))
+    assert_close(got, ref, what="scatter_add")
+    assert k.rows_gather(x.to(DEV), idx[:0].to(DEV)).shape == (0, 64)
