@@ -50,11 +50,11 @@ def _compact_dicts(g, direct):
 def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
     R, H, Kd, D = W.shape
-    if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0 and H >= 4
+    if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0
             and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
         return False
     if mulfirst:  # er = x[dst] . (W . attn_r): the one-head row-dot kernels (seg_rowdot.hip)
-        return H in (4, 8) and Kd >= 4 * H and Kd & (Kd - 1) == 0 and Kd <= 256
+        return H in (1, 2, 4, 8) and Kd >= 4 * H and Kd & (Kd - 1) == 0 and Kd <= 256
     if compact:
         return True
     _, _, by_dst = _lists(g)

@@ -151,7 +151,7 @@ class _FusedGatCompactWithAttnL(th.autograd.Function):
 def relational_fused_gat_compact_with_attn_l_ok(g, feat_compact, attn_l, negative_slope):
     """Shapes / state for which the compact GAT backward runs on its groupings (the fold lives there)."""
     H, D = attn_l.shape[1], attn_l.shape[2]
-    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and H >= 4 and feat_compact.is_cuda
+    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat_compact.is_cuda
             and g.get_num_edges() > 0)
 
 

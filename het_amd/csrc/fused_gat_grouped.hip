@@ -702,7 +702,7 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
 
 bool gat_backward_compact_supported(const het_grouping* by_srow, const het_grouping* by_drow, int64_t E,
                                     int64_t n_dst_rows, int H, int D, float slope) {
-  return by_srow && by_drow && grouped_shape_ok(H, D) && segment_sum_supported(H) && slope >= 0.f && by_srow->E == E &&
+  return by_srow && by_drow && grouped_shape_ok(H, D) && segment_rows_supported(H) && slope >= 0.f && by_srow->E == E &&
          by_drow->E == E && by_srow->R == 0 && by_drow->R == 0 && by_srow->p0 && by_srow->p1 && by_drow->p0 &&
          by_drow->S == n_dst_rows;
 }

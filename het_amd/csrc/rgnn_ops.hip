@@ -47,7 +47,7 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
     const het_grouping* g = by_rel_gather;
     if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 && g->S > 0 &&
-        segment_sum_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
+        segment_rows_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
         (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
       // positions sharing (relation, x row) hold the same [H] product: form the S distinct ones, then duplicate
       float* dots = static_cast<float*>(workspace);
@@ -104,7 +104,7 @@ extern "C" int het_rgnn_relational_matmul_attn_dot(int64_t kind, const int64_t* 
   if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_sum_supported((int)X) &&
       H <= X / 4 && workspace && workspace_bytes >= ws_need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(ret) & 15) == 0 && (reinterpret_cast<uintptr_t>(comp_rows) & 15) == 0 && num_rows > 0 &&
-      segment_sum_supported((int)H)) {
+      segment_rows_supported((int)H)) {
     // Rows that share (relation, gather_idx) are identical: project the S distinct rows once (dense, into comp_rows
     // or the workspace), then duplicate every row to the positions of its segment -- same values as the per-position
     // GEMM.  ret == NULL: the caller wants the attention term only; just the [S,H] dots are duplicated.
@@ -161,7 +161,7 @@ extern "C" int het_backward_rgnn_relational_matmul_attn_dot_only(
   HET_REQUIRE(num_rows == 0 || (weights_t && x && dot_w && grad_dot && grad_x && grad_w), "%s: null data pointer", op);
   const het_grouping* g = by_rel_gather;
   const int64_t X = H * D;
-  if (!(g && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_sum_supported((int)H) && (D % 4) == 0 &&
+  if (!(g && g->R == (int)num_rels && g->E == num_rows && g->p0 && segment_rows_supported((int)H) && (D % 4) == 0 &&
         mfma_shape_supported((int)X, (int)K) && mfma_dw_supported((int)K, (int)X) && workspace &&
         workspace_bytes >= (int64_t)sizeof(float) * g->S * (H + X) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(grad_dot) & 15) == 0 && (reinterpret_cast<uintptr_t>(dot_w) & 15) == 0 &&
@@ -253,7 +253,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     q.A = x; q.gather = gather_idx; q.W = weights_t; q.scatter = scatter; q.go = gradout; q.seg_ptrs = rel_ptrs;
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
     if (g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
-        segment_sum_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
+        segment_rows_supported((int)H) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H &&
         (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
       // positions sharing (relation, x row) share both factors: sum their [H] gradients first
       float* gsum = static_cast<float*>(workspace);

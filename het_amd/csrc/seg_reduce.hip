@@ -95,13 +95,42 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   }
 }
 
+// Rows of 1 or 2 floats ([E,H] attention terms with fewer than 4 heads): a thread per (item, float), plain loop.
+__global__ __launch_bounds__(kBlock) void HET_segment_sum_narrow(const int32_t* __restrict__ item_seg,
+                                                                 const int32_t* __restrict__ item_begin,
+                                                                 const int32_t* __restrict__ item_end,
+                                                                 const int32_t* __restrict__ seg_ptr, int64_t num_items,
+                                                                 const int32_t* __restrict__ p_row, int X,
+                                                                 const float* __restrict__ in, float* __restrict__ out,
+                                                                 int accumulate) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= num_items * X) return;
+  const int64_t item = t / X;
+  const int c = (int)(t - item * X);
+  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
+  float acc = 0.f;
+  for (int j = b; j < e; ++j) acc += in[(int64_t)p_row[j] * X + c];
+  float* p = out + (int64_t)seg * X + c;
+  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) *p = accumulate ? *p + acc : acc;
+  else atomicAdd(p, acc);
+}
 }  // namespace
 
 bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
+bool segment_rows_supported(int X) { return X == 1 || X == 2 || segment_sum_supported(X); }
 
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
                        int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0, int nt_in) {
-  HET_REQUIRE(segment_sum_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
+  HET_REQUIRE(segment_rows_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
+  if (X < 4) {
+    HET_REQUIRE(!scale && scatter_rows < 0, "segment sum: rows of fewer than 4 floats take no scale / scatter");
+    if (!accumulate && g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+    if (g->S == 0) return HET_OK;
+    hipLaunchKernelGGL(HET_segment_sum_narrow, dim3((unsigned)ceil_div64(g->num_items * X, kBlock)), dim3(kBlock), 0, s,
+                       g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->num_items, g->p0, X, in, out, accumulate);
+    HET_LAUNCH_CHECK("HET_segment_sum_narrow");
+    return HET_OK;
+  }
   HET_REQUIRE(scale_heads == 0 || scale_heads == X || (X % scale_heads == 0 && (X / scale_heads) % 4 == 0),
               "segment sum: a head must cover whole float4 pieces (or scale_heads == X: one scale per element)");
   // scatter_rows >= 0: out has that many rows and segment s lands in row seg_key[s] (rows without a
@@ -153,6 +182,16 @@ __global__ __launch_bounds__(kBlock) void HET_grouping_seg_of_rank(const int32_t
   }
 }
 
+__global__ __launch_bounds__(kBlock) void HET_segment_broadcast_narrow(const int32_t* __restrict__ seg_of_rank,
+                                                                        const int32_t* __restrict__ p_row, int64_t total, int X,
+                                                                        const float* __restrict__ in, float* __restrict__ out) {
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t j = t / X;
+    const int c = (int)(t - j * X);
+    out[(int64_t)p_row[j] * X + c] = in[(int64_t)seg_of_rank[j] * X + c];
+  }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_segment_broadcast(const int32_t* __restrict__ seg_of_rank,
                                                                  const int32_t* __restrict__ p_row, int64_t E,
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_broadcast(const int32_t* _
 
 int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,
                              int X2, hipStream_t s) {
-  HET_REQUIRE(segment_sum_supported(X) && g->p0 && (!in2 || (out2 && X2 >= 1 && X2 <= X / 4)),
+  HET_REQUIRE(segment_rows_supported(X) && g->p0 && (!in2 || (X >= 4 && out2 && X2 >= 1 && X2 <= X / 4)),
               "segment broadcast: unsupported shape or grouping");
   if (g->S == 0 || g->E == 0) return HET_OK;
   if (!g->seg_of_rank) {  // one-time, cached in the grouping
@@ -204,6 +243,14 @@ int launch_segment_broadcast(const het_grouping* g, const float* in, float* out,
       HET_REQUIRE(false, "HET_grouping_seg_of_rank: launch failed");
     }
     g->seg_of_rank = p;
+  }
+  if (X < 4) {
+    int64_t nbn = ceil_div64(g->E * X, kBlock);
+    if (nbn > 65536) nbn = 65536;
+    hipLaunchKernelGGL(HET_segment_broadcast_narrow, dim3((unsigned)nbn), dim3(kBlock), 0, s, g->seg_of_rank, g->p0, g->E * X, X,
+                       in, out);
+    HET_LAUNCH_CHECK("HET_segment_broadcast_narrow");
+    return HET_OK;
   }
   const int epw = 64 / (X / 4);
   int64_t nb = ceil_div64(g->E, (int64_t)(kBlock / 64) * epw * 4);

@@ -6,6 +6,8 @@
 // scale_heads = H > 0 the scale is per (row, head): scale[g->p1[j] * H + h] for the X/H floats of head h.
 // X floats per row, X/4 a power of two <= 64.  `out` has g->S rows and is fully overwritten.
 bool segment_sum_supported(int X);
+// also rows of 1 or 2 floats (no scale, no scatter, no second pair): the [E,H] attention terms of RGAT with 1 or 2 heads
+bool segment_rows_supported(int X);
 // scatter_rows >= 0: `out` has scatter_rows rows and segment s is written to row seg_key[s] instead of row s.
 // accumulate: add to `out` instead of overwriting it.  The scale index is payload1, or payload0 without one
 // (scale_by_p0: payload0 even when the grouping carries a payload1).  scale_heads == X: one scale per element,

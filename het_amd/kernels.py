@@ -153,7 +153,7 @@ def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, I
     _chk("rgnn_relational_matmul", (weights, node_feat, ret), tuple(t for t in (rp, g, s) if t is not None))
     R, H, K, D = weights.shape
     grp = ws = None
-    if (IntKind == 0 and InputNumHeadOneFlag and D == 1 and H >= 4 and H & (H - 1) == 0 and _plan.enabled and ret.is_cuda
+    if (IntKind == 0 and InputNumHeadOneFlag and D == 1 and H & (H - 1) == 0 and _plan.enabled and ret.is_cuda
             and g.numel() > 0 and g.data_ptr() != s.data_ptr()):
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
         if grp is not None:
@@ -172,7 +172,7 @@ def matmul_attn_dot_only_ok(args_tensor_dict, weights, node_feat) -> bool:
     """Whether the attention term can be formed without materialising the per-edge projection (kind 0 lists)."""
     R, H, K, D = weights.shape
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
-    return (_plan.enabled and node_feat.is_cuda and matmul_attn_dot_ok(H, K, D) and H >= 4 and H & (H - 1) == 0 and H <= H * D // 4
+    return (_plan.enabled and node_feat.is_cuda and matmul_attn_dot_ok(H, K, D) and H & (H - 1) == 0 and H <= H * D // 4
             and g.numel() > 0 and g.data_ptr() != s.data_ptr())
 
 
@@ -235,7 +235,7 @@ def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_fea
     path does not apply (no grouping / shape), leaving the outputs untouched."""
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
     R, H, D, K = weights_transposed.shape
-    if not (_plan.enabled and H >= 4 and H & (H - 1) == 0 and D % 4 == 0 and g.numel() > 0):
+    if not (_plan.enabled and H & (H - 1) == 0 and D % 4 == 0 and g.numel() > 0):
         return False
     grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
     if grp is None:
@@ -510,7 +510,7 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
     g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                 separate_coo_eids, N) if IntKind == 0 else None
     gs = gd = ws = None
-    if IntKind != 0 and _plan.enabled and slope >= 0 and gat_grouped_shape_ok(H, D) and H >= 4 and E > 0:
+    if IntKind != 0 and _plan.enabled and slope >= 0 and gat_grouped_shape_ok(H, D) and E > 0:
         srow = _src_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_eids)
         drow = _dst_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
         gs = _plan.get_grouping(None, srow, feat_src.shape[0], separate_coo_eids, separate_coo_col_indices)

@@ -60,6 +60,14 @@ def test_rgat_layer_mag_like_small():
     _run_rgat(mag_graph(2e-3), H=4, K=64, X=64, compact=False, direct=False, mulfirst=False)
 
 
+@pytest.mark.parametrize("H", [1, 2])
+@pytest.mark.parametrize("compact,mulfirst", [(False, False), (True, False), (False, True), (True, True)])
+def test_rgat_layer_one_and_two_heads(H, compact, mulfirst):
+    """--num_heads 1 is the reference's CLI default (RGAT/train_dgl.py): [E,H] tensors of 1 or 2 floats per row."""
+    _run_rgat(random_graph(seed=44, n=320, r=4, e=5000, shuffle=False), H=H, K=64, X=64, compact=compact, direct=compact,
+              mulfirst=mulfirst)
+
+
 def test_rgat_layer_heads1_feat128():
     _run_rgat(random_graph(seed=43, n=300, r=5, e=4000, shuffle=False), H=1, K=128, X=128, compact=False, direct=False, mulfirst=False)
 

@@ -509,7 +509,7 @@ def test_matmul_with_attn_dot_epilogue(H, Kd, D):
         assert_close(v, u.cpu(), what=name + " (dot only)")
 
 
-@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (8, 128, 4), (4, 32, 8)])
+@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (8, 128, 4), (4, 32, 8), (1, 64, 64), (2, 64, 32)])
 def test_attn_dot_only_without_the_per_edge_projection(H, Kd, D):
     """er[e,h] = <x[dst_e] . W[r,h], attn[r,h,:]> formed on the distinct (relation, node) rows and duplicated as [E,H]
     only, against the two reference-named ops; values and all gradients."""
@@ -548,7 +548,7 @@ def test_rows_add_bias():
         assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("H,D,nrel", [(4, 16, 4), (8, 8, 3), (4, 16, 11)])
+@pytest.mark.parametrize("H,D,nrel", [(4, 16, 4), (8, 8, 3), (4, 16, 11), (1, 64, 4), (2, 32, 4)])
 def test_gat_rank_order_extensions(H, D, nrel):
     """The kind-0 GAT ops with their attention terms in the destination-grouped ("rank") order of the kernels
     (include/het_amd.h: el_sorted / er_sorted of a4, grad_el_sorted of a5, het_grouping_rank_of_position) against the
