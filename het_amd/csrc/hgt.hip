@@ -433,6 +433,55 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_grad_attn_rows(const idx_t* __
   }
 }
 
+// grad_a for any head width: msg[(r,u), h, :] = v[u, h, :] . W[r, h] is formed once per distinct (relation, source) row by
+// the block-diagonal MFMA GEMM, then   grad_a[eid, h] = < gradout[dst, h, :], msg[seg, h, :] >   rank-parallel over the
+// (relation, source) grouping (payload0 = destination, payload1 = edge id): a lane group per edge, UR edges in flight.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_hgt_grad_attn_msg(const int32_t* __restrict__ seg_of_rank,
+                                                                 const int32_t* __restrict__ p_dst,
+                                                                 const int32_t* __restrict__ p_eid, int64_t E,
+                                                                 const float* __restrict__ msg,
+                                                                 const float* __restrict__ gradout,
+                                                                 float* __restrict__ grad_a, int H, int D) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, UG = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t step = (int64_t)gridDim.x * 4 * EPW * UG;
+  for (int64_t base = (int64_t)blockIdx.x * 4 * EPW * UG; base < E; base += step) {
+    int64_t sg[UG], ds[UG], ed[UG];
+    bool ok[UG];
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      const int64_t j = base + (wave * UG + u) * EPW + slot;
+      ok[u] = j < E;
+      const int64_t jc = ok[u] ? j : E - 1;
+      sg[u] = seg_of_rank[jc]; ds[u] = p_dst[jc]; ed[u] = p_eid[jc];
+    }
+    float4 m[UG], g[UG];
+#pragma unroll
+    for (int u = 0; u < UG; ++u) m[u] = ld4(msg + sg[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < UG; ++u) g[u] = ld4(gradout + ds[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+      float t = m[u].x * g[u].x + m[u].y * g[u].y + m[u].z * g[u].z + m[u].w * g[u].w;
+      for (int off = DL >> 1; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      if (ok[u] && (sub & (DL - 1)) == 0) grad_a[ed[u] * H + h] = t;
+    }
+  }
+}
+
+// W[r, h, k, d] = Wt[r, h, d, k]  (the op receives the transposed weight only)
+__global__ __launch_bounds__(kBlock) void HET_hgt_untranspose_w(const float* __restrict__ Wt, float* __restrict__ W, int64_t RH,
+                                                                 int dk, int dout) {
+  const int64_t total = RH * dk * dout;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t rh = t / ((int64_t)dk * dout);
+    const int rem = (int)(t - rh * dk * dout), k = rem / dout, d = rem - k * dout;
+    W[t] = Wt[(rh * dout + d) * dk + k];
+  }
+}
+
 inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
 inline bool rows_shape_ok(int64_t H, int64_t D) {  // X/4 a power of two <= 64, a head = whole float4 pieces
   const int64_t X = H * D;
@@ -572,10 +621,17 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
   if (num_edges == 0) return HET_OK;
   hipStream_t s = (hipStream_t)stream;
   const het_grouping* gr = by_rel_src;
-  if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && dk == dout && (dk == 4 || dk == 8 || dk == 16) &&
+  // grad_a: from the per-(relation, source) message rows when the workspace has room for them (3.2 ms for the op on
+  // ogbn-mag at any head count), else -- narrow heads only -- with the Wt slice of a head in a lane's registers (4.0-4.6 ms)
+  const int64_t ws_rows = (int64_t)sizeof(float) * (gr ? gr->S * H * dout + num_rels * H * dk * dout : 0);
+  const bool msg_rows = gr && workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout + ws_rows;
+  const bool reg_w = !msg_rows && dk == dout && (dk == 4 || dk == 8 || dk == 16);
+  const int64_t ws_msg = msg_rows ? ws_rows : 0;
+  if (!msg_rows && !reg_w) gr = nullptr;  // neither fits: the generic kernels below
+  if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && dk == dout &&
       rows_shape_ok(H, dk) && segment_sum_supported((int)(H * dout)) &&
       mfma_shape_supported((int)(H * dout), (int)(H * dk)) && mfma_dw_supported((int)(H * dk), (int)(H * dout)) && workspace &&
-      workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+      workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout + ws_msg && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(grad_v) & 15) == 0) {
     // gsum[(r,u)] = SUM over the out-edges of u in relation r of a[e,h] * gradout[dst_e,h,:]; then
@@ -592,6 +648,28 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
     w.dw_rel_stride = H * dk * dout; w.headcat = 2; w.headcat_d = (int)dout; w.blockdiag_k = (int)dk;
     w.seg_ptrs = gr->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gr->S; w.K = (int)(H * dk); w.X = (int)(H * dout);
     if (int rc = launch_seg_dw_mfma(w, s)) return rc;
+    if (!reg_w) {  // wide heads (dk = 32, 64, 128: 1 or 2 heads): grad_a from the per-(relation, source) message rows
+      float* msg = gsum + gr->S * H * dout;
+      float* W = msg + gr->S * H * dout;
+      const int64_t wn = num_rels * H * dk * dout;
+      hipLaunchKernelGGL(HET_hgt_untranspose_w, dim3((unsigned)ceil_div64(wn, kBlock)), dim3(kBlock), 0, s, weights_t, W,
+                         num_rels * H, (int)dk, (int)dout);
+      HET_LAUNCH_CHECK("HET_hgt_untranspose_w");
+      MfmaGemmArgs f;
+      f.A = v; f.a_ld = H * dk; f.gather = gr->seg_key64; f.B = W; f.b_rel_stride = H * dk * dout; f.b_headcat = 2;
+      f.headcat_d = (int)dout; f.blockdiag_k = (int)dk; f.C = msg; f.c_ld = H * dout; f.scatter = nullptr;
+      f.seg_ptrs = gr->seg_rel_ptr64; f.num_segs = (int)num_rels; f.num_rows = gr->S; f.K = (int)(H * dk); f.X = (int)(H * dout);
+      if (int rc = launch_seg_gemm_mfma(f, s)) return rc;
+      if (int rc = grouping_seg_of_rank(gr, s)) return rc;
+      const int epw = 64 / (int)(H * dout / 4);
+      int64_t nbm = ceil_div64(num_edges, (int64_t)4 * epw * 4);
+      if (nbm > 256 * 64) nbm = 256 * 64;
+      HET_HGT_LPR((int)(H * dout / 4), hipLaunchKernelGGL(HET_hgt_grad_attn_msg<LPR>, dim3((unsigned)nbm), dim3(kBlock), 0, s,
+                                                          gr->seg_of_rank, gr->p0, gr->p1, num_edges, msg, gradout, grad_a,
+                                                          (int)H, (int)dout));
+      HET_LAUNCH_CHECK("HET_hgt_grad_attn_msg");
+      return HET_OK;
+    }
     int64_t chunk = 4096;
     dim3 grid((unsigned)(ceil_div64(num_edges, chunk) + num_rels)), block(kBlock);
 #define HET_GA(DKV) HET_HGT_LPR((int)(H * dk / 4), hipLaunchKernelGGL((HET_hgt_grad_attn_rows<LPR, DKV>), grid, block, 0, s, \

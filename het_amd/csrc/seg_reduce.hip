@@ -227,23 +227,27 @@ __global__ __launch_bounds__(kBlock) void HET_segment_broadcast(const int32_t* _
 }
 }  // namespace
 
+int grouping_seg_of_rank(const het_grouping* g, hipStream_t s) {
+  if (g->seg_of_rank || g->E == 0) return HET_OK;  // one-time, cached in the grouping
+  int32_t* p = nullptr;
+  HET_HIP(hipMalloc((void**)&p, sizeof(int32_t) * g->E));
+  int64_t nb0 = ceil_div64(g->E, kBlock);
+  hipLaunchKernelGGL(HET_grouping_seg_of_rank, dim3((unsigned)(nb0 > 65536 ? 65536 : nb0)), dim3(kBlock), 0, s, g->seg_ptr,
+                     g->S, g->E, p);
+  if (hipGetLastError() != hipSuccess) {
+    (void)hipFree(p);
+    HET_REQUIRE(false, "HET_grouping_seg_of_rank: launch failed");
+  }
+  g->seg_of_rank = p;
+  return HET_OK;
+}
+
 int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,
                              int X2, hipStream_t s) {
   HET_REQUIRE(segment_rows_supported(X) && g->p0 && (!in2 || (X >= 4 && out2 && X2 >= 1 && X2 <= X / 4)),
               "segment broadcast: unsupported shape or grouping");
   if (g->S == 0 || g->E == 0) return HET_OK;
-  if (!g->seg_of_rank) {  // one-time, cached in the grouping
-    int32_t* p = nullptr;
-    HET_HIP(hipMalloc((void**)&p, sizeof(int32_t) * g->E));
-    int64_t nb0 = ceil_div64(g->E, kBlock);
-    hipLaunchKernelGGL(HET_grouping_seg_of_rank, dim3((unsigned)(nb0 > 65536 ? 65536 : nb0)), dim3(kBlock), 0, s, g->seg_ptr,
-                       g->S, g->E, p);
-    if (hipGetLastError() != hipSuccess) {
-      (void)hipFree(p);
-      HET_REQUIRE(false, "HET_grouping_seg_of_rank: launch failed");
-    }
-    g->seg_of_rank = p;
-  }
+  if (int rc = grouping_seg_of_rank(g, s)) return rc;
   if (X < 4) {
     int64_t nbn = ceil_div64(g->E * X, kBlock);
     if (nbn > 65536) nbn = 65536;

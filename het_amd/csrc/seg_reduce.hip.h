@@ -19,3 +19,6 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
 // out[p0[j], :] = in[s, :] for every sorted rank j of segment s; optionally a second, narrower pair (X2 <= X/4 floats)
 int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,
                              int X2, hipStream_t s);
+
+// g->seg_of_rank ([E]: segment of every sorted rank), built on first use and cached in the grouping
+int grouping_seg_of_rank(const het_grouping* g, hipStream_t s);

@@ -866,7 +866,9 @@ def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo
     R, H, dout, dk = weights_transposed.shape
     g = _plan.get_grouping(separate_coo_relptrs, separate_coo_row_indices, inputs.shape[0], separate_coo_col_indices,
                            separate_coo_eids)
-    ws = None if g is None else torch.empty(max(1, g.num_segments) * H * dout, dtype=torch.float32, device=gradout.device)
+    # segment sums of the gradient; for wide heads also the per-(relation, source) message rows and the untransposed weight
+    ws = None if g is None else torch.empty(2 * max(1, g.num_segments) * H * dout + weights_transposed.numel(),
+                                            dtype=torch.float32, device=gradout.device)
     _call(gradout, "het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo",
           _p(separate_coo_relptrs), _p(separate_coo_eids), _p(separate_coo_row_indices), _p(separate_coo_col_indices),
           R, separate_coo_eids.numel(), new_h.shape[0], _p(inputs), _p(weights_transposed), _p(edge_norm), _p(new_h),

@@ -338,7 +338,9 @@ int het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(
  *   grad_a[eids[i],h]   = < gradout[col[i],h,:] . Wt[r,h], v[row[i],h,:] >            Wt [R,H,dout,dk]
  *   Optional fast paths: by_rel_dst / by_rel_src are the groupings of rgcn_layer1 (by (relation, col) with
  *   payload0 = row, payload1 = eids; by (relation, row) with payload0 = col, payload1 = eids) and a workspace of
- *   num_segments * H * dk (forward) / num_segments * H * dout (backward) floats. */
+ *   num_segments * H * dk (forward) / num_segments * H * dout (backward) floats; heads wider than 16 floats
+ *   (dk = dout = 32, 64, 128: the reference sweep's --num_heads 1) need 2 * num_segments * H * dout + R*H*dk*dout
+ *   in the backward (grad_a is then taken from the per-(relation, source) message rows). */
 int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
     const int64_t* rel_ptrs, const int64_t* eids, const int64_t* row, const int64_t* col, int64_t num_rels,
     int64_t num_edges, int64_t num_nodes, const float* v, const float* weights, const float* a, float* new_h,

@@ -339,7 +339,7 @@ def test_hgt_edge_softmax_fwd_bwd(K, plan_mode, H, dk, hub):
     assert_close(gs, gs_r, what="grad_score"); assert_close(gmu, gmu_r, what="grad_mu")
 
 
-@pytest.mark.parametrize("H,dk", [(8, 8), (4, 16), (2, 6)])
+@pytest.mark.parametrize("H,dk", [(8, 8), (4, 16), (2, 6), (1, 64), (2, 32), (1, 32), (1, 128)])
 def test_hgt_fused_message_fwd_bwd(K, plan_mode, H, dk):
     g = random_graph(seed=62, n=280, r=4, e=4500)
     s = g.get_separate_coo_original()
