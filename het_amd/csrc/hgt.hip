@@ -5,6 +5,7 @@
 #include "edge_view.hip.h"
 #include "seg_gemm.hip.h"
 #include "seg_gemm_mfma.hip.h"
+#include "seg_gemm_any.hip.h"
 #include "seg_reduce.hip.h"
 
 namespace {
@@ -583,7 +584,7 @@ extern "C" int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separa
   HET_REQUIRE(H > 0 && dk > 0 && dout > 0 && (num_edges == 0 || (v && weights && a && new_h)), "%s: null data pointer", op);
   const het_grouping* gr = by_rel_dst;
   if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && rows_shape_ok(H, dk) &&
-      segment_sum_supported((int)(H * dk)) && mfma_shape_supported((int)(H * dk), (int)(H * dout)) && workspace &&
+      segment_sum_supported((int)(H * dk)) && workspace &&
       workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dk && (reinterpret_cast<uintptr_t>(v) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(new_h) & 15) == 0) {
     // new_h[dst] += SUM_r ( SUM_{e in (r,dst)} a[e,h] * v[src_e,h,:] ) . W[r,h]: attention-weighted segment sum of
@@ -595,7 +596,7 @@ extern "C" int het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separa
     m.A = ssum; m.a_ld = H * dk; m.B = weights; m.b_rel_stride = H * dk * dout; m.b_headcat = 2; m.headcat_d = (int)dout;
     m.blockdiag_k = (int)dk; m.C = new_h; m.c_ld = H * dout; m.scatter = gr->seg_key64; m.atomic = 1;
     m.seg_ptrs = gr->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = gr->S; m.K = (int)(H * dk); m.X = (int)(H * dout);
-    return launch_seg_gemm_mfma(m, s);
+    return launch_rows_gemm(m, s);
   }
   SegGemmArgs g;  // new_h[col, h, :] += (v[row, h, :] * a[eid, h]) . W[r, h]
   g.A = v; g.a_ld = H * dk; g.a_head_stride = dk; g.gather = row;
@@ -630,8 +631,7 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
   if (!msg_rows && !reg_w) gr = nullptr;  // neither fits: the generic kernels below
   if (gr && gr->R == (int)num_rels && gr->E == num_edges && gr->p0 && gr->p1 && dk == dout &&
       rows_shape_ok(H, dk) && segment_sum_supported((int)(H * dout)) &&
-      mfma_shape_supported((int)(H * dout), (int)(H * dk)) && mfma_dw_supported((int)(H * dk), (int)(H * dout)) && workspace &&
-      workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout + ws_msg && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * gr->S * H * dout + ws_msg && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(grad_v) & 15) == 0) {
     // gsum[(r,u)] = SUM over the out-edges of u in relation r of a[e,h] * gradout[dst_e,h,:]; then
@@ -642,12 +642,12 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
     m.A = gsum; m.a_ld = H * dout; m.B = weights_t; m.b_rel_stride = H * dout * dk; m.b_headcat = 2; m.headcat_d = (int)dk;
     m.blockdiag_k = (int)dout; m.C = grad_v; m.c_ld = H * dk; m.scatter = gr->seg_key64; m.atomic = 1;
     m.seg_ptrs = gr->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = gr->S; m.K = (int)(H * dout); m.X = (int)(H * dk);
-    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    if (int rc = launch_rows_gemm(m, s)) return rc;
     MfmaDwArgs w;
     w.A = v; w.a_ld = H * dk; w.gather = gr->seg_key64; w.G = gsum; w.g_ld = H * dout; w.dW = grad_w;
     w.dw_rel_stride = H * dk * dout; w.headcat = 2; w.headcat_d = (int)dout; w.blockdiag_k = (int)dk;
     w.seg_ptrs = gr->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gr->S; w.K = (int)(H * dk); w.X = (int)(H * dout);
-    if (int rc = launch_seg_dw_mfma(w, s)) return rc;
+    if (int rc = launch_rows_dw(w, s)) return rc;
     if (!reg_w) {  // wide heads (dk = 32, 64, 128: 1 or 2 heads): grad_a from the per-(relation, source) message rows
       float* msg = gsum + gr->S * H * dout;
       float* W = msg + gr->S * H * dout;
@@ -659,7 +659,7 @@ extern "C" int het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregati
       f.A = v; f.a_ld = H * dk; f.gather = gr->seg_key64; f.B = W; f.b_rel_stride = H * dk * dout; f.b_headcat = 2;
       f.headcat_d = (int)dout; f.blockdiag_k = (int)dk; f.C = msg; f.c_ld = H * dout; f.scatter = nullptr;
       f.seg_ptrs = gr->seg_rel_ptr64; f.num_segs = (int)num_rels; f.num_rows = gr->S; f.K = (int)(H * dk); f.X = (int)(H * dout);
-      if (int rc = launch_seg_gemm_mfma(f, s)) return rc;
+      if (int rc = launch_rows_gemm(f, s)) return rc;
       if (int rc = grouping_seg_of_rank(gr, s)) return rc;
       const int epw = 64 / (int)(H * dout / 4);
       int64_t nbm = ceil_div64(num_edges, (int64_t)4 * epw * 4);

@@ -1,6 +1,7 @@
 // C ABI of the typed linear projections (segment GEMM ops) and the fused RGCN layer.
 #include "seg_gemm.hip.h"
 #include "seg_gemm_mfma.hip.h"
+#include "seg_gemm_any.hip.h"
 #include "seg_rowdot.hip.h"
 #include "seg_reduce.hip.h"
 
@@ -66,6 +67,21 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     m.headcat_d = (int)D; m.blockdiag_k = (int)K; m.C = ret; m.c_ld = H * D; m.scatter = scatter;
     m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * K); m.X = (int)(H * D);
     return launch_seg_gemm_mfma(m, s);
+  }
+  if (in1head && by_rel_gather && kind == HET_KIND_DISABLED && by_rel_gather->R == (int)num_rels &&
+      by_rel_gather->E == num_rows && by_rel_gather->p0 && by_rel_gather->S > 0 && segment_rows_supported((int)(H * D)) &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * by_rel_gather->S * H * D &&
+      ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ret)) & 15) == 0) {
+    // a shape the matrix-core kernel does not take (an 8- or 16-wide output layer): still project only the S distinct
+    // (relation, x row) rows and duplicate them, instead of one generic-kernel GEMM row per position
+    const het_grouping* g = by_rel_gather;
+    float* comp = static_cast<float*>(workspace);
+    MfmaGemmArgs m;
+    m.A = x; m.a_ld = K; m.gather = g->seg_key64; m.B = weights; m.b_rel_stride = H * K * D; m.b_headcat = 1;
+    m.headcat_d = (int)D; m.C = comp; m.c_ld = H * D; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels;
+    m.num_rows = g->S; m.K = (int)K; m.X = (int)(H * D);
+    if (int rc = launch_rows_gemm(m, s)) return rc;
+    return launch_segment_broadcast(g, comp, ret, (int)(H * D), nullptr, nullptr, 0, s);
   }
   SegGemmArgs a;
   a.A = x; a.gather = gather_idx; a.B = weights; a.C = ret; a.scatter = scatter;
@@ -293,7 +309,6 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     return launch_seg_dw_mfma(w, s);
   }
   if (in1head && g && kind == HET_KIND_DISABLED && g->R == (int)num_rels && g->E == num_rows && g->p0 &&
-      mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
       segment_sum_supported((int)(H * D)) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * H * D &&
       (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
     // Rows that share (relation, gather_idx) share x row and weight: by linearity sum their gradout rows
@@ -304,12 +319,12 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     m.A = gsum; m.a_ld = H * D; m.B = weights_t; m.b_rel_stride = H * D * K;
     m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64; m.atomic = 1;
     m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)(H * D); m.X = (int)K;
-    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    if (int rc = launch_rows_gemm(m, s)) return rc;  // matrix cores for their shapes, LDS-tiled FMA otherwise
     MfmaDwArgs w;
     w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = gsum; w.g_ld = H * D;
     w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
     w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S; w.K = (int)K; w.X = (int)(H * D);
-    return launch_seg_dw_mfma(w, s);
+    return launch_rows_dw(w, s);
   }
   if (in1head && mfma_shape_supported((int)(H * D), (int)K) && mfma_dw_supported((int)K, (int)(H * D)) &&
       (reinterpret_cast<uintptr_t>(gradout) & 15) == 0) {
@@ -453,7 +468,7 @@ extern "C" int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64
   HET_REQUIRE(rel_ptrs && (num_edges == 0 || (eids && row && col && x && weights && norm && ret)), "%s: null pointer", op);
   const het_grouping* g = by_rel_dst;
   if (g && g->R == (int)num_rels && g->E == num_edges && g->p0 && g->p1 && segment_sum_supported((int)K) &&
-      mfma_shape_supported((int)K, (int)D) && workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * K &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * K &&
       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(ret) & 15) == 0) {
     // Edges that share (relation, destination) share weight and output row: sum their scaled source rows first
@@ -464,7 +479,7 @@ extern "C" int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64
     MfmaGemmArgs m;
     m.A = ssum; m.a_ld = K; m.B = weights; m.b_rel_stride = K * D; m.C = ret; m.c_ld = D; m.scatter = g->seg_key64;
     m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)K; m.X = (int)D;
-    return launch_seg_gemm_mfma(m, s);
+    return launch_rows_gemm(m, s);
   }
   SegGemmArgs a;
   a.A = x; a.a_ld = K; a.gather = row; a.row_scale = norm; a.scale_idx = eids;
@@ -488,8 +503,7 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
   hipStream_t s = (hipStream_t)stream;
   const het_grouping* g = by_rel_src;
   if (g && g->R == (int)num_rels && g->E == num_edges && g->p0 && g->p1 && segment_sum_supported((int)D) &&
-      mfma_shape_supported((int)D, (int)K) && mfma_dw_supported((int)K, (int)D) && workspace &&
-      workspace_bytes >= (int64_t)sizeof(float) * g->S * D && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * g->S * D && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
     // gsum[(r,u)] = SUM over the out-edges of u in relation r of norm * gradout[dst]; then
     //   grad_x[u] += gsum[(r,u)] . Wt[r]      and      grad_w[r] += x[u]^T (x) gsum[(r,u)]
@@ -498,11 +512,11 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
     MfmaGemmArgs m;
     m.A = gsum; m.a_ld = D; m.B = weights_t; m.b_rel_stride = D * K; m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64;
     m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)D; m.X = (int)K;
-    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    if (int rc = launch_rows_gemm(m, s)) return rc;
     MfmaDwArgs w;
     w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = gsum; w.g_ld = D; w.dW = grad_w; w.dw_rel_stride = K * D;
     w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S; w.K = (int)K; w.X = (int)D;
-    return launch_seg_dw_mfma(w, s);
+    return launch_rows_dw(w, s);
   }
   SegGemmArgs a;  // grad_x[row] += (gradout[col] * norm) . Wt[r]
   a.A = gradout; a.a_ld = D; a.gather = col; a.row_scale = norm; a.scale_idx = eids;

@@ -153,11 +153,15 @@ def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, I
     _chk("rgnn_relational_matmul", (weights, node_feat, ret), tuple(t for t in (rp, g, s) if t is not None))
     R, H, K, D = weights.shape
     grp = ws = None
-    if (IntKind == 0 and InputNumHeadOneFlag and D == 1 and H & (H - 1) == 0 and _plan.enabled and ret.is_cuda
-            and g.numel() > 0 and g.data_ptr() != s.data_ptr()):
+    X = H * D
+    mfma = K in (32, 64, 128) and X in (32, 64, 128)
+    # distinct (relation, node) rows + broadcast: the row-dot shape (D == 1), and projections the matrix-core kernel does
+    # not take (e.g. an 8-wide output layer)
+    if (IntKind == 0 and InputNumHeadOneFlag and ((D == 1 and H & (H - 1) == 0) or (D > 1 and not mfma and X & (X - 1) == 0 and X <= 256))
+            and _plan.enabled and ret.is_cuda and g.numel() > 0 and g.data_ptr() != s.data_ptr()):
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
         if grp is not None:
-            ws = torch.empty(max(1, grp.num_segments) * H, dtype=torch.float32, device=ret.device)
+            ws = torch.empty(max(1, grp.num_segments) * X, dtype=torch.float32, device=ret.device)
     _call(ret, "het_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(), _p(weights), _p(node_feat),
           _p(ret), H, K, D, int(InputNumHeadOneFlag), None if grp is None else grp.handle, _p(ws),
           0 if ws is None else ws.numel() * 4, _stream(ret))
