@@ -12,6 +12,7 @@ synthetic graph of the same shape (het_amd/synth.py) or ``--edges_npy`` a ``[3, 
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import sys
 import time
@@ -143,7 +144,7 @@ def aggregate_times(ms):
 def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=(), batches=None):
     """``batches``: None for full-graph training, else a callable returning (blocks, seeds) per step -- the sampled
     mini-batch path (het_amd/sampling.py); sampling + per-batch layout building is timed separately."""
-    from .sampling import run_blocks
+    from .sampling import one_shot_graphs, run_blocks
     prep_ms = []
 
     def one_step(timed):
@@ -160,14 +161,15 @@ def HET_RGNN_train(g, model, node_embed_layer, optimizer, labels, args, extra=()
         th.cuda.synchronize()
         ev = [th.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        if batches is None:
-            logits = model(g, node_embed, *extra)
-        else:
-            logits = run_blocks(model.layers, blocks, node_embed, extra[0] if extra else None)
-        ev[1].record()
-        loss = F.nll_loss(logits.log_softmax(dim=-1), cur_labels)
-        ev[2].record()
-        loss.backward()
+        with (one_shot_graphs(blocks) if batches is not None else contextlib.nullcontext()):
+            if batches is None:
+                logits = model(g, node_embed, *extra)
+            else:
+                logits = run_blocks(model.layers, blocks, node_embed, extra[0] if extra else None)
+            ev[1].record()
+            loss = F.nll_loss(logits.log_softmax(dim=-1), cur_labels)
+            ev[2].record()
+            loss.backward()
         optimizer.step()  # the reference times the optimizer inside "backward" (RGNNUtils.py:304-311)
         ev[3].record()
         th.cuda.synchronize()
