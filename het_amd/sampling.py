@@ -34,11 +34,14 @@ class NeighborSampler:
     """Uniform in-neighbour sampling without replacement, ``fanouts[l]`` edges per destination for layer l
     (-1 or 0: all in-edges), as dgl.dataloading.MultiLayerNeighborSampler does for the reference."""
 
-    def __init__(self, g: HetGraph, fanouts: List[int], seed: int = 0):
+    def __init__(self, g: HetGraph, fanouts: List[int], seed: int = 0, full_layouts: bool = True):
         t = g.get_in_csr()  # rows = destinations, col_indices = sources
         self.ptr, self.src, self.rel, self.eid = t["row_ptrs"], t["col_indices"], t["rel_types"], t["eids"]
         self.num_nodes, self.num_rels = g.get_num_nodes(), g.get_num_rels()
         self.fanouts = list(fanouts)
+        # full_layouts False: blocks get the separate COO only (all the default-flag RGAT / RGCN layers read); True adds the
+        # CSRs and the unique (relation, node) lists of the compact flags and the CSR ops
+        self.full_layouts = full_layouts
         self.dev = self.ptr.device
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(seed)
@@ -75,7 +78,7 @@ class NeighborSampler:
                             m[src_g][o].contiguous(), owner[o].contiguous(), rel[o].contiguous(),
                             torch.arange(pos.numel(), device=self.dev))
         m[nodes] = -1  # reset the scratch map
-        return Block(HetGraph.from_integrated_coo(coo, full=True), nodes, B, self.eid[pos][o].contiguous())
+        return Block(HetGraph.from_integrated_coo(coo, full=self.full_layouts), nodes, B, self.eid[pos][o].contiguous())
 
     def sample_blocks(self, seeds: torch.Tensor) -> List[Block]:
         """Blocks in layer order (first layer first); blocks[-1].nodes[:num_dst] == seeds and

@@ -230,7 +230,8 @@ def main(argv=None):
     if not args.full_graph_training:  # sampled blocks, one batch of --batch_size seeds per step ("epoch" = one step here)
         from .sampling import NeighborSampler
         fan = list(args.fanout)[: args.num_layers] + [args.fanout[-1]] * max(0, args.num_layers - len(args.fanout))
-        sampler = NeighborSampler(g, fan, seed=args.seed)
+        sampler = NeighborSampler(g, fan, seed=args.seed,
+                                  full_layouts=bool(args.compact_as_of_node_flag) or not args.gat_edge_parallel_flag)
         gen = th.Generator(device=dev)
         gen.manual_seed(args.seed)
 
