@@ -33,6 +33,22 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
   HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const idx_t* scatter = kind == HET_KIND_ENABLED ? nullptr : scatter_idx;
+  if (in1head && by_rel_gather && kind == HET_KIND_DISABLED && by_rel_gather->R == (int)num_rels &&
+      by_rel_gather->E == num_rows && by_rel_gather->p0 && by_rel_gather->S > 0 && D > 1 && segment_rows_supported((int)(H * D)) &&
+      workspace && workspace_bytes >= (int64_t)sizeof(float) * by_rel_gather->S * H * D &&
+      ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ret)) & 15) == 0) {
+    // the caller passed the (relation, x row) grouping (het_amd.kernels does for shapes outside the 32..128 MFMA tiles: an
+    // 8- or 16-wide output layer, 256-wide features): project only the S distinct rows and duplicate them, instead of
+    // one GEMM row per position
+    const het_grouping* g = by_rel_gather;
+    float* comp = static_cast<float*>(workspace);
+    MfmaGemmArgs m;
+    m.A = x; m.a_ld = K; m.gather = g->seg_key64; m.B = weights; m.b_rel_stride = H * K * D; m.b_headcat = 1;
+    m.headcat_d = (int)D; m.C = comp; m.c_ld = H * D; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels;
+    m.num_rows = g->S; m.K = (int)K; m.X = (int)(H * D);
+    if (int rc = launch_rows_gemm(m, s)) return rc;
+    return launch_segment_broadcast(g, comp, ret, (int)(H * D), nullptr, nullptr, 0, s);
+  }
   if (in1head && mfma_fwd_supported((int)K, (int)(H * D)) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
     return launch_seg_gemm_mfma_fwd(x, K, gather_idx, weights, H * K * D, (int)H, (int)D, ret, H * D, scatter, rel_ptrs,
                                     (int)num_rels, num_rows, (int)K, s);
@@ -67,21 +83,6 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
     m.headcat_d = (int)D; m.blockdiag_k = (int)K; m.C = ret; m.c_ld = H * D; m.scatter = scatter;
     m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * K); m.X = (int)(H * D);
     return launch_seg_gemm_mfma(m, s);
-  }
-  if (in1head && by_rel_gather && kind == HET_KIND_DISABLED && by_rel_gather->R == (int)num_rels &&
-      by_rel_gather->E == num_rows && by_rel_gather->p0 && by_rel_gather->S > 0 && segment_rows_supported((int)(H * D)) &&
-      workspace && workspace_bytes >= (int64_t)sizeof(float) * by_rel_gather->S * H * D &&
-      ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(ret)) & 15) == 0) {
-    // a shape the matrix-core kernel does not take (an 8- or 16-wide output layer): still project only the S distinct
-    // (relation, x row) rows and duplicate them, instead of one generic-kernel GEMM row per position
-    const het_grouping* g = by_rel_gather;
-    float* comp = static_cast<float*>(workspace);
-    MfmaGemmArgs m;
-    m.A = x; m.a_ld = K; m.gather = g->seg_key64; m.B = weights; m.b_rel_stride = H * K * D; m.b_headcat = 1;
-    m.headcat_d = (int)D; m.C = comp; m.c_ld = H * D; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels;
-    m.num_rows = g->S; m.K = (int)K; m.X = (int)(H * D);
-    if (int rc = launch_rows_gemm(m, s)) return rc;
-    return launch_segment_broadcast(g, comp, ret, (int)(H * D), nullptr, nullptr, 0, s);
   }
   SegGemmArgs a;
   a.A = x; a.gather = gather_idx; a.B = weights; a.C = ret; a.scatter = scatter;

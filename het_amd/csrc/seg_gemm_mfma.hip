@@ -43,16 +43,18 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
   float* Bs = smem;                                           // [K][X] (unused when B_REGS)
   float* Ws = smem + (B_REGS ? 0 : K * X) + wave * WREG;      // wave-private: A tile [32][LDA], then C tile [32][LDC]
   const float* __restrict__ Bm = a.B + (int64_t)r * a.b_rel_stride;
-  auto b_elem = [&](int k, int n) -> float {
+  const int KF = a.b_kfull ? a.b_kfull : K, XF = a.b_xfull ? a.b_xfull : X;  // the weight's full size (see b_k0 / b_n0)
+  auto b_elem = [&](int kw, int nw) -> float {
+    const int k = kw + a.b_k0, n = nw + a.b_n0;
     if (a.b_headcat == 1) {
       const int Dh = a.headcat_d, h = n / Dh, d = n - h * Dh;
-      return Bm[(int64_t)h * K * Dh + (int64_t)k * Dh + d];
+      return Bm[(int64_t)h * KF * Dh + (int64_t)k * Dh + d];
     }
     if (a.b_headcat == 2) {  // block diagonal: per-head [Kh x Dh] blocks, A and C rows are [H*Kh] / [H*Dh]
       const int Dh = a.headcat_d, Kh = a.blockdiag_k, hk = k / Kh, hn = n / Dh;
       return hk == hn ? Bm[((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (n - hn * Dh)] : 0.f;
     }
-    return Bm[k * X + n];
+    return Bm[(int64_t)k * XF + n];
   };
   float breg[B_REGS ? KH * NT : 1];
   if (B_REGS) {
@@ -398,12 +400,34 @@ int launch_k(const MfmaGemmArgs& a, hipStream_t s) {
 }  // namespace
 
 bool mfma_shape_supported(int K, int X) {
-  return (K == 32 || K == 64 || K == 128) && (X == 32 || X == 64 || X == 128);
+  return (K == 32 || K == 64 || K == 128 || K == 256) && (X == 32 || X == 64 || X == 128 || X == 256);
 }
 
 int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   HET_REQUIRE(mfma_shape_supported(a.K, a.X), "segment GEMM (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
+  if (a.K > 128 || a.X > 128) {
+    // 256-wide sides as 128-wide slabs of the weight (one launch each; K slabs after the first add atomically)
+    HET_REQUIRE(!a.dot_w && !a.b_k0 && !a.b_n0, "segment GEMM (MFMA): the dot epilogue needs X <= 128");
+    for (int n0 = 0; n0 < a.X; n0 += 128) {
+      bool first = true;  // the first window of a column slab stores (unless the caller accumulates), the others add
+      for (int k0 = 0; k0 < a.K; k0 += 128) {
+        MfmaGemmArgs w = a;
+        w.K = a.K - k0 < 128 ? a.K - k0 : 128;
+        w.X = a.X - n0 < 128 ? a.X - n0 : 128;
+        if (a.b_headcat == 2) {  // block diagonal: a window that no head's block touches is all zeros
+          const int Kh = a.blockdiag_k, Dh = a.headcat_d;
+          if ((k0 + w.K - 1) / Kh < n0 / Dh || k0 / Kh > (n0 + w.X - 1) / Dh) continue;
+        }
+        w.A = a.A + k0; w.C = a.C + n0;
+        w.b_k0 = k0; w.b_n0 = n0; w.b_kfull = a.K; w.b_xfull = a.X;
+        w.atomic = a.atomic || !first;
+        first = false;
+        if (int rc = launch_seg_gemm_mfma(w, s)) return rc;
+      }
+    }
+    return HET_OK;
+  }
   HET_REQUIRE(a.a_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "segment GEMM (MFMA): A rows must be 16-byte aligned");
   HET_REQUIRE(a.c_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0, "segment GEMM (MFMA): C rows must be 16-byte aligned");
   HET_REQUIRE(!a.row_scale, "segment GEMM (MFMA): row scales are applied by the segment-sum pre-pass, not here");
@@ -420,7 +444,9 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   }
 }
 
-bool mfma_dw_supported(int K, int X) { return (K == 32 || K == 64 || K == 128) && (X == 32 || X == 64 || X == 128); }
+bool mfma_dw_supported(int K, int X) {
+  return (K == 32 || K == 64 || K == 128 || K == 256) && (X == 32 || X == 64 || X == 128 || X == 256);
+}
 
 int launch_seg_dw_mfma(const MfmaDwArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;

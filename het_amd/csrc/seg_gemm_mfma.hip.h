@@ -13,6 +13,9 @@ struct MfmaGemmArgs {
   int64_t b_rel_stride = 0;
   int b_headcat = 0, headcat_d = 1;  // 0 plain [K][X]; 1 head-concatenated [Hc][K][Dh]; 2 block diagonal [H][Kh][Dh]
   int blockdiag_k = 1;               // Kh for layout 2
+  // a launch may cover a K x X window of a larger weight (K or X = 256 are run as 128-wide slabs by the launcher):
+  // window origin and the full sizes the layouts above are indexed with (0 = the launch's own K / X)
+  int b_k0 = 0, b_n0 = 0, b_kfull = 0, b_xfull = 0;
   float* C = nullptr;             // [*, X]
   int64_t c_ld = 0;
   const idx_t* scatter = nullptr; // NULL: identity

@@ -255,7 +255,8 @@ def test_rgat_mulfirst_op_by_op_and_heads8(compact, monkeypatch):
     _run_rgat(g, H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=True)
 
 
-@pytest.mark.parametrize("H,K,X,compact", [(4, 128, 128, False), (8, 64, 64, False), (8, 32, 128, True), (16, 64, 64, True)])
+@pytest.mark.parametrize("H,K,X,compact", [(4, 128, 128, False), (8, 64, 64, False), (8, 32, 128, True), (16, 64, 64, True),
+                                           (4, 256, 256, False), (4, 256, 256, True), (1, 64, 8, False), (2, 64, 16, True)])
 def test_rgat_layer_other_shapes_single_node(H, K, X, compact):
     """feat = 128 (BASELINE.json configs[4]), 8 and 16 heads, K != X: the single-node layer on its other shapes."""
     _run_rgat(random_graph(seed=48, n=260, r=3, e=4000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,

@@ -47,6 +47,9 @@ SHAPES = [  # (H, K, D, in1head)
     (4, 128, 32, True),   # feat = 128 (BASELINE.json configs[4]): K = X = 128, dW in 64-wide blocks
     (1, 128, 64, True),
     (2, 32, 64, True),    # X = 128 from K = 32
+    (4, 256, 64, True),   # K = X = 256: 128-wide slabs of the weight
+    (1, 256, 32, True),   # K = 256 only
+    (2, 64, 128, True),   # X = 256 only
 ]
 
 
