@@ -1,5 +1,5 @@
 // Row GEMM / weight-gradient launchers that take the MFMA argument structs and pick the kernel: the matrix-core kernels
-// for their shapes (K, X in {32, 64, 128}), else the LDS-tiled FMA kernels of seg_gemm.hip with the same semantics.
+// for their shapes (K, X in {32, 64, 128, 256}), else the LDS-tiled FMA kernels of seg_gemm.hip with the same semantics.
 // The grouped dataflows (segment sum -> GEMMs on the S distinct rows, distinct rows -> broadcast) are worth far more
 // than the choice of GEMM kernel, so small or odd feature widths (an 8- or 16-wide output layer: the reference CLI's
 // default --num_classes 8) keep them.

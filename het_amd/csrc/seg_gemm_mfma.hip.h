@@ -1,5 +1,5 @@
 // fp32 MFMA (v_mfma_f32_32x32x2_f32) segment GEMM for the feature-width shapes
-// (K, X in {32, 64, 128}); everything else goes through seg_gemm.hip.
+// (K, X in {32, 64, 128}; 256 as 128-wide slabs of the weight); everything else goes through seg_gemm.hip.
 #pragma once
 #include "common.hip.h"
 
