@@ -101,7 +101,7 @@ def test_rgcn_layer(compact, direct, K, D, R):
 
 @pytest.mark.parametrize("fused_attn,compact,direct", [(False, False, False), (True, False, False), (False, True, False),
                                                        (False, True, True)])
-@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8), (1, 64, 64), (2, 64, 64)])
+@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8), (1, 64, 64), (2, 64, 64), (4, 256, 256), (1, 64, 8)])
 def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
     """HGT layer (BASELINE.json configs[3]: feat 64, heads 8) against the plain-PyTorch fp64 oracle."""
     from het_amd.graph import HetGraph
