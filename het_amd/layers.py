@@ -256,11 +256,15 @@ class HET_HGTLayerHetero(nn.Module):
         for p in (self.relation_att, self.relation_msg, self.k_linears, self.q_linears, self.v_linears, self.a_linears):
             nn.init.xavier_uniform_(p)
 
-    def forward(self, G, h):
+    def forward(self, G, h, num_dst=None):
+        """``num_dst``: ``G`` is a sampled block whose first ``num_dst`` nodes are its destinations (only their rows are
+        returned); its nodes are runs of equal type (``node_segment_types``, het_amd/sampling.py) instead of one run per type."""
         offs = G.get_original_node_type_offsets()
-        k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.k_linears, h).view(-1, self.num_heads, self.d_k)
-        q = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.q_linears, h).view(-1, self.num_heads, self.d_k)
-        v = B.rgnn_relational_matmul_no_scatter_gather_list(offs, self.v_linears, h).view(-1, self.num_heads, self.d_k)
+        seg_types = G.graph_data["original"].get("node_segment_types") if hasattr(G, "graph_data") else None
+        per_run = (lambda w: w) if seg_types is None else (lambda w: w.index_select(0, seg_types))
+        k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.k_linears), h).view(-1, self.num_heads, self.d_k)
+        q = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.q_linears), h).view(-1, self.num_heads, self.d_k)
+        v = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.v_linears), h).view(-1, self.num_heads, self.d_k)
         # The per-edge tensor q[dst] . relation_att[r] of the default flags (models.py:215-241) is read by the inner
         # product only and its rows repeat for every edge of a (relation, destination) pair: when the graph carries the
         # unique (relation, node) lists it is formed on those rows and indexed directly -- the reference's compact
@@ -284,5 +288,6 @@ class HET_HGTLayerHetero(nn.Module):
             attn_score = B.rgnn_inner_product_right_node(G, per_edge, k, 0, "_col")
         new_h = B.hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(
             self.relation_msg, v, G, (self.relation_pri / self.sqrt_dk), attn_score)
-        return B.rgnn_relational_matmul_no_scatter_gather_list(
-            offs, (th.sigmoid(self.skip) * self.a_linears), new_h.view(-1, self.out_dim))
+        out = B.rgnn_relational_matmul_no_scatter_gather_list(
+            offs, per_run(th.sigmoid(self.skip) * self.a_linears), new_h.view(-1, self.out_dim))
+        return out if num_dst is None else out[:num_dst]

@@ -7,8 +7,10 @@ CPU (hrt/python/utils/mydglgraph_converters.py:18-71).  Here both steps run on t
 on the block (the native builders of layouts.hip), so that the same ops and layers run on the block unchanged.
 
 A block follows DGL's convention: its destination nodes are the first ``num_dst`` of its nodes; a layer's output rows
-``[:num_dst]`` are the inputs of the next block.  (RGAT / RGCN layers; HGT needs type-contiguous node ids, which a
-block does not have.)
+``[:num_dst]`` are the inputs of the next block.  HGT's per-node-type linears need runs of equal node type: with
+``by_type=True`` the seeds are ordered by type and every block's nodes are a few type-sorted runs
+(``node_type_offsets`` of the block = the run boundaries, ``node_segment_types`` = the type of every run), over which the
+layer indexes its per-type weights.
 """
 from __future__ import annotations
 
@@ -28,13 +30,14 @@ class Block:
     nodes: torch.Tensor        # [num_nodes] global id of every local node; the first num_dst are the destinations
     num_dst: int
     edge_ids: torch.Tensor     # [E_block] global edge id of every block edge, in the block's separate-COO order
+    runs: Optional[tuple] = None  # by_type: (types [n_runs], offsets [n_runs + 1]) of the type-sorted runs of `nodes`
 
 
 class NeighborSampler:
     """Uniform in-neighbour sampling without replacement, ``fanouts[l]`` edges per destination for layer l
     (-1 or 0: all in-edges), as dgl.dataloading.MultiLayerNeighborSampler does for the reference."""
 
-    def __init__(self, g: HetGraph, fanouts: List[int], seed: int = 0, full_layouts: bool = True):
+    def __init__(self, g: HetGraph, fanouts: List[int], seed: int = 0, full_layouts: bool = True, by_type: bool = False):
         t = g.get_in_csr()  # rows = destinations, col_indices = sources
         self.ptr, self.src, self.rel, self.eid = t["row_ptrs"], t["col_indices"], t["rel_types"], t["eids"]
         self.num_nodes, self.num_rels = g.get_num_nodes(), g.get_num_rels()
@@ -46,6 +49,13 @@ class NeighborSampler:
         self.gen = torch.Generator(device=self.dev)
         self.gen.manual_seed(seed)
         self._map = torch.full((self.num_nodes,), -1, dtype=torch.int64, device=self.dev)
+        self.by_type = by_type
+        self.type_offsets = g.get_original_node_type_offsets().to(self.dev)  # node ids are type-contiguous in the full graph
+        self.num_types = int(self.type_offsets.numel() - 1)
+
+    def _type_counts(self, nodes: torch.Tensor) -> torch.Tensor:
+        t = torch.searchsorted(self.type_offsets[1:].contiguous(), nodes, right=True).clamp(max=self.num_types - 1)
+        return torch.bincount(t, minlength=self.num_types)
 
     def _sample_in_edges(self, dst: torch.Tensor, fanout: int):
         deg = self.ptr[dst + 1] - self.ptr[dst]
@@ -63,7 +73,8 @@ class NeighborSampler:
             pos, owner = pos[keep], owner[keep]
         return pos, owner
 
-    def sample_block(self, dst: torch.Tensor, fanout: int) -> Block:
+    def sample_block(self, dst: torch.Tensor, fanout: int, dst_runs=None) -> Block:
+        """``dst_runs`` (by_type): (types [n_runs], offsets [n_runs + 1]) of the type-sorted runs ``dst`` consists of."""
         pos, owner = self._sample_in_edges(dst, fanout)
         src_g = self.src[pos]
         B = dst.numel()
@@ -74,21 +85,35 @@ class NeighborSampler:
         nodes = torch.cat([dst, extra])
         rel = self.rel[pos]
         o = torch.sort(rel, stable=True).indices  # relation-major, as the integrated COO of a graph is stored
-        coo = IntegratedCOO(int(nodes.numel()), self.num_rels, torch.tensor([0, int(nodes.numel())], device=self.dev),
+        runs = None
+        if dst_runs is not None:  # `extra` is sorted by global id, i.e. by type: one more run per type
+            types = torch.cat([dst_runs[0], torch.arange(self.num_types, device=self.dev)])
+            offs = torch.cat([dst_runs[1], B + torch.cumsum(self._type_counts(extra), 0)])
+            runs = (types, offs)
+        node_offs = torch.tensor([0, int(nodes.numel())], device=self.dev) if runs is None else runs[1]
+        coo = IntegratedCOO(int(nodes.numel()), self.num_rels, node_offs,
                             m[src_g][o].contiguous(), owner[o].contiguous(), rel[o].contiguous(),
                             torch.arange(pos.numel(), device=self.dev))
         m[nodes] = -1  # reset the scratch map
-        return Block(HetGraph.from_integrated_coo(coo, full=self.full_layouts), nodes, B, self.eid[pos][o].contiguous())
+        g = HetGraph.from_integrated_coo(coo, full=self.full_layouts)
+        if runs is not None:
+            g.graph_data["original"]["node_segment_types"] = runs[0]
+        return Block(g, nodes, B, self.eid[pos][o].contiguous(), runs)
 
     def sample_blocks(self, seeds: torch.Tensor) -> List[Block]:
-        """Blocks in layer order (first layer first); blocks[-1].nodes[:num_dst] == seeds and
-        blocks[l].nodes[:blocks[l].num_dst] == blocks[l+1].nodes."""
+        """Blocks in layer order (first layer first); blocks[-1].nodes[:num_dst] == seeds (by_type: the seeds ordered by
+        node type -- read them back from there) and blocks[l].nodes[:blocks[l].num_dst] == blocks[l+1].nodes."""
         blocks: List[Block] = []
-        dst = seeds
+        dst, runs = seeds, None
+        if self.by_type:
+            t = torch.searchsorted(self.type_offsets[1:].contiguous(), seeds, right=True).clamp(max=self.num_types - 1)
+            dst = seeds[torch.sort(t, stable=True).indices]
+            z = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            runs = (torch.arange(self.num_types, device=self.dev), torch.cat([z, torch.cumsum(self._type_counts(dst), 0)]))
         for fanout in reversed(self.fanouts):
-            b = self.sample_block(dst, fanout)
+            b = self.sample_block(dst, fanout, runs)
             blocks.insert(0, b)
-            dst = b.nodes
+            dst, runs = b.nodes, b.runs
         return blocks
 
 

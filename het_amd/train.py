@@ -193,8 +193,6 @@ def main(argv=None):
     p = argparse.ArgumentParser(description="HET RGAT / RGCN / HGT benchmark driver on het_amd (MI355X)")
     add_generic_RGNN_args(p, "het_amd_train.json")
     args = p.parse_args(argv)
-    if not args.full_graph_training and args.model == "hgt":
-        raise SystemExit("mini-batch blocks have no type-contiguous node ids: HGT runs with --full_graph_training only")
     dev = th.device("cuda")
     th.manual_seed(args.seed)
     coo = load_graph(args)
@@ -231,13 +229,15 @@ def main(argv=None):
         from .sampling import NeighborSampler
         fan = list(args.fanout)[: args.num_layers] + [args.fanout[-1]] * max(0, args.num_layers - len(args.fanout))
         sampler = NeighborSampler(g, fan, seed=args.seed,
-                                  full_layouts=bool(args.compact_as_of_node_flag) or not args.gat_edge_parallel_flag)
+                                  full_layouts=bool(args.compact_as_of_node_flag) or not args.gat_edge_parallel_flag
+                                  or args.model == "hgt", by_type=args.model == "hgt")
         gen = th.Generator(device=dev)
         gen.manual_seed(args.seed)
 
         def batches():
             seeds = th.randperm(N, device=dev, generator=gen)[: args.batch_size]
-            return sampler.sample_blocks(seeds), seeds
+            blocks = sampler.sample_blocks(seeds)
+            return blocks, blocks[-1].nodes[: blocks[-1].num_dst]  # the seeds in block order (by node type for HGT)
     fwd, bwd, losses = HET_RGNN_train(g, model, embed, optimizer, labels, args, extra, batches)
     res = {"model": args.model, "dataset": args.edges_npy or args.dataset, "num_nodes": N, "num_edges": E, "num_rels": R,
            "mean_forward_ms": round(aggregate_times(fwd), 4), "mean_backward_ms": round(aggregate_times(bwd), 4),
