@@ -84,14 +84,23 @@ def hgt_layer(h, node_type_offsets, rel_ptrs, row, col, num_nodes, k_lin, q_lin,
     q = typed_linear(h, q_lin).view(-1, H, dk)
     v = typed_linear(h, v_lin).view(-1, H, dk)
     rel = rel_of_position(rel_ptrs)
+    R = rel_ptrs.numel() - 1
+
+    def per_relation(x_rows, W):  # [E,H,dk] rows times the [H,dk,dk] matrix of each row's relation (relation-bucketed rows)
+        parts = []
+        for r in range(R):
+            a, b = int(rel_ptrs[r]), int(rel_ptrs[r + 1])
+            parts.append(torch.einsum("nhk,hkd->nhd", x_rows[a:b], W[r]))
+        return torch.cat(parts)
+
     if fused_attn:
-        s = (torch.einsum("nhk,nhkd->nhd", k[row], rel_att[rel]) * q[col]).sum(-1)
+        s = (per_relation(k[row], rel_att) * q[col]).sum(-1)
     else:
-        s = (torch.einsum("nhk,nhkd->nhd", q[col], rel_att[rel]) * k[row]).sum(-1)
+        s = (per_relation(q[col], rel_att) * k[row]).sum(-1)
     mu = (rel_pri / (dk ** 0.5))[rel]
     m = torch.exp(s * mu)
-    den = torch.zeros(num_nodes, H, dtype=h.dtype).index_add(0, col, m)
+    den = torch.zeros(num_nodes, H, dtype=h.dtype, device=h.device).index_add(0, col, m)
     a = m / den[col]
-    msg = torch.einsum("nhk,nhkd->nhd", v[row] * a.unsqueeze(-1), rel_msg[rel])
-    new_h = torch.zeros(num_nodes, H, dk, dtype=h.dtype).index_add(0, col, msg).view(num_nodes, out_dim)
+    msg = per_relation(v[row] * a.unsqueeze(-1), rel_msg)
+    new_h = torch.zeros(num_nodes, H, dk, dtype=h.dtype, device=h.device).index_add(0, col, msg).view(num_nodes, out_dim)
     return typed_linear(new_h, torch.sigmoid(skip) * a_lin)

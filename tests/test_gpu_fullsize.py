@@ -185,3 +185,81 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags):
         tol_l2, tol_max = (2e-5, 1e-3) if name in ("out", "grad_x") else (3e-3, 6e-3)
         print(f"[full-size vs fp64 oracle] heads={heads} flags={sorted(flags)} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
         assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+
+def _errors(got, want):
+    d = got.double() - want
+    return float(d.norm() / want.norm().clamp(min=1e-30)), float(d.abs().max() / want.abs().max().clamp(min=1e-30))
+
+
+def _full_graph():
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_mag_like
+    coo = make_mag_like(scale=1.0)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(DEV))
+    return HetGraph.from_integrated_coo(coo, full=True)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgcn_layer_matches_the_fp64_oracle_at_full_size(compact):
+    """BASELINE.json configs[1] (RGCN on the ogbn-mag shape, feat 64) against oracle/layers.py in fp64 on the GPU."""
+    from oracle import layers as OL
+    from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
+    g = _full_graph()
+    s = g.get_separate_coo_original()
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator(device=DEV).manual_seed(13)
+    x0 = torch.randn(N, 64, device=DEV, generator=gen) * 0.3
+    norm = torch.rand(E, 1, device=DEV, generator=gen)
+    go = torch.randn(N, 64, device=DEV, generator=gen)
+    torch.manual_seed(0)
+    layer = HET_EglRelGraphConv_EdgeParallel(64, 64, R, compact_as_of_node_flag=compact, compact_direct_indexing_flag=compact).to(DEV)
+    x = x0.clone().requires_grad_(True)
+    out = layer(g, x, norm)
+    out.backward(go)
+    w64 = layer.weight.detach().double().requires_grad_(True)
+    b64 = layer.h_bias.detach().double().requires_grad_(True)
+    x64 = x0.double().requires_grad_(True)
+    ref = OL.rgcn_layer(x64, w64, norm.double(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N, b64)
+    ref.backward(go.double())
+    for name, a, b in (("out", out.detach(), ref.detach()), ("grad_x", x.grad, x64.grad), ("grad_weight", layer.weight.grad, w64.grad),
+                       ("grad_h_bias", layer.h_bias.grad, b64.grad)):
+        rel_l2, worst = _errors(a, b)
+        print(f"[full-size vs fp64 oracle] rgcn compact={compact} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
+        assert rel_l2 < 2e-5 and worst < 1e-3, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+
+@pytest.mark.parametrize("heads", [8, 1])
+def test_hgt_layer_matches_the_fp64_oracle_at_full_size(heads):
+    """BASELINE.json configs[3] (HGT on the ogbn-mag shape, feat 64, 8 heads; and the reference sweep's 1 head) against
+    oracle/layers.py in fp64 on the GPU: output, input gradient, every parameter gradient."""
+    from oracle import layers as OL
+    from het_amd.layers import HET_HGTLayerHetero
+    g = _full_graph()
+    s = g.get_separate_coo_original()
+    N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
+    gen = torch.Generator(device=DEV).manual_seed(14)
+    h0 = torch.randn(N, 64, device=DEV, generator=gen) * 0.5
+    go = torch.randn(N, 64, device=DEV, generator=gen)
+    torch.manual_seed(0)
+    layer = HET_HGTLayerHetero(T, R, 64, 64, num_heads=heads, dropout=0.0).to(DEV)
+    with torch.no_grad():
+        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.skip.uniform_(-1, 1)
+    h = h0.clone().requires_grad_(True)
+    out = layer(g, h)
+    out.backward(go)
+    names = ["k_linears", "q_linears", "v_linears", "a_linears", "relation_att", "relation_msg", "relation_pri", "skip"]
+    p = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
+    h64 = h0.double().requires_grad_(True)
+    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N,
+                       p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
+                       p["relation_pri"], p["skip"], heads)
+    ref.backward(go.double())
+    checks = [("out", out.detach(), ref.detach()), ("grad_h", h.grad, h64.grad)] + [("grad_" + n, getattr(layer, n).grad, p[n].grad) for n in names]
+    for name, a, b in checks:
+        rel_l2, worst = _errors(a, b)
+        print(f"[full-size vs fp64 oracle] hgt heads={heads} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
+        tol_l2, tol_max = (2e-5, 1e-3) if name in ("out", "grad_h") else (1e-3, 3e-3)
+        assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
