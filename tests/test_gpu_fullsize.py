@@ -263,3 +263,54 @@ def test_hgt_layer_matches_the_fp64_oracle_at_full_size(heads):
         print(f"[full-size vs fp64 oracle] hgt heads={heads} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
         tol_l2, tol_max = (2e-5, 1e-3) if name in ("out", "grad_h") else (1e-3, 3e-3)
         assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+
+def test_reference_named_ops_match_the_fp64_oracle_at_full_size():
+    """a1 / a2 (segment GEMM, per-edge projection by source) and a4 / a5 (fused GAT, kind 0) called through the
+    torch_hrt op names on the full ogbn-mag-shaped graph, against oracle/ops.py evaluated in fp64 on the GPU."""
+    from oracle import ops as O
+    import het_amd.kernels as k
+    g = _full_graph()
+    s = g.get_separate_coo_original()
+    N, E, R, H, Kd, D = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels(), 4, 64, 16
+    gen = torch.Generator(device=DEV).manual_seed(15)
+    x = torch.randn(N, Kd, device=DEV, generator=gen) * 0.3
+    W = torch.randn(R, H, Kd, D, device=DEV, generator=gen) * 0.2
+    by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"], "separate_coo_eids": s["eids"]}
+    # a1
+    feat = torch.empty(E, H, D, device=DEV)
+    k.K.rgnn_relational_matmul(by_src, 0, W, x, feat, True)
+    feat64 = torch.zeros(E, H, D, dtype=torch.float64, device=DEV)
+    O.rgnn_relational_matmul(by_src, 0, W.double(), x.double(), feat64, True)
+    rel_l2, worst = _errors(feat, feat64)
+    assert rel_l2 < 1e-6 and worst < 1e-5, f"a1: {rel_l2:.2e} {worst:.2e}"
+    # a2
+    gfeat = torch.randn(E, H, D, device=DEV, generator=gen)
+    gx, gW = torch.zeros(N, Kd, device=DEV), torch.zeros(R, H, Kd, D, device=DEV)
+    Wt = W.transpose(2, 3).contiguous()
+    k.K.backward_rgnn_relational_matmul(by_src, 0, Wt, x, gfeat, gx, gW, True)
+    gx64, gW64 = torch.zeros(N, Kd, dtype=torch.float64, device=DEV), torch.zeros(R, H, Kd, D, dtype=torch.float64, device=DEV)
+    O.backward_rgnn_relational_matmul(by_src, 0, Wt.double(), x.double(), gfeat.double(), gx64, gW64, True)
+    for name, a, b in (("a2 grad_x", gx, gx64), ("a2 grad_w", gW, gW64)):
+        rel_l2, worst = _errors(a, b)
+        assert rel_l2 < 2e-6 and worst < 1e-4, f"{name}: {rel_l2:.2e} {worst:.2e}"
+    # a4 / a5, edge-order el / er / exp as the reference op defines them
+    el, er = torch.randn(E, H, device=DEV, generator=gen) * 0.5, torch.randn(E, H, device=DEV, generator=gen) * 0.5
+    sm, ex, ret = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(N, H, D, device=DEV)
+    idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    k.K.relational_fused_gat_separate_coo(*idx, 0, {}, feat, el, er, sm, ex, ret, 0.2)
+    sm64, ex64, ret64 = (torch.zeros(N, H, dtype=torch.float64, device=DEV), torch.zeros(E, H, dtype=torch.float64, device=DEV),
+                         torch.zeros(N, H, D, dtype=torch.float64, device=DEV))
+    O.relational_fused_gat_separate_coo(*idx, 0, {}, feat.double(), el.double(), er.double(), sm64, ex64, ret64, 0.2)
+    for name, a, b in (("a4 sum", sm, sm64), ("a4 exp", ex, ex64), ("a4 ret", ret, ret64)):
+        rel_l2, worst = _errors(a, b)
+        assert rel_l2 < 2e-6 and worst < 1e-4, f"{name}: {rel_l2:.2e} {worst:.2e}"
+    go = torch.randn(N, H, D, device=DEV, generator=gen)
+    gf, gl, gr = torch.empty(E, H, D, device=DEV), torch.empty(E, H, device=DEV), torch.empty(E, H, device=DEV)
+    k.K.backward_relational_fused_gat_separate_coo(*idx, 0, {}, feat, el, er, sm, ex, ret, go, gf, gl, gr, 0.2)
+    gf64, gl64, gr64 = torch.zeros_like(feat64), torch.zeros_like(ex64), torch.zeros_like(ex64)
+    O.backward_relational_fused_gat_separate_coo(*idx, 0, {}, feat.double(), el.double(), er.double(), sm64, ex64, ret64, go.double(),
+                                                 gf64, gl64, gr64, 0.2)
+    for name, a, b in (("a5 grad_feat", gf, gf64), ("a5 grad_el", gl, gl64), ("a5 grad_er", gr, gr64)):
+        rel_l2, worst = _errors(a, b)
+        assert rel_l2 < 5e-6 and worst < 1e-3, f"{name}: {rel_l2:.2e} {worst:.2e}"
