@@ -36,7 +36,7 @@ def rel_of_position(rel_ptrs: Tensor) -> Tensor:
     """Relation id of every position of a relation-bucketed list (the device
     code recovers it by searching ``rel_ptrs``: hrt/include/utils.cu.h:94-121)."""
     R = rel_ptrs.numel() - 1
-    return torch.repeat_interleave(torch.arange(R, dtype=torch.int64), rel_ptrs[1:] - rel_ptrs[:-1])
+    return torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=rel_ptrs.device), rel_ptrs[1:] - rel_ptrs[:-1])
 
 
 def _search_rows(rel_ptrs_u: Tensor, nodes_u: Tensor, rel: Tensor, node: Tensor, num_nodes_bound: int) -> Tensor:
@@ -81,7 +81,7 @@ def _matmul_lists(d: Dict[str, Tensor], kind: int):
         return d["separate_coo_rel_ptrs"], d["separate_coo_node_indices"], d["separate_coo_eids"]
     if kind == 1:
         rp = d["unique_srcs_and_dests_rel_ptrs"]
-        return rp, d["unique_srcs_and_dests_node_indices"], torch.arange(int(rp[-1]), dtype=torch.int64)
+        return rp, d["unique_srcs_and_dests_node_indices"], torch.arange(int(rp[-1]), dtype=torch.int64, device=rp.device)
     raise NotImplementedError(f"CompactAsOfNodeKind {kind} (the reference asserts, RGNNOps.inc.h:292-294)")
 
 
@@ -231,7 +231,7 @@ def relational_fused_gat_csr(in_row_ptrs, in_col, in_eids, in_reltypes, uniq_rel
     same math as the separate-COO op.  RGATOps.inc.h:251-277; kernels
     GAT/FusedGAT.cu.h:107-116, 213-222."""
     N = in_row_ptrs.numel() - 1
-    dst = torch.repeat_interleave(torch.arange(N, dtype=torch.int64), in_row_ptrs[1:] - in_row_ptrs[:-1])
+    dst = torch.repeat_interleave(torch.arange(N, dtype=torch.int64, device=in_row_ptrs.device), in_row_ptrs[1:] - in_row_ptrs[:-1])
     H = el.shape[1]
     if compact:
         bound = N
@@ -253,7 +253,7 @@ def backward_relational_fused_gat_csr(out_row_ptrs, out_col, out_eids, out_relty
     """Backward over the out-CSR (rows = src, col_indices = dst).
     RGATOps.inc.h:430-460; kernels GAT/FusedGATBackward.cu.h:138-362."""
     N = out_row_ptrs.numel() - 1
-    src = torch.repeat_interleave(torch.arange(N, dtype=torch.int64), out_row_ptrs[1:] - out_row_ptrs[:-1])
+    src = torch.repeat_interleave(torch.arange(N, dtype=torch.int64, device=out_row_ptrs.device), out_row_ptrs[1:] - out_row_ptrs[:-1])
     dst = out_col
     H = el.shape[1]
     if compact:

@@ -314,3 +314,62 @@ def test_reference_named_ops_match_the_fp64_oracle_at_full_size():
     for name, a, b in (("a5 grad_feat", gf, gf64), ("a5 grad_el", gl, gl64), ("a5 grad_er", gr, gr64)):
         rel_l2, worst = _errors(a, b)
         assert rel_l2 < 5e-6 and worst < 1e-3, f"{name}: {rel_l2:.2e} {worst:.2e}"
+
+
+def test_rgcn_and_hgt_ops_match_the_fp64_oracle_at_full_size():
+    """a7 / a8 (RGCN layer op), a10 (HGT edge softmax and its backward) and a11 (HGT fused message + aggregation and its
+    backward, 8 heads) through the torch_hrt op names on the full graph, against oracle/ops.py in fp64 on the GPU."""
+    from oracle import ops as O
+    import het_amd.kernels as k
+    K = k.K
+    g = _full_graph()
+    s = g.get_separate_coo_original()
+    N, E, R = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels()
+    gen = torch.Generator(device=DEV).manual_seed(16)
+    rnd = lambda *shape: torch.randn(*shape, device=DEV, generator=gen)
+    z64 = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=DEV)
+
+    def check(name, got, want, tol_l2=2e-6, tol_max=1e-4):
+        rel_l2, worst = _errors(got, want)
+        assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+    # a7 / a8
+    a = (s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"])
+    x, W, norm, go = rnd(N, 64) * 0.3, rnd(R, 64, 64) * 0.2, torch.rand(E, 1, device=DEV, generator=gen), rnd(N, 64)
+    ret, ref = torch.zeros(N, 64, device=DEV), z64(N, 64)
+    K.rgcn_layer1_separate_coo(*a, x, W, norm, ret)
+    O.rgcn_layer1_separate_coo(*a, x.double(), W.double(), norm.double(), ref)
+    check("a7 ret", ret, ref)
+    Wt = W.transpose(1, 2).contiguous()
+    gx, gW, gn = torch.zeros(N, 64, device=DEV), torch.zeros(R, 64, 64, device=DEV), torch.zeros(E, 1, device=DEV)
+    K.backward_rgcn_layer1_separate_coo(*a, x, Wt, norm, gn, gx, go, gW)
+    gx64, gW64, gn64 = z64(N, 64), z64(R, 64, 64), z64(E, 1)
+    O.backward_rgcn_layer1_separate_coo(*a, x.double(), Wt.double(), norm.double(), gn64, gx64, go.double(), gW64)
+    check("a8 grad_x", gx, gx64); check("a8 grad_W", gW, gW64)
+    del ret, ref, gx, gW, gx64, gW64
+    # a10
+    H, dk = 8, 8
+    idx = (s["row_indices"], s["col_indices"], s["eids"], s["rel_ptrs"])
+    score, mu, ga = rnd(E, H), torch.rand(R, H, device=DEV, generator=gen) + 0.5, rnd(E, H)
+    sm, m, at = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(E, H, device=DEV)
+    K.hgt_full_graph_edge_softmax_ops_separate_coo(*idx, score, mu, sm, m, at)
+    sm64, m64, a64 = z64(N, H), z64(E, H), z64(E, H)
+    O.hgt_full_graph_edge_softmax_ops_separate_coo(*idx, score.double(), mu.double(), sm64, m64, a64)
+    check("a10 sum", sm, sm64); check("a10 m", m, m64); check("a10 a", at, a64)
+    gs, gmu, tmp = torch.empty(E, H, device=DEV), torch.zeros(R, H, device=DEV), torch.empty(N, H, device=DEV)
+    K.backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(*idx, score, at, ga, mu, gs, gmu, tmp)
+    gs64, gmu64, tmp64 = z64(E, H), z64(R, H), z64(N, H)
+    O.backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(*idx, score.double(), a64, ga.double(), mu.double(), gs64, gmu64, tmp64)
+    check("a10 grad_score", gs, gs64, 5e-6, 1e-3); check("a10 grad_mu", gmu, gmu64, 1e-4, 1e-3)
+    # a11
+    v, Wm, gon = rnd(N, H, dk) * 0.5, rnd(R, H, dk, dk) * 0.4, rnd(N, H, dk)
+    nh, nh64 = torch.zeros(N, H, dk, device=DEV), z64(N, H, dk)
+    K.hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*a, v, Wm, at, nh)
+    O.hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*a, v.double(), Wm.double(), a64, nh64)
+    check("a11 new_h", nh, nh64)
+    Wmt = Wm.transpose(2, 3).contiguous()
+    gv, gWm, gat = torch.zeros(N, H, dk, device=DEV), torch.zeros(R, H, dk, dk, device=DEV), torch.empty(E, H, device=DEV)
+    K.backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*a, v, Wmt, at, nh, gv, gWm, gat, gon)
+    gv64, gWm64, gat64 = z64(N, H, dk), z64(R, H, dk, dk), z64(E, H)
+    O.backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(*a, v.double(), Wmt.double(), a64, nh64, gv64, gWm64, gat64, gon.double())
+    check("a11 grad_v", gv, gv64); check("a11 grad_W", gWm, gWm64, 1e-5, 1e-4); check("a11 grad_a", gat, gat64)
