@@ -1,6 +1,8 @@
 """CPU oracle for the relational-GNN hot path -- TEST INFRASTRUCTURE ONLY.
 
-A plain-PyTorch (CPU, fp32 or fp64) restatement of what each
+A plain-PyTorch restatement (torch's own index / matmul ops, none of this repo's kernels; fp32 or fp64; evaluated on
+the CPU by the small tests and -- it is device-agnostic -- in fp64 on the GPU by the full-size checks of
+tests/test_gpu_fullsize.py, where the CPU would take minutes) of what each
 ``torch.ops.torch_hrt.*`` op on the hot path computes, one function per op,
 with the reference's argument order and its in-place, caller-allocated-output
 convention.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
