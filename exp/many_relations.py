@@ -3,7 +3,7 @@ kernel's per-relation tiling fall over?  Random graph of wikikg2's size by defau
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from het_amd.graph import HetGraph
-from het_amd.layers import HET_RGATLayer, HET_EglRelGraphConv_EdgeParallel
+from het_amd.layers import HET_RGATLayer, HET_EglRelGraphConv_EdgeParallel, HET_HGTLayerHetero
 from het_amd.synth import make_random
 
 dev = torch.device("cuda")
@@ -20,7 +20,9 @@ for R in (int(r) for r in os.environ.get("RELS", "4 104 535").split()):
                                ("rgat heads 4", HET_RGATLayer(64, 64, R, 4, self_loop=True, dropout=0.0).to(dev), ()),
                                ("rgat compact", HET_RGATLayer(64, 64, R, 4, self_loop=True, dropout=0.0, compact_as_of_node_flag=True,
                                                               compact_direct_indexing_flag=True).to(dev), ()),
-                               ("rgcn", HET_EglRelGraphConv_EdgeParallel(64, 64, R).to(dev), (norm,))):
+                               ("rgcn", HET_EglRelGraphConv_EdgeParallel(64, 64, R).to(dev), (norm,)),
+                               ("hgt heads 1", HET_HGTLayerHetero(1, R, 64, 64, num_heads=1, dropout=0.0).to(dev), ()),
+                               ("hgt heads 8", HET_HGTLayerHetero(1, R, 64, 64, num_heads=8, dropout=0.0).to(dev), ())):
         def step():
             layer.zero_grad(set_to_none=True)
             x.grad = None
