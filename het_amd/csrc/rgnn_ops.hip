@@ -29,6 +29,7 @@ extern "C" int het_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs,
                                           int64_t D, int in1head, const het_grouping* by_rel_gather, void* workspace,
                                           int64_t workspace_bytes, het_stream stream) {
   const char* op = "rgnn_relational_matmul";
+  if (H == 1) in1head = 1;  // one head: x [*, 1, K] and x [*, K] are the same rows -- take the paths of the shared-input form
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights && x && ret), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;
@@ -232,6 +233,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
                                                    const het_grouping* by_rel_gather, void* workspace,
                                                    int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul";
+  if (H == 1 && D > 1) in1head = 1;  // as in the forward (the D == 1 row-dot shapes keep their own per-head kernels)
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_w), "%s: null data pointer", op);
   hipStream_t s = (hipStream_t)stream;

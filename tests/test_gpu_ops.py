@@ -50,6 +50,8 @@ SHAPES = [  # (H, K, D, in1head)
     (4, 256, 64, True),   # K = X = 256: 128-wide slabs of the weight
     (1, 256, 32, True),   # K = 256 only
     (2, 64, 128, True),   # X = 256 only
+    (1, 64, 64, False),   # one head, per-head input form (HGT relation_att at --num_heads 1): same rows as the shared form
+    (1, 8, 8, False),
 ]
 
 
