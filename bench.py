@@ -58,11 +58,24 @@ def layer_flags(variant):
                 multiply_among_weights_first_flag=variant.endswith("mulfirst"))
 
 
-def gat_bwd_bytes(E, N, H, X):
-    """Algorithmic bytes of backward_relational_fused_gat_separate_coo, kind 0:
-    per edge reads col,eids (8 B each), el,er,exp (H floats each), feat (X); writes grad_el, grad_er (H),
-    grad_feat (X); per node reads sum (H), ret, gradout (X each)."""
-    return E * (2 * 8 + 4 * (3 * H + X) + 4 * (2 * H + X)) + N * 4 * (H + 2 * X)
+def gat_fwd_bytes(E, N, H, X, S_row=None, S_col=None):
+    """Algorithmic bytes of relational_fused_gat_separate_coo (every API-visible tensor touched once,
+    index arrays at their API width of 8 B).  kind 0 (S_row None): per edge reads col, eids, el, er (H), feat (X), writes
+    exp (H); per node writes sum (H), ret (X).  Direct-index compact kind 4: per edge reads col, eids and the two
+    inverse-index entries, writes exp; feat / el are [S_row, .] and er [S_col, H], read once each."""
+    if S_row is None:
+        return E * (2 * 8 + 4 * (2 * H + X) + 4 * H) + N * 4 * (H + X)
+    return E * (4 * 8 + 4 * H) + S_row * 4 * (X + H) + S_col * 4 * H + N * 4 * (H + X)
+
+
+def gat_bwd_bytes(E, N, H, X, S_row=None, S_col=None):
+    """Algorithmic bytes of backward_relational_fused_gat_separate_coo.  kind 0: per edge reads col, eids
+    (8 B each), el, er, exp (H floats each), feat (X); writes grad_el, grad_er (H), grad_feat (X); per node reads sum (H),
+    ret, gradout (X each).  Kind 4: per edge reads col, eids, two inverse-index entries and exp; feat, el, grad_feat,
+    grad_el live on the S_row (relation, source) rows, er / grad_er on the S_col (relation, destination) rows."""
+    if S_row is None:
+        return E * (2 * 8 + 4 * (3 * H + X) + 4 * (2 * H + X)) + N * 4 * (H + 2 * X)
+    return E * (4 * 8 + 4 * H) + S_row * 4 * 2 * (X + H) + S_col * 4 * 2 * H + N * 4 * (H + 2 * X)
 
 
 def cpu_baseline(args):
@@ -93,7 +106,7 @@ def cpu_baseline(args):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(g.get_num_edges() / med / 1e6, 3), "unit": "million edges/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "scale": args.cpu_scale, "sample_edges": g.get_num_edges(), "sample_seconds_per_step": round(med, 3),
             "sample": f"oracle/layers.py rgat_layer fwd+bwd (torch CPU fp32, HET cross-relation softmax) on a mag-like "
                       f"graph at scale {args.cpu_scale} ({g.get_num_edges()} edges, {N} nodes), median of 3 after 1 warm-up; "
                       f"os.cpu_count()={os.cpu_count()}"}
@@ -107,13 +120,19 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
     res = {"default": {"ms_per_step": round(default_ms, 4), "million_edges_per_s": round(default_value, 2)}}
     g = HetGraph.from_integrated_coo(coo, full=True)
     E, N = coo.num_edges, coo.num_nodes
-    flag_names = {"compact": "--compact_as_of_node_flag --compact_direct_indexing_flag",
+    flag_names = {"reference_op_sequence": "default flags, the reference's op sequence literally: only reference-named torch_hrt "
+                                           "ops with the reference wrappers' zero-filled buffers (het_amd/backend/"
+                                           "reference_protocol.py = RGAT/models.py:265-385 after the kernels/__init__.py swap)",
+                  "compact": "--compact_as_of_node_flag --compact_direct_indexing_flag",
                   "mulfirst": "--multiply_among_weights_first_flag",
                   "compact_mulfirst": "--compact_as_of_node_flag --compact_direct_indexing_flag --multiply_among_weights_first_flag"}
-    for variant in ("compact", "mulfirst", "compact_mulfirst"):
+    for variant in ("reference_op_sequence", "compact", "mulfirst", "compact_mulfirst"):
         torch.manual_seed(0)
+        if variant == "reference_op_sequence" and torch.cuda.mem_get_info(dev)[0] < 80 * 2**30 * args.scale:
+            continue  # needs about ten [E,H,D] tensors (54 GB on ogbn-mag)
         layer = HET_RGATLayer(args.feat, args.feat, g.get_num_rels(), args.heads, self_loop=True, dropout=0.0,
-                              **layer_flags(variant)).to(dev)
+                              reference_op_sequence=variant == "reference_op_sequence",
+                              **(layer_flags(variant) if variant != "reference_op_sequence" else {})).to(dev)
         embed = torch.nn.Parameter(torch.empty(N, args.feat, device=dev))
         torch.nn.init.xavier_uniform_(embed)
         go = torch.randn(N, args.feat, device=dev)
@@ -135,6 +154,7 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
         res[variant] = {"ms_per_step": round(dt * 1e3, 4), "million_edges_per_s": round(E / dt / 1e6, 2),
                         "flags": flag_names[variant]}
         del layer, embed, go
+        torch.cuda.empty_cache()
     return res
 
 
@@ -144,12 +164,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run "
+                         f"--nproc-per-node N (and pass the same N as --gpus)")
     # (rehearsals of the multi-rank flow on a one-GPU box: HET_DIST_BACKEND=gloo lets the ranks share the device)
     backend = os.environ.get("HET_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPUs are visible (RCCL needs one GPU per rank)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("HET_FORCE_DIST") == "1":
@@ -220,8 +242,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    bwd_name, mm_name = "het_backward_relational_fused_gat_separate_coo", "het_rgnn_relational_matmul"
-    HK.event_timers[bwd_name] = []
+    mm_name = "het_rgnn_relational_matmul"
+    from het_amd import _lib as HL
+    HL.kernel_timing(True)  # HIP-event pairs on the launch stream around the library's dominant kernels (include/het_amd.h)
     step_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -232,9 +255,16 @@ def main():
         step_events.append((a, b))
     barrier()
     dt = time.perf_counter() - t0
+    HL.kernel_timing(False)
     per_step = sorted(a.elapsed_time(b) for a, b in step_events)  # device time of every step (events, this rank)
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
-    ev = HK.event_timers.pop(bwd_name)
+    # live per-kernel durations of the timed region: {kernel: (avg ms per launch, launches per step, ms per step)}
+    kt = {}
+    for name in ("HET_gat_backward_src", "HET_gat_backward_grouped", "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
+                 "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_dw_mfma", "HET_segment_sum"):
+        ms, n = HL.kernel_timing_read(name)
+        if n:
+            kt[name] = (ms / n, n / args.steps, ms / args.steps)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -243,40 +273,73 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = E_global / (dt / args.steps) / 1e6
 
+    prof_dir = os.path.join(ROOT, "profiles", "r02")
+
     def pmc(kernel, field):
-        """Per-launch PMC figure from the committed counter passes of this same command (profiles/r01/, written by
-        profiles/tools/collect.sh): rocprofv3 cannot run inside the timed process.  None when no profile matches
-        this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
-        path = os.path.join(ROOT, "profiles", "r01", "default_pmc.json")
-        if args.scale != 1.0 or args.variant != "default" or world != 1 or args.model != "rgat" or not os.path.exists(path):
+        """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/r02/,
+        written by profiles/tools/collect.sh on an earlier box): rocprofv3 cannot run inside the timed process, so
+        this is not an observation of this run -- the JSON says so (`traffic_source`).  None when no committed
+        profile matches this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
+        path = os.path.join(prof_dir, f"{args.variant}_pmc.json")
+        if args.scale != 1.0 or world != 1 or args.model != "rgat" or args.feat != 64 or args.heads != 4 or not os.path.exists(path):
             return None
         recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in json.load(open(path))["kernels"].items()
                 if k.startswith(kernel) and field in v]
-        return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel (E rows)
+        return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel
 
-    roofline = None
-    if ev and not args.variant.startswith("compact") and args.model == "rgat":
-        k_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)
-        nbytes = gat_bwd_bytes(E_local, N_local, H, X)
-        parts = {"a5 backward_relational_fused_gat_separate_coo": nbytes}
-        if args.variant in ("default", "mulfirst") and g_rels <= 8:
-            # the launch also performs the weight gradient of el = <feat, attn_l> (a2 with D_out = 1: reads feat [E,X] and
-            # grad_el [E,H], index lists at 8 B), fused into the same pass over feat (fold_attn_l / grad_fold_attn_l)
-            parts["a2 weight gradient of el = <feat, attn_l> (D_out = 1), fused into the same launch"] = E_local * (4 * X + 4 * H + 16)
-            nbytes += E_local * (4 * X + 4 * H + 16)
+    def hbm_view(kernel, k_ms, nbytes, extra=None, pmc_name=None):
         ach = nbytes / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "HET_gat_backward_grouped (backward_relational_fused_gat_separate_coo, kind 0)",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc("HET_gat_backward_grouped", "hbm_bytes_per_launch"),
-                    "kernel_ms": round(k_ms, 4), "algorithmic_bytes": nbytes, "algorithmic_bytes_by_op": parts,
-                    "frac_a5_bytes_only": round(parts["a5 backward_relational_fused_gat_separate_coo"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if roofline["traffic"]:  # physical rate: PMC bytes of the launch over the same duration (measured copy rate of the box: 4.7-5.1 TB/s)
-            roofline["traffic_rate_GBps"] = round(roofline["traffic"] / (k_ms * 1e-3) / 1e9, 1)
-    # second view, the MFMA side of the path (north_star: MFMA utilisation of the segment GEMM): the reference-named op
-    # rgnn_relational_matmul exactly as the reference calls it for the per-edge projection (kind 0, gather by source,
-    # E rows, one input head), launched a few times after the timed region, HIP events on the launch stream.
-    # (Inside the layer the same product runs on the distinct (relation, node) rows only, see DESIGN.md.)
-    roofline_gemm = None
+        r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
+             "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(nbytes),
+             "traffic": pmc(pmc_name or kernel.split(" ")[0], "hbm_bytes_per_launch")}
+        r["traffic_source"] = (f"profiles/r02/{args.variant}_pmc.json (committed rocprofv3 --pmc passes of this command on "
+                               "another box; not measured in this run)") if r["traffic"] else None
+        if r["traffic"]:
+            r["traffic_rate_GBps"] = round(r["traffic"] / (k_ms * 1e-3) / 1e9, 1)
+        if extra:
+            r.update(extra)
+        return r
+
+    # roofline of the step's dominant kernels: algorithmic bytes of the op the kernel implements (SURVEY.md 8d: every
+    # API-visible tensor once, indices at 8 B) / the kernel's own average duration in the timed region.  Only the
+    # bytes of THAT op are counted -- work fused into the launch from other ops is reported beside it, not added.
+    roofline = roofline_fwd = None
+    if args.model == "rgat":
+        S_row = S_col = None
+        if "HET_gat_backward_src" in kt and not use_dist:
+            ss = g.get_separate_unique_node_indices_single_sided()
+            S_row, S_col = int(ss["node_indices_row"].numel()), int(ss["node_indices_col"].numel())
+        gather = {}
+        if S_row is not None:
+            # the [S_row, X] / [N, X] tables the passes gather from (0.9 / 0.5 GB) exceed the 256 MiB Infinity Cache, so
+            # every edge's row really crosses the memory fabric: the bytes the kernel is REQUIRED to move
+            gather = {"S_row": S_row, "S_col": S_col}
+        bname = "HET_gat_backward_src" if "HET_gat_backward_src" in kt else "HET_gat_backward_grouped"
+        if bname in kt:
+            nb_ = gat_bwd_bytes(E_local, N_local, H, X, S_row, S_col)
+            ex = dict(gather)
+            if S_row is not None:
+                req = nb_ + (E_local - S_row) * 4 * X  # one gradout row per edge instead of per source row
+                ex.update(bytes_with_per_edge_row_gather=int(req),
+                          frac_with_per_edge_row_gather=round(req / (kt[bname][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {'4: rows of the distinct (relation, node) projections' if S_row else 0})",
+                                kt[bname][0], nb_, ex, pmc_name=bname)
+        if "HET_gat_aggregate_grouped" in kt:
+            nf_ = gat_fwd_bytes(E_local, N_local, H, X, S_row, S_col)
+            ex = dict(gather)
+            if S_row is not None:
+                req = nf_ + (E_local - S_row) * 4 * X
+                ex.update(bytes_with_per_edge_row_gather=int(req),
+                          frac_with_per_edge_row_gather=round(req / (kt["HET_gat_aggregate_grouped"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roofline_fwd = hbm_view(f"HET_gat_aggregate_grouped (relational_fused_gat_separate_coo, kind {4 if S_row else 0})",
+                                    kt["HET_gat_aggregate_grouped"][0], nf_, ex, pmc_name="HET_gat_aggregate_grouped")
+    kernel_ms = {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}
+
+    # the reference-named ops exactly as the reference's model code calls them (kind 0, [E,H,D] feat), each launched a
+    # few times on its own after the timed region: these are the SURVEY 8(d) worked figures (a4 7.28 GB, a5 13.86 GB,
+    # a1 172.9 GFLOP at C3).  Entry-point HIP events on the launch stream: the whole op (its fills and every kernel).
+    roofline_ops = roofline_gemm = None
     if args.model == "rgat" and world == 1 and not use_dist:
         sc = g.get_separate_coo_original()
         d_src = {"separate_coo_rel_ptrs": sc["rel_ptrs"], "separate_coo_node_indices": sc["row_indices"],
@@ -284,20 +347,50 @@ def main():
         Wp = torch.randn(g.get_num_rels(), H, K, X // H, device=dev) * 0.1
         retp = torch.empty(E_local, H, X // H, device=dev)
         HK.event_timers[mm_name] = []
+        HL.kernel_timing(True)
         with torch.no_grad():
             for _ in range(6):
                 HK.K.rgnn_relational_matmul(d_src, 0, Wp, embed.detach(), retp, True)
         torch.cuda.synchronize()
-        proj = HK.event_timers.pop(mm_name)[1:]
-        g_ms = sum(a.elapsed_time(b) for a, b, _ in proj) / len(proj)
+        HL.kernel_timing(False)
+        HK.event_timers.pop(mm_name)
+        ms, n = HL.kernel_timing_read("HET_seg_gemm_mfma<store>")
+        g_ms = ms / max(1, n)
         flops = 2.0 * E_local * K * X
         tf = flops / (g_ms * 1e-3) / 1e12
+        busy = pmc("HET_seg_gemm_mfma<64, 2, false, false>", "mfma_busy_frac")
         roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
-                         "mfma_busy_frac_pmc": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "mfma_busy_frac"),
-                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "hbm_bytes_per_launch")}
-        del Wp, retp
+                         "mfma_busy_frac_pmc": busy,
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "hbm_bytes_per_launch"),
+                         "traffic_source": f"profiles/r02/{args.variant}_pmc.json (committed; not measured in this run)" if busy else None}
+        # a4 / a5 on the per-edge tensor retp just written (feat_src_per_edge), reference argument order
+        el = torch.randn(E_local, H, device=dev)
+        er = torch.randn(E_local, H, device=dev)
+        sm, ex_, rt = torch.empty(N_local, H, device=dev), torch.empty(E_local, H, device=dev), torch.empty(N_local, H, X // H, device=dev)
+        gfe, gel, ger = torch.empty_like(retp), torch.empty_like(el), torch.empty_like(er)
+        fn, bn = "het_relational_fused_gat_separate_coo", "het_backward_relational_fused_gat_separate_coo"
+        HK.event_timers[fn], HK.event_timers[bn] = [], []
+        with torch.no_grad():
+            for _ in range(5):
+                HK.K.relational_fused_gat_separate_coo(sc["eids"], sc["rel_ptrs"], sc["row_indices"], sc["col_indices"], 0, {},
+                                                       retp, el, er, sm, ex_, rt, 0.2)
+                HK.K.backward_relational_fused_gat_separate_coo(sc["eids"], sc["rel_ptrs"], sc["row_indices"], sc["col_indices"],
+                                                                0, {}, retp, el, er, sm, ex_, rt, go.view(N_local, H, X // H),
+                                                                gfe, gel, ger, 0.2)
+        torch.cuda.synchronize()
+        f_ev, b_ev = HK.event_timers.pop(fn)[1:], HK.event_timers.pop(bn)[1:]
+        f_ms = sum(a.elapsed_time(b) for a, b, _ in f_ev) / len(f_ev)
+        b_ms = sum(a.elapsed_time(b) for a, b, _ in b_ev) / len(b_ev)
+        fb, bb = gat_fwd_bytes(E_local, N_local, H, X), gat_bwd_bytes(E_local, N_local, H, X)
+        roofline_ops = {
+            "what": "the reference-named kind-0 ops on [E,H,D] inputs, one op per entry-point call (all its kernels and fills)",
+            "a4 relational_fused_gat_separate_coo": {"op_ms": round(f_ms, 4), "algorithmic_bytes": fb,
+                                                     "achieved_GBps": round(fb / f_ms / 1e6, 1), "frac": round(fb / f_ms / 1e6 / HBM_PEAK_GBS, 4)},
+            "a5 backward_relational_fused_gat_separate_coo": {"op_ms": round(b_ms, 4), "algorithmic_bytes": bb,
+                                                              "achieved_GBps": round(bb / b_ms / 1e6, 1), "frac": round(bb / b_ms / 1e6 / HBM_PEAK_GBS, 4)}}
+        del Wp, retp, el, er, sm, ex_, rt, gfe, gel, ger
 
     # per-entry-point device time, from a few extra steps after the timed region (HIP events around every C-ABI call)
     per_op = None
@@ -326,7 +419,10 @@ def main():
                        "layout_build_ms": None if layout_ms is None else round(layout_ms, 1),
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world}, RCCL all-to-all halo"},
             "roofline": roofline,
+            "roofline_forward": roofline_fwd,
             "roofline_segment_gemm": roofline_gemm,
+            "roofline_reference_named_ops": roofline_ops,
+            "kernel_ms": kernel_ms,
             "per_op_ms": per_op,
             "peak_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
         }

@@ -71,6 +71,10 @@ def lib() -> C.CDLL:
         L.het_grouping_destroy.restype = None
         L.het_grouping_num_segments.argtypes = [P]
         L.het_grouping_num_segments.restype = I64
+        L.het_kernel_timing_enable.argtypes = [INT]
+        L.het_kernel_timing_enable.restype = INT
+        L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]
+        L.het_kernel_timing_read.restype = INT
         for name, args in _SIGNATURES.items():
             f = getattr(L, name)
             f.argtypes = args
@@ -84,6 +88,23 @@ def call(name: str, *args) -> None:
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise HetError(f"{name} failed (code {rc}): {L.het_last_error().decode()}")
+
+
+def kernel_timing(on: bool) -> None:
+    """Start (clearing earlier records) / stop the library's per-kernel HIP-event timing (include/het_amd.h)."""
+    rc = lib().het_kernel_timing_enable(int(bool(on)))
+    if rc != 0:
+        raise HetError(f"het_kernel_timing_enable failed (code {rc})")
+
+
+def kernel_timing_read(prefix: str):
+    """(total ms, launches) of the recorded kernels whose name starts with ``prefix``; synchronises their events."""
+    L = lib()
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    rc = L.het_kernel_timing_read(prefix.encode(), C.byref(ms), C.byref(n))
+    if rc != 0:
+        raise HetError(f"het_kernel_timing_read failed (code {rc}): {L.het_last_error().decode()}")
+    return ms.value, n.value
 
 
 def build_info() -> str:

@@ -7,15 +7,25 @@ their atomic epilogues) and the weight gradients into one buffer, instead of aut
 consumer and summing them with elementwise kernels; the output ``h + loop_message + h_bias`` is one pass.  On ogbn-mag
 this removes ~1 ms of elementwise adds and fills per step.
 
-Two dataflows, selected by the layer flags exactly as in the op-by-op path:
-  kind 0 (default flags)   per-edge projections; the fusions of het_amd/layers.py (distinct-row projection + broadcast,
-                           attention terms from the GEMM epilogue, er without its per-edge tensor, el folded into the GAT
-                           node); the [E,H] tensors el, er, exp and grad_el are kept in the destination-grouped order of
-                           the GAT kernels (kernels.gat_rank_of_position), where those kernels stream them
-  compact (kinds 3 / 4)    projections on the unique (relation, node) rows, el folded into the compact GAT backward
+Two dataflows:
+  distinct rows (kinds 3 / 4)   projections on the unique (relation, node) rows, gathered by the GAT kernels through the
+                           (relation, source) -> row map; el folded into the compact GAT backward.  This is what the
+                           reference's --compact_as_of_node_flag selects AND what the default flags run on here: inside
+                           one autograd node no per-edge tensor is visible to the caller, the values are the same
+                           (feat_src_per_edge[e] == feat_compact[row(e)] bit for bit), and the [E,H,D] tensor and its
+                           gradient (5.4 GB each on ogbn-mag) are never written.  The unique lists are the ones the
+                           reference's RGAT script builds for every run (RGAT/train_dgl.py:160, unconditional); a graph
+                           that lacks them gets them from the device-side builders once.
+  per edge (kind 0)        the round-1 dataflow of the default flags: [E,H,D] projections (distinct-row projection +
+                           broadcast), el / er / exp / grad_el in the destination-grouped order of the GAT kernels.  Kept
+                           behind HET_RGAT_PER_EDGE=1 for A/B runs and as the path tests/ compare the other with.
 and, for either, ``mulfirst`` (--multiply_among_weights_first_flag, RGAT/models.py:300-326): er = x[dst] . (W . attn_r)
-as a row-dot product on the distinct (relation, destination) rows instead of a projection followed by a dot.
+as a row-dot product on the distinct (relation, destination) rows instead of a projection followed by a dot.  The two
+forms of er are the same real number (associativity); the reference offers the flag because it is cheaper, and so the
+node takes it whenever the one-head row-dot kernels cover the shape (HET_RGAT_LITERAL_ER=1 keeps (x . W) . attn_r).
 """
+import os
+
 import torch as th
 
 from .. import kernels as _k
@@ -23,6 +33,27 @@ from ..kernels import K
 
 
 _OFFS = {}
+PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
+LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
+
+
+def _mulfirst_shape_ok(H, Kd):
+    """er = x[dst] . (W . attn_r) through the one-head row-dot kernels (seg_rowdot.hip)."""
+    return H in (1, 2, 4, 8) and Kd >= 4 * H and Kd & (Kd - 1) == 0 and Kd <= 256
+
+
+def _has_single_sided_lists(g):
+    return "unique_node_indices_single_sided" in getattr(g, "graph_data", {}).get("separate", {})
+
+
+def effective_flags(g, W, compact, direct, mulfirst):
+    """(compact, direct, mulfirst) the node runs with for the layer flags given (see the module docstring)."""
+    R, H, Kd, D = W.shape
+    if not compact and not PER_EDGE and (_has_single_sided_lists(g) or hasattr(g, "generate_separate_unique_node_indices_single_sided_for_each_etype")):
+        compact, direct = True, True
+    if not mulfirst and not LITERAL_ER and _mulfirst_shape_ok(H, Kd):
+        mulfirst = True
+    return bool(compact), bool(direct), bool(mulfirst)
 
 
 def _lists(g):
@@ -53,9 +84,11 @@ def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0
             and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
         return False
-    if mulfirst:  # er = x[dst] . (W . attn_r): the one-head row-dot kernels (seg_rowdot.hip)
-        return H in (1, 2, 4, 8) and Kd >= 4 * H and Kd & (Kd - 1) == 0 and Kd <= 256
-    if compact:
+    compact, _, mulfirst_eff = effective_flags(g, W, compact, True, mulfirst)
+    if mulfirst and not _mulfirst_shape_ok(H, Kd):
+        return False
+    mulfirst = mulfirst_eff
+    if compact or mulfirst:
         return True
     _, _, by_dst = _lists(g)
     return _k.matmul_attn_dot_only_ok(by_dst, W, x)
@@ -221,5 +254,7 @@ class RgatLayerFunction(th.autograd.Function):
 
 
 def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None, mulfirst=False):
-    return RgatLayerFunction.apply(g, bool(compact), bool(direct), bool(mulfirst), float(slope), num_dst, x, W, attn_l, attn_r,
-                                   loop_w, bias)
+    compact, direct, mulfirst = effective_flags(g, W, compact, direct, mulfirst)
+    if compact and not _has_single_sided_lists(g):
+        g.generate_separate_unique_node_indices_single_sided_for_each_etype()
+    return RgatLayerFunction.apply(g, compact, direct, mulfirst, float(slope), num_dst, x, W, attn_l, attn_r, loop_w, bias)

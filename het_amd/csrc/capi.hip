@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "common.hip.h"
 
 static thread_local char g_err[512] = "";
@@ -22,4 +26,63 @@ extern "C" const char* het_last_error(void) { return g_err; }
 extern "C" const char* het_build_info(void) {
   return "het_amd (libhet_amd.so) git " HET_GIT_SHA " | target gfx950 (MI355X, CDNA4) | hipcc " __VERSION__
          " | built " __DATE__ " " __TIME__;
+}
+
+// ---- per-kernel timing ---------------------------------------------------------------
+namespace {
+struct KRec { const char* name; hipEvent_t a, b; };
+std::mutex g_kmu;
+std::vector<KRec> g_krecs;
+std::atomic<bool> g_kon{false};
+thread_local int g_kcur = -1;  // record opened by this thread's current launch
+
+void krecs_clear() {
+  for (auto& r : g_krecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_krecs.clear();
+}
+}  // namespace
+
+bool het_ktime_on() { return g_kon.load(std::memory_order_relaxed); }
+
+void het_ktime_begin(const char* name, hipStream_t s) {
+  KRec r{name, nullptr, nullptr};
+  g_kcur = -1;
+  if (hipEventCreate(&r.a) != hipSuccess) return;
+  if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+  (void)hipEventRecord(r.a, s);
+  std::lock_guard<std::mutex> lk(g_kmu);
+  g_krecs.push_back(r);
+  g_kcur = (int)g_krecs.size() - 1;
+}
+
+void het_ktime_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_kmu);
+  if (g_kcur >= 0 && g_kcur < (int)g_krecs.size()) (void)hipEventRecord(g_krecs[g_kcur].b, s);
+  g_kcur = -1;
+}
+
+extern "C" int het_kernel_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_kmu);
+  if (on) krecs_clear();
+  g_kon.store(on != 0);
+  return HET_OK;
+}
+
+extern "C" int het_kernel_timing_read(const char* name_prefix, double* total_ms, int64_t* launches) {
+  HET_REQUIRE(name_prefix && total_ms && launches, "het_kernel_timing_read: null argument");
+  std::lock_guard<std::mutex> lk(g_kmu);
+  const size_t n = strlen(name_prefix);
+  double t = 0.0;
+  int64_t c = 0;
+  for (auto& r : g_krecs) {
+    if (strncmp(r.name, name_prefix, n) != 0) continue;
+    HET_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HET_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    t += ms;
+    ++c;
+  }
+  *total_ms = t;
+  *launches = c;
+  return HET_OK;
 }

@@ -39,6 +39,18 @@ void het_set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
+// ---- optional per-kernel timing (het_kernel_timing_*; capi.hip) ---------------------
+bool het_ktime_on();
+void het_ktime_begin(const char* name, hipStream_t s);
+void het_ktime_end(hipStream_t s);
+struct HetKTimer {  // scope guard: { HET_KTIME("HET_kernel", s); hipLaunchKernelGGL(...); }
+  hipStream_t s;
+  bool on;
+  HetKTimer(const char* name, hipStream_t st) : s(st), on(het_ktime_on()) { if (on) het_ktime_begin(name, s); }
+  ~HetKTimer() { if (on) het_ktime_end(s); }
+};
+#define HET_KTIME(name, s) HetKTimer het_ktimer__(name, s)
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers -----------------------------------------------------------

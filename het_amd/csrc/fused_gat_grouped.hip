@@ -566,6 +566,12 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   // prefetched during the current item's rows -- was 25-40 % slower at 2048..16384 workgroups, same box: the hardware's
   // own workgroup turnover already overlaps the per-item prologues; the pass runs at the rate random 256-byte rows
   // come out of HBM)
+  if (!el_sorted) {
+    hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
+    HET_LAUNCH_CHECK("HET_gat_exp_edge");
+  }
+  {
+  HET_KTIME("HET_gat_aggregate_grouped", s);
   if (el_sorted && short_items(g)) {
     const unsigned nbs = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true, true>), dim3(nbs), dim3(kBlock), 0,
@@ -576,10 +582,9 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
                                                       it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
                                                       H, D, el_sorted, er_sorted, exp, slope));
   } else {
-    hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
-    HET_LAUNCH_CHECK("HET_gat_exp_edge");
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, false>), dim3(nb), dim3(kBlock), 0, s,
                                                       it, g->p0, srow, feat, exp, sum, ret, exp_sorted, H, D));
+  }
   }
   HET_LAUNCH_CHECK("HET_gat_aggregate_grouped");
   if (g->num_split > 0) {
@@ -611,6 +616,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   const unsigned nb = (unsigned)ceil_div64(g->num_items, kBlock / 64);
   const bool sorted = exp_sorted && slope >= 0.f;
   const float* ex = sorted ? exp_sorted : exp;
+  HetKTimer* kt = nullptr;  // closed right after the kernel launch (before the tiny replica reduction)
 #define HET_GAT_BWD(SORTED, FOLD)                                                                                    \
   HET_DISPATCH_LPR((int)(X / 4),                                                                                     \
                    hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, FOLD>), dim3(nb), dim3(kBlock), 0, s, it, \
@@ -632,6 +638,7 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
       dw_out = workspace;
       HET_HIP(hipMemsetAsync(dw_out, 0, sizeof(float) * replicas * n_w, s));
     }
+    if (het_ktime_on()) kt = new HetKTimer("HET_gat_backward_grouped", s);
 #define HET_GAT_BWD_DW(SORTED, RM, SLOT)                                                                                 \
   HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_backward_grouped<LPR, SORTED, true, RM, SLOT>), dim3(nbw),    \
                                                     dim3(kBlock), 0, s, it, g->p0, feat, el, er, sum, ex, ret, gradout, \
@@ -645,14 +652,18 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
       if (sorted) { HET_GAT_BWD_DW(true, 8, false); } else { HET_GAT_BWD_DW(false, 8, false); }
     }
 #undef HET_GAT_BWD_DW
+    delete kt;
+    kt = nullptr;
     if (replicas > 1) {
       HET_LAUNCH_CHECK("HET_gat_backward_grouped");
       hipLaunchKernelGGL(HET_gat_fold_w_reduce, dim3((n_w + kBlock - 1) / kBlock), dim3(kBlock), 0, s, dw_out, replicas, n_w,
                          grad_fold_w);
     }
   } else if (fold_w) {
+    HET_KTIME("HET_gat_backward_grouped", s);
     if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
   } else {
+    HET_KTIME("HET_gat_backward_grouped", s);
     if (sorted) { HET_GAT_BWD(true, false); } else { HET_GAT_BWD(false, false); }
   }
 #undef HET_GAT_BWD
@@ -683,6 +694,7 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
     // short segments (5.7 edges per (relation, source) row on ogbn-mag): a lane group per item, two edges in flight
     // (same box: wave per item 3.4-3.5 ms for the whole op, lane group per item with U = 1 / 2 / 4: 3.7 / 3.1 / 3.65 ms)
     const unsigned nbs = (unsigned)ceil_div64(by_srow->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+    HET_KTIME("HET_gat_backward_src", s);
     HET_DISPATCH_LPR((int)(X / 4),
                      hipLaunchKernelGGL((HET_gat_backward_src_slot<LPR, 2>), dim3(nbs), dim3(kBlock), 0, s, it, by_srow->p0,
                                         by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,
@@ -690,6 +702,7 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
     HET_LAUNCH_CHECK("HET_gat_backward_src_slot");
   } else {
     const unsigned nb = (unsigned)ceil_div64(by_srow->num_items, kBlock / 64);
+    HET_KTIME("HET_gat_backward_src", s);
     HET_DISPATCH_LPR((int)(X / 4),
                      hipLaunchKernelGGL(HET_gat_backward_src_grouped<LPR>, dim3(nb), dim3(kBlock), 0, s, it, by_srow->p0,
                                         by_srow->p1, feat, exp, pack, gradout, grad_feat, grad_el, tbuf, H, D, slope, fold_w,

@@ -360,7 +360,10 @@ int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
   const unsigned gy = (unsigned)((a.K / (KT * 32)) * (a.X / (NT * 32)));
   HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx, gy), dim3(256), lds, s, a, (int)chunk);
+  {
+    HET_KTIME("HET_seg_dw_mfma", s);
+    hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx, gy), dim3(256), lds, s, a, (int)chunk);
+  }
   HET_LAUNCH_CHECK("HET_seg_dw_mfma");
   return HET_OK;
 }
@@ -374,6 +377,7 @@ int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
   dim3 grid((unsigned)gx), block(256);
+  HET_KTIME(a.dot_w ? "HET_seg_gemm_mfma<dot>" : (a.atomic ? "HET_seg_gemm_mfma<atomic>" : "HET_seg_gemm_mfma<store>"), s);
   if (a.dot_w) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a, chunk);

@@ -144,6 +144,7 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   const int32_t* p_scale = (g->p1 && !scale_by_p0) ? g->p1 : g->p0;
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   const int contig = g->p0_contiguous;  // same box: 2.35 -> 2.25 ms for the a2 backward of C3
+  HET_KTIME("HET_segment_sum", s);
 #define HET_SS(L)                                                                                                   \
   hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \
                      g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, nt_in,  \

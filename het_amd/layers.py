@@ -36,7 +36,7 @@ class HET_RGATLayer(nn.Module):
     def __init__(self, in_feat, out_feat, num_rels, num_heads, *, bias=True, activation=None, self_loop=False,
                  compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
                  multiply_among_weights_first_flag=False, gat_edge_parallel_flag=True, dropout=0.5,
-                 leaky_relu_slope=0.2):
+                 leaky_relu_slope=0.2, reference_op_sequence=False):
         super().__init__()
         assert out_feat % num_heads == 0, "out_feat must be a multiple of num_heads"
         self.in_feat, self.out_feat, self.num_rels, self.num_heads = in_feat, out_feat, num_rels, num_heads
@@ -46,6 +46,10 @@ class HET_RGATLayer(nn.Module):
         self.multiply_among_weights_first_flag = multiply_among_weights_first_flag
         self.gat_edge_parallel_flag = gat_edge_parallel_flag
         self.leaky_relu_slope = leaky_relu_slope
+        # True: run the reference's op sequence literally (only reference-named torch_hrt ops, the reference wrappers'
+        # zero-filled "+=" buffers; het_amd/backend/reference_protocol.py) -- the drop-in path bench.py times as
+        # variants.reference_op_sequence.  Non-compact flags, full graph.
+        self.reference_op_sequence = reference_op_sequence
         self.conv_weights = nn.Parameter(th.Tensor(num_rels, num_heads, in_feat, out_feat // num_heads))
         self.attn_l = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
         self.attn_r = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
@@ -74,6 +78,10 @@ class HET_RGATLayer(nn.Module):
     def forward(self, g, inputs: th.Tensor, num_dst=None):
         """``num_dst``: the destination nodes of ``g`` are its first ``num_dst`` nodes (a sampled block, or the owned
         nodes of a partition followed by halo nodes): only their rows are returned and the self-loop runs on them only."""
+        if self.reference_op_sequence:
+            assert not self.compact_as_of_node_flag and num_dst is None and self.gat_edge_parallel_flag
+            from .backend.reference_protocol import rgat_layer_reference_sequence
+            return rgat_layer_reference_sequence(self, g, inputs)
         if (self.gat_edge_parallel_flag and
                 FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                        self.multiply_among_weights_first_flag)):

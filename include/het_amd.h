@@ -53,6 +53,15 @@ typedef void* het_stream; /* hipStream_t */
 const char* het_build_info(void);
 const char* het_last_error(void);
 
+/* Per-kernel device timing for bench.py's roofline figures (no reference counterpart: the reference times whole
+ * forward / backward passes with CUDA events, RGNNUtils.py:291-311).  While enabled, the library records a HIP event
+ * pair on the launch stream around every launch of its dominant kernels (the kernel alone, not the entry point's
+ * fills or neighbouring launches).  het_kernel_timing_read synchronises the recorded events and returns the summed
+ * duration and the number of launches of the kernels whose name starts with `name_prefix` (the __global__ name as
+ * rocprofv3 prints it, without template arguments, e.g. "HET_gat_aggregate").  Enabling clears earlier records. */
+int het_kernel_timing_enable(int on);
+int het_kernel_timing_read(const char* name_prefix, double* total_ms, int64_t* launches);
+
 /* ------------------------------------------------------------------------
  * Groupings: a one-time, device-side preprocessing of an index list that the
  * fast paths use to replace float atomics by segmented reductions.  A grouping

@@ -40,9 +40,19 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # every declared compute entry point has a ctypes signature (so the Python side calls it typed)
     untyped = [n for n in names if n not in _lib._SIGNATURES and n not in
-               ("het_build_info", "het_last_error", "het_grouping_destroy", "het_grouping_num_segments")]
+               ("het_build_info", "het_last_error", "het_grouping_destroy", "het_grouping_num_segments",
+                "het_kernel_timing_enable", "het_kernel_timing_read")]
     assert not untyped, untyped
     assert "gfx950" in _lib.build_info()
+
+
+def test_kernel_timing_api_without_gpu():
+    """The per-kernel timing switch works with no device: nothing recorded, zero launches."""
+    from het_amd import _lib
+    _lib.kernel_timing(True)
+    ms, n = _lib.kernel_timing_read("HET_")
+    assert ms == 0.0 and n == 0
+    _lib.kernel_timing(False)
 
 
 def test_torch_hrt_namespace_has_reference_op_names():

@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0):
+def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0, **layer_kw):
     from het_amd.layers import HET_RGATLayer
     torch.manual_seed(seed)
     R, N = g.get_num_rels(), g.get_num_nodes()
     layer = HET_RGATLayer(K, X, R, H, bias=True, self_loop=True, compact_as_of_node_flag=compact,
                           compact_direct_indexing_flag=direct, multiply_among_weights_first_flag=mulfirst,
-                          gat_edge_parallel_flag=edge_parallel, dropout=0.0)
+                          gat_edge_parallel_flag=edge_parallel, dropout=0.0, **layer_kw)
     with torch.no_grad():
         layer.h_bias.uniform_(-0.1, 0.1)
     x = torch.randn(N, K) * 0.5
@@ -48,6 +48,47 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0)
                                                      (True, True, False), (True, True, True), (True, False, True)])
 def test_rgat_layer_variants(compact, direct, mulfirst):
     _run_rgat(random_graph(seed=41, n=400, r=4, e=6000, shuffle=False), H=4, K=64, X=64, compact=compact, direct=direct, mulfirst=mulfirst)
+
+
+@pytest.mark.parametrize("literal_er", [False, True])
+@pytest.mark.parametrize("mulfirst", [False, True])
+def test_rgat_layer_per_edge_dataflow(mulfirst, literal_er, monkeypatch):
+    """Default flags on the per-edge (kind 0) dataflow of round 1 (HET_RGAT_PER_EDGE=1), with er as the reference's
+    literal (x . W) . attn_r and as x . (W . attn_r): same layer, same oracle."""
+    from het_amd.backend import rgat_fused_layer as FL
+    monkeypatch.setattr(FL, "PER_EDGE", True)
+    monkeypatch.setattr(FL, "LITERAL_ER", literal_er)
+    _run_rgat(random_graph(seed=43, n=400, r=4, e=6000, shuffle=False), H=4, K=64, X=64, compact=False, direct=False, mulfirst=mulfirst)
+
+
+def test_rgat_layer_default_flags_literal_er(monkeypatch):
+    """Default flags on the distinct-row dataflow with er = (x . W) . attn_r as two products (HET_RGAT_LITERAL_ER=1)."""
+    from het_amd.backend import rgat_fused_layer as FL
+    monkeypatch.setattr(FL, "LITERAL_ER", True)
+    _run_rgat(random_graph(seed=44, n=400, r=4, e=6000, shuffle=False), H=4, K=64, X=64, compact=False, direct=False, mulfirst=False)
+
+
+@pytest.mark.parametrize("mulfirst", [False, True])
+def test_rgat_reference_op_sequence_calls_only_reference_ops(mulfirst, monkeypatch):
+    """The drop-in path (het_amd/backend/reference_protocol.py = RGAT/models.py:265-385 on the reference's wrappers):
+    same values as the oracle, and every C entry point it reaches belongs to a reference-named torch_hrt op (plus the
+    one-time grouping construction those ops do internally)."""
+    from het_amd import _lib
+    import het_amd.kernels as k
+    called = []
+    real = _lib.call
+
+    def spy(name, *a):
+        called.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(_lib, "call", spy)
+    _run_rgat(random_graph(seed=45, n=300, r=4, e=5000, shuffle=False), H=4, K=64, X=64, compact=False, direct=False,
+              mulfirst=mulfirst, reference_op_sequence=True)
+    allowed = {"het_" + n for n in k.REGISTERED_OPS} | {"het_grouping_create", "het_grouping_rank_of_position"}
+    assert called and set(called) <= allowed, sorted(set(called) - allowed)
+    assert {"het_rgnn_relational_matmul", "het_backward_rgnn_relational_matmul", "het_relational_fused_gat_separate_coo",
+            "het_backward_relational_fused_gat_separate_coo"} <= set(called)
 
 
 def test_rgat_layer_csr_path():
