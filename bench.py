@@ -258,9 +258,11 @@ def main():
     HL.kernel_timing(False)
     per_step = sorted(a.elapsed_time(b) for a, b in step_events)  # device time of every step (events, this rank)
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
-    # live per-kernel durations of the timed region: {kernel: (avg ms per launch, launches per step, ms per step)}
+    # live per-kernel durations of the timed region: {kernel: (avg ms per launch, launches per step, ms per step)}; the roofline
+    # objects use ms per step = the summed duration of the launches that together implement the op in one step
     kt = {}
-    for name in ("HET_gat_backward_src", "HET_gat_backward_grouped", "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
+    for name in ("HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_src", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
+                 "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
                  "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_dw_mfma", "HET_segment_sum"):
         ms, n = HL.kernel_timing_read(name)
         if n:
@@ -307,7 +309,8 @@ def main():
     roofline = roofline_fwd = None
     if args.model == "rgat":
         S_row = S_col = None
-        if "HET_gat_backward_src" in kt and not use_dist:
+        compact_flow = "HET_rgat_backward_src" in kt or "HET_gat_backward_src" in kt
+        if compact_flow and not use_dist:
             ss = g.get_separate_unique_node_indices_single_sided()
             S_row, S_col = int(ss["node_indices_row"].numel()), int(ss["node_indices_col"].numel())
         gather = {}
@@ -315,25 +318,26 @@ def main():
             # the [S_row, X] / [N, X] tables the passes gather from (0.9 / 0.5 GB) exceed the 256 MiB Infinity Cache, so
             # every edge's row really crosses the memory fabric: the bytes the kernel is REQUIRED to move
             gather = {"S_row": S_row, "S_col": S_col}
-        bname = "HET_gat_backward_src" if "HET_gat_backward_src" in kt else "HET_gat_backward_grouped"
-        if bname in kt:
+        bname = next((n for n in ("HET_rgat_backward_src", "HET_gat_backward_src", "HET_gat_backward_grouped") if n in kt), None)
+        if bname:
             nb_ = gat_bwd_bytes(E_local, N_local, H, X, S_row, S_col)
             ex = dict(gather)
             if S_row is not None:
                 req = nb_ + (E_local - S_row) * 4 * X  # one gradout row per edge instead of per source row
                 ex.update(bytes_with_per_edge_row_gather=int(req),
-                          frac_with_per_edge_row_gather=round(req / (kt[bname][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                          frac_with_per_edge_row_gather=round(req / (kt[bname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {'4: rows of the distinct (relation, node) projections' if S_row else 0})",
-                                kt[bname][0], nb_, ex, pmc_name=bname)
-        if "HET_gat_aggregate_grouped" in kt:
+                                kt[bname][2], nb_, ex, pmc_name=bname)
+        fname = next((n for n in ("HET_rgat_aggregate", "HET_gat_aggregate_grouped") if n in kt), None)
+        if fname:
             nf_ = gat_fwd_bytes(E_local, N_local, H, X, S_row, S_col)
             ex = dict(gather)
             if S_row is not None:
                 req = nf_ + (E_local - S_row) * 4 * X
                 ex.update(bytes_with_per_edge_row_gather=int(req),
-                          frac_with_per_edge_row_gather=round(req / (kt["HET_gat_aggregate_grouped"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-            roofline_fwd = hbm_view(f"HET_gat_aggregate_grouped (relational_fused_gat_separate_coo, kind {4 if S_row else 0})",
-                                    kt["HET_gat_aggregate_grouped"][0], nf_, ex, pmc_name="HET_gat_aggregate_grouped")
+                          frac_with_per_edge_row_gather=round(req / (kt[fname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0})",
+                                    kt[fname][2], nf_, ex, pmc_name=fname)
     kernel_ms = {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}
 
     # the reference-named ops exactly as the reference's model code calls them (kind 0, [E,H,D] feat), each launched a

@@ -34,6 +34,8 @@ _SIGNATURES = {
     "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P, P],
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
+    "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P],
+    "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],
     "het_backward_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P, I64, P],
     "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P, P],
@@ -71,6 +73,8 @@ def lib() -> C.CDLL:
         L.het_grouping_destroy.restype = None
         L.het_grouping_num_segments.argtypes = [P]
         L.het_grouping_num_segments.restype = I64
+        L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
+        L.het_rgat_backward_compact_workspace.restype = I64
         L.het_kernel_timing_enable.argtypes = [INT]
         L.het_kernel_timing_enable.restype = INT
         L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]

@@ -78,6 +78,16 @@ def _compact_dicts(g, direct):
     return ss, 3, fwd, bwd
 
 
+def _edge_rows(g, ss, direct, rp, row, col, eids):
+    """(feat row, er row) of every edge position, [E] int64 each: the graph's inverse indices when it carries them
+    (indexed by edata id == position after canonicalize_eids), else located in the unique lists once and cached."""
+    sep = getattr(g, "graph_data", {}).get("separate", {}).get("unique_node_indices_single_sided", {})
+    if "inverse_indices_row" in sep and getattr(g, "sequential_eids_format", None) == "separate_coo":
+        return sep["inverse_indices_row"], sep["inverse_indices_col"]
+    maps = (ss["rel_ptrs_row"], ss["node_indices_row"], ss["rel_ptrs_col"], ss["node_indices_col"])
+    return _k._src_rows_by_position(3, maps, rp, row, eids), _k._dst_rows_by_position(3, maps, rp, col, eids)
+
+
 def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
     R, H, Kd, D = W.shape
@@ -109,25 +119,26 @@ class RgatLayerFunction(th.autograd.Function):
         if mulfirst:  # RGAT/models.py:300-326: the attention vector folded into the weight, [R,H,K,1]
             wa = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd, 1)
         if compact:
-            ss, kind, fwd, bwd = _compact_dicts(g, direct)
+            ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
-            ex = new(E, H)
             featc = new(ss["node_indices_row"].numel(), H, D)
-            K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
             elc = new(featc.shape[0], H)
-            K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc)
+            _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
             erc = new(ss["node_indices_col"].numel(), H)
             if mulfirst:
                 K.rgnn_relational_matmul(d_col, 1, wa, x, erc.view(-1, H, 1), True)
                 saved = (featc, elc, erc)
             else:
                 featd = new(erc.shape[0], H, D)
-                K.rgnn_relational_matmul(d_col, 1, W, x, featd, True)
-                K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_col"], attn_r.unsqueeze(-1), featd, erc)
-                saved = (featc, elc, featd, erc)
-            _k.fused_gat_forward(eids, rp, row, col, kind, fwd, featc, elc, erc, sm, ex, ret, slope, None)
-            ctx.bwd_dict, ctx.kind = bwd, kind
+                _k.matmul_attn_dot(d_col, 1, W, x, featd, attn_r, erc)
+                saved = (featc, elc, erc, featd)
+            # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
+            srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
+            grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])
+            _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope)
+            ctx.grp = grp
+            ex = x.new_empty(0)
         else:
             # el / er are produced directly in the destination-grouped order of the GAT kernels (rank of every position):
             # the aggregation pass forms exp from two coalesced streams, no exp pass, no per-edge 16-byte gathers
@@ -177,7 +188,7 @@ class RgatLayerFunction(th.autograd.Function):
         R, H, _, D = W.shape
         X = H * D
         grad_h = grad_h.contiguous()
-        grad_bias = grad_h.sum(0) if ctx.has_bias else None
+        grad_bias = grad_h.sum(0) if (ctx.has_bias and not ctx.compact) else None
         Wt = th.transpose(W, 2, 3).contiguous()
         grad_W = th.zeros_like(W)
         # one input-gradient buffer: the self-loop writes its rows with plain stores, the projections add to it
@@ -199,17 +210,16 @@ class RgatLayerFunction(th.autograd.Function):
             wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)  # [R,H,K,1] transposed(2,3): same memory
             grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
         if ctx.compact:
-            if mulfirst:
-                (featc, elc, erc), featd = saved, None
-            else:
-                featc, elc, featd, erc = saved
+            featc, elc, erc = saved[:3]
+            featd = None if mulfirst else saved[3]
             ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"], "unique_srcs_and_dests_node_indices": ss["node_indices_row"]}
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
-            # (the grouped compact backward overwrites all three: rgat_layer_fused_ok guarantees that path)
-            g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
-            _k.fused_gat_backward(eids, rp, row, col, ctx.kind, ctx.bwd_dict, featc, elc, erc, sm, ex, ret, go, g_featc, g_elc,
-                                  g_erc, slope, None, fold_attn_l=attn_l, fold_row_rel_ptrs=ss["rel_ptrs_row"])
+            g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
+            if ctx.has_bias:  # the bias gradient (column sums of grad_h) from the pass that reads every gradout row anyway
+                grad_bias = th.empty(X, dtype=x.dtype, device=x.device)
+            _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm, ret, go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
+                                     row_rel_ptrs=ss["rel_ptrs_row"], grad_bias=grad_bias if ctx.has_bias else None, bias_rows=nd)
             grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
             _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
                                                  grad_attn_l.unsqueeze(-1), accumulate=False)

@@ -1,0 +1,778 @@
+// RGAT on the distinct (relation, node) rows, without any per-edge float tensor between forward and backward.
+//
+// The layer's projections live on the S_row distinct (relation, source) rows (feat_c [S_row,H,D], el_c [S_row,H]) and
+// the S_col distinct (relation, destination) rows (er_c [S_col,H]).  The reference's ops pass exp [E,H] from the forward
+// to the backward (RGAT/RGATKernelsSeparateCOO.cu.h:190-196 writes it, RGATBackwardKernelsSeparateCOO.cu.h:60-80 reads
+// it); here both passes form exp(leaky_relu(el_c[srow] + er_c[drow])) from the two small tables (38 MB + 20 MB on
+// ogbn-mag: they live in L2 / Infinity Cache), so the [E,H] tensor, its pass (HET_gat_exp_edge) and its 16-byte-per-128-
+// byte-line gathers are gone.  Same values: exp is a pure function of el + er.
+//
+//   forward   wave per destination work item (het_grouping by destination, payload0 = feat row, payload1 = er row)
+//   backward  SHORT (relation, source) segments (<= HET_PACK_T edges; the median is 2): lane group per PACK of whole
+//             segments (grouping_packs) -- a work unit per segment would spend its time in dependent prologues (item
+//             record -> ids -> rows); a pack of ~32 consecutive ranks streams its ids a step ahead and keeps 4 gradient
+//             rows in flight per lane group whatever the segment lengths are; rows of a segment are summed in registers
+//             and stored once.  LONG segments (61 % of the edges of the skewed ogbn-mag-like graph): wave per work item
+//             of <= HET_ITEM_MAX edges, lane groups round-robin, one cross-group reduction and store per item.
+#include <stdlib.h>
+
+#include "fused_gat.hip.h"
+#include "seg_reduce.hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+struct Items {
+  const int32_t *seg, *begin, *end, *seg_ptr, *seg_key;
+  int64_t n;
+};
+
+// ret[v,h,:] = SUM_e w_e * feat[srow_e,h,:] / SUM_e w_e,  w_e = exp(leaky(el[srow_e,h] + er[drow_e,h])); sum[v,h] = SUM_e w_e
+// Same schedule as HET_gat_aggregate_grouped (fused_gat_grouped.hip): 64/LPR lane groups take the item's edges
+// round-robin, U rows per group in flight, ids of the next step prefetched.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, const int32_t* __restrict__ p_srow,
+                                                                      const int32_t* __restrict__ p_drow,
+                                                                      const float* __restrict__ feat,
+                                                                      const float* __restrict__ el,
+                                                                      const float* __restrict__ er,
+                                                                      float* __restrict__ sum, float* __restrict__ ret,
+                                                                      int H, int D, float slope) {
+  constexpr int EPW = 64 / LPR, U = 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t X = (int64_t)H * D;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f;
+  int jn[U];
+  int64_t srown[U], drown[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) jn[u] = b + slot + u * EPW < e ? b + slot + u * EPW : e - 1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
+#pragma unroll
+  for (int u = 0; u < U; ++u) drown[u] = p_drow[jn[u]];
+  const int64_t v = it.seg_key[seg];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    float zl[U], zr[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zl[u] = el[srown[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zr[u] = er[drown[u] * H + h];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + srown[u] * X + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) jn[u] = j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) drown[u] = p_drow[jn[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = j0 + u * EPW < e ? leaky_exp(zl[u] + zr[u], slope) : 0.f;
+      acc.x = fmaf(w, f[u].x, acc.x);
+      acc.y = fmaf(w, f[u].y, acc.y);
+      acc.z = fmaf(w, f[u].z, acc.z);
+      acc.w = fmaf(w, f[u].w, acc.w);
+      ssum += w;
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  float* rp = ret + v * X + x;
+  if (whole) {
+    const float inv = 1.f / ssum;
+    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    if (x % D == 0) sum[v * H + h] = ssum;
+  } else {  // hub destination: unnormalised partials, normalised by HET_rgat_normalize_split
+    atomicAdd(rp + 0, acc.x);
+    atomicAdd(rp + 1, acc.y);
+    atomicAdd(rp + 2, acc.z);
+    atomicAdd(rp + 3, acc.w);
+    if (x % D == 0) atomicAdd(&sum[v * H + h], ssum);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void HET_rgat_normalize_split(const int32_t* __restrict__ split_seg,
+                                                                    const int32_t* __restrict__ seg_key,
+                                                                    int64_t num_split, const float* __restrict__ sum,
+                                                                    float* __restrict__ ret, int H, int D) {
+  const int64_t X = (int64_t)H * D, total = num_split * X;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t k = t / X;
+    const int x = (int)(t - k * X);
+    const int64_t v = seg_key[split_seg[k]];
+    ret[v * X + x] /= sum[v * H + x / D];
+  }
+}
+
+// pack[v] = { 1/sum[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }, or interleaved per head ([N,H,2]); bias_part (optional, [gridDim.x * waves, X]):
+// per-wave column sums of gradout over the nodes the wave visited (the bias gradient, reduced by HET_rgat_colsum_finish).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_dst_pack(const float* __restrict__ sum, const float* __restrict__ ret,
+                                                             const float* __restrict__ gradout, float* __restrict__ pack,
+                                                             int64_t N, int H, int D, float* __restrict__ bias_part,
+                                                             int64_t bias_rows, int interleaved) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t step = (int64_t)gridDim.x * (kBlock / 64) * EPW;
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t v0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * EPW; v0 < N; v0 += step) {
+    const bool ok = v0 + slot < N;
+    const int64_t v = ok ? v0 + slot : N - 1;  // past the end: the last node again (same bytes rewritten)
+    const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
+    float dot = g.x * r.x + g.y * r.y + g.z * r.z + g.w * r.w;
+    for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if ((sub & (DL - 1)) == 0) {
+      if (interleaved) {
+        *reinterpret_cast<float2*>(pack + (v * H + h) * 2) = make_float2(1.f / sum[v * H + h], dot);
+      } else {
+        pack[v * 2 * H + h] = 1.f / sum[v * H + h];
+        pack[v * 2 * H + H + h] = dot;
+      }
+    }
+    if (bias_part && ok && v < bias_rows) { bs.x += g.x; bs.y += g.y; bs.z += g.z; bs.w += g.w; }
+  }
+  if (bias_part) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      bs.x += __shfl_xor(bs.x, off); bs.y += __shfl_xor(bs.y, off);
+      bs.z += __shfl_xor(bs.z, off); bs.w += __shfl_xor(bs.w, off);
+    }
+    if (slot == 0) st4(bias_part + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * X + x, bs);
+  }
+}
+
+// out[x] = SUM_p part[p, x]: one workgroup per 64 columns... X <= 256 columns, P partial rows: thread per (column, slice)
+__global__ __launch_bounds__(kBlock) void HET_rgat_colsum_finish(const float* __restrict__ part, int64_t P, int X,
+                                                                  float* __restrict__ out) {
+  __shared__ float red[kBlock];
+  const int x = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int64_t p = t; p < P; p += kBlock) a += part[p * X + x];
+  red[t] = a;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[x] = red[0];
+}
+
+struct Packs {
+  const int32_t *ptr, *key;
+  int64_t n;
+};
+
+// Lane group per pack of the grouping by feat row u (payload0 = destination, payload1 = er row):
+//   a_e = exp(leaky(el[u,h] + er[drow_e,h])) / sum[dst_e,h];  dl_e = (el + er > 0) ? 1 : slope
+//   grad_feat[u,h,:] = SUM_e a_e * gradout[dst_e,h,:]  (+ grad_el[u,h] * fold_w[r(u),h,:])
+//   t_e = a_e * dl_e * (<gradout[dst_e,h,:], feat[u,h,:]> - <gradout, ret>[dst_e,h]);   grad_el[u,h] = SUM_e t_e
+//   tbuf[j,h] = t_e for the edge at sorted rank j   (summed per er row by a segmented pass over the grouping by er row)
+template <int LPR, int U>
+__global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
+    Packs pk, const int32_t* __restrict__ p_dst, const int32_t* __restrict__ p_drow, const float* __restrict__ feat,
+    const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack,
+    const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
+    float* __restrict__ tbuf, int H, int D, float slope, const float* __restrict__ fold_w,
+    const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
+  if (pid >= pk.n) return;
+  const uint32_t pb = (uint32_t)pk.ptr[pid];
+  const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
+  constexpr bool partial = false;  // (a long segment is one pack here: summed by this lane group alone, stored once)
+  const int64_t X = (int64_t)H * D;
+  const bool head_lane = (sub & (DL - 1)) == 0;
+  // ids of the first batch (clamped to the pack); keyn[U] = key of the rank after the batch
+  int keyn[U + 1];
+  int64_t dstn[U], drown[U];
+#pragma unroll
+  for (int q = 0; q <= U; ++q) keyn[q] = pk.key[b + q < e ? b + q : e];  // key[e] belongs to the next pack (or -1)
+#pragma unroll
+  for (int q = 0; q < U; ++q) dstn[q] = p_dst[b + q < e ? b + q : e - 1];
+#pragma unroll
+  for (int q = 0; q < U; ++q) drown[q] = p_drow[b + q < e ? b + q : e - 1];
+  int prev_key = -1;  // no segment open
+  float4 fcur = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float zlcur = 0.f, acc_el = 0.f;
+  for (int j0 = b; j0 < e; j0 += U) {
+    int key[U + 1];
+    int64_t dst[U];
+    float zr[U], sinv[U], gr[U], zlq[U];
+    float4 g[U], fq[U];
+#pragma unroll
+    for (int q = 0; q <= U; ++q) key[q] = keyn[q];
+#pragma unroll
+    for (int q = 0; q < U; ++q) dst[q] = dstn[q];
+#pragma unroll
+    for (int q = 0; q < U; ++q) zr[q] = er[drown[q] * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) sinv[q] = pack[dst[q] * 2 * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) gr[q] = pack[dst[q] * 2 * H + H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + dst[q] * X + x);
+    // the feat row / el of a segment are loaded where the segment starts inside this batch (predicated: uniform per lane group)
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const bool start = j0 + q < e && key[q] != (q == 0 ? prev_key : key[q - 1]);
+      fq[q] = fcur;
+      zlq[q] = zlcur;
+      if (start) {
+        fq[q] = ld4(feat + (int64_t)key[q] * X + x);
+        zlq[q] = el[(int64_t)key[q] * H + h];
+      }
+    }
+    // ids of the next batch, in flight while this batch's rows arrive
+#pragma unroll
+    for (int q = 0; q <= U; ++q) keyn[q] = pk.key[j0 + U + q < e ? j0 + U + q : e];
+#pragma unroll
+    for (int q = 0; q < U; ++q) dstn[q] = p_dst[j0 + U + q < e ? j0 + U + q : e - 1];
+#pragma unroll
+    for (int q = 0; q < U; ++q) drown[q] = p_drow[j0 + U + q < e ? j0 + U + q : e - 1];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const bool ok = j0 + q < e;  // uniform within the lane group
+      const bool start = ok && key[q] != (q == 0 ? prev_key : key[q - 1]);
+      if (start) { fcur = fq[q]; zlcur = zlq[q]; }
+      const float z = zlcur + zr[q];
+      const float a = ok ? leaky_exp(z, slope) * sinv[q] : 0.f;
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * fcur.x + g[q].y * fcur.y + g[q].z * fcur.z + g[q].w * fcur.w;
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float t = a * (z > 0.f ? 1.f : slope) * (dot - gr[q]);
+      if (ok && head_lane) tbuf[(int64_t)(j0 + q) * H + h] = t;
+      acc_el += t;  // identical in the DL lanes of a head
+      const bool last = ok && (j0 + q == e - 1 || key[q + 1] != key[q]);
+      if (last) {  // the segment (or this pack's piece of it) ends here: one store of its gradient row
+        const int64_t u = key[q];
+        float4 o = acc;
+        if (fold_w) {  // el[u,h] = <feat[u,h,:], fold_w[r(u),h,:]>: its gradient joins grad_feat here (linear: also per piece)
+          const float4 w = ld4(fold_w + (int64_t)find_segment(fold_row_rel_ptrs, R, (idx_t)u) * X + x);
+          o.x = fmaf(acc_el, w.x, o.x); o.y = fmaf(acc_el, w.y, o.y);
+          o.z = fmaf(acc_el, w.z, o.z); o.w = fmaf(acc_el, w.w, o.w);
+        }
+        float* gp = grad_feat + u * X + x;
+        if (!partial) {
+          st4(gp, o);
+          if (head_lane) grad_el[u * H + h] = acc_el;
+        } else {
+          atomicAdd(gp + 0, o.x); atomicAdd(gp + 1, o.y); atomicAdd(gp + 2, o.z); atomicAdd(gp + 3, o.w);
+          if (head_lane) atomicAdd(&grad_el[u * H + h], acc_el);
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc_el = 0.f;
+      }
+    }
+    prev_key = key[U - 1];
+  }
+}
+
+
+// ---- cooperative scalar loads -------------------------------------------------------------------------------------
+// Both passes were bound by the NUMBER of vector-memory instructions, not by bytes: every per-edge scalar (an index, an
+// attention term) cost a wave instruction that fetched 4 distinct values for 64 lanes, and a step of 4 edges per lane
+// group issued 20 (forward) / 41 (backward) of them against 4 row loads (measured: 1.15 / 2.4 ms, i.e. the same ~60 us
+// per instruction-per-step in both).  Here lane (head h, d) of a lane group fetches the scalar of edge d of the step --
+// one instruction per step and stream instead of one per edge -- and the DL = D/4 lanes of a head exchange the values
+// with DPP quad broadcasts (DL == 4: no LDS, no extra instruction slot) or a bpermute.
+template <int Q>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, Q * 0x55, 0xf, 0xf, false);  // quad_perm:[Q,Q,Q,Q]
+}
+template <int DL>
+__device__ __forceinline__ int head_bcast_i(int v, int q, int lane) {
+  if constexpr (DL == 4) {
+    switch (q) {
+      case 0: return quad_bcast_i<0>(v);
+      case 1: return quad_bcast_i<1>(v);
+      case 2: return quad_bcast_i<2>(v);
+      default: return quad_bcast_i<3>(v);
+    }
+  } else {
+    return __shfl(v, (lane & ~(DL - 1)) | q, 64);
+  }
+}
+template <int DL>
+__device__ __forceinline__ float head_bcast(float v, int q, int lane) {
+  return __int_as_float(head_bcast_i<DL>(__float_as_int(v), q, lane));
+}
+__device__ __forceinline__ float fast_leaky_exp(float z, float slope) { return __expf(z > 0.f ? z : slope * z); }
+
+// Forward, cooperative form of HET_rgat_aggregate_compact (DL = D/4 >= 4 lanes per head, 4 edges per lane group and step).
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, const int32_t* __restrict__ p_srow,
+                                                                   const int32_t* __restrict__ p_drow,
+                                                                   const float* __restrict__ feat,
+                                                                   const float* __restrict__ el,
+                                                                   const float* __restrict__ er,
+                                                                   float* __restrict__ sum, float* __restrict__ ret,
+                                                                   int H, float slope) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;  // the edge of the step whose scalars this lane fetches
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f;
+  int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
+  int srown = p_srow[jn], drown = p_drow[jn];
+  const int64_t v = it.seg_key[seg];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int srowv = srown, drowv = drown;
+    const float zlv = el[(int64_t)srowv * H + h];
+    const float zrv = er[(int64_t)drowv * H + h];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
+    jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
+    srown = p_srow[jn];
+    drown = p_drow[jn];
+    const float wv = j0 + dq * EPW < e ? fast_leaky_exp(zlv + zrv, slope) : 0.f;  // one exp per (edge, head)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = head_bcast<DL>(wv, u, lane);
+      acc.x = fmaf(w, f[u].x, acc.x);
+      acc.y = fmaf(w, f[u].y, acc.y);
+      acc.z = fmaf(w, f[u].z, acc.z);
+      acc.w = fmaf(w, f[u].w, acc.w);
+      ssum += w;
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  float* rp = ret + v * X + x;
+  if (whole) {
+    const float inv = 1.f / ssum;
+    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    if (d == 0) sum[v * H + h] = ssum;
+  } else {
+    atomicAdd(rp + 0, acc.x);
+    atomicAdd(rp + 1, acc.y);
+    atomicAdd(rp + 2, acc.z);
+    atomicAdd(rp + 3, acc.w);
+    if (d == 0) atomicAdd(&sum[v * H + h], ssum);
+  }
+}
+
+// Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {1/sum, <gradout, ret>} interleaved.
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
+    Packs pk, const int32_t* __restrict__ p_dst, const int32_t* __restrict__ p_drow, const float* __restrict__ feat,
+    const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack2,
+    const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
+    float* __restrict__ tbuf, int H, float slope, const float* __restrict__ fold_w,
+    const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
+  if (pid >= pk.n) return;
+  const uint32_t pb = (uint32_t)pk.ptr[pid];
+  const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
+  if (pb >> 31) return;  // a long segment: HET_rgat_backward_src_long takes its work items
+  constexpr bool partial = false;
+  // first feat row of relations 1 .. 7 in scalar registers: the relation of a row is a few compares (rows are relation-major)
+  int rp[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) rp[i] = (fold_w && i + 1 < R) ? (int)fold_row_rel_ptrs[i + 1] : 0x7fffffff;
+  int jn = b + dq < e ? b + dq : e - 1;
+  int keyn = pk.key[jn], dstn = p_dst[jn], drown = p_drow[jn];
+  int prev_key = -1, rel_cur = -1;
+  float4 fcur = make_float4(0.f, 0.f, 0.f, 0.f), wcur = fcur, acc = fcur;
+  float acc_el = 0.f;
+  for (int j0 = b; j0 < e; j0 += U) {
+    const int keyv = keyn, dstv = dstn, drowv = drown;
+    // scalars of the step: lane (h, q) fetches those of edge q, head h
+    const float zrv = er[(int64_t)drowv * H + h];
+    const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    const float zlv = el[(int64_t)keyv * H + h];
+    int key[U];
+    float4 g[U], fq[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) key[q] = head_bcast_i<DL>(keyv, q, lane);
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {  // feat row of a segment that starts inside this step (uniform per lane group)
+      fq[q] = fcur;
+      if (j0 + q < e && key[q] != (q == 0 ? prev_key : key[q - 1])) fq[q] = ld4(feat + (int64_t)key[q] * X + x);
+    }
+    // ids of the next step, in flight while this step's rows arrive
+    jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
+    keyn = pk.key[jn];
+    dstn = p_dst[jn];
+    drown = p_drow[jn];
+    // per (edge, head) once: attention weight, its leaky-ReLU branch, the destination's <gradout, ret>
+    const float zv = zlv + zrv;
+    const float av = j0 + dq < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
+    const float adv = av * (zv > 0.f ? 1.f : slope);
+    float tq[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const bool ok = j0 + q < e;  // uniform within the lane group
+      if (ok && key[q] != (q == 0 ? prev_key : key[q - 1])) {
+        fcur = fq[q];
+        if (fold_w) {
+          const int u = key[q];
+          int rel = 0;
+          if (R <= 8) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) rel += u >= rp[i];
+          } else {
+            rel = find_segment(fold_row_rel_ptrs, R, (idx_t)u);
+          }
+          if (rel != rel_cur) {  // rows are relation-major: a handful of times per launch
+            wcur = ld4(fold_w + (int64_t)rel * X + x);
+            rel_cur = rel;
+          }
+        }
+      }
+      const float a = head_bcast<DL>(av, q, lane), ad = head_bcast<DL>(adv, q, lane), gr = head_bcast<DL>(pkv.y, q, lane);
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * fcur.x + g[q].y * fcur.y + g[q].z * fcur.z + g[q].w * fcur.w;
+#pragma unroll
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float t = ad * (dot - gr);  // 0 for the padding edges of the last step (a == 0)
+      tq[q] = t;
+      acc_el += t;  // identical in the DL lanes of a head
+      const int key_next = q + 1 < U ? key[q + 1] : head_bcast_i<DL>(keyn, 0, lane);
+      if (ok && (j0 + q == e - 1 || key_next != key[q])) {  // the segment (or this pack's piece of it) ends: one store
+        const int64_t u = key[q];
+        float4 o = acc;
+        if (fold_w) {  // el[u,h] = <feat[u,h,:], fold_w[r(u),h,:]>: its gradient joins grad_feat here (linear: also per piece)
+          o.x = fmaf(acc_el, wcur.x, o.x); o.y = fmaf(acc_el, wcur.y, o.y);
+          o.z = fmaf(acc_el, wcur.z, o.z); o.w = fmaf(acc_el, wcur.w, o.w);
+        }
+        float* gp = grad_feat + u * X + x;
+        if (!partial) {
+          st4(gp, o);
+          if (d == 0) grad_el[u * H + h] = acc_el;
+        } else {
+          atomicAdd(gp + 0, o.x); atomicAdd(gp + 1, o.y); atomicAdd(gp + 2, o.z); atomicAdd(gp + 3, o.w);
+          if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+        }
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc_el = 0.f;
+      }
+    }
+    // t of edge q, head h leaves through lane (h, q): one 16-byte-per-edge store instruction per step
+    float ts = tq[0];
+#pragma unroll
+    for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
+    if (d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;
+    prev_key = key[U - 1];
+  }
+}
+
+
+// Backward for the LONG (relation, source) segments (> HET_PACK_T edges; 61 % of the edges of the skewed ogbn-mag-like
+// graph): wave per work item (<= HET_ITEM_MAX edges of ONE feat row), the 64/LPR lane groups take its edges round-robin
+// as the forward does, scalars fetched cooperatively; feat row, el and the fold row are per item.  One store per item
+// (atomic adds only for the items of a segment longer than HET_ITEM_MAX, whose rows HET_rgat_zero_long_rows cleared).
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
+    Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int32_t* __restrict__ p_dst,
+    const int32_t* __restrict__ p_drow, const float* __restrict__ feat, const float* __restrict__ el,
+    const float* __restrict__ er, const float* __restrict__ pack2, const float* __restrict__ gradout,
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, float slope,
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (wid >= num_long_items) return;
+  const int item = long_items[wid];
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
+  int dstn = p_dst[jn], drown = p_drow[jn];
+  const int64_t u = it.seg_key[seg];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  const float4 f = ld4(feat + u * X + x);
+  const float zl = el[u * H + h];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc_el = 0.f;
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int dstv = dstn, drowv = drown;
+    const float zrv = er[(int64_t)drowv * H + h];
+    const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    float4 g[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
+    jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
+    dstn = p_dst[jn];
+    drown = p_drow[jn];
+    const float zv = zl + zrv;
+    const float av = j0 + dq * EPW < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
+    const float adv = av * (zv > 0.f ? 1.f : slope);
+    float tq[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const float a = head_bcast<DL>(av, q, lane), ad = head_bcast<DL>(adv, q, lane), gr = head_bcast<DL>(pkv.y, q, lane);
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
+#pragma unroll
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      tq[q] = ad * (dot - gr);  // 0 for the padding edges of the last step
+      acc_el += tq[q];
+    }
+    float ts = tq[0];
+#pragma unroll
+    for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
+    if (d < U && j0 + d * EPW < e) tbuf[(int64_t)(j0 + d * EPW) * H + h] = ts;
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    acc_el += __shfl_xor(acc_el, off);
+  }
+  if (slot != 0) return;
+  if (fold_w) {
+    const float4 w = ld4(fold_w + (int64_t)find_segment(fold_row_rel_ptrs, R, (idx_t)u) * X + x);
+    acc.x = fmaf(acc_el, w.x, acc.x); acc.y = fmaf(acc_el, w.y, acc.y);
+    acc.z = fmaf(acc_el, w.z, acc.z); acc.w = fmaf(acc_el, w.w, acc.w);
+  }
+  float* gp = grad_feat + u * X + x;
+  if (whole) {
+    st4(gp, acc);
+    if (d == 0) grad_el[u * H + h] = acc_el;
+  } else {
+    atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
+    if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+  }
+}
+
+// rows of the long segments start from zero (their pieces add atomically)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_zero_long_rows(const int32_t* __restrict__ long_seg,
+                                                                   const int32_t* __restrict__ seg_key, int64_t n,
+                                                                   float* __restrict__ grad_feat, float* __restrict__ grad_el,
+                                                                   int H) {
+  constexpr int X = LPR * 4;
+  const int64_t total = n * LPR;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t k = t / LPR;
+    const int sub = (int)(t - k * LPR);
+    const int64_t u = seg_key[long_seg[k]];
+    st4(grad_feat + u * X + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (sub < H) grad_el[u * H + sub] = 0.f;
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t b = ceil_div64(total, kBlock);
+  const int64_t cap = 256 * 64;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+#define HET_DISPATCH_LPR(LPRV, CALL)           \
+  switch (LPRV) {                              \
+    case 1: { constexpr int LPR = 1; CALL; break; }   \
+    case 2: { constexpr int LPR = 2; CALL; break; }   \
+    case 4: { constexpr int LPR = 4; CALL; break; }   \
+    case 8: { constexpr int LPR = 8; CALL; break; }   \
+    case 16: { constexpr int LPR = 16; CALL; break; } \
+    case 32: { constexpr int LPR = 32; CALL; break; } \
+    default: { constexpr int LPR = 64; CALL; break; } \
+  }
+
+// (lanes per row, lanes per head) pairs the cooperative kernels are built for: rows of 32 / 64 / 128 floats, heads of >= 16
+#define HET_DISPATCH_COOP(LPRV, DLV, CALL)                                  \
+  switch ((LPRV) * 64 + (DLV)) {                                            \
+    case 8 * 64 + 4: { constexpr int LPR = 8, DL = 4; CALL; break; }        \
+    case 8 * 64 + 8: { constexpr int LPR = 8, DL = 8; CALL; break; }        \
+    case 16 * 64 + 4: { constexpr int LPR = 16, DL = 4; CALL; break; }      \
+    case 16 * 64 + 8: { constexpr int LPR = 16, DL = 8; CALL; break; }      \
+    case 16 * 64 + 16: { constexpr int LPR = 16, DL = 16; CALL; break; }    \
+    case 32 * 64 + 4: { constexpr int LPR = 32, DL = 4; CALL; break; }      \
+    case 32 * 64 + 8: { constexpr int LPR = 32, DL = 8; CALL; break; }      \
+    case 32 * 64 + 16: { constexpr int LPR = 32, DL = 16; CALL; break; }    \
+    default: { constexpr int LPR = 32, DL = 32; CALL; break; }              \
+  }
+static bool coop_shape_ok(int64_t H, int64_t D) {
+  static const bool off = [] { const char* v = getenv("HET_RGAT_COOP"); return v && v[0] == '0'; }();  // A/B switch
+  const int64_t lpr = H * D / 4, dl = D / 4;
+  return !off && (lpr == 8 || lpr == 16 || lpr == 32) && dl >= 4 && dl <= lpr;
+}
+
+static bool compact_shape_ok(int64_t H, int64_t D) {
+  const int64_t X = H * D;
+  return is_pow2(D) && D >= 4 && is_pow2(X) && X / 4 <= 64 && H <= X / 4;
+}
+
+extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c,
+                                          const float* er_c, float* sum, float* ret, int64_t num_nodes, int64_t H,
+                                          int64_t D, double slope, het_stream stream) {
+  const char* op = "het_rgat_aggregate_compact";
+  hipStream_t s = (hipStream_t)stream;
+  HET_REQUIRE(by_dst && sum && ret && num_nodes >= 0, "%s: null argument", op);
+  if (!compact_shape_ok(H, D)) { het_set_error("%s: unsupported shape H=%lld D=%lld", op, (long long)H, (long long)D); return HET_ERR_UNSUPPORTED; }
+  HET_REQUIRE(by_dst->R == 0 && by_dst->key_bound <= num_nodes && (by_dst->E == 0 || (by_dst->p0 && by_dst->p1 && feat_c && el_c && er_c)),
+              "%s: by_dst must group the positions by destination with payload0 = feat row and payload1 = er row", op);
+  const int64_t X = H * D;
+  HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));  // destinations without in-edges; split hubs add atomically
+  HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
+  if (by_dst->E == 0) return HET_OK;
+  Items it{by_dst->item_seg, by_dst->item_begin, by_dst->item_end, by_dst->seg_ptr, by_dst->seg_key, by_dst->num_items};
+  const unsigned nb = (unsigned)ceil_div64(by_dst->num_items, kBlock / 64);
+  {
+    HET_KTIME("HET_rgat_aggregate", s);
+    if (coop_shape_ok(H, D)) {
+      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                        hipLaunchKernelGGL((HET_rgat_aggregate_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p0,
+                                           by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (float)slope));
+    } else {
+      HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_aggregate_compact<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
+                                                        by_dst->p0, by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (int)D,
+                                                        (float)slope));
+    }
+  }
+  HET_LAUNCH_CHECK("HET_rgat_aggregate_compact");
+  if (by_dst->num_split > 0) {
+    hipLaunchKernelGGL(HET_rgat_normalize_split, dim3(grid_for(by_dst->num_split * X)), dim3(kBlock), 0, s, by_dst->split_seg,
+                       by_dst->seg_key, by_dst->num_split, sum, ret, (int)H, (int)D);
+    HET_LAUNCH_CHECK("HET_rgat_normalize_split");
+  }
+  return HET_OK;
+}
+
+extern "C" int64_t het_rgat_backward_compact_workspace(int64_t num_nodes, int64_t num_edges, int64_t H, int64_t D, int with_bias) {
+  const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = (num_edges * H + 3) / 4 * 4;
+  return (int64_t)sizeof(float) * (n_pack + n_tbuf + (with_bias ? (int64_t)2048 * (kBlock / 64) * H * D : 0));
+}
+
+extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
+                                         const float* el_c, const float* er_c, const float* sum, const float* ret,
+                                         const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
+                                         const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
+                                         float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
+                                         int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
+                                         int64_t workspace_bytes, het_stream stream) {
+  const char* op = "het_rgat_backward_compact";
+  hipStream_t s = (hipStream_t)stream;
+  HET_REQUIRE(by_srow && by_drow && sum && ret && gradout && grad_feat_c && grad_el_c && grad_er_c, "%s: null argument", op);
+  if (!compact_shape_ok(H, D) || !segment_rows_supported((int)H) || slope < 0) {
+    het_set_error("%s: unsupported shape H=%lld D=%lld (or slope < 0)", op, (long long)H, (long long)D);
+    return HET_ERR_UNSUPPORTED;
+  }
+  const int64_t E = by_srow->E, X = H * D;
+  HET_REQUIRE(by_srow->R == 0 && by_drow->R == 0 && by_drow->E == E && by_srow->key_bound <= num_src_rows &&
+                  by_drow->S == num_dst_rows && (E == 0 || (by_srow->p0 && by_srow->p1 && by_drow->p0)),
+              "%s: by_srow groups the positions by feat row (payload0 = destination, payload1 = er row); by_drow groups them by "
+              "er row with payload0 = their rank in by_srow and has one segment per er row", op);
+  HET_REQUIRE(!fold_attn_l || (row_rel_ptrs && num_rels > 0), "%s: fold_attn_l needs the relation pointers of the feat rows", op);
+  const bool coop = coop_shape_ok(H, D);
+  constexpr int kBiasBlocks = 2048;
+  const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
+  const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
+  const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X);
+  HET_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_backward_compact_workspace)", op, (long long)need);
+  float* pack = (float*)workspace;  // [N, 2H]
+  float* tbuf = pack + n_pack;      // [E, H], rank order of by_srow
+  float* bias_part = grad_bias ? tbuf + n_tbuf : nullptr;
+  if (by_srow->S != num_src_rows) {  // feat rows without an edge (none when the lists come from the graph): zero gradient
+    HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
+    HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
+  }
+  if (num_nodes > 0) {
+    const unsigned nbp = grad_bias ? kBiasBlocks : grid_for(num_nodes * (X / 4));
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_dst_pack<LPR>, dim3(nbp), dim3(kBlock), 0, s, sum, ret, gradout,
+                                                      pack, num_nodes, (int)H, (int)D, bias_part, bias_rows, (int)coop));
+    HET_LAUNCH_CHECK("HET_rgat_dst_pack");
+    if (grad_bias) {
+      hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s, bias_part, bias_part_rows, (int)X, grad_bias);
+      HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
+    }
+  } else if (grad_bias) {
+    HET_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * X, s));
+  }
+  if (E == 0) {
+    HET_HIP(hipMemsetAsync(grad_er_c, 0, sizeof(float) * num_dst_rows * H, s));
+    return HET_OK;
+  }
+  if (int rc = grouping_packs(by_srow, s)) return rc;
+  if (by_srow->num_split > 0) {  // segments of several work items (> HET_ITEM_MAX edges): their items add atomically
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_zero_long_rows<LPR>, dim3(grid_for(by_srow->num_split * (X / 4))),
+                                                      dim3(kBlock), 0, s, by_srow->split_seg, by_srow->seg_key, by_srow->num_split,
+                                                      grad_feat_c, grad_el_c, (int)H));
+    HET_LAUNCH_CHECK("HET_rgat_zero_long_rows");
+  }
+  Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
+  const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  if (coop) {
+    {
+      HET_KTIME("HET_rgat_backward_src_short", s);
+      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                        hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->p0,
+                                           by_srow->p1, feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
+                                           (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels));
+    }
+    HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
+    if (by_srow->num_long_items > 0) {
+      Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
+      const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
+      HET_KTIME("HET_rgat_backward_src_long", s);
+      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                        hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s, it,
+                                           by_srow->long_items, by_srow->num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c,
+                                           er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
+                                           row_rel_ptrs, (int)num_rels));
+    }
+  } else {
+    static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
+    HET_KTIME("HET_rgat_backward_src", s);
+#define HET_BWD_PACKED(UU)                                                                                                 \
+  HET_DISPATCH_LPR((int)(X / 4),                                                                                           \
+                   hipLaunchKernelGGL((HET_rgat_backward_src_packed<LPR, UU>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->p0, \
+                                      by_srow->p1, feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, \
+                                      (int)D, (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels))
+    if (u_rows == 2) { HET_BWD_PACKED(2); } else if (u_rows == 8) { HET_BWD_PACKED(8); } else { HET_BWD_PACKED(4); }
+#undef HET_BWD_PACKED
+  }
+  HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
+  // grad_er[w, :] = SUM over the edges of er row w of tbuf[rank, :]   (segments of by_drow are the er rows in order)
+  return launch_segment_sum(by_drow, tbuf, grad_er_c, (int)H, nullptr, s);
+}

@@ -1,7 +1,10 @@
 // Device-side construction of het_grouping (radix sort + run-length encode via hipCUB).
 #include <hipcub/hipcub.hpp>
 
+#include <mutex>
+
 #include "grouping.hip.h"
+#include "seg_reduce.hip.h"
 
 namespace {
 
@@ -74,6 +77,48 @@ __global__ void HET_grouping_rank_of_position(const int32_t* __restrict__ perm, 
     out[perm[j]] = j;
 }
 
+// flag[j] = 1: a pack starts at rank j; 2: a piece of a long segment starts there.  One thread per segment: a short segment
+// opens a pack when it is the first to start inside its HET_PACK_T-block of ranks (or follows a long segment); a long
+// one is a pack of its own, flagged (its work goes to the wave-per-item kernels through long_items).  Every flag lies
+// inside the writing segment's own range: no races.
+__global__ void HET_grouping_long_items(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ item_seg,
+                                        int64_t num_items, uint8_t* __restrict__ is_long) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < num_items; t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = item_seg[t];
+    is_long[t] = seg_ptr[s + 1] - seg_ptr[s] > HET_PACK_T;
+  }
+}
+
+__global__ void HET_grouping_pack_flags(const int32_t* __restrict__ seg_ptr, int64_t S, uint8_t* __restrict__ flag) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t b = seg_ptr[s], e = seg_ptr[s + 1];
+    const bool lng = e - b > HET_PACK_T;
+    if (lng) {
+      flag[b] = 2;
+    } else if (e > b) {
+      const int32_t pb = s > 0 ? seg_ptr[s - 1] : -1;
+      const bool prev_long = s > 0 && b - pb > HET_PACK_T;
+      if (s == 0 || prev_long || b / HET_PACK_T != pb / HET_PACK_T) flag[b] = 1;
+    }
+  }
+}
+
+__global__ void HET_grouping_pack_finish(int32_t* __restrict__ pack_ptr, const int32_t* __restrict__ d_num,
+                                         const uint8_t* __restrict__ flag, int64_t E) {
+  const int64_t n = *d_num;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= n; k += (int64_t)gridDim.x * blockDim.x) {
+    if (k == n) { pack_ptr[k] = (int32_t)E; continue; }
+    const int32_t j = pack_ptr[k];
+    if (flag[j] == 2) pack_ptr[k] = (int32_t)((uint32_t)j | 0x80000000u);
+  }
+}
+
+__global__ void HET_grouping_key_of_rank(const int32_t* __restrict__ seg_of_rank, const int32_t* __restrict__ seg_key,
+                                         int64_t E, int32_t* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= E; j += (int64_t)gridDim.x * blockDim.x)
+    out[j] = j < E ? seg_key[seg_of_rank[j]] : -1;
+}
+
 int bits_for(int64_t n) {  // bits to represent values in [0, n)
   int b = 1;
   while (b < 63 && (1ll << b) < n) ++b;
@@ -101,7 +146,7 @@ struct Scratch {  // frees device temporaries on every exit path
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -247,5 +292,63 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
 #undef GALLOC
   guard.g = nullptr;
   *out = g;
+  return HET_OK;
+}
+
+static std::mutex g_pack_mu;
+
+int grouping_packs(const het_grouping* g, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->pack_ptr || g->E == 0 || g->S == 0) return HET_OK;
+  const int64_t E = g->E, S = g->S;
+  if (int rc = grouping_seg_of_rank(g, s)) return rc;
+  Scratch tmp;
+  const int64_t NI = g->num_items;
+  uint8_t *flag = nullptr, *is_long = nullptr;
+  int32_t* d_num = nullptr;
+  HET_HIP(tmp.alloc((void**)&flag, (size_t)E));
+  HET_HIP(tmp.alloc((void**)&is_long, (size_t)NI));
+  HET_HIP(tmp.alloc((void**)&d_num, sizeof(int32_t) * 2));
+  HET_HIP(hipMemsetAsync(flag, 0, (size_t)E, s));
+  hipLaunchKernelGGL(HET_grouping_pack_flags, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, S, flag);
+  HET_LAUNCH_CHECK("HET_grouping_pack_flags");
+  hipLaunchKernelGGL(HET_grouping_long_items, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->item_seg, NI, is_long);
+  HET_LAUNCH_CHECK("HET_grouping_long_items");
+  int32_t *pack_tmp = nullptr, *long_tmp = nullptr;
+  HET_HIP(tmp.alloc((void**)&pack_tmp, sizeof(int32_t) * (size_t)(E + 1)));
+  HET_HIP(tmp.alloc((void**)&long_tmp, sizeof(int32_t) * (size_t)NI));
+  hipcub::CountingInputIterator<int32_t> ranks(0);
+  size_t tb = 0, tb2 = 0;
+  HET_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, ranks, flag, pack_tmp, d_num, (int)E, s));
+  HET_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, ranks, is_long, long_tmp, d_num + 1, (int)NI, s));
+  void* t0 = nullptr;
+  HET_HIP(tmp.alloc(&t0, tb > tb2 ? tb : tb2));
+  HET_HIP(hipcub::DeviceSelect::Flagged(t0, tb, ranks, flag, pack_tmp, d_num, (int)E, s));
+  HET_HIP(hipcub::DeviceSelect::Flagged(t0, tb2, ranks, is_long, long_tmp, d_num + 1, (int)NI, s));
+  int32_t h_num[2] = {0, 0};
+  HET_HIP(hipMemcpyAsync(h_num, d_num, sizeof(h_num), hipMemcpyDeviceToHost, s));
+  HET_HIP(hipStreamSynchronize(s));
+  int32_t *pack_ptr = nullptr, *key_of_rank = nullptr, *long_items = nullptr;
+  HET_HIP(hipMalloc((void**)&pack_ptr, sizeof(int32_t) * ((size_t)h_num[0] + 1)));
+  hipError_t e = hipMalloc((void**)&key_of_rank, sizeof(int32_t) * ((size_t)E + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&long_items, sizeof(int32_t) * ((size_t)h_num[1] + 1));
+  if (e == hipSuccess) e = hipMemcpyAsync(pack_ptr, pack_tmp, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(long_items, long_tmp, sizeof(int32_t) * (size_t)h_num[1], hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(HET_grouping_pack_finish, dim3(blocks_for(h_num[0] + 1)), dim3(256), 0, s, pack_ptr, d_num, flag, E);
+    hipLaunchKernelGGL(HET_grouping_key_of_rank, dim3(blocks_for(E + 1)), dim3(256), 0, s, g->seg_of_rank, g->seg_key, E,
+                       key_of_rank);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete: later users may be on other streams
+  if (e != hipSuccess) {
+    (void)hipFree(pack_ptr); (void)hipFree(key_of_rank); (void)hipFree(long_items);
+    HET_HIP(e);
+  }
+  g->key_of_rank = key_of_rank;
+  g->long_items = long_items;
+  g->num_long_items = h_num[1];
+  g->num_packs = h_num[0];
+  g->pack_ptr = pack_ptr;
   return HET_OK;
 }

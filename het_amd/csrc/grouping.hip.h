@@ -28,4 +28,17 @@ struct het_grouping {
   int32_t* p1 = nullptr;         // [E] payload1[perm[j]] or NULL
   bool p0_contiguous = false;    // p0[j] == j for every rank: the list already was in (relation, key) order
   mutable int32_t* seg_of_rank = nullptr;  // [E] segment of sorted rank j; built on first use (segment broadcast)
+  // "Packs" (grouping_packs): the SHORT segments (<= HET_PACK_T positions) gathered into runs of whole segments of about
+  // HET_PACK_T consecutive ranks (< 2 * HET_PACK_T) -- the work unit of the lane-group-per-pack kernels; a few edges per
+  // (relation, source) row is the common case, and a work unit per segment would spend its time in dependent
+  // prologues.  A longer segment is a pack of its own with bit 31 of pack_ptr set: the pack kernels skip it and the
+  // wave-per-item kernels take its work items (long_items: indices into item_seg / item_begin / item_end).
+  mutable int32_t* pack_ptr = nullptr;     // [num_packs+1] first rank of pack k (| 1u<<31: a long segment)
+  mutable int32_t* key_of_rank = nullptr;  // [E+1] seg_key of the segment of rank j; sentinel -1 at E
+  mutable int32_t* long_items = nullptr;   // [num_long_items] work items of segments with more than HET_PACK_T positions
+  mutable int64_t num_packs = 0, num_long_items = 0;
 };
+
+constexpr int HET_PACK_T = 32;
+// Builds g->pack_ptr / key_of_rank / long_seg once (thread-safe; synchronises `s` before publishing them).
+int grouping_packs(const het_grouping* g, hipStream_t s);

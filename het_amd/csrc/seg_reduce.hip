@@ -1,4 +1,6 @@
 // Segmented sum of gathered rows, one lane group per work item (no atomics except for split hub segments).
+#include <mutex>
+
 #include "seg_reduce.hip.h"
 
 namespace {
@@ -228,8 +230,13 @@ __global__ __launch_bounds__(kBlock) void HET_segment_broadcast(const int32_t* _
 }
 }  // namespace
 
+static std::mutex g_seg_of_rank_mu;
+
 int grouping_seg_of_rank(const het_grouping* g, hipStream_t s) {
-  if (g->seg_of_rank || g->E == 0) return HET_OK;  // one-time, cached in the grouping
+  // one-time, cached in the grouping.  Built under a lock and published only after the fill kernel has finished, so a
+  // second stream or thread that finds the pointer set never reads a half-written buffer
+  std::lock_guard<std::mutex> lk(g_seg_of_rank_mu);
+  if (g->seg_of_rank || g->E == 0) return HET_OK;
   int32_t* p = nullptr;
   HET_HIP(hipMalloc((void**)&p, sizeof(int32_t) * g->E));
   int64_t nb0 = ceil_div64(g->E, kBlock);
@@ -238,6 +245,10 @@ int grouping_seg_of_rank(const het_grouping* g, hipStream_t s) {
   if (hipGetLastError() != hipSuccess) {
     (void)hipFree(p);
     HET_REQUIRE(false, "HET_grouping_seg_of_rank: launch failed");
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipFree(p);
+    HET_REQUIRE(false, "HET_grouping_seg_of_rank: kernel failed");
   }
   g->seg_of_rank = p;
   return HET_OK;

@@ -532,6 +532,52 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
           None if fold_row_rel_ptrs is None else _p(fold_row_rel_ptrs), _p(grad_el_sorted), _stream(ret))
 
 
+def grouping_rank_of_position(g):
+    """[E] int64: sorted rank of every position of grouping ``g`` (cached on the grouping object, built at plan time)."""
+    r = getattr(g, "rank_of_position", None)
+    if r is None:
+        keys = g._keep[1]
+        r = torch.empty(keys.numel(), dtype=torch.int64, device=keys.device)
+        _call(r, "het_grouping_rank_of_position", g.handle, _p(r), _stream(r))
+        g.rank_of_position = r  # lives (and is evicted) with the grouping
+    return r
+
+
+def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_rows):
+    """The three groupings of the compact RGAT passes (include/het_amd.h: het_rgat_aggregate_compact): by destination,
+    by feat row and by er row.  ``srow`` / ``drow`` [E] int64: feat row and er row of every edge position."""
+    by_dst = _plan.get_grouping(None, col, num_nodes, srow, drow)
+    by_srow = _plan.get_grouping(None, srow, num_src_rows, col, drow)
+    if by_dst is None or by_srow is None:
+        return None
+    by_drow = _plan.get_grouping(None, drow, num_dst_rows, grouping_rank_of_position(by_srow), None)
+    return by_dst, by_srow, by_drow
+
+
+def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope):
+    _chk("rgat_aggregate_compact", (feat_c, el_c, er_c, sum, ret))
+    N, H = sum.shape[0], sum.shape[1]
+    D = ret.numel() // max(1, N * H)
+    _call(ret, "het_rgat_aggregate_compact", groupings[0].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), N, H, D,
+          float(slope), _stream(ret))
+
+
+def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c, slope,
+                          fold_attn_l=None, row_rel_ptrs=None, grad_bias=None, bias_rows=0):
+    _chk("rgat_backward_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c,
+                                                    fold_attn_l, grad_bias) if t is not None),
+         () if row_rel_ptrs is None else (row_rel_ptrs,))
+    N, H = sum.shape[0], sum.shape[1]
+    D = ret.numel() // max(1, N * H)
+    E = groupings[1]._keep[1].numel()
+    nbytes = int(_lib.lib().het_rgat_backward_compact_workspace(N, E, H, D, int(grad_bias is not None)))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device)
+    _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum),
+          _p(ret), _p(gradout), _p(grad_feat_c), _p(grad_el_c), _p(grad_er_c), _p(fold_attn_l), _p(row_rel_ptrs),
+          0 if row_rel_ptrs is None else row_rel_ptrs.numel() - 1, _p(grad_bias), int(bias_rows), N, feat_c.shape[0],
+          er_c.shape[0], H, D, float(slope), _p(ws), ws.numel() * 4, _stream(ret))
+
+
 def gat_rank_of_position(rel_ptrs, row, col, eids, num_nodes):
     """[E] int64: the rank of every separate-COO position in the destination-grouped order of the kind-0 GAT kernels
     (row j of exp_sorted / grad_el_sorted belongs to the position whose rank is j).  None without groupings."""

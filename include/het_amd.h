@@ -405,6 +405,35 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
                                                          const het_grouping* by_rel_src, int64_t n_q_rows,
                                                          void* workspace, int64_t workspace_bytes, het_stream stream);
 
+/* ------------------------------------------------------------------------
+ * RGAT on the distinct (relation, node) rows without a per-edge float tensor (layer-level fusion; no reference op of
+ * its own).  Replaces the pair relational_fused_gat_separate_coo / backward_... with CompactAsOfNodeKind 4
+ * (OpExport/RGATOps.inc.h:170-245, 465-551; kernels RGAT/RGATKernelsSeparateCOO.cu.h:17-204,
+ * RGATBackwardKernelsSeparateCOO.cu.h:9-117) inside the one-node RGAT layer: both passes form
+ * exp(leaky_relu(el_c[srow] + er_c[drow])) from the compact tables instead of writing / re-reading exp [E,H].
+ *   feat_c [S_row,H,D], el_c [S_row,H]: per distinct (relation, source) row;  er_c [S_col,H]: per (relation, destination)
+ *   by_dst:  het_grouping_create(NULL, 0, col, E, N, payload0 = feat row of every position, payload1 = its er row)
+ *   by_srow: het_grouping_create(NULL, 0, feat row of every position, E, S_row, payload0 = col, payload1 = er row)
+ *   by_drow: het_grouping_create(NULL, 0, er row of every position, E, S_col, payload0 = rank of the position in by_srow
+ *            (het_grouping_rank_of_position), NULL)
+ * forward:  sum [N,H], ret [N,H,D] are overwritten (a4's outputs; exp is not produced).
+ * backward: grad_feat_c, grad_el_c, grad_er_c are overwritten (a5's outputs on the compact rows).  fold_attn_l [R,H,D]
+ *   (optional, with row_rel_ptrs [R+1] = relation pointers of the feat rows): adds grad_el_c[u,h] * fold_attn_l[r(u),h,:]
+ *   into grad_feat_c -- the gradient through el_c = <feat_c, attn_l[r]>.  grad_bias [H*D] (optional): column sums of
+ *   gradout's first bias_rows rows (the layer's bias gradient) from the pass that reads gradout anyway.
+ *   workspace: het_rgat_backward_compact_workspace(N, E, H, D, grad_bias != NULL) bytes, 16-byte aligned. */
+int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c, const float* er_c,
+                               float* sum, float* ret, int64_t num_nodes, int64_t H, int64_t D, double slope,
+                               het_stream stream);
+int64_t het_rgat_backward_compact_workspace(int64_t num_nodes, int64_t num_edges, int64_t H, int64_t D, int with_bias);
+int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
+                              const float* el_c, const float* er_c, const float* sum, const float* ret,
+                              const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
+                              const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
+                              float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
+                              int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
+                              int64_t workspace_bytes, het_stream stream);
+
 /* layer epilogue (RGAT/models.py:377-383: h + loop_message + h_bias): out[i,:] = a[i,:] (+ b[i,:]) (+ bias[:]) in one
  * pass; b and bias optional, X % 4 == 0 */
 int het_rows_add_bias(const float* a, const float* b, const float* bias, float* out, int64_t num_rows, int64_t X,

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import layers as OL
-from tests.util import assert_close, mag_graph, random_graph
+from tests.util import assert_close, mag_graph, random_graph, rgat_min_abs_preactivation
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -25,6 +25,8 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0,
     go = torch.randn(N, X)
     # oracle (fp64, autograd)
     s = g.get_separate_coo_original()
+    while rgat_min_abs_preactivation(x, layer.conv_weights, layer.attn_l, layer.attn_r, s) < 1e-5:
+        x = x + 1e-3 * torch.randn(N, K)  # no (edge, head) on the leaky-ReLU kink (see tests/util.py)
     p = {n: t.detach().double().requires_grad_(True) for n, t in layer.named_parameters()}
     x64 = x.double().requires_grad_(True)
     ref = OL.rgat_layer(x64, p["conv_weights"], p["attn_l"], p["attn_r"], s["rel_ptrs"], s["row_indices"], s["col_indices"],

@@ -183,6 +183,52 @@ def test_fused_gat_separate_coo(K, plan_mode, kind, H, D, n):
     assert_close(gr, gr_r, what="grad_er")
 
 
+@pytest.mark.parametrize("fold,bias", [(False, False), (True, True)])
+@pytest.mark.parametrize("H,D,n,e", [(4, 16, 300, 5000), (1, 64, 300, 5000), (8, 8, 40, 9000), (2, 4, 300, 5000), (4, 16, 12, 9000), (4, 32, 300, 700)])
+def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
+    """het_rgat_aggregate_compact / het_rgat_backward_compact (no exp tensor between the passes) against the oracle's
+    relational_fused_gat_separate_coo pair with CompactAsOfNodeKind 4.  n = 12 / 40: (relation, source) rows with
+    hundreds of edges (pieces of long segments add atomically, hub destinations are split over work items);
+    n = 300: a few edges per row (several whole segments per pack); e = 700: packs of a single short segment."""
+    import het_amd.kernels as k
+    g = random_graph(seed=27, n=n, r=4, e=e)
+    s, feat, el, er, go, df, db = _gat_case(g, 4, H, D, seed=11)
+    N, E, slope = g.get_num_nodes(), g.get_num_edges(), 0.2
+    idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    sm_r, ex_r, ret_r = (torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64),
+                         torch.empty(N, H, D, dtype=torch.float64))
+    O.relational_fused_gat_separate_coo(*idx, 4, df, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, slope)
+    gf_r, gl_r, gr_r = torch.zeros_like(to64(feat)), torch.zeros_like(to64(el)), torch.zeros_like(to64(er))
+    O.backward_relational_fused_gat_separate_coo(*idx, 4, db, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r,
+                                                 to64(go), gf_r, gl_r, gr_r, slope)
+    ss = g.get_separate_unique_node_indices_single_sided()
+    R = g.get_num_rels()
+    gen = torch.Generator().manual_seed(5)
+    attn = torch.randn(R, H, D, generator=gen)
+    if fold:  # grad_feat += grad_el (x) attn[r(row)]
+        rel_of_row = torch.repeat_interleave(torch.arange(R), ss["rel_ptrs_row"][1:] - ss["rel_ptrs_row"][:-1])
+        gf_r = gf_r + gl_r.unsqueeze(-1) * attn.double()[rel_of_row]
+    # rows of every edge POSITION (eids of the test graphs are a permutation)
+    srow = df["edata_idx_to_inverse_idx_row"][s["eids"]].contiguous().to(DEV)
+    drow = df["edata_idx_to_inverse_idx_col"][s["eids"]].contiguous().to(DEV)
+    grp = k.rgat_compact_groupings(s["col_indices"].to(DEV), srow, drow, N, feat.shape[0], er.shape[0])
+    f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
+    sm, ret = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
+    k.rgat_aggregate_compact(grp, f, l, r_, sm, ret, slope)
+    assert_close(sm, sm_r, what="sum")
+    assert_close(ret, ret_r, what="ret")
+    gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
+    gb = torch.full((H * D,), float("nan"), device=DEV) if bias else None
+    nb = N - 3
+    k.rgat_backward_compact(grp, f, l, r_, sm, ret, go.to(DEV), gf, gl, gr, slope, fold_attn_l=attn.to(DEV) if fold else None,
+                            row_rel_ptrs=ss["rel_ptrs_row"].to(DEV) if fold else None, grad_bias=gb, bias_rows=nb)
+    assert_close(gf, gf_r, what="grad_feat")
+    assert_close(gl, gl_r, what="grad_el")
+    assert_close(gr, gr_r, what="grad_er")
+    if bias:
+        assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
+
+
 def test_fused_gat_hub_destination(K, plan_mode):
     """One destination with thousands of in-edges (its segment is split over several work
     items), many destinations with none, and eids a non-trivial permutation."""
