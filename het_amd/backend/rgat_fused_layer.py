@@ -115,6 +115,15 @@ class RgatLayerFunction(th.autograd.Function):
         X = H * D
         new = lambda *shape: th.empty(shape, dtype=x.dtype, device=x.device)
         sm, ret = new(N, H), new(N, H, D)
+        nd = N if num_dst is None else min(int(num_dst), N)
+        offs = h = None
+        if loop_w is not None:
+            loop_w = loop_w.contiguous()
+            offs = _OFFS.get((nd, x.device))  # built once per (rows, device): no per-step host-to-device copy
+            if offs is None:
+                if len(_OFFS) > 64:
+                    _OFFS.clear()
+                offs = _OFFS[(nd, x.device)] = th.tensor([0, nd], dtype=th.int64, device=x.device)
         wa = None
         if mulfirst:  # RGAT/models.py:300-326: the attention vector folded into the weight, [R,H,K,1]
             wa = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd, 1)
@@ -136,7 +145,11 @@ class RgatLayerFunction(th.autograd.Function):
             # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
             srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
             grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])
-            _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope)
+            if loop_w is not None and _k.rows_linear_bias_ok(Kd, X):
+                # self-loop + bias first (bias in the GEMM epilogue); the aggregation adds its rows into h in place: no
+                # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
+                h = _k.rows_linear_bias(offs, x[:nd], loop_w, None if bias is None else bias.contiguous())
+            _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h)
             ctx.grp = grp
             ex = x.new_empty(0)
         else:
@@ -157,20 +170,13 @@ class RgatLayerFunction(th.autograd.Function):
                                         el_sorted=el_s, er_sorted=er_s)
             assert used
             ex = x.new_empty(0)
-        nd = N if num_dst is None else min(int(num_dst), N)
-        out = ret.view(N, X)[:nd]
-        loop = None
-        offs = None
-        if loop_w is not None:
-            loop_w = loop_w.contiguous()
-            offs = _OFFS.get((nd, x.device))  # built once per (rows, device): no per-step host-to-device copy
-            if offs is None:
-                if len(_OFFS) > 64:
-                    _OFFS.clear()
-                offs = _OFFS[(nd, x.device)] = th.tensor([0, nd], dtype=th.int64, device=x.device)
-            loop = new(nd, X)
-            K.rgnn_relational_matmul_no_scatter_gather_list(offs, loop_w.view(1, 1, Kd, X), x[:nd], loop)
-        h = _k.rows_add_bias(out, loop, None if bias is None else bias.contiguous()) if (loop is not None or bias is not None) else out.clone()
+        if h is None:
+            out = ret.view(N, X)[:nd]
+            loop = None
+            if loop_w is not None:
+                loop = new(nd, X)
+                K.rgnn_relational_matmul_no_scatter_gather_list(offs, loop_w.view(1, 1, Kd, X), x[:nd], loop)
+            h = _k.rows_add_bias(out, loop, None if bias is None else bias.contiguous()) if (loop is not None or bias is not None) else out.clone()
         ctx.g, ctx.compact, ctx.mulfirst, ctx.slope, ctx.nd = g, compact, mulfirst, slope, nd
         ctx.has_loop, ctx.has_bias = loop_w is not None, bias is not None
         ctx.save_for_backward(x, W, attn_l, attn_r, loop_w if loop_w is not None else x.new_empty(0), offs if offs is not None else eids,

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
                                                                       const float* __restrict__ el,
                                                                       const float* __restrict__ er,
                                                                       float* __restrict__ sum, float* __restrict__ ret,
-                                                                      int H, int D, float slope) {
+                                                                      int H, int D, float slope, float* __restrict__ hio,
+                                                                      int64_t hio_rows) {
   constexpr int EPW = 64 / LPR, U = 4;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
@@ -61,6 +62,11 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
   for (int u = 0; u < U; ++u) drown[u] = p_drow[jn[u]];
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  // hio (optional): the layer output so far (self-loop + bias rows); the aggregated row is added to it in place.  Its row
+  // is requested here so that the read-modify-write at the end of the item does not wait for it
+  const bool add_h = hio && whole && slot == 0 && v < hio_rows;
+  float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (add_h) h0 = ld4(hio + v * X + x);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     float zl[U], zr[U];
     float4 f[U];
@@ -98,7 +104,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
   float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
-    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    st4(rp, r4);
+    if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
     if (x % D == 0) sum[v * H + h] = ssum;
   } else {  // hub destination: unnormalised partials, normalised by HET_rgat_normalize_split
     atomicAdd(rp + 0, acc.x);
@@ -112,13 +120,27 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
 __global__ __launch_bounds__(kBlock) void HET_rgat_normalize_split(const int32_t* __restrict__ split_seg,
                                                                     const int32_t* __restrict__ seg_key,
                                                                     int64_t num_split, const float* __restrict__ sum,
-                                                                    float* __restrict__ ret, int H, int D) {
+                                                                    float* __restrict__ ret, int H, int D,
+                                                                    float* __restrict__ hio, int64_t hio_rows) {
   const int64_t X = (int64_t)H * D, total = num_split * X;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
     const int64_t k = t / X;
     const int x = (int)(t - k * X);
     const int64_t v = seg_key[split_seg[k]];
-    ret[v * X + x] /= sum[v * H + x / D];
+    const float r = ret[v * X + x] / sum[v * H + x / D];
+    ret[v * X + x] = r;
+    if (hio && v < hio_rows) hio[v * X + x] += r;
+  }
+}
+
+// rows of the split (hub) destinations start from zero: their work items add unnormalised partial sums atomically
+__global__ __launch_bounds__(kBlock) void HET_rgat_zero_split_rows(const int32_t* __restrict__ split_seg,
+                                                                    const int32_t* __restrict__ seg_key,
+                                                                    int64_t num_split, float* __restrict__ ret, int X) {
+  const int64_t total = num_split * X;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t k = t / X;
+    ret[(int64_t)seg_key[split_seg[k]] * X + (t - k * X)] = 0.f;
   }
 }
 
@@ -328,7 +350,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
                                                                    const float* __restrict__ el,
                                                                    const float* __restrict__ er,
                                                                    float* __restrict__ sum, float* __restrict__ ret,
-                                                                   int H, float slope) {
+                                                                   int H, float slope, float* __restrict__ hio,
+                                                                   int64_t hio_rows) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
@@ -343,6 +366,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
   int srown = p_srow[jn], drown = p_drow[jn];
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  const bool add_h = hio && whole && slot == 0 && v < hio_rows;  // see HET_rgat_aggregate_compact
+  float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (add_h) h0 = ld4(hio + v * X + x);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     const int srowv = srown, drowv = drown;
     const float zlv = el[(int64_t)srowv * H + h];
@@ -376,7 +402,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
   float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
-    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    st4(rp, r4);
+    if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
     if (d == 0) sum[v * H + h] = ssum;
   } else {
     atomicAdd(rp + 0, acc.x);
@@ -495,6 +523,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     float ts = tq[0];
 #pragma unroll
     for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
+    // (writing tbuf in the order of the grouping by er row instead -- scattered 16-byte stores, a streaming segmented
+    //  sum afterwards -- was measured: +0.38 ms here and in the long-segment kernel, -0.40 ms there)
     if (d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;
     prev_key = key[U - 1];
   }
@@ -644,7 +674,7 @@ static bool compact_shape_ok(int64_t H, int64_t D) {
 
 extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c,
                                           const float* er_c, float* sum, float* ret, int64_t num_nodes, int64_t H,
-                                          int64_t D, double slope, het_stream stream) {
+                                          int64_t D, double slope, float* h_inout, int64_t h_rows, het_stream stream) {
   const char* op = "het_rgat_aggregate_compact";
   hipStream_t s = (hipStream_t)stream;
   HET_REQUIRE(by_dst && sum && ret && num_nodes >= 0, "%s: null argument", op);
@@ -653,7 +683,15 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
               "%s: by_dst must group the positions by destination with payload0 = feat row and payload1 = er row", op);
   const int64_t X = H * D;
   HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));  // destinations without in-edges; split hubs add atomically
-  HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
+  // ret: zero rows for destinations without in-edges -- unless the caller takes the layer output through h_inout and
+  // reads ret only where edges point (the backward): then only the split hubs' rows are cleared (0.5 GB less to fill)
+  if (!h_inout) {
+    HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
+  } else if (by_dst->num_split > 0) {
+    hipLaunchKernelGGL(HET_rgat_zero_split_rows, dim3(grid_for(by_dst->num_split * X)), dim3(kBlock), 0, s, by_dst->split_seg,
+                       by_dst->seg_key, by_dst->num_split, ret, (int)X);
+    HET_LAUNCH_CHECK("HET_rgat_zero_split_rows");
+  }
   if (by_dst->E == 0) return HET_OK;
   Items it{by_dst->item_seg, by_dst->item_begin, by_dst->item_end, by_dst->seg_ptr, by_dst->seg_key, by_dst->num_items};
   const unsigned nb = (unsigned)ceil_div64(by_dst->num_items, kBlock / 64);
@@ -662,17 +700,17 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
     if (coop_shape_ok(H, D)) {
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
                         hipLaunchKernelGGL((HET_rgat_aggregate_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p0,
-                                           by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (float)slope));
+                                           by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows));
     } else {
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_aggregate_compact<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
                                                         by_dst->p0, by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (int)D,
-                                                        (float)slope));
+                                                        (float)slope, h_inout, h_rows));
     }
   }
   HET_LAUNCH_CHECK("HET_rgat_aggregate_compact");
   if (by_dst->num_split > 0) {
     hipLaunchKernelGGL(HET_rgat_normalize_split, dim3(grid_for(by_dst->num_split * X)), dim3(kBlock), 0, s, by_dst->split_seg,
-                       by_dst->seg_key, by_dst->num_split, sum, ret, (int)H, (int)D);
+                       by_dst->seg_key, by_dst->num_split, sum, ret, (int)H, (int)D, h_inout, h_rows);
     HET_LAUNCH_CHECK("HET_rgat_normalize_split");
   }
   return HET_OK;

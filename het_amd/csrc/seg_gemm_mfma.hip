@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
   const int rc = lane / LPRC, cc = (lane % LPRC) * 4;  // C-store mapping
   float4 dotw = make_float4(0.f, 0.f, 0.f, 0.f);
   if (DOT) dotw = *reinterpret_cast<const float4*>(a.dot_w + (int64_t)r * X + cc);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!ATOMIC && a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + cc);
   const int dot_dl = DOT ? a.headcat_d >> 2 : 1, dot_h = DOT ? cc / a.headcat_d : 0, dot_H = DOT ? X / a.headcat_d : 1;
 
   // Global loads are software-pipelined two tiles deep and issued in branch-free phases of independent
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
           Ws[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LDC + nt * 32 + row] = acc[nt][reg];
 #pragma unroll
       for (int it = 0; it < NITC; ++it) {
-        const float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
+        float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
 #ifdef HET_ABL_NOSTORE
         if (a.num_rows < 0)
 #endif
@@ -412,7 +415,7 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   HET_REQUIRE(mfma_shape_supported(a.K, a.X), "segment GEMM (MFMA): unsupported shape K=%d X=%d", a.K, a.X);
   if (a.K > 128 || a.X > 128) {
     // 256-wide sides as 128-wide slabs of the weight (one launch each; K slabs after the first add atomically)
-    HET_REQUIRE(!a.dot_w && !a.b_k0 && !a.b_n0, "segment GEMM (MFMA): the dot epilogue needs X <= 128");
+    HET_REQUIRE(!a.dot_w && !a.bias && !a.b_k0 && !a.b_n0, "segment GEMM (MFMA): the dot / bias epilogues need K, X <= 128");
     for (int n0 = 0; n0 < a.X; n0 += 128) {
       bool first = true;  // the first window of a column slab stores (unless the caller accumulates), the others add
       for (int k0 = 0; k0 < a.K; k0 += 128) {

@@ -27,6 +27,8 @@ struct MfmaGemmArgs {
   // optional epilogue (plain stores, b_headcat == 1): dot_out[cs(i), h] = < C[cs(i), h, :], dot_w[r, h, :] >
   const float* dot_w = nullptr;  // [num_segs, X]
   float* dot_out = nullptr;      // [*, X / headcat_d]
+  // optional epilogue (plain stores, K, X <= 128): C row += bias[:]   (one [X] vector for all segments)
+  const float* bias = nullptr;
 };
 
 bool mfma_shape_supported(int K, int X);

@@ -554,12 +554,25 @@ def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_row
     return by_dst, by_srow, by_drow
 
 
-def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope):
-    _chk("rgat_aggregate_compact", (feat_c, el_c, er_c, sum, ret))
+def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None):
+    """h_inout [rows, H*D] (optional): ret's rows are also added into it in place (include/het_amd.h)."""
+    _chk("rgat_aggregate_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, h_inout) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
     _call(ret, "het_rgat_aggregate_compact", groupings[0].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), N, H, D,
-          float(slope), _stream(ret))
+          float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0], _stream(ret))
+
+
+def rows_linear_bias_ok(K: int, X: int) -> bool:
+    return K in (32, 64, 128) and X in (32, 64, 128)
+
+
+def rows_linear_bias(offsets, x, w, bias):
+    """x . w + bias for the rows [offsets[0], offsets[1]) of x (include/het_amd.h: het_rows_linear_bias)."""
+    _chk("rows_linear_bias", tuple(t for t in (x, w, bias) if t is not None), (offsets,))
+    out = torch.empty((x.shape[0], w.shape[1]), dtype=x.dtype, device=x.device)
+    _call(x, "het_rows_linear_bias", _p(offsets), _p(x), _p(w), _p(bias), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(x))
+    return out
 
 
 def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c, slope,

@@ -416,7 +416,9 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
  *   by_srow: het_grouping_create(NULL, 0, feat row of every position, E, S_row, payload0 = col, payload1 = er row)
  *   by_drow: het_grouping_create(NULL, 0, er row of every position, E, S_col, payload0 = rank of the position in by_srow
  *            (het_grouping_rank_of_position), NULL)
- * forward:  sum [N,H], ret [N,H,D] are overwritten (a4's outputs; exp is not produced).
+ * forward:  sum [N,H], ret [N,H,D] are overwritten (a4's outputs; exp is not produced).  h_inout [h_rows, H*D] (optional):
+ *   the layer output so far (self-loop + bias, het_rows_linear_bias); ret's row is added to it in place for every
+ *   destination < h_rows, and ret is then defined only for destinations WITH in-edges (no 0.5 GB zero fill).
  * backward: grad_feat_c, grad_el_c, grad_er_c are overwritten (a5's outputs on the compact rows).  fold_attn_l [R,H,D]
  *   (optional, with row_rel_ptrs [R+1] = relation pointers of the feat rows): adds grad_el_c[u,h] * fold_attn_l[r(u),h,:]
  *   into grad_feat_c -- the gradient through el_c = <feat_c, attn_l[r]>.  grad_bias [H*D] (optional): column sums of
@@ -424,7 +426,7 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
  *   workspace: het_rgat_backward_compact_workspace(N, E, H, D, grad_bias != NULL) bytes, 16-byte aligned. */
 int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c, const float* er_c,
                                float* sum, float* ret, int64_t num_nodes, int64_t H, int64_t D, double slope,
-                               het_stream stream);
+                               float* h_inout, int64_t h_rows, het_stream stream);
 int64_t het_rgat_backward_compact_workspace(int64_t num_nodes, int64_t num_edges, int64_t H, int64_t D, int with_bias);
 int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
                               const float* el_c, const float* er_c, const float* sum, const float* ret,
@@ -433,6 +435,12 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
                               float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
                               int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
                               int64_t workspace_bytes, het_stream stream);
+
+/* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
+ * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.
+ * Matrix-core shapes only (HET_ERR_UNSUPPORTED otherwise). */
+int het_rows_linear_bias(const int64_t* offsets, const float* x, const float* w, const float* bias, float* out,
+                         int64_t num_rows, int64_t K, int64_t X, het_stream stream);
 
 /* layer epilogue (RGAT/models.py:377-383: h + loop_message + h_bias): out[i,:] = a[i,:] (+ b[i,:]) (+ bias[:]) in one
  * pass; b and bias optional, X % 4 == 0 */

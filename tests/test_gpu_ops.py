@@ -217,6 +217,15 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
     k.rgat_aggregate_compact(grp, f, l, r_, sm, ret, slope)
     assert_close(sm, sm_r, what="sum")
     assert_close(ret, ret_r, what="ret")
+    # h_inout: the rows are also added into a caller tensor (the first nh destinations), ret untouched elsewhere
+    nh = N - 2
+    h0 = torch.randn(nh, H * D, generator=gen)
+    hio, ret2 = h0.to(DEV), torch.full((N, H, D), 7.0, device=DEV)
+    k.rgat_aggregate_compact(grp, f, l, r_, sm, ret2, slope, h_inout=hio)
+    assert_close(hio, h0.double() + ret_r.view(N, -1)[:nh], what="h_inout")
+    has_in = torch.zeros(N, dtype=torch.bool)
+    has_in[s["col_indices"]] = True
+    assert_close(ret2[has_in.to(DEV)], ret_r[has_in], what="ret (destinations with in-edges)")
     gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
     gb = torch.full((H * D,), float("nan"), device=DEV) if bias else None
     nb = N - 3
