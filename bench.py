@@ -310,8 +310,8 @@ def main():
     if args.model == "rgat":
         S_row = S_col = None
         compact_flow = "HET_rgat_backward_src" in kt or "HET_gat_backward_src" in kt
-        if compact_flow and not use_dist:
-            ss = g.get_separate_unique_node_indices_single_sided()
+        if compact_flow:
+            ss = (runner.dl.graph if use_dist else g).get_separate_unique_node_indices_single_sided()
             S_row, S_col = int(ss["node_indices_row"].numel()), int(ss["node_indices_col"].numel())
         gather = {}
         if S_row is not None:

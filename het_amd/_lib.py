@@ -35,6 +35,8 @@ _SIGNATURES = {
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P],
+    "het_rows_matmul_backward_dx": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],

@@ -106,8 +106,13 @@ def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
 
 class RgatLayerFunction(th.autograd.Function):
     @staticmethod
-    def forward(ctx, g, compact, direct, mulfirst, slope, num_dst, x, W, attn_l, attn_r, loop_w, bias):
+    def forward(ctx, g, compact, direct, mulfirst, slope, num_dst, halo, x, W, attn_l, attn_r, loop_w, bias):
         x, W, attn_l, attn_r = x.contiguous(), W.contiguous(), attn_l.contiguous(), attn_r.contiguous()
+        if halo is not None:
+            # multi-GPU (het_amd/dist.py): x holds the owned rows; the halo rows of x_local arrive through an all-to-all
+            # that is in flight until halo.finish_push() -- everything before that reads owned rows only
+            assert compact and mulfirst and loop_w is not None, "rgat_layer_halo_ok guards this path"
+            x = halo.start_push(x)
         s, by_src, by_dst = _lists(g)
         rp, row, col, eids = s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"]
         E, N = eids.numel(), x.shape[0]
@@ -133,8 +138,8 @@ class RgatLayerFunction(th.autograd.Function):
             d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
             featc = new(ss["node_indices_row"].numel(), H, D)
             elc = new(featc.shape[0], H)
-            _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
             erc = new(ss["node_indices_col"].numel(), H)
+            # (the destination side and the self-loop read rows of destination nodes only -- owned rows on a partition)
             if mulfirst:
                 K.rgnn_relational_matmul(d_col, 1, wa, x, erc.view(-1, H, 1), True)
                 saved = (featc, elc, erc)
@@ -142,13 +147,16 @@ class RgatLayerFunction(th.autograd.Function):
                 featd = new(erc.shape[0], H, D)
                 _k.matmul_attn_dot(d_col, 1, W, x, featd, attn_r, erc)
                 saved = (featc, elc, erc, featd)
-            # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
-            srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
-            grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])
             if loop_w is not None and _k.rows_linear_bias_ok(Kd, X):
                 # self-loop + bias first (bias in the GEMM epilogue); the aggregation adds its rows into h in place: no
                 # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
                 h = _k.rows_linear_bias(offs, x[:nd], loop_w, None if bias is None else bias.contiguous())
+            if halo is not None:
+                halo.finish_push()
+            _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
+            # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
+            srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
+            grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])
             _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h)
             ctx.grp = grp
             ex = x.new_empty(0)
@@ -177,6 +185,7 @@ class RgatLayerFunction(th.autograd.Function):
                 loop = new(nd, X)
                 K.rgnn_relational_matmul_no_scatter_gather_list(offs, loop_w.view(1, 1, Kd, X), x[:nd], loop)
             h = _k.rows_add_bias(out, loop, None if bias is None else bias.contiguous()) if (loop is not None or bias is not None) else out.clone()
+        ctx.halo = halo
         ctx.g, ctx.compact, ctx.mulfirst, ctx.slope, ctx.nd = g, compact, mulfirst, slope, nd
         ctx.has_loop, ctx.has_bias = loop_w is not None, bias is not None
         ctx.save_for_backward(x, W, attn_l, attn_r, loop_w if loop_w is not None else x.new_empty(0), offs if offs is not None else eids,
@@ -194,6 +203,8 @@ class RgatLayerFunction(th.autograd.Function):
         R, H, _, D = W.shape
         X = H * D
         grad_h = grad_h.contiguous()
+        if ctx.halo is not None:
+            return RgatLayerFunction._backward_with_halo(ctx, grad_h)
         grad_bias = grad_h.sum(0) if (ctx.has_bias and not ctx.compact) else None
         Wt = th.transpose(W, 2, 3).contiguous()
         grad_W = th.zeros_like(W)
@@ -266,11 +277,64 @@ class RgatLayerFunction(th.autograd.Function):
         if mulfirst:  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
             grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))
             grad_attn_r = (W * grad_wa).sum(2)
-        return None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
+        return None, None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
 
 
-def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None, mulfirst=False):
+    @staticmethod
+    def _backward_with_halo(ctx, grad_h):
+        """The backward on a partition, ordered around the reverse halo exchange: the input gradient through the
+        (relation, source) projection -- the only one that reaches halo rows -- is formed first and its halo rows leave with
+        an all-to-all; the weight gradients, the destination side and the rest of the self-loop run while it is in flight;
+        the returned rows are added to the owners' gradients at the end."""
+        x, W, attn_l, attn_r, loop_w, offs, sm, ex, ret, featc, elc, erc = ctx.saved_tensors
+        g, nd, slope, halo = ctx.g, ctx.nd, ctx.slope, ctx.halo
+        N, Kd = x.shape
+        R, H, _, D = W.shape
+        X = H * D
+        ss = g.get_separate_unique_node_indices_single_sided()
+        rp_row, rows_node = ss["rel_ptrs_row"], ss["node_indices_row"]
+        d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+        Wt = th.transpose(W, 2, 3).contiguous()
+        grad_x = th.empty_like(x)
+        grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
+        _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
+        go = grad_h.view(nd, H, D)
+        if nd != N:  # rows of the halo nodes receive no gradient
+            go = th.zeros((N, H, D), dtype=x.dtype, device=x.device)
+            go.view(N, X)[:nd] = grad_h
+        g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
+        grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm, ret, go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
+                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
+        _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=True)
+        halo.start_return(grad_x)
+        grad_W, grad_loop = th.empty_like(W), th.empty_like(loop_w)
+        _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)
+        _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+        grad_attn_l = th.empty_like(attn_l)
+        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                             accumulate=False)
+        wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)
+        grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
+        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True)  # owned rows only
+        grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
+        grad_attn_r = (W * grad_wa).sum(2)
+        grad_own = halo.finish_return(grad_x[:nd])
+        return None, None, None, None, None, None, None, grad_own, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
+
+
+def rgat_layer_halo_ok(g, x_own, W, slope, compact, mulfirst=False):
+    """Whether the one-node layer can run the halo exchange itself (forward_with_halo): the distinct-row dataflow with er
+    from the folded weight, and the matrix-core shapes of the split backward GEMMs."""
+    R, H, Kd, D = W.shape
+    if not rgat_layer_fused_ok(g, x_own, W, slope, compact, mulfirst):
+        return False
+    c, _, m = effective_flags(g, W, compact, True, mulfirst)
+    return c and m and _k.rows_linear_bias_ok(Kd, H * D) and _k.rows_matmul_backward_split_ok(H, Kd, D)
+
+
+def rgat_layer_fused(g, x, W, attn_l, attn_r, loop_w, bias, slope, compact, direct, num_dst=None, mulfirst=False, halo=None):
     compact, direct, mulfirst = effective_flags(g, W, compact, direct, mulfirst)
     if compact and not _has_single_sided_lists(g):
         g.generate_separate_unique_node_indices_single_sided_for_each_etype()
-    return RgatLayerFunction.apply(g, compact, direct, mulfirst, float(slope), num_dst, x, W, attn_l, attn_r, loop_w, bias)
+    return RgatLayerFunction.apply(g, compact, direct, mulfirst, float(slope), num_dst, halo, x, W, attn_l, attn_r, loop_w, bias)

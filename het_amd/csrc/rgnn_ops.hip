@@ -367,6 +367,51 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
   return launch_seg_dw(w, s);
 }
 
+// The two halves of a2 (one input head, matrix-core shapes) as separate entry points, so that a caller can order them
+// around a collective (het_amd/dist.py: the input gradient of the halo rows leaves first, the weight gradient is formed
+// while the reverse all-to-all is in flight).  gather_idx NULL: row i of x / grad_x; g_rows NULL: row i of gradout.
+extern "C" int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
+                                           const int64_t* g_rows, int64_t num_rows, const float* weights_t,
+                                           const float* gradout, float* grad_x, int64_t H, int64_t K, int64_t D,
+                                           int atomic, het_stream stream) {
+  const char* op = "het_rows_matmul_backward_dx";
+  HET_REQUIRE(rel_ptrs && num_rels > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0, "%s: bad arguments", op);
+  if (num_rows == 0) return HET_OK;
+  HET_REQUIRE(weights_t && gradout && grad_x, "%s: null data pointer", op);
+  if (!(mfma_shape_supported((int)(H * D), (int)K) && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0)) {
+    het_set_error("%s: only the matrix-core shapes", op);
+    return HET_ERR_UNSUPPORTED;
+  }
+  MfmaGemmArgs m;  // grad_x[gather] (+)= gradout[g_rows] . Wt[r]: Wt[r] read as one [H*D, K] matrix (heads summed by the GEMM)
+  m.A = gradout; m.a_ld = H * D; m.gather = g_rows; m.B = weights_t; m.b_rel_stride = H * D * K;
+  m.C = grad_x; m.c_ld = K; m.scatter = gather_idx; m.atomic = atomic ? 1 : 0;
+  m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
+  return launch_seg_gemm_mfma(m, (hipStream_t)stream);
+}
+
+extern "C" int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
+                                           const int64_t* g_rows, int64_t num_rows, const float* x, const float* gradout,
+                                           float* grad_w, int64_t H, int64_t K, int64_t D, int accumulate,
+                                           het_stream stream) {
+  const char* op = "het_rows_matmul_backward_dw";
+  HET_REQUIRE(rel_ptrs && num_rels > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && grad_w, "%s: bad arguments", op);
+  hipStream_t s = (hipStream_t)stream;
+  if (!(mfma_dw_supported((int)K, (int)(H * D)) && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+    het_set_error("%s: only the matrix-core shapes", op);
+    return HET_ERR_UNSUPPORTED;
+  }
+  if (!accumulate) HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
+  if (num_rows == 0) return HET_OK;
+  HET_REQUIRE(x && gradout, "%s: null data pointer", op);
+  MfmaDwArgs w;
+  w.A = x; w.a_ld = K; w.gather = gather_idx; w.G = gradout; w.g_ld = H * D; w.g_gather = g_rows;
+  w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
+  w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_rows; w.K = (int)K; w.X = (int)(H * D);
+  return launch_seg_dw_mfma(w, s);
+}
+
 extern "C" int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* offsets, int64_t num_types,
                                                                  int64_t num_rows, const float* weights,
                                                                  const float* x, float* ret, int64_t H, int64_t K,

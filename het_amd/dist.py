@@ -170,6 +170,55 @@ def _scatter_add_rows(out, idx, src):
     return out.index_add_(0, idx, src)
 
 
+class HaloContext:
+    """The halo exchange of one layer step as explicit start / finish calls, for a layer that overlaps it with its own
+    work (het_amd/backend/rgat_fused_layer.py): with the nccl backend the all-to-all runs on RCCL's stream while the
+    launch stream keeps going (``async_op=True``; ``wait()`` makes the launch stream wait for it).  With gloo (CPU tests, or
+    test ranks sharing one GPU) the calls complete immediately.
+
+      forward   x_local = start_push(x_own)   ... work that reads owned rows only ...   finish_push()
+      backward  start_return(grad_local)      ... work that leaves the halo rows alone ...   finish_return(grad_own)
+    """
+
+    def __init__(self, plan: DistPlan, group):
+        self.plan, self.group = plan, group
+        self._work = self._keep = None
+
+    def _a2a(self, recv, send, recv_counts, send_counts):
+        if send.is_cuda and dist.get_backend(self.group) != "gloo":
+            self._work = dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group, async_op=True)
+            self._keep = (recv, send)  # alive until the collective has finished
+        else:
+            _all_to_all(recv, send, recv_counts, send_counts, self.group)
+
+    def _wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = self._keep = None
+
+    def start_push(self, x_own):
+        p = self.plan
+        send = _gather_rows(x_own, p.send_idx)
+        x_local = x_own.new_empty((p.n_own + p.n_halo, x_own.shape[1]))
+        x_local[: p.n_own].copy_(x_own)
+        self._a2a(x_local[p.n_own:], send, p.recv_counts, p.send_counts)  # straight into the halo rows
+        return x_local
+
+    def finish_push(self):
+        self._wait()
+
+    def start_return(self, grad_local):
+        p = self.plan
+        self._back = grad_local.new_empty((int(p.send_idx.numel()), grad_local.shape[1]))
+        self._a2a(self._back, grad_local[p.n_own:], p.send_counts, p.recv_counts)
+
+    def finish_return(self, grad_own):
+        self._wait()
+        _scatter_add_rows(grad_own, self.plan.send_idx, self._back)
+        self._back = None
+        return grad_own
+
+
 class HaloExchange(torch.autograd.Function):
     """x_own [n_own, K] -> [n_own + n_halo, K]: owned rows followed by the halo rows received from
     their owners.  Backward sends the halo gradients home and adds them to the owners' rows."""
@@ -200,15 +249,24 @@ class DistLayer:
     [n_local, X] or only its first n_own rows; rows of owned nodes are kept.  ``params`` are replicated and their gradients
     all-reduced after backward."""
 
-    def __init__(self, coo: IntegratedCOO, layer_fn: Callable, params, group=None, full_layouts: bool = False):
+    def __init__(self, coo: IntegratedCOO, layer_fn: Callable, params, group=None, full_layouts: bool = False,
+                 halo_layer_fn: Callable = None):
+        """``halo_layer_fn(graph, x_own, halo)`` (optional): a layer that runs the exchange itself through a HaloContext and
+        overlaps it with its own work; it returns None when it cannot (then ``layer_fn`` runs behind HaloExchange)."""
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.plan = build_plan(coo, self.rank, self.world)
         self.graph = HetGraph.from_integrated_coo(self.plan.local, full=full_layouts)
         self.layer_fn = layer_fn
+        self.halo_layer_fn = halo_layer_fn
+        self.halo = HaloContext(self.plan, group)
         self.params = list(params)
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
+        if self.halo_layer_fn is not None:
+            out = self.halo_layer_fn(self.graph, x_own, self.halo)
+            if out is not None:
+                return out
         x_local = HaloExchange.apply(x_own, self.plan, self.group)
         return self.layer_fn(self.graph, x_local, self.plan.n_own)[: self.plan.n_own]
 
@@ -234,8 +292,10 @@ class DistRGAT:
         torch.manual_seed(0)  # same weights on every rank
         self.layer = HET_RGATLayer(in_feat, out_feat, coo.num_rels, heads, self_loop=True, dropout=0.0,
                                    **layer_flags).to(device)
+        overlap = os.environ.get("HET_DIST_OVERLAP", "1") == "1"
         self.dl = DistLayer(coo, lambda g, x, n_own: self.layer(g, x, num_dst=n_own), self.layer.parameters(),
-                            full_layouts=bool(layer_flags.get("compact_as_of_node_flag")))
+                            full_layouts=bool(layer_flags.get("compact_as_of_node_flag")),
+                            halo_layer_fn=(lambda g, x_own, halo: self.layer.forward_with_halo(g, x_own, halo)) if overlap else None)
         p = self.dl.plan
         self.embed = torch.nn.Parameter(torch.empty(p.n_own, in_feat, device=device))
         torch.nn.init.xavier_uniform_(self.embed)

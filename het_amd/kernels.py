@@ -563,6 +563,27 @@ def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_ino
           float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0], _stream(ret))
 
 
+def rows_matmul_backward_split_ok(H: int, K: int, D: int) -> bool:
+    """Shapes het_rows_matmul_backward_dx / _dw cover (one input head on the matrix cores)."""
+    return K in (32, 64, 128) and H * D in (32, 64, 128)
+
+
+def rows_matmul_backward_dx(rel_ptrs, gather_idx, weights_transposed, gradout, grad_x, atomic: bool):
+    """grad_x[gather_idx[i]] (+)= gradout[i] . Wt[r(i)] (include/het_amd.h: het_rows_matmul_backward_dx)."""
+    _chk("rows_matmul_backward_dx", (weights_transposed, gradout, grad_x), (rel_ptrs,) + (() if gather_idx is None else (gather_idx,)))
+    R, H, D, K = weights_transposed.shape
+    _call(gradout, "het_rows_matmul_backward_dx", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(weights_transposed),
+          _p(gradout), _p(grad_x), H, K, D, int(atomic), _stream(gradout))
+
+
+def rows_matmul_backward_dw(rel_ptrs, gather_idx, x, gradout, grad_w, accumulate: bool):
+    """grad_w[r(i)] (+)= x[gather_idx[i]]^T (x) gradout[i] (include/het_amd.h: het_rows_matmul_backward_dw)."""
+    _chk("rows_matmul_backward_dw", (x, gradout, grad_w), (rel_ptrs,) + (() if gather_idx is None else (gather_idx,)))
+    R, H, K, D = grad_w.shape
+    _call(gradout, "het_rows_matmul_backward_dw", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(x), _p(gradout),
+          _p(grad_w), H, K, D, int(accumulate), _stream(gradout))
+
+
 def rows_linear_bias_ok(K: int, X: int) -> bool:
     return K in (32, 64, 128) and X in (32, 64, 128)
 

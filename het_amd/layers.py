@@ -75,6 +75,23 @@ class HET_RGATLayer(nn.Module):
         return th.bmm(self.conv_weights.view(-1, self.in_feat, dk), self.attn_r.view(-1, dk, 1)).view(
             -1, self.num_heads, self.in_feat, 1)
 
+    def forward_with_halo(self, g, x_own: th.Tensor, halo):
+        """Multi-GPU form (het_amd/dist.py): ``g`` is this rank's local graph (owned nodes first, then halo nodes), ``x_own``
+        the features of the owned nodes; the layer runs the halo exchange itself (``halo``: a dist.HaloContext) and overlaps
+        it with the work that needs owned rows only.  Returns the owned rows, or None when the one-node path does not
+        cover the configuration (the caller then exchanges first and calls forward)."""
+        if not (self.gat_edge_parallel_flag and self.self_loop and not self.reference_op_sequence and
+                FL.rgat_layer_halo_ok(g, x_own, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
+                                      self.multiply_among_weights_first_flag)):
+            return None
+        h = FL.rgat_layer_fused(g, x_own, self.conv_weights, self.attn_l, self.attn_r, self.loop_weight,
+                                self.h_bias if self.bias else None, self.leaky_relu_slope, self.compact_as_of_node_flag,
+                                self.compact_direct_indexing_flag, x_own.shape[0], self.multiply_among_weights_first_flag,
+                                halo=halo)
+        if self.activation:
+            h = self.activation(h)
+        return self.dropout(h)
+
     def forward(self, g, inputs: th.Tensor, num_dst=None):
         """``num_dst``: the destination nodes of ``g`` are its first ``num_dst`` nodes (a sampled block, or the owned
         nodes of a partition followed by halo nodes): only their rows are returned and the self-loop runs on them only."""

@@ -436,6 +436,18 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
                               int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
                               int64_t workspace_bytes, het_stream stream);
 
+/* The two halves of a2 (backward_rgnn_relational_matmul, one input head, matrix-core shapes) as separate calls, so that a
+ * caller can order them around a collective (het_amd/dist.py).  Rows i in [0, num_rows) of relation-bucketed lists:
+ *   dx: grad_x[gather_idx[i], :] (+)= gradout[g_rows[i], :] . Wt[r(i)]      atomic != 0: "+=" (rows may repeat), else "="
+ *   dw: grad_w[r(i)]             (+)= x[gather_idx[i], :]^T (x) gradout[g_rows[i], :]
+ * gather_idx / g_rows NULL = row i.  weights_t [R,H,D,K], grad_w [R,H,K,D]. */
+int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* g_rows,
+                                int64_t num_rows, const float* weights_t, const float* gradout, float* grad_x, int64_t H,
+                                int64_t K, int64_t D, int atomic, het_stream stream);
+int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* g_rows,
+                                int64_t num_rows, const float* x, const float* gradout, float* grad_w, int64_t H, int64_t K,
+                                int64_t D, int accumulate, het_stream stream);
+
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.
  * Matrix-core shapes only (HET_ERR_UNSUPPORTED otherwise). */

@@ -21,7 +21,7 @@ def _free_port():
 
 
 def _coo(kind):
-    return make_mag_like(scale=5e-4) if kind == "mag" else make_random(97, 3, 800, seed=4)
+    return make_mag_like(scale=5e-4) if kind.startswith("mag") else make_random(97, 3, 800, seed=4)
 
 
 def _params(R, H, K, D):
@@ -30,14 +30,39 @@ def _params(R, H, K, D):
     return dict(W=mk(R, H, K, D), al=mk(R, H, D), ar=mk(R, H, D), lw=mk(K, H * D), b=mk(H * D))
 
 
-def _worker(rank, world, port, kind, outdir):
+_DIMS = {"mag": (2, 8, 4), "random": (2, 8, 4), "mag128": (4, 128, 32)}  # (heads, in feat, per-head out); mag128 = configs[4]
+
+
+class _HaloOracleLayer(torch.autograd.Function):
+    """A layer that runs the halo exchange itself through dist.HaloContext (as the HIP one-node RGAT layer does on a
+    partition): start_push / finish_push around the forward, start_return / finish_return around the backward."""
+
+    @staticmethod
+    def forward(ctx, x_own, halo, fn, n_own, *params):
+        x_local = halo.start_push(x_own.detach())
+        halo.finish_push()
+        with torch.enable_grad():
+            xl = x_local.requires_grad_(True)
+            out = fn(xl)[:n_own]
+        ctx.halo, ctx.xl, ctx.out, ctx.params, ctx.n_own = halo, xl, out, params, n_own
+        return out.detach()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = torch.autograd.grad(ctx.out, (ctx.xl,) + tuple(ctx.params), grad_out)
+        ctx.halo.start_return(grads[0])
+        g_own = ctx.halo.finish_return(grads[0][: ctx.n_own].clone())
+        return (g_own, None, None, None) + tuple(grads[1:])
+
+
+def _worker(rank, world, port, kind, outdir, use_halo=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from het_amd.dist import DistLayer
         from oracle import layers as OL
         coo = _coo(kind)
-        H, K, D = 2, 8, 4
+        H, K, D = _DIMS[kind]
         p = _params(coo.num_rels, H, K, D)
 
         def layer_fn(g, x, n_own):
@@ -45,7 +70,10 @@ def _worker(rank, world, port, kind, outdir):
             return OL.rgat_layer(x, p["W"], p["al"], p["ar"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
                                  g.get_num_nodes(), 0.2, p["lw"], p["b"])
 
-        dl = DistLayer(coo, layer_fn, p.values())
+        def halo_layer_fn(g, x_own, halo):
+            return _HaloOracleLayer.apply(x_own, halo, lambda xl: layer_fn(g, xl, x_own.shape[0]), x_own.shape[0], *p.values())
+
+        dl = DistLayer(coo, layer_fn, p.values(), halo_layer_fn=halo_layer_fn if use_halo else None)
         lo, hi = int(dl.plan.bounds[rank]), int(dl.plan.bounds[rank + 1])
         gen = torch.Generator().manual_seed(2)
         x_full = torch.randn(coo.num_nodes, K, generator=gen, dtype=torch.float64)
@@ -62,15 +90,18 @@ def _worker(rank, world, port, kind, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("mag", 2), ("random", 3)])
-def test_partitioned_layer_matches_single_process(kind, world):
+@pytest.mark.parametrize("kind,world,use_halo", [("mag", 2, False), ("random", 3, False), ("mag128", 2, False), ("mag", 2, True),
+                                                 ("random", 3, True)])
+def test_partitioned_layer_matches_single_process(kind, world, use_halo):
+    """mag128: feat 128, 4 heads -- the shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition).  use_halo: the
+    layer drives the exchange through dist.HaloContext (the overlapped form of the HIP layer) instead of HaloExchange."""
     from het_amd.graph import HetGraph
     from oracle import layers as OL
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), kind, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), kind, d, use_halo), nprocs=world, join=True)
         parts = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
     coo = _coo(kind)
-    H, K, D = 2, 8, 4
+    H, K, D = _DIMS[kind]
     p = _params(coo.num_rels, H, K, D)
     g = HetGraph.from_integrated_coo(coo, full=False)
     s = g.get_separate_coo_original()

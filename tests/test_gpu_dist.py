@@ -76,3 +76,38 @@ def test_two_ranks_on_one_gpu_match_single_process(compact):
         torch.testing.assert_close(q["gx"], x.grad.cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
         for n, p in layer.named_parameters():
             torch.testing.assert_close(q["grads"][n], p.grad.cpu(), rtol=5e-4, atol=1e-4)
+
+
+def _bench_line(cmd, env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_distributed_flow_one_rank():
+    """bench.py's multi-GPU code path (DistRGAT: plan, halo exchange inside the layer node, gradient all-reduce) with a
+    process group of one rank on the test box's GPU."""
+    import sys
+    env = dict(os.environ, HET_FORCE_DIST="1", HET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = _bench_line([sys.executable, "bench.py", "--gpus", "1", "--scale", "0.02", "--steps", "3", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-variants"], env)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "strong"
+
+
+def test_bench_two_ranks_through_torchrun():
+    """The driver's launch line for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), both ranks on the one GPU
+    of the test box with the gloo backend standing in for RCCL (HET_DIST_BACKEND): rank 0 prints the one JSON line."""
+    import sys
+    env = dict(os.environ, HET_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HET_FORCE_DIST"):
+        env.pop(k, None)
+    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                       "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--scale", "0.02", "--steps",
+                       "3", "--warmup", "1", "--no-cpu-baseline"], env)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "RCCL all-to-all" in out["config"]["parallelism"]
