@@ -26,7 +26,9 @@ def timeit(fn, n=20):
 
 import het_amd.dist as D
 ONLY = os.environ.get("ONLY")  # "world,rank": just that share (for rocprofv3)
-for world, beta in [(1, 0.0)] + [(w, b) for w in (2, 4, 8) for b in (12.0,)]:
+BETAS = [float(t) for t in os.environ.get("BETAS", "12").split(",")]
+WORLDS = [int(t) for t in os.environ.get("WORLDS", "2,4,8").split(",")]
+for world, beta in ([(1, 0.0)] if 1 in WORLDS or "WORLDS" not in os.environ else []) + [(w, b) for w in WORLDS if w > 1 for b in BETAS]:
     D.NODE_WEIGHT = beta
     rows = []
     for rank in range(world):

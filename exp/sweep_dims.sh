@@ -3,6 +3,7 @@
 # train driver with the reference's flag names; prints forward + backward ms per full-graph epoch
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$R
+# (the reference's sweep also crosses MulFlag = "" / --multiply_among_weights_first_flag for RGAT and HGT: pass the flag as "$@")
 for m in rgat hgt rgcn; do
   for dx in 32 64 128; do
     for dy in 32 64 128; do

@@ -345,6 +345,33 @@ class HetGraph:
     def get_original_node_type_offsets(self):
         return self.graph_data["original"]["node_type_offsets"]
 
+    def get_rel_node_types(self):
+        """(src_type [R], dst_type [R]) int64: the node type of the sources / destinations of every relation, for graphs
+        whose relations are canonical edge types (one source type, one destination type each) -- what the reference's HGT
+        receives as src_ / dst_node_type_per_canonical_edge_type (hrt/python/HGT/models.py:31-52).  Read off the first
+        edge of each relation (an empty relation gets type 0); raises when a relation mixes node types."""
+        hit = self._plans.get("rel_node_types")
+        if hit is None:
+            s = self.graph_data["separate"]["coo"]["original"]
+            offs = self.graph_data["original"]["node_type_offsets"]
+            rp = s["rel_ptrs"]
+            first = rp[:-1].clamp(max=max(0, s["row_indices"].numel() - 1))
+            empty = rp[1:] == rp[:-1]
+            typ = lambda nodes: torch.searchsorted(offs[1:].contiguous(), nodes, right=True).clamp(max=offs.numel() - 2)
+            E = s["row_indices"].numel()
+            if E == 0:
+                z = torch.zeros(rp.numel() - 1, dtype=_I64, device=rp.device)
+                hit = (z, z.clone())
+            else:
+                st, dt = typ(s["row_indices"][first]), typ(s["col_indices"][first])
+                st, dt = torch.where(empty, torch.zeros_like(st), st), torch.where(empty, torch.zeros_like(dt), dt)
+                rel = torch.repeat_interleave(torch.arange(rp.numel() - 1, device=rp.device), rp[1:] - rp[:-1], output_size=E)
+                if not (bool((typ(s["row_indices"]) == st[rel]).all()) and bool((typ(s["col_indices"]) == dt[rel]).all())):
+                    raise ValueError("get_rel_node_types: a relation mixes node types (not a canonical edge type)")
+                hit = (st.contiguous(), dt.contiguous())
+            self._plans["rel_node_types"] = hit
+        return hit
+
     def get_separate_coo_original(self):
         return dict(self.graph_data["separate"]["coo"]["original"])
 

@@ -248,15 +248,29 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
         return self.dropout(node_repr)
 
 
+def _heads_first(w, H):
+    """[R, 1, in, H*dk] typed projection weights -> [R, H, in, dk] (head h = columns h*dk .. (h+1)*dk)."""
+    R, _, K, X = w.shape
+    return w.view(R, K, H, X // H).permute(0, 2, 1, 3)
+
+
 class HET_HGTLayerHetero(nn.Module):
     """Heterogeneous graph transformer layer (HGT/models.py:15-286): typed K/Q/V projections per node type,
     per-relation attention and message weights, edge softmax with the relation prior as temperature, typed
-    output projection gated by sigmoid(skip).  (The multiply_among_weights_first variant, which the reference
-    restricts to one head and leaves with a FIXME, is not built.)"""
+    output projection gated by sigmoid(skip).
+
+    ``multiply_among_weights_first_flag`` (HGT/models.py:124-151, in the reference's sweep hrt/utils/_do_all_cases.sh:6,34
+    with --num_heads 1): the typed K / Q / V projections are folded into the per-relation weights --
+    W_att[r,h] = Q_dt(r),h . att[r,h] . K_st(r),h^T ([in,in]; K . att . Q^T for the fused score op) and
+    W_msg[r,h] = V_st(r),h . msg[r,h] ([in,dk]) -- and the edge ops take the layer input itself as k = q = v.  The
+    reference's code for it reshapes with ``view`` where a transpose is meant, multiplies relation_msg and V in the
+    opposite order and indexes V by the destination type (its own "fixme"s): taken literally it is a different model and
+    only type-checks for one head with in_dim == d_k.  Built here with the INTENDED meaning -- the same function as the
+    layer without the flag (associativity), any number of heads -- which is what oracle/layers.py::hgt_layer checks."""
 
     def __init__(self, num_ntypes, num_rels, in_dim, out_dim, num_heads=1, dropout=0.2, use_norm=False,
                  hgt_fused_attn_score_flag=False, compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
-                 fused_message_mean_aggregation_flag=True):
+                 fused_message_mean_aggregation_flag=True, multiply_among_weights_first_flag=False):
         super().__init__()
         assert fused_message_mean_aggregation_flag, "only the fused message + aggregation op is built (the reference default)"
         assert not use_norm, "use_norm is off in the reference scripts"
@@ -266,6 +280,7 @@ class HET_HGTLayerHetero(nn.Module):
         self.hgt_fused_attn_score_flag = hgt_fused_attn_score_flag
         self.compact_as_of_node_flag = compact_as_of_node_flag
         self.compact_direct_indexing_flag = compact_direct_indexing_flag
+        self.multiply_among_weights_first_flag = multiply_among_weights_first_flag
         self.k_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
         self.q_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
         self.v_linears = nn.Parameter(th.Tensor(num_ntypes, 1, in_dim, out_dim))
@@ -287,6 +302,8 @@ class HET_HGTLayerHetero(nn.Module):
         offs = G.get_original_node_type_offsets()
         seg_types = G.graph_data["original"].get("node_segment_types") if hasattr(G, "graph_data") else None
         per_run = (lambda w: w) if seg_types is None else (lambda w: w.index_select(0, seg_types))
+        if self.multiply_among_weights_first_flag:
+            return self._forward_weights_first(G, h, offs, per_run, num_dst)
         k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.k_linears), h).view(-1, self.num_heads, self.d_k)
         q = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.q_linears), h).view(-1, self.num_heads, self.d_k)
         v = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.v_linears), h).view(-1, self.num_heads, self.d_k)
@@ -313,6 +330,35 @@ class HET_HGTLayerHetero(nn.Module):
             attn_score = B.rgnn_inner_product_right_node(G, per_edge, k, 0, "_col")
         new_h = B.hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(
             self.relation_msg, v, G, (self.relation_pri / self.sqrt_dk), attn_score)
+        out = B.rgnn_relational_matmul_no_scatter_gather_list(
+            offs, per_run(th.sigmoid(self.skip) * self.a_linears), new_h.view(-1, self.out_dim))
+        return out if num_dst is None else out[:num_dst]
+
+    def _forward_weights_first(self, G, h, offs, per_run, num_dst):
+        """--multiply_among_weights_first_flag (see the class docstring): two small batched products per step replace the three
+        typed projections of the nodes; the per-relation [in,in] / [in,dk] weights then meet the layer input directly."""
+        H, dk = self.num_heads, self.d_k
+        st, dt = G.get_rel_node_types()
+        Kr = _heads_first(self.k_linears.index_select(0, st), H)  # [R,H,in,dk]
+        Qr = _heads_first(self.q_linears.index_select(0, dt), H)
+        Vr = _heads_first(self.v_linears.index_select(0, st), H)
+        if self.hgt_fused_attn_score_flag:  # s = < k[src] . att, q[dst] > = h[src] . (K att Q^T) . h[dst]^T
+            w_att = th.matmul(th.matmul(Kr, self.relation_att), Qr.transpose(2, 3))
+        else:                               # s = < q[dst] . att, k[src] > = h[dst] . (Q att K^T) . h[src]^T
+            w_att = th.matmul(th.matmul(Qr, self.relation_att), Kr.transpose(2, 3))
+        w_msg = th.matmul(Vr, self.relation_msg)  # [R,H,in,dk]
+        hh = h.unsqueeze(1) if H == 1 else h.unsqueeze(1).expand(-1, H, -1)
+        hh = hh.contiguous()  # k = q = v: the layer input once per head (the reference: h.unsqueeze(1).repeat(1, H, 1))
+        if self.hgt_fused_attn_score_flag:
+            attn_score = B.hgt_full_graph_hetero_attention_ops_coo(G, w_att.contiguous(), hh, hh)
+        else:
+            s = G.get_separate_coo_original()
+            per_edge = B.rgnn_relational_matmul(
+                {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["col_indices"],
+                 "separate_coo_eids": s["eids"]}, w_att.contiguous(), h, True, 0)  # [E,H,in] = h[dst] . W_att[r,h]
+            attn_score = B.rgnn_inner_product_right_node(G, per_edge, hh, 0, "_col")
+        new_h = B.hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(
+            w_msg.contiguous(), hh, G, (self.relation_pri / self.sqrt_dk), attn_score)
         out = B.rgnn_relational_matmul_no_scatter_gather_list(
             offs, per_run(th.sigmoid(self.skip) * self.a_linears), new_h.view(-1, self.out_dim))
         return out if num_dst is None else out[:num_dst]

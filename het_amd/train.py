@@ -73,11 +73,14 @@ class HET_RGCNModel(nn.Module):
 class HET_HGTModel(nn.Module):
     """hrt/python/HGT/models.py:246-347 (stack of HET_HGTLayerHetero)."""
 
-    def __init__(self, num_ntypes, num_rels, h_dim, out_dim, num_heads, num_layers=1, dropout=0.2):
+    def __init__(self, num_ntypes, num_rels, h_dim, out_dim, num_heads, num_layers=1, dropout=0.2,
+                 multiply_among_weights_first_flag=False, hgt_fused_attn_score_flag=False):
         super().__init__()
         dims = [h_dim] * num_layers + [out_dim]
         self.layers = nn.ModuleList([HET_HGTLayerHetero(num_ntypes, num_rels, dims[i], dims[i + 1], num_heads=num_heads,
-                                                        dropout=dropout) for i in range(num_layers)])
+                                                        dropout=dropout, hgt_fused_attn_score_flag=hgt_fused_attn_score_flag,
+                                                        multiply_among_weights_first_flag=multiply_among_weights_first_flag)
+                                     for i in range(num_layers)])
 
     def forward(self, g, h):
         for layer in self.layers:
@@ -220,7 +223,9 @@ def main(argv=None):
         extra = (th.rand(E, 1, device=dev),)  # edge norm as RGCN.py:527-530
     else:
         model = HET_HGTModel(g.get_num_ntypes(), R, args.n_infeat, args.num_classes, args.num_heads,
-                             num_layers=args.num_layers, dropout=args.dropout)
+                             num_layers=args.num_layers, dropout=args.dropout,
+                             multiply_among_weights_first_flag=args.multiply_among_weights_first_flag,
+                             hgt_fused_attn_score_flag=getattr(args, "hgt_fused_attn_score_flag", False))
     model = model.to(dev)
     labels = th.randint(0, args.num_classes, (N,), device=dev)  # random labels as train_dgl.py:132-148
     optimizer = th.optim.Adam(list(model.parameters()) + list(embed.parameters()), lr=args.lr)

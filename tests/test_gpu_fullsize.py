@@ -145,7 +145,7 @@ def test_rgat_layer_dataflows_agree_at_full_size(heads):
                                                             "multiply_among_weights_first_flag": True}),
                                          (4, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True}),
                                          (4, {"multiply_among_weights_first_flag": True})])
-def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags):
+def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, feat=64):
     """BASELINE.json's RGAT configuration (ogbn-mag shape, feat 64) against oracle/layers.py evaluated in fp64 -- the
     oracle is plain torch, so at this size it runs on the GPU (minutes on the CPU): output, input gradient and every
     parameter gradient of the HIP layer."""
@@ -160,10 +160,10 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags):
     s = g.get_separate_coo_original()
     N = g.get_num_nodes()
     gen = torch.Generator(device=DEV).manual_seed(12)
-    x0 = torch.randn(N, 64, device=DEV, generator=gen) * 0.3
-    go = torch.randn(N, 64, device=DEV, generator=gen)
+    x0 = torch.randn(N, feat, device=DEV, generator=gen) * 0.3
+    go = torch.randn(N, feat, device=DEV, generator=gen)
     torch.manual_seed(0)
-    layer = HET_RGATLayer(64, 64, g.get_num_rels(), heads, self_loop=True, dropout=0.0, **flags).to(DEV)
+    layer = HET_RGATLayer(feat, feat, g.get_num_rels(), heads, self_loop=True, dropout=0.0, **flags).to(DEV)
     x = x0.clone().requires_grad_(True)
     out = layer(g, x)
     out.backward(go)
@@ -183,8 +183,16 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags):
         # typical: 1.5e-7 (out, grad_x), 1e-6 .. 8e-6 (parameter gradients); the parameter bound leaves room for an edge whose
         # fp32 pre-activation falls on the other side of the leaky-ReLU kink than the fp64 one (see the test above)
         tol_l2, tol_max = (2e-5, 1e-3) if name in ("out", "grad_x") else (3e-3, 6e-3)
-        print(f"[full-size vs fp64 oracle] heads={heads} flags={sorted(flags)} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
+        print(f"[full-size vs fp64 oracle] feat={feat} heads={heads} flags={sorted(flags)} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
         assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+
+def test_rgat_feat128_layer_matches_the_fp64_oracle_at_full_size():
+    """BASELINE.json configs[4]'s single-GPU shape: RGAT on the full ogbn-mag-shaped graph at feat 128, 4 heads (the fp64
+    oracle peaks at 173 GB of the 288 GB here)."""
+    torch.cuda.empty_cache()
+    test_rgat_layer_matches_the_fp64_oracle_at_full_size(4, {}, feat=128)
+    torch.cuda.empty_cache()
 
 
 def _errors(got, want):

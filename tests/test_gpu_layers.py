@@ -120,8 +120,24 @@ def test_rgat_layer_heads1_feat128():
 @pytest.mark.parametrize("compact,direct", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("K,D,R", [(16, 16, 4), (64, 64, 7)])
 def test_rgcn_layer(compact, direct, K, D, R):
+    _run_rgcn(random_graph(seed=44, n=350, r=R, e=5000, shuffle=False), compact, direct, K, D, R)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("R", [4, 104])
+def test_rgcn_layer_on_the_aifb_shaped_graph(R, compact):
+    """BASELINE.json configs[0] (C1): one RGCN layer, feat 16, on the AIFB-shaped graph (N = 8 285, E = 58 086) with 4
+    relations (as BASELINE.json states) and 104 (what the reference observes for DGL's AIFB,
+    hrt/python/test/test_graphiler_load_data.py:18) against oracle/layers.py -- output, input and weight gradients."""
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_aifb_like
+    g = HetGraph.from_integrated_coo(make_aifb_like(R))
+    assert g.get_num_nodes() == 8285 and g.get_num_edges() == 58086 and g.get_num_rels() == R
+    _run_rgcn(g, compact, compact, 16, 16, R)
+
+
+def _run_rgcn(g, compact, direct, K, D, R):
     from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
-    g = random_graph(seed=44, n=350, r=R, e=5000, shuffle=False)
     torch.manual_seed(1)
     N, E = g.get_num_nodes(), g.get_num_edges()
     layer = HET_EglRelGraphConv_EdgeParallel(K, D, R, bias=True, compact_as_of_node_flag=compact,
@@ -158,6 +174,42 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
     N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
     layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn,
                                compact_as_of_node_flag=compact, compact_direct_indexing_flag=direct)
+    with torch.no_grad():
+        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.skip.uniform_(-1, 1)
+    h, go = torch.randn(N, in_dim) * 0.5, torch.randn(N, out_dim)
+    s = g.get_separate_coo_original()
+    names = ["k_linears", "q_linears", "v_linears", "a_linears", "relation_att", "relation_msg", "relation_pri", "skip"]
+    p = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
+    h64 = h.double().requires_grad_(True)
+    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N,
+                       p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
+                       p["relation_pri"], p["skip"], H, fused_attn=fused_attn)
+    grads_ref = torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double())
+    g.to_(DEV)
+    layer = layer.to(DEV)
+    hd = h.to(DEV).requires_grad_(True)
+    out = layer(g, hd)
+    out.backward(go.to(DEV))
+    g.cpu_()
+    assert_close(out, ref, what="out")
+    assert_close(hd.grad, grads_ref[0], what="grad_h")
+    for n, gr in zip(names, grads_ref[1:]):
+        assert_close(getattr(layer, n).grad, gr, what="grad_" + n)
+
+
+@pytest.mark.parametrize("fused_attn", [False, True])
+@pytest.mark.parametrize("H,in_dim,out_dim", [(1, 64, 64), (2, 32, 64), (1, 32, 64)])
+def test_hgt_layer_multiply_among_weights_first(fused_attn, H, in_dim, out_dim):
+    """--multiply_among_weights_first_flag of HGT (HGT/models.py:124-151; heads = 1 in the reference's sweep): the typed
+    K / Q / V projections folded into the relation weights.  Same function as the layer without the flag, so it is
+    checked against the same fp64 oracle: output and the gradients of the input and of all eight parameters."""
+    from het_amd.layers import HET_HGTLayerHetero
+    g = mag_graph(1.5e-3)  # typed node ranges, relations = canonical edge types
+    torch.manual_seed(3)
+    N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
+    layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn,
+                               multiply_among_weights_first_flag=True)
     with torch.no_grad():
         layer.relation_pri.uniform_(0.5, 1.5)
         layer.skip.uniform_(-1, 1)

@@ -316,3 +316,35 @@ def test_hgt_ops_compose_to_layer_and_match_autograd():
         torch.testing.assert_close(g_att, grads_ref[5])
         torch.testing.assert_close(g_msgW, grads_ref[6])
         torch.testing.assert_close(g_mu / dk ** 0.5, grads_ref[7])
+
+
+@pytest.mark.parametrize("R", [4, 104])
+def test_rgcn_oracle_on_the_aifb_shaped_graph(R):
+    """BASELINE.json configs[0] (C1) is the CPU path: one RGCN layer, feat 16, on the AIFB-shaped graph (4 relations as
+    BASELINE.json states, 104 as the reference observes for DGL's AIFB).  The layer oracle (the reference's op
+    composition, RGCN/RGCN.py:264-350) runs on it and agrees with an independent dense formulation -- one [N,N]
+    normalised adjacency per relation -- in value and in the input / weight gradients."""
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_aifb_like
+    from oracle import layers as OL
+    g = HetGraph.from_integrated_coo(make_aifb_like(R), full=False)
+    s = g.get_separate_coo_original()
+    N, E, K, D = g.get_num_nodes(), g.get_num_edges(), 16, 16
+    assert (N, E) == (8285, 58086)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(N, K, generator=gen, dtype=torch.float64).requires_grad_(True)
+    W = (torch.randn(R, K, D, generator=gen, dtype=torch.float64) * 0.3).requires_grad_(True)
+    norm = torch.rand(E, 1, generator=gen, dtype=torch.float64)
+    go = torch.randn(N, D, generator=gen, dtype=torch.float64)
+    out = OL.rgcn_layer(x, W, norm, s["rel_ptrs"], s["row_indices"], s["col_indices"], N)
+    gx, gW = torch.autograd.grad(out, [x, W], go)
+    # independent formulation: sparse [N,N] adjacency per relation with the norms as values, ret = SUM_r A_r x W_r
+    ref = torch.zeros(N, D, dtype=torch.float64)
+    for r in range(R):
+        a, b = int(s["rel_ptrs"][r]), int(s["rel_ptrs"][r + 1])
+        A = torch.sparse_coo_tensor(torch.stack([s["col_indices"][a:b], s["row_indices"][a:b]]), norm[a:b, 0], (N, N)).coalesce()
+        ref = ref + torch.sparse.mm(A, x @ W[r])
+    gx2, gW2 = torch.autograd.grad(ref, [x, W], go)
+    torch.testing.assert_close(out, ref)
+    torch.testing.assert_close(gx, gx2)
+    torch.testing.assert_close(gW, gW2)

@@ -67,6 +67,62 @@ def test_rgat_on_full_fanout_blocks_matches_full_graph(compact):
     torch.testing.assert_close(layers[0].conv_weights.grad, gw_full, rtol=2e-4, atol=1e-4)
 
 
+def _oracle_rgat_on_blocks(layers, blocks, x64):
+    """oracle/layers.py evaluated on every block's own sub-graph (fp64): layer l on block l, destination rows kept -- what
+    the reference's mini-batch loop computes block by block (hrt/python/RGNNUtils/RGNNUtils.py:164-196 feeds DGL blocks
+    converted by hrt/python/utils/mydglgraph_converters.py:18-71 to the same layer code)."""
+    from oracle import layers as OL
+    params = []
+    h = x64
+    for layer, b in zip(layers, blocks):
+        p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in layer.named_parameters()}
+        params.append(p)
+        s = {k: v.cpu() for k, v in b.graph.get_separate_coo_original().items()}
+        n = b.graph.get_num_nodes()
+        # the self-loop and the bias apply to destination rows; the oracle computes them for every row and the first
+        # num_dst rows are kept (rows of source-only nodes aggregate nothing and are dropped)
+        out = OL.rgat_layer(h, p["conv_weights"], p["attn_l"], p["attn_r"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
+                            n, layer.leaky_relu_slope, p.get("loop_weight"), p.get("h_bias"))[: b.num_dst]
+        h = layer.activation(out) if layer.activation else out
+    return h, params
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("one_shot", [False, True])
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_on_sampled_blocks_matches_the_oracle_on_the_blocks(compact, one_shot):
+    """Fan-out-limited blocks (the sampled neighbourhood is NOT the full one): the HIP layers on the blocks against the fp64
+    oracle on the same block sub-graphs -- values, input gradient, weight gradients of both layers -- with the ops'
+    groupings (plans) and, as a training step on small blocks runs, without them (sampling.one_shot_graphs)."""
+    import contextlib
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.sampling import one_shot_graphs
+    from tests.util import assert_close
+    coo, g = _graph("cuda")
+    torch.manual_seed(6)
+    flags = dict(compact_as_of_node_flag=compact, compact_direct_indexing_flag=compact, self_loop=True, dropout=0.0)
+    layers = torch.nn.ModuleList([HET_RGATLayer(64, 64, 4, 4, activation=torch.relu, **flags),
+                                  HET_RGATLayer(64, 64, 4, 1, **flags)]).cuda()
+    x = torch.randn(coo.num_nodes, 64, device="cuda", requires_grad=True)
+    seeds = torch.tensor([7, 300, 42, 9, 111, 250, 18, 77], device="cuda")
+    blocks = NeighborSampler(g, [4, 6], seed=3).sample_blocks(seeds)
+    indeg = torch.bincount(coo.col, minlength=coo.num_nodes)
+    assert int(indeg[blocks[-1].nodes[: blocks[-1].num_dst]].max()) > 6  # the fan-out really truncates neighbourhoods
+    go = torch.randn(seeds.numel(), 64, device="cuda")
+    with (one_shot_graphs(blocks) if one_shot else contextlib.nullcontext()):
+        out = run_blocks(layers, blocks, x[blocks[0].nodes])
+        out.backward(go)
+    x64 = x.detach().double().cpu()[blocks[0].nodes.cpu()].requires_grad_(True)
+    ref, params = _oracle_rgat_on_blocks(layers, blocks, x64)
+    ref.backward(go.double().cpu())
+    assert_close(out, ref, what="out")
+    gx = torch.zeros(coo.num_nodes, 64, dtype=torch.float64).index_add_(0, blocks[0].nodes.cpu(), x64.grad)
+    assert_close(x.grad, gx, what="grad_x")
+    for layer, p in zip(layers, params):
+        for name in ("conv_weights", "attn_l", "attn_r", "loop_weight", "h_bias"):
+            assert_close(getattr(layer, name).grad, p[name].grad, what="grad_" + name)
+
+
 @pytest.mark.gpu
 def test_rgcn_on_sampled_blocks_and_driver(tmp_path):
     from het_amd import train
