@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         L.het_grouping_destroy.restype = None
         L.het_grouping_num_segments.argtypes = [P]
         L.het_grouping_num_segments.restype = I64
+        L.het_grouping_bytes.argtypes = [P]
+        L.het_grouping_bytes.restype = I64
         L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
         L.het_rgat_backward_compact_workspace.restype = I64
         L.het_kernel_timing_enable.argtypes = [INT]

@@ -105,6 +105,17 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_edge(
 
 inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
 
+// CompactAsOfNodeKind 2 (EnabledWithDirectIndexing) in the reference's fused GAT maps BOTH edge ends through the one
+// inverse index of the two-sided unique list (RGATKernelsSeparateCOO.cu.h:163-170: the non-dual branch hands the same
+// mapper to the source and the destination lookup, and direct indexing ignores the node id): it is kind 4 with
+// map_col_a == map_row_a.
+void normalize_kind(int64_t& kind, const idx_t*& ra, const idx_t*& ca) {
+  if (kind == HET_KIND_DIRECT_INDEX && ra) {
+    kind = HET_KIND_DUAL_LIST_DIRECT_INDEX;
+    if (!ca) ca = ra;
+  }
+}
+
 int check_maps(const char* op, int64_t kind, const idx_t* ra, const idx_t* rb, const idx_t* ca, const idx_t* cb) {
   switch (kind) {
     case HET_KIND_DISABLED: return HET_OK;
@@ -116,8 +127,8 @@ int check_maps(const char* op, int64_t kind, const idx_t* ra, const idx_t* rb, c
       HET_REQUIRE(ra && ca, "%s: kind 4 needs edata_idx_to_inverse_idx_row/_col", op);
       return HET_OK;
     default:
-      het_set_error("%s: CompactAsOfNodeKind %lld is not supported (kind 2 maps both edge ends through one "
-                    "inverse index in the reference and is unreachable from its models)", op, (long long)kind);
+      het_set_error("%s: CompactAsOfNodeKind %lld is not supported (kind 2 needs edata_idx_to_inverse_idx as map_row_a)", op,
+                    (long long)kind);
       return HET_ERR_UNSUPPORTED;
   }
 }
@@ -183,6 +194,7 @@ extern "C" int het_relational_fused_gat_separate_coo(
   HET_REQUIRE(sum && ret && (num_edges == 0 || (eids && rel_ptrs && row && col && feat && (el_sorted || (el && er && exp)))),
               "%s: null pointer", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
+  normalize_kind(kind, map_row_a, map_col_a);
   if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
     if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
   EdgeView v;
@@ -215,6 +227,7 @@ extern "C" int het_backward_relational_fused_gat_separate_coo(
               "%s: null pointer", op);
   HET_REQUIRE(!grad_el_sorted || (by_dst && kind == HET_KIND_DISABLED), "%s: grad_el_sorted needs kind 0 and the by_dst grouping", op);
   HET_REQUIRE(num_edges < (1ll << 31) && num_nodes < (1ll << 31), "%s: more than 2^31 edges or nodes", op);
+  normalize_kind(kind, map_row_a, map_col_a);
   if (num_edges > 0)  // empty index lists of an edgeless graph arrive as NULL
     if (int rc = check_maps(op, kind, map_row_a, map_row_b, map_col_a, map_col_b)) return rc;
   EdgeView v;

@@ -154,6 +154,21 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
 
 extern "C" int64_t het_grouping_num_segments(const het_grouping* g) { return g ? g->S : -1; }
 
+// Device bytes the grouping holds right now (hipMalloc, outside any caller's allocator): what a memory report has to add.
+extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
+  if (!g) return 0;
+  const int64_t E = g->E, S = g->S, I = g->num_items, R = g->R;
+  int64_t b = 4 * (E > 0 ? E : 1);                                   // perm
+  b += 4 * (S + 1) + 4 * (S > 0 ? S : 1) + 8 * (S > 0 ? S : 1);      // seg_ptr, seg_key, seg_key64
+  if (R > 0) b += 4 * (R + 1) + 8 * (R + 1);                         // seg_rel_ptr, seg_rel_ptr64
+  b += 3 * 4 * (I > 0 ? I : 1) + 4 * (E / HET_ITEM_MAX + 1);         // item_seg / begin / end, split_seg
+  if (g->p0) b += 4 * E;
+  if (g->p1) b += 4 * E;
+  if (g->seg_of_rank) b += 4 * E;
+  if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
+  return b;
+}
+
 extern "C" int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream) {
   HET_REQUIRE(g && (g->E == 0 || (out && g->perm)), "het_grouping_rank_of_position: null argument");
   if (g->E == 0) return HET_OK;

@@ -14,6 +14,7 @@ device-side builders (csrc/layouts.hip) on GPU tensors and torch index ops on CP
 from __future__ import annotations
 
 import ctypes as C
+from collections import OrderedDict
 from typing import Dict, List, Optional
 
 import torch
@@ -331,21 +332,52 @@ def _gat_maps(kind: int, d: Dict[str, Tensor], backward: bool):
                 d["unique_srcs_and_dests_node_indices_col"])
     if kind == 4:
         return d["edata_idx_to_inverse_idx_row"], None, d["edata_idx_to_inverse_idx_col"], None
+    if kind == 2:  # one inverse index for both edge ends, as the reference's non-dual direct-indexing branch reads it
+        m = d["edata_idx_to_inverse_idx"]
+        return m, None, m, None
     raise _lib.HetError(f"relational_fused_gat: CompactAsOfNodeKind {kind} is not supported")
 
 
-_derived: Dict[tuple, tuple] = {}
+_derived: "OrderedDict[tuple, tuple]" = OrderedDict()
+_DERIVED_MAX = 64
+
+
+def _derived_get(tag, tensors, build):
+    """Per-graph derived index tensors (row maps, relation of every position ...), built once and looked up by the
+    identity of ALL the tensors they were derived from: (data_ptr, numel, _version) each, as het_amd/plan.py keys its
+    groupings -- an in-place edit of any of them (a renumbering of the eids, a reordered block) misses the cache instead of
+    returning stale rows.  The entry keeps the source tensors alive, which pins their storage (a data_ptr cannot be
+    recycled for other contents while the entry lives).  Least recently used entries go first."""
+    key = (tag,) + tuple(_plan._ident(t) for t in tensors)
+    hit = _derived.get(key)
+    if hit is None:
+        hit = (build(), tensors)
+        _derived[key] = hit
+        while len(_derived) > _DERIVED_MAX:
+            _derived.popitem(last=False)
+    else:
+        _derived.move_to_end(key)
+    return hit[0]
+
+
+def _rows_by_search(rel_ptrs, nodes, ua, ub):
+    """Row of every (relation of the position, node) pair in the unique list (ua = its relation pointers, ub = node ids)."""
+    R = rel_ptrs.numel() - 1
+    bound = int(max(int(nodes.max().item()), int(ub.max().item()))) + 1
+    rel_e = torch.repeat_interleave(torch.arange(R, device=nodes.device), rel_ptrs[1:] - rel_ptrs[:-1])
+    rel_u = torch.repeat_interleave(torch.arange(R, device=nodes.device), ua[1:] - ua[:-1])
+    return torch.searchsorted(rel_u * bound + ub, rel_e * bound + nodes).contiguous()
 
 
 def _gat_direct(kind, maps, rel_ptrs, row, col, eids):
     """(kind, maps) as handed to the C entry points: the binary-search kinds 1 / 3 are turned into the direct-index
     kind 4 once per graph (feat / er row of every edge id, cached) -- the maps the kernels read without searching."""
+    if kind == 2:
+        return 4, maps  # (maps[2] is maps[0]: see _gat_maps)
     if kind not in (1, 3) or not _plan.enabled or eids.numel() == 0:
         return kind, maps
-    key = ("gatmap", kind, maps[0].data_ptr(), maps[0]._version, maps[1].data_ptr(), maps[2].data_ptr(), maps[3].data_ptr(),
-           row.data_ptr(), col.data_ptr(), eids.data_ptr())
-    hit = _derived.get(key)
-    if hit is None:
+
+    def build():
         srow = _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
         drow = _dst_rows_by_position(kind, maps, rel_ptrs, col, eids)
         n = int(eids.max().item()) + 1
@@ -353,82 +385,40 @@ def _gat_direct(kind, maps, rel_ptrs, row, col, eids):
         mc = torch.empty(n, dtype=torch.int64, device=eids.device)
         mr[eids] = srow
         mc[eids] = drow
-        if len(_derived) > 16:
-            _derived.clear()
-        hit = _derived[key] = ((mr, None, mc, None), (maps, row, col, eids))
-    return 4, hit[0]
+        return (mr, None, mc, None)
+
+    return 4, _derived_get(("gatmap", kind), (maps[0], maps[1], maps[2], maps[3], rel_ptrs, row, col, eids), build)
 
 
 def _src_rows_by_position(kind, maps, rel_ptrs, row, eids):
     """feat row of every edge position for the compact kinds (cached per graph)."""
     ra, rb = maps[0], maps[1]
-    key = (kind, ra.data_ptr(), ra._version, None if rb is None else rb.data_ptr(), row.data_ptr(), eids.data_ptr())
-    hit = _derived.get(key)
-    if hit is not None:
-        return hit[0]
     if kind == 4:
-        srow = ra[eids]
-    else:
-        R = rel_ptrs.numel() - 1
-        bound = int(max(int(row.max().item()), int(rb.max().item()))) + 1
-        rel_e = torch.repeat_interleave(torch.arange(R, device=row.device), rel_ptrs[1:] - rel_ptrs[:-1])
-        rel_u = torch.repeat_interleave(torch.arange(R, device=row.device), ra[1:] - ra[:-1])
-        srow = torch.searchsorted(rel_u * bound + rb, rel_e * bound + row)
-    srow = srow.contiguous()
-    if len(_derived) > 16:
-        _derived.clear()
-    _derived[key] = (srow, (ra, rb, row, eids))
-    return srow
+        return _derived_get("srow4", (ra, eids), lambda: ra[eids].contiguous())
+    return _derived_get("srow", (ra, rb, rel_ptrs, row), lambda: _rows_by_search(rel_ptrs, row, ra, rb))
 
 
 def _dst_rows_by_position(kind, maps, rel_ptrs, col, eids):
     """er row of every edge position for the compact kinds (cached per graph)."""
     ca, cb = maps[2], maps[3]
-    key = ("d", kind, ca.data_ptr(), ca._version, None if cb is None else cb.data_ptr(), col.data_ptr(), eids.data_ptr())
-    hit = _derived.get(key)
-    if hit is not None:
-        return hit[0]
     if kind == 4:
-        drow = ca[eids]
-    else:
-        R = rel_ptrs.numel() - 1
-        bound = int(max(int(col.max().item()), int(cb.max().item()))) + 1
-        rel_e = torch.repeat_interleave(torch.arange(R, device=col.device), rel_ptrs[1:] - rel_ptrs[:-1])
-        rel_u = torch.repeat_interleave(torch.arange(R, device=col.device), ca[1:] - ca[:-1])
-        drow = torch.searchsorted(rel_u * bound + cb, rel_e * bound + col)
-    drow = drow.contiguous()
-    if len(_derived) > 16:
-        _derived.clear()
-    _derived[key] = (drow, (ca, cb, col, eids))
-    return drow
+        return _derived_get("drow4", (ca, eids), lambda: ca[eids].contiguous())
+    return _derived_get("drow", (ca, cb, rel_ptrs, col), lambda: _rows_by_search(rel_ptrs, col, ca, cb))
 
 
 def _csr_expanded_rows(row_ptrs, num_edges):
     """(row id of every CSR position, a one-relation rel_ptrs [0, E]) -- cached per CSR."""
-    key = ("csr", row_ptrs.data_ptr(), row_ptrs._version, num_edges)
-    hit = _derived.get(key)
-    if hit is None:
-        rows = _graph.csr_to_coo_rows(row_ptrs).contiguous()
-        rp1 = torch.tensor([0, num_edges], dtype=torch.int64, device=row_ptrs.device)
-        if len(_derived) > 16:
-            _derived.clear()
-        hit = _derived[key] = ((rows, rp1), (row_ptrs,))
-    return hit[0]
+    return _derived_get(("csr", num_edges), (row_ptrs,),
+                        lambda: (_graph.csr_to_coo_rows(row_ptrs).contiguous(),
+                                 torch.tensor([0, num_edges], dtype=torch.int64, device=row_ptrs.device)))
 
 
 def _rel_by_position(rel_ptrs, num_positions):
     """Relation of every edge position of the separate COO (cached per graph)."""
-    key = ("rel", rel_ptrs.data_ptr(), rel_ptrs._version, num_positions)
-    hit = _derived.get(key)
-    if hit is not None:
-        return hit[0]
     R = rel_ptrs.numel() - 1
-    rel = torch.repeat_interleave(torch.arange(R, device=rel_ptrs.device), rel_ptrs[1:] - rel_ptrs[:-1],
-                                  output_size=num_positions).contiguous()
-    if len(_derived) > 16:
-        _derived.clear()
-    _derived[key] = (rel, (rel_ptrs,))
-    return rel
+    return _derived_get(("rel", num_positions), (rel_ptrs,),
+                        lambda: torch.repeat_interleave(torch.arange(R, device=rel_ptrs.device), rel_ptrs[1:] - rel_ptrs[:-1],
+                                                        output_size=num_positions).contiguous())
 
 
 def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
@@ -793,19 +783,13 @@ def _ip_direct(d: Dict[str, Tensor], kind: int, rel_ptrs, col, eids):
     a, b = _ip_maps(d, kind)
     if kind != 1 or not _plan.enabled or eids.numel() == 0:
         return kind, a, b
-    key = ("ipmap", a.data_ptr(), a._version, b.data_ptr(), col.data_ptr(), eids.data_ptr())
-    hit = _derived.get(key)
-    if hit is None:
-        R = rel_ptrs.numel() - 1
-        bound = int(max(int(col.max().item()), int(b.max().item()))) + 1
-        rel_e = _rel_by_position(rel_ptrs, eids.numel())
-        rel_u = torch.repeat_interleave(torch.arange(R, device=col.device), a[1:] - a[:-1])
-        lrow = torch.searchsorted(rel_u * bound + b, rel_e * bound + col)
+    def build():
+        lrow = _rows_by_search(rel_ptrs, col, a, b)
         m = torch.empty(int(eids.max().item()) + 1, dtype=torch.int64, device=col.device)
         m[eids] = lrow
-        if len(_derived) > 16:
-            _derived.clear()
-        hit = _derived[key] = (m, (a, b, col, eids))
+        return m
+
+    hit = (_derived_get("ipmap", (a, b, rel_ptrs, col, eids), build),)
     return 2, hit[0], None
 
 
@@ -864,10 +848,7 @@ def inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, sepa
         if IntKind == 0:
             lrow = separate_coo_eids
         else:
-            key = ("iplrow", a.data_ptr(), a._version, separate_coo_eids.data_ptr())
-            hit = _derived.get(key)
-            lrow = hit[0] if hit is not None else a[separate_coo_eids].contiguous()
-            _derived[key] = (lrow, (a, separate_coo_eids))
+            lrow = _derived_get("iplrow", (a, separate_coo_eids), lambda: a[separate_coo_eids].contiguous())
             # compact left rows are shared by many edges: their gradient is a segmented sum over the edges of a row
             gl = _plan.get_grouping(None, lrow, left_side_data.shape[0], separate_coo_row_indices, separate_coo_eids)
         g = _plan.get_grouping(None, separate_coo_row_indices, right_node_vectors.shape[0], lrow, separate_coo_eids)

@@ -34,13 +34,17 @@ class Grouping:
     def num_segments(self) -> int:
         return int(_lib.lib().het_grouping_num_segments(self.handle))
 
+    @property
+    def nbytes(self) -> int:
+        """Device bytes the grouping holds (hipMalloc'ed by the library, invisible to torch's allocator statistics)."""
+        return int(_lib.lib().het_grouping_bytes(self.handle)) if self.handle else 0
+
     def __del__(self):
-        try:
-            if self.handle:
-                _lib.lib().het_grouping_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+        # (the library may already be unloaded at interpreter exit: nothing left to free then)
+        handle, self.handle = self.handle, None
+        lib = getattr(_lib, "_lib", None) if _lib is not None else None  # (module globals are cleared at shutdown)
+        if handle and lib is not None:
+            lib.het_grouping_destroy(handle)
 
 
 def _ident(t: Optional[torch.Tensor]):
@@ -75,6 +79,11 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
     while len(_cache) > _MAX_ENTRIES:
         _cache.popitem(last=False)
     return g
+
+
+def cached_bytes() -> int:
+    """Device bytes of all cached groupings (add to torch.cuda.max_memory_allocated for a true footprint)."""
+    return sum(g.nbytes for g in _cache.values())
 
 
 def clear():

@@ -83,6 +83,8 @@ int het_grouping_create(const int64_t* rel_ptrs /* [R+1] or NULL */, int64_t num
 void het_grouping_destroy(het_grouping* g);
 /* number of segments (distinct (relation, key) pairs) */
 int64_t het_grouping_num_segments(const het_grouping* g);
+/* device bytes the grouping currently holds (allocated with hipMalloc, outside the caller's allocator) */
+int64_t het_grouping_bytes(const het_grouping* g);
 /* out[i] = sorted rank of position i (the inverse of the grouping's permutation), [E] */
 int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream);
 

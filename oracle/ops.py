@@ -70,9 +70,11 @@ def _gat_rows(kind: int, d: Dict[str, Tensor], rel_ptrs, row, col, eids):
         )
     if kind == 4:  # EnabledWithDualListWithDirectIndexing: inverse index by edata idx
         return d["edata_idx_to_inverse_idx_row"][eids], d["edata_idx_to_inverse_idx_col"][eids]
-    raise NotImplementedError(
-        "CompactAsOfNodeKind 2 maps src and dst through the same per-edge inverse index in the "
-        "reference (kernel_enums.h:117) and is not reachable from its models")
+    if kind == 2:  # EnabledWithDirectIndexing: the reference hands ONE mapper to both lookups and direct indexing ignores
+        # the node id (RGATKernelsSeparateCOO.cu.h:163-170, kernel_enums.h:117): both rows are that index of the edge
+        m = d["edata_idx_to_inverse_idx"][eids]
+        return m, m
+    raise NotImplementedError(f"CompactAsOfNodeKind {kind}")
 
 
 # --------------------------------------------------------------------------

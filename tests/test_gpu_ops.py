@@ -152,7 +152,7 @@ def _gat_case(g, kind, H, D, seed):
     return s, feat, el, er, go, df, db
 
 
-@pytest.mark.parametrize("kind", [0, 1, 3, 4])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("H,D,n", [(4, 16, 300), (1, 64, 300), (3, 5, 300), (8, 8, 300), (2, 2, 300), (4, 16, 24)])
 def test_fused_gat_separate_coo(K, plan_mode, kind, H, D, n):
     # n = 24: ~50 edges per (relation, node) row, rows with several hundred -- the wave-per-item compact backward and

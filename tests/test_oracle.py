@@ -116,6 +116,10 @@ def _gat_dict(g, kind):
              "unique_srcs_and_dests_node_indices_col": u["node_indices_col"]}
         db = dict(d); db["unique_srcs_and_dests_rel_col"] = db.pop("unique_srcs_and_dests_rel_ptrs_col")
         return d, db
+    if kind == 2:  # one inverse index for both edge ends (as the reference reads it): the source-side one here
+        u = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+        d = {"edata_idx_to_inverse_idx": u["inverse_indices_row"]}
+        return d, d
     u = g.get_separate_unique_node_indices_single_sided_inverse_idx()
     d = {"edata_idx_to_inverse_idx_row": u["inverse_indices_row"], "edata_idx_to_inverse_idx_col": u["inverse_indices_col"]}
     return d, d
@@ -129,6 +133,8 @@ def _gat_sizes(g, kind):
         u = int(g.get_separate_unique_node_indices()["rel_ptrs"][-1])
         return u, u
     ss = g.get_separate_unique_node_indices_single_sided()
+    if kind == 2:
+        return int(ss["rel_ptrs_row"][-1]), int(ss["rel_ptrs_row"][-1])
     return int(ss["rel_ptrs_row"][-1]), int(ss["rel_ptrs_col"][-1])
 
 
