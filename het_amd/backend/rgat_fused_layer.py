@@ -306,7 +306,7 @@ class RgatLayerFunction(th.autograd.Function):
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm, ret, go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
-        _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=True)
+        _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=2)  # rows of a relation: distinct nodes
         halo.start_return(grad_x)
         grad_W, grad_loop = th.empty_like(W), th.empty_like(loop_w)
         _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)

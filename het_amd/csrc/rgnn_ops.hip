@@ -280,7 +280,16 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
       q.gather = g->seg_key64; q.scatter = nullptr; q.go = gsum; q.seg_ptrs = g->seg_rel_ptr64; q.num_rows = g->S;
     }
     q.out = grad_x;
-    if (int rc = launch_rowdot1h_bwd_dx(q, s)) return rc;
+    if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments) {
+      // rows of one relation are distinct nodes: relation by relation, plain read-modify-write instead of atomics
+      for (int r = 0; r < (int)num_rels; ++r) {
+        RowDotArgs qr = q;
+        qr.seg_ptrs = q.seg_ptrs + r; qr.num_segs = 1; qr.W = q.W + (int64_t)r * H * K; qr.rmw = 1;
+        if (int rc = launch_rowdot1h_bwd_dx(qr, s)) return rc;
+      }
+    } else {
+      if (int rc = launch_rowdot1h_bwd_dx(q, s)) return rc;
+    }
     q.out = grad_w;
     return launch_rowdot1h_bwd_dw(q, s);
   }
@@ -336,7 +345,13 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     m.A = gradout; m.a_ld = H * D; m.gather = scatter; m.B = weights_t; m.b_rel_stride = H * D * K;
     m.C = grad_x; m.c_ld = K; m.scatter = gather_idx; m.atomic = 1;
     m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
-    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    // kind 1: a relation's rows are distinct nodes (its unique list) -- relation by relation the gradient rows are added
+    // with plain read-modify-write instead of float atomics (0.52 -> 0.3 ms for the 2.4 M rows of ogbn-mag)
+    if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments && H * D <= 128 && K <= 128) {
+      if (int rc = launch_seg_gemm_mfma_rmw_per_segment(m, s)) return rc;
+    } else {
+      if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+    }
     MfmaDwArgs w;
     w.A = x; w.a_ld = K; w.gather = gather_idx; w.G = gradout; w.g_ld = H * D; w.g_gather = scatter;
     w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
@@ -387,6 +402,8 @@ extern "C" int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_
   m.A = gradout; m.a_ld = H * D; m.gather = g_rows; m.B = weights_t; m.b_rel_stride = H * D * K;
   m.C = grad_x; m.c_ld = K; m.scatter = gather_idx; m.atomic = atomic ? 1 : 0;
   m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
+  if (atomic == 2 && num_rels <= kRmwMaxSegments && H * D <= 128 && K <= 128)  // rows distinct inside every relation
+    return launch_seg_gemm_mfma_rmw_per_segment(m, (hipStream_t)stream);
   return launch_seg_gemm_mfma(m, (hipStream_t)stream);
 }
 

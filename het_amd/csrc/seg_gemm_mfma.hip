@@ -24,7 +24,10 @@ inline int chunk_rows_for(int64_t num_rows) {
 
 // DOT (plain stores only): additionally dot_out[cs(i), h] = < C row (h, :), dot_w[r, h, :] > from the row pieces the
 // epilogue already holds -- the attention-vector product of RGAT without re-reading the tensor just written.
-template <int K, int NT, bool ATOMIC, bool DOT = false>
+// RMW (plain stores only): C row += the product, read-modify-write WITHOUT atomics -- for launches whose rows hit
+// distinct C rows (one relation of a unique (relation, node) list): 256-byte rows added at the plain load / store rate
+// instead of the float-atomic rate (1.3 TB/s chip-wide).  The old C rows are requested before the MFMAs of the tile.
+template <int K, int NT, bool ATOMIC, bool DOT = false, bool RMW = false>
 __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chunk_rows) {
   constexpr int X = NT * 32, KH = K / 2;
   constexpr int LDA = K + 4, LPRA = K / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;  // A tile: rows per load instr
@@ -149,6 +152,11 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
     for (int it = 0; it < NITC; ++it) crow_cur[it] = crow_next[it];
     load_ids(wb + 256, ar_next, crow_next);
     load_rows(wb + 128, ar_cur);
+    float4 cold[RMW ? NITC : 1];
+    if (RMW) {
+#pragma unroll
+      for (int it = 0; it < NITC; ++it) cold[RMW ? it : 0] = *reinterpret_cast<const float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc);
+    }
     __builtin_amdgcn_sched_barrier(0);  // the prefetch stays above the MFMAs
 
     float af[KH];
@@ -200,10 +208,18 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
       for (int it = 0; it < NITC; ++it) {
         float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        bool real = true;
+        if (RMW) {
+          // rows past the end of the segment are clamped copies of its last row: only the real one adds and stores (a
+          // copy storing anything could land after the real row's store)
+          real = wb + it * RPIC + rc < re;
+          const float4 c = cold[RMW ? it : 0];
+          v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+        }
 #ifdef HET_ABL_NOSTORE
         if (a.num_rows < 0)
 #endif
-        *reinterpret_cast<float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc) = v;
+        if (!RMW || real) *reinterpret_cast<float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc) = v;
         if (DOT) {
           float p = v.x * dotw.x + v.y * dotw.y + v.z * dotw.z + v.w * dotw.w;
           for (int off = dot_dl >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
@@ -380,8 +396,12 @@ int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row chunks");
   dim3 grid((unsigned)gx), block(256);
-  HET_KTIME(a.dot_w ? "HET_seg_gemm_mfma<dot>" : (a.atomic ? "HET_seg_gemm_mfma<atomic>" : "HET_seg_gemm_mfma<store>"), s);
-  if (a.dot_w) {
+  HET_KTIME(a.dot_w ? "HET_seg_gemm_mfma<dot>" : (a.atomic == 2 ? "HET_seg_gemm_mfma<rmw>" : (a.atomic ? "HET_seg_gemm_mfma<atomic>" : "HET_seg_gemm_mfma<store>")), s);
+  if (a.atomic == 2) {
+    HET_REQUIRE(!a.dot_w && !a.bias, "segment GEMM (MFMA): the read-modify-write epilogue takes no dot / bias");
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, false, true>), grid, block, lds, s, a, chunk);
+  } else if (a.dot_w) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a, chunk);
   } else if (a.atomic) {
@@ -408,6 +428,21 @@ int launch_k(const MfmaGemmArgs& a, hipStream_t s) {
 
 bool mfma_shape_supported(int K, int X) {
   return (K == 32 || K == 64 || K == 128 || K == 256) && (X == 32 || X == 64 || X == 128 || X == 256);
+}
+
+int launch_seg_gemm_mfma_rmw_per_segment(const MfmaGemmArgs& a, hipStream_t s) {
+  if (a.num_rows == 0) return HET_OK;
+  HET_REQUIRE(a.num_segs <= kRmwMaxSegments && a.K <= 128 && a.X <= 128 && !a.dot_w && !a.bias,
+              "segment GEMM (MFMA): per-segment read-modify-write needs few segments and K, X <= 128");
+  for (int r = 0; r < a.num_segs; ++r) {
+    MfmaGemmArgs m = a;
+    m.seg_ptrs = a.seg_ptrs + r;  // the one segment [seg_ptrs[r], seg_ptrs[r+1]); row indices stay absolute
+    m.num_segs = 1;
+    m.B = a.B + (int64_t)r * a.b_rel_stride;
+    m.atomic = 2;
+    if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
+  }
+  return HET_OK;
 }
 
 int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {

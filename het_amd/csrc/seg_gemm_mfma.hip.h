@@ -19,7 +19,8 @@ struct MfmaGemmArgs {
   float* C = nullptr;             // [*, X]
   int64_t c_ld = 0;
   const idx_t* scatter = nullptr; // NULL: identity
-  int atomic = 0;
+  int atomic = 0;                 // 0: C rows are stored; 1: float atomic adds; 2: non-atomic read-modify-write (the rows of
+                                  // the LAUNCH hit distinct C rows -- launch_seg_gemm_mfma_rmw_per_segment)
   const idx_t* seg_ptrs = nullptr;
   int num_segs = 0;
   int64_t num_rows = 0;
@@ -33,6 +34,11 @@ struct MfmaGemmArgs {
 
 bool mfma_shape_supported(int K, int X);
 int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s);
+// C[scatter(i)] += A . B_r with the scatter rows distinct INSIDE every segment (a unique (relation, node) list) but
+// shared between segments: one launch per segment (stream order serialises them), each adding with plain
+// read-modify-write.  Few segments only (every launch is sized for all rows): callers fall back to atomics above 8.
+constexpr int kRmwMaxSegments = 8;
+int launch_seg_gemm_mfma_rmw_per_segment(const MfmaGemmArgs& a, hipStream_t s);
 
 // forward projection with one input head: C[scatter(i), (h,d)] = A[gather(i), :] . W[r, h, :, d]
 inline bool mfma_fwd_supported(int K, int X) { return mfma_shape_supported(K, X); }

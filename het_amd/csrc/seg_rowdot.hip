@@ -220,9 +220,18 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dx(RowDotArgs a, int 
 #pragma unroll
         for (int h = 0; h < H; ++h) o[u] = fmaf(a.go[si[u] * H + h], w[h], o[u]);
       }
+      if (a.rmw) {  // the launch's rows hit distinct output rows: plain read-modify-write
+        float c[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (ok[u]) atomicAdd(a.out + gi[u] * K + col, o[u]);
+        for (int u = 0; u < U; ++u) c[u] = a.out[gi[u] * K + col];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u]) a.out[gi[u] * K + col] = c[u] + o[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u]) atomicAdd(a.out + gi[u] * K + col, o[u]);
+      }
     }
   }
 }

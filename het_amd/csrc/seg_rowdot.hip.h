@@ -16,6 +16,7 @@ struct RowDotArgs {
   int H = 0, K = 0;
   int unique_rows = 0;             // bwd dX: gather rows are pairwise distinct -> no atomics
   int overwrite = 0;               // bwd dX with unique rows: store instead of read-modify-write
+  int rmw = 0;                     // one-head bwd dX: the launch's rows hit distinct output rows -> plain read-modify-write
 };
 
 bool rowdot_supported(int H, int K);

@@ -558,8 +558,10 @@ def rows_matmul_backward_split_ok(H: int, K: int, D: int) -> bool:
     return K in (32, 64, 128) and H * D in (32, 64, 128)
 
 
-def rows_matmul_backward_dx(rel_ptrs, gather_idx, weights_transposed, gradout, grad_x, atomic: bool):
-    """grad_x[gather_idx[i]] (+)= gradout[i] . Wt[r(i)] (include/het_amd.h: het_rows_matmul_backward_dx)."""
+def rows_matmul_backward_dx(rel_ptrs, gather_idx, weights_transposed, gradout, grad_x, atomic):
+    """grad_x[gather_idx[i]] (+)= gradout[i] . Wt[r(i)] (include/het_amd.h: het_rows_matmul_backward_dx).  atomic: False "=",
+    True "+=" with float atomics, 2 "+=" for lists whose rows are distinct inside every relation (unique (relation, node)
+    lists): added relation by relation with plain read-modify-write."""
     _chk("rows_matmul_backward_dx", (weights_transposed, gradout, grad_x), (rel_ptrs,) + (() if gather_idx is None else (gather_idx,)))
     R, H, D, K = weights_transposed.shape
     _call(gradout, "het_rows_matmul_backward_dx", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(weights_transposed),

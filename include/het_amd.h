@@ -440,7 +440,9 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
 
 /* The two halves of a2 (backward_rgnn_relational_matmul, one input head, matrix-core shapes) as separate calls, so that a
  * caller can order them around a collective (het_amd/dist.py).  Rows i in [0, num_rows) of relation-bucketed lists:
- *   dx: grad_x[gather_idx[i], :] (+)= gradout[g_rows[i], :] . Wt[r(i)]      atomic != 0: "+=" (rows may repeat), else "="
+ *   dx: grad_x[gather_idx[i], :] (+)= gradout[g_rows[i], :] . Wt[r(i)]      atomic 0: "=";  1: "+=" with float atomics (rows
+ *       may repeat);  2: "+=" for lists whose gather_idx are distinct inside every relation (a unique (relation, node)
+ *       list): relation by relation with plain read-modify-write (up to 8 relations, atomics beyond)
  *   dw: grad_w[r(i)]             (+)= x[gather_idx[i], :]^T (x) gradout[g_rows[i], :]
  * gather_idx / g_rows NULL = row i.  weights_t [R,H,D,K], grad_w [R,H,K,D]. */
 int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* g_rows,
