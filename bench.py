@@ -45,7 +45,8 @@ def parse():
                    help="rgat = the BASELINE.json metric; rgcn / hgt time BASELINE.json configs[1] / configs[3] (single GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
-    p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample")
+    p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample (1.0 = the full workload: "
+                   "one warm-up + one timed iteration, about 3 minutes of host time -- outside the default run)")
     a = p.parse_args()
     if a.heads is None:
         a.heads = 8 if a.model == "hgt" else 4
@@ -96,7 +97,7 @@ def cpu_baseline(args):
     lw = (torch.randn(K, K) * 0.1).requires_grad_(True)
     go = torch.randn(N, K)
     times = []
-    for it in range(4):
+    for it in range(2 if args.cpu_scale >= 0.5 else 4):
         t0 = time.perf_counter()
         out = OL.rgat_layer(x, W, al, ar, s["rel_ptrs"], s["row_indices"], s["col_indices"], N, 0.2, lw, None)
         torch.autograd.grad(out, [x, W, al, ar, lw], go)
@@ -108,7 +109,7 @@ def cpu_baseline(args):
     return {"value": round(g.get_num_edges() / med / 1e6, 3), "unit": "million edges/s", "cores": torch.get_num_threads(),
             "kind": "port", "scale": args.cpu_scale, "sample_edges": g.get_num_edges(), "sample_seconds_per_step": round(med, 3),
             "sample": f"oracle/layers.py rgat_layer fwd+bwd (torch CPU fp32, HET cross-relation softmax) on a mag-like "
-                      f"graph at scale {args.cpu_scale} ({g.get_num_edges()} edges, {N} nodes), median of 3 after 1 warm-up; "
+                      f"graph at scale {args.cpu_scale} ({g.get_num_edges()} edges, {N} nodes), median of {len(times)} after 1 warm-up; "
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
