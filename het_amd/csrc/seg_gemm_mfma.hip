@@ -8,6 +8,8 @@
 // accumulators.  The k index is permuted between the two lane halves
 // (half h owns k in [h*K/2, (h+1)*K/2)) -- A and B use the same permutation, so
 // the sum is unchanged while every lane's fragment is one contiguous half row.
+#include <stdlib.h>
+
 #include "seg_gemm_mfma.hip.h"
 
 namespace {
@@ -170,16 +172,31 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    // PAIRED (two 32-wide column tiles, plain stores): a lane reads the weight columns (2*row, 2*row + 1) of k-step s with
+    // ONE ds_read_b64 instead of two ds_read_b32 -- tile nt then holds the columns 2*n + nt, a relabelling the LDS transpose
+    // of the epilogue undoes (64 instead of 128 LDS reads per 32-row tile; the atomic epilogue keeps the contiguous
+    // mapping its 128-byte-segment adds need).
+    constexpr bool PAIRED = NT == 2 && !ATOMIC && !B_REGS;
 #pragma unroll
     for (int s = 0; s < KH; ++s) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float b = B_REGS ? breg[B_REGS ? s * NT + nt : 0] : Bs[(half * KH + s) * X + nt * 32 + row];
-#ifdef HET_ABL_NOMFMA  // diagnostic builds only (exp/mfma_bench.hip)
-        acc[nt][s & 15] += af[s] * b;
+      if (PAIRED) {
+        const float2 b2 = *reinterpret_cast<const float2*>(&Bs[(half * KH + s) * X + 2 * row]);
+#ifdef HET_ABL_NOMFMA
+        acc[0][s & 15] += af[s] * b2.x; acc[NT - 1][s & 15] += af[s] * b2.y;
 #else
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b, acc[nt], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b2.x, acc[0], 0, 0, 0);
+        acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b2.y, acc[NT - 1], 0, 0, 0);
 #endif
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = B_REGS ? breg[B_REGS ? s * NT + nt : 0] : Bs[(half * KH + s) * X + nt * 32 + row];
+#ifdef HET_ABL_NOMFMA  // diagnostic builds only (exp/mfma_bench.hip)
+          acc[nt][s & 15] += af[s] * b;
+#else
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], b, acc[nt], 0, 0, 0);
+#endif
+        }
       }
     }
     // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-          Ws[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LDC + nt * 32 + row] = acc[nt][reg];
+          Ws[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LDC + (PAIRED ? 2 * row + nt : nt * 32 + row)] = acc[nt][reg];
 #pragma unroll
       for (int it = 0; it < NITC; ++it) {
         float4 v = *reinterpret_cast<const float4*>(&Ws[(it * RPIC + rc) * LDC + cc]);
@@ -294,13 +311,27 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
         G[st] = has_gg ? vg : (int)ic;
       }
     };
+    // Operand loads: with two 32-wide tiles along K (or X) a lane fetches the float PAIR (2*col, 2*col + 1) of its row with
+    // one 8-byte load -- tile t then holds the features 2*m + t instead of t*32 + m, a relabelling of the product's rows
+    // (columns) that the epilogue undoes.  Half the vector-memory instructions of one dword per tile (the kernel was
+    // bound by their number).
     auto load_rows = [&](const int (&A)[SB], const int (&G)[SB], float (&AV)[SB][KT], float (&GV)[SB][NT]) {
 #pragma unroll
       for (int st = 0; st < SB; ++st) {
+        if (KT == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(a.A + (int64_t)A[st] * a.a_ld + kbase + 2 * col);
+          AV[st][0] = t.x; AV[st][KT - 1] = t.y;
+        } else {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) AV[st][kt] = a.A[(int64_t)A[st] * a.a_ld + kbase + kt * 32 + col];
+          for (int kt = 0; kt < KT; ++kt) AV[st][kt] = a.A[(int64_t)A[st] * a.a_ld + kbase + kt * 32 + col];
+        }
+        if (NT == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(a.G + (int64_t)G[st] * a.g_ld + nbase + 2 * col);
+          GV[st][0] = t.x; GV[st][NT - 1] = t.y;
+        } else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) GV[st][nt] = a.G[(int64_t)G[st] * a.g_ld + nbase + nt * 32 + col];
+          for (int nt = 0; nt < NT; ++nt) GV[st][nt] = a.G[(int64_t)G[st] * a.g_ld + nbase + nt * 32 + col];
+        }
       }
     };
     auto mma = [&](idx_t base, const float (&AV)[SB][KT], const float (&GV)[SB][NT]) {
@@ -351,7 +382,8 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
         for (int e = 0; e < 16; ++e) {
           const int o = ((kt * NT + nt) * 16 + e) * 64 + lane;
           const float v = acc[kt][nt][e] + smem[o] + smem[NACC * 64 + o] + smem[2 * NACC * 64 + o];
-          const int k = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half, nn = nbase + nt * 32 + col;
+          const int m = (e & 3) + 8 * (e >> 2) + 4 * half;  // row of the 32x32 product tile, column = col
+          const int k = kbase + (KT == 2 ? 2 * m + kt : kt * 32 + m), nn = nbase + (NT == 2 ? 2 * col + nt : nt * 32 + col);
           int64_t off;
           if (a.headcat == 1) {
             const int h = nn / Dh, d = nn - h * Dh;
@@ -372,8 +404,11 @@ template <int KT, int NT>
 int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
   const size_t lds = sizeof(float) * 3 * KT * NT * 16 * 64;
   HET_REQUIRE(!a.row_scale, "segment dW (MFMA): row scales are applied by the segment-sum pre-pass, not here");
+  HET_REQUIRE(a.a_ld % 2 == 0 && a.g_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.G) & 7) == 0,
+              "segment dW (MFMA): rows must be 8-byte aligned");
   // 48 KiB of LDS per workgroup -> 3 resident per CU, 768 on the chip: aim for about 4 rounds of them
-  int64_t chunk = ceil_div64(a.num_rows, 3072);
+  static const int64_t n_chunks = [] { const char* v = getenv("HET_DW_CHUNKS"); return v ? (int64_t)atoi(v) : 1536; }();  // A/B switch (same box: 768 0.325, 1536 0.316, 3072 0.354, 6144 0.380 ms per launch on ogbn-mag: every workgroup ends with K*X atomic adds)
+  int64_t chunk = ceil_div64(a.num_rows, n_chunks);
   if (chunk < 512) chunk = 512;
   chunk = (chunk + 7) & ~7ll;
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;

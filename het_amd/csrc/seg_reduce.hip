@@ -1,4 +1,6 @@
 // Segmented sum of gathered rows, one lane group per work item (no atomics except for split hub segments).
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "seg_reduce.hip.h"
@@ -97,6 +99,157 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   }
 }
 
+
+// ---- cooperative forms (the gather kernels are bound by the NUMBER of vector-memory instructions) ------
+// Per-edge scalars (row id, scale index, scale) are fetched by lane (sub % 4) for edge (sub % 4) of the step -- one
+// instruction per step and stream -- and spread inside each quad with DPP broadcasts; rows: 4 per lane group and step.
+// Valid when a scale (if any) is the same for the 4 lanes of a quad: per row, or per head with >= 16 floats per head.
+template <int Q>
+__device__ __forceinline__ int ss_quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, Q * 0x55, 0xf, 0xf, false); }
+__device__ __forceinline__ int ss_bcast_i(int v, int q) {
+  switch (q) {
+    case 0: return ss_quad_i<0>(v);
+    case 1: return ss_quad_i<1>(v);
+    case 2: return ss_quad_i<2>(v);
+    default: return ss_quad_i<3>(v);
+  }
+}
+__device__ __forceinline__ float ss_bcast(float v, int q) { return __int_as_float(ss_bcast_i(__float_as_int(v), q)); }
+
+// SHORT segments: a lane group per pack of whole segments (grouping_packs), rows of a segment summed in registers and
+// stored once; ids a step ahead.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_segment_sum_packed(const int32_t* __restrict__ pack_ptr, int64_t num_packs,
+                                                                  const int32_t* __restrict__ seg_of_rank,
+                                                                  const int32_t* __restrict__ p_row,
+                                                                  const int32_t* __restrict__ p_scale,
+                                                                  const float* __restrict__ scale, int scale_heads,
+                                                                  const float* __restrict__ in, float* __restrict__ out,
+                                                                  const int32_t* __restrict__ out_row, int accumulate,
+                                                                  int contig, int scale_quad) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
+  static_assert(LPR >= 4, "needs whole quads per lane group");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, q4 = sub & 3;
+  const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
+  if (pid >= num_packs) return;
+  const uint32_t pb = (uint32_t)pack_ptr[pid];
+  if (pb >> 31) return;  // a long segment: HET_segment_sum_long takes its work items
+  const int b = (int)pb, e = (int)((uint32_t)pack_ptr[pid + 1] & 0x7fffffffu);
+  const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
+  int jn = b + q4 < e ? b + q4 : e - 1;
+  int rown = contig ? jn : p_row[jn], segn = seg_of_rank[jn], sin = scale ? p_scale[jn] : 0;
+  int cur = -1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto flush = [&](int seg) {
+    float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + x;
+    if (accumulate) {
+      const float4 c = ld4(p);
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+    }
+    st4(p, acc);
+  };
+  for (int j0 = b; j0 < e; j0 += U) {
+    const int rowv = rown, segv = segn;
+    // scale_quad: the scale is the same for the 4 lanes of a quad (per row, or heads of >= 16 floats): fetched
+    // cooperatively too; else (narrow heads, e.g. HGT's 8 floats per head) each lane loads its own head's scale per edge
+    const float wv = (scale && scale_quad) ? scale[(int64_t)sin * sld + sh] : 1.f;
+    float wq[U];
+    if (scale && !scale_quad) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) wq[u] = scale[(int64_t)ss_bcast_i(sin, u) * sld + sh];
+    }
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(in + (int64_t)ss_bcast_i(rowv, u) * X + x);
+    jn = j0 + U + q4 < e ? j0 + U + q4 : e - 1;
+    rown = contig ? jn : p_row[jn];
+    segn = seg_of_rank[jn];
+    if (scale) sin = p_scale[jn];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u < e) {  // uniform within the lane group
+        const int sg = ss_bcast_i(segv, u);
+        if (sg != cur) {
+          if (cur >= 0) flush(cur);
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          cur = sg;
+        }
+        const float w = (scale && !scale_quad) ? wq[u] : ss_bcast(wv, u);
+        acc.x = fmaf(w, f[u].x, acc.x); acc.y = fmaf(w, f[u].y, acc.y);
+        acc.z = fmaf(w, f[u].z, acc.z); acc.w = fmaf(w, f[u].w, acc.w);
+      }
+    }
+  }
+  if (cur >= 0) flush(cur);
+}
+
+// LONG segments: a wave per work item (<= HET_ITEM_MAX rows of one segment), lane groups round-robin, one cross-group
+// reduction; an item that is not its whole segment adds atomically (the launcher cleared those rows).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_segment_sum_long(const int32_t* __restrict__ long_items, int64_t num_long,
+                                                                const int32_t* __restrict__ item_seg,
+                                                                const int32_t* __restrict__ item_begin,
+                                                                const int32_t* __restrict__ item_end,
+                                                                const int32_t* __restrict__ seg_ptr,
+                                                                const int32_t* __restrict__ p_row,
+                                                                const int32_t* __restrict__ p_scale,
+                                                                const float* __restrict__ scale, int scale_heads,
+                                                                const float* __restrict__ in, float* __restrict__ out,
+                                                                const int32_t* __restrict__ out_row, int accumulate,
+                                                                int contig, int scale_quad) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
+  static_assert(LPR >= 4, "needs whole quads per lane group");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, q4 = sub & 3;
+  const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (wid >= num_long) return;
+  const int item = long_items[wid];
+  const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
+  const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
+  int jn = b + slot + q4 * EPW < e ? b + slot + q4 * EPW : e - 1;
+  int rown = contig ? jn : p_row[jn], sin = scale ? p_scale[jn] : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int rowv = rown;
+    const float wv = (j0 + q4 * EPW < e) ? ((scale && scale_quad) ? scale[(int64_t)sin * sld + sh] : 1.f) : 0.f;
+    float wq[U];
+    if (scale && !scale_quad) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) wq[u] = scale[(int64_t)ss_bcast_i(sin, u) * sld + sh];
+    }
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(in + (int64_t)ss_bcast_i(rowv, u) * X + x);
+    jn = j0 + (U + q4) * EPW < e ? j0 + (U + q4) * EPW : e - 1;
+    rown = contig ? jn : p_row[jn];
+    if (scale) sin = p_scale[jn];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // (padding edges of the last step: wv is 0 there; the per-lane scales are masked the same way)
+      const float w = (scale && !scale_quad) ? (j0 + u * EPW < e ? wq[u] : 0.f) : ss_bcast(wv, u);
+      acc.x = fmaf(w, f[u].x, acc.x); acc.y = fmaf(w, f[u].y, acc.y);
+      acc.z = fmaf(w, f[u].z, acc.z); acc.w = fmaf(w, f[u].w, acc.w);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  if (slot != 0) return;
+  float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + x;
+  if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) {
+    if (accumulate) {
+      const float4 c = ld4(p);
+      acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+    }
+    st4(p, acc);
+  } else {
+    atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
+  }
+}
+
 // Rows of 1 or 2 floats ([E,H] attention terms with fewer than 4 heads): a thread per (item, float), plain loop.
 __global__ __launch_bounds__(kBlock) void HET_segment_sum_narrow(const int32_t* __restrict__ item_seg,
                                                                  const int32_t* __restrict__ item_begin,
@@ -147,6 +300,45 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   const int contig = g->p0_contiguous;  // same box: 2.35 -> 2.25 ms for the a2 backward of C3
   HET_KTIME("HET_segment_sum", s);
+  // cooperative kernels: rows of >= 16 floats, a scale shared by the 4 lanes of a quad (per row, or heads of >= 16 floats),
+  // cached rows (nt_in streams keep the item kernel)
+  static const bool coop_off = [] { const char* v = getenv("HET_SEGSUM_COOP"); return v && v[0] == '0'; }();  // A/B switch
+  const int LPRv = X / 4;
+  const bool coop = !coop_off && LPRv >= 4 && LPRv <= 64 && !nt_in && !(scale && scale_heads == X);
+  const int scale_quad = !scale || scale_heads == 0 || (X / scale_heads) % 16 == 0;
+  if (coop) {
+    if (int rc = grouping_packs(g, s)) return rc;
+    const unsigned nbp = (unsigned)ceil_div64(g->num_packs, (int64_t)(kBlock / 64) * (64 / LPRv));
+#define HET_SSP(L)                                                                                                         \
+  hipLaunchKernelGGL(HET_segment_sum_packed<L>, dim3(nbp), dim3(kBlock), 0, s, g->pack_ptr, g->num_packs, g->seg_of_rank,   \
+                     g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, contig, scale_quad)
+    switch (LPRv) {
+      case 4: HET_SSP(4); break;
+      case 8: HET_SSP(8); break;
+      case 16: HET_SSP(16); break;
+      case 32: HET_SSP(32); break;
+      default: HET_SSP(64); break;
+    }
+#undef HET_SSP
+    HET_LAUNCH_CHECK("HET_segment_sum_packed");
+    if (g->num_long_items > 0) {
+      const unsigned nbl = (unsigned)ceil_div64(g->num_long_items, kBlock / 64);
+#define HET_SSL(L)                                                                                                         \
+  hipLaunchKernelGGL(HET_segment_sum_long<L>, dim3(nbl), dim3(kBlock), 0, s, g->long_items, g->num_long_items, g->item_seg, \
+                     g->item_begin, g->item_end, g->seg_ptr, g->p0, p_scale, scale, scale_heads, in, out, out_row,          \
+                     accumulate, contig, scale_quad)
+      switch (LPRv) {
+        case 4: HET_SSL(4); break;
+        case 8: HET_SSL(8); break;
+        case 16: HET_SSL(16); break;
+        case 32: HET_SSL(32); break;
+        default: HET_SSL(64); break;
+      }
+#undef HET_SSL
+      HET_LAUNCH_CHECK("HET_segment_sum_long");
+    }
+    return HET_OK;
+  }
 #define HET_SS(L)                                                                                                   \
   hipLaunchKernelGGL(HET_segment_sum<L>, dim3(nb), dim3(kBlock), 0, s, g->item_seg, g->item_begin, g->item_end,     \
                      g->seg_ptr, g->num_items, g->p0, p_scale, scale, scale_heads, in, out, out_row, accumulate, nt_in,  \
