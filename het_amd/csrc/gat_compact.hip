@@ -343,6 +343,13 @@ __device__ __forceinline__ float head_bcast(float v, int q, int lane) {
 __device__ __forceinline__ float fast_leaky_exp(float z, float slope) { return __expf(z > 0.f ? z : slope * z); }
 
 // Forward, cooperative form of HET_rgat_aggregate_compact (DL = D/4 >= 4 lanes per head, 4 edges per lane group and step).
+// Measured and dropped (same box, ogbn-mag):
+//  * splitting it like the backward (packs of short destination segments per lane group, long ones per wave): 0.94-0.96 ms
+//    against 0.93 ms for this kernel alone -- the pass runs at the memory system's rate either way;
+//  * also accumulating P[(r,v),h,:] = SUM_e w_e dl_e feat_c[srow_e] per (relation, destination) here, so that the backward
+//    gets grad_er from S_col rows instead of a per-edge term [E,H] + a segmented sum of 16-byte gathers (0.59 ms, 3 GB):
+//    the per-relation accumulators take the kernel from 53 to 104 VGPRs = 8 -> 4 waves per SIMD and 0.93 -> 1.44-1.81 ms,
+//    more than the 0.7 ms it saves in the backward.
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, const int32_t* __restrict__ p_srow,
                                                                    const int32_t* __restrict__ p_drow,
