@@ -4,6 +4,9 @@
 // step; partial sums are combined with xor-shuffles and every destination row
 // is written once -- no float atomics except for hub destinations whose
 // segment was split over several items (> HET_ITEM_MAX in-edges).
+#include <stdlib.h>
+
+#include "coop.hip.h"
 #include "fused_gat.hip.h"
 #include "seg_reduce.hip.h"
 
@@ -151,6 +154,89 @@ __global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped(Items it, co
     atomicAdd(rp + 2, acc.z);
     atomicAdd(rp + 3, acc.w);
     if (x % D == 0) atomicAdd(&sum[v * H + h], ssum);
+  }
+}
+
+
+// Cooperative form of HET_gat_aggregate_grouped<LPR, false> (exp gathered by edge id; the reference-named op for every
+// kind): the edge id, the feat row and exp[eid, h] of the 4 edges of a step are fetched by the lanes (head h, d = edge) --
+// 3 scalar instructions per step instead of 12 -- and spread with quad broadcasts.
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_gat_aggregate_grouped_coop(Items it, const int32_t* __restrict__ p_eid,
+                                                                          const int32_t* __restrict__ p_srow,
+                                                                          const float* __restrict__ feat,
+                                                                          const float* __restrict__ exp,
+                                                                          float* __restrict__ sum, float* __restrict__ ret,
+                                                                          float* __restrict__ exp_sorted, int H) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f;
+  int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
+  int eidn = p_eid[jn], srown = p_srow ? p_srow[jn] : eidn;
+  const int64_t v = it.seg_key[seg];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int jc = jn, srowv = srown;
+    const float wraw = exp[(int64_t)eidn * H + h];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
+    const bool okq = j0 + dq * EPW < e;
+    jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
+    eidn = p_eid[jn];
+    srown = p_srow ? p_srow[jn] : eidn;
+    const float wv = okq ? wraw : 0.f;
+    if (exp_sorted && okq && d < U) exp_sorted[(int64_t)jc * H + h] = wv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = head_bcast<DL>(wv, u, lane);
+      acc.x = fmaf(w, f[u].x, acc.x);
+      acc.y = fmaf(w, f[u].y, acc.y);
+      acc.z = fmaf(w, f[u].z, acc.z);
+      acc.w = fmaf(w, f[u].w, acc.w);
+      ssum += w;
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  float* rp = ret + v * X + x;
+  if (whole) {
+    const float inv = 1.f / ssum;
+    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    if (d == 0) sum[v * H + h] = ssum;
+  } else {  // hub destination: unnormalised partials, normalised by HET_gat_normalize_split
+    atomicAdd(rp + 0, acc.x);
+    atomicAdd(rp + 1, acc.y);
+    atomicAdd(rp + 2, acc.z);
+    atomicAdd(rp + 3, acc.w);
+    if (d == 0) atomicAdd(&sum[v * H + h], ssum);
+  }
+}
+
+// exp[eid,h] for kind 0 with 4 heads: a thread per edge, 16-byte loads / stores (the generic kernel runs a thread per
+// (edge, head) with scalar accesses: 0.33 ms for ogbn-mag's 21 M edges, this one streams them)
+__global__ __launch_bounds__(kBlock) void HET_gat_exp_edge_h4(const idx_t* __restrict__ eids, int64_t E,
+                                                               const float* __restrict__ el, const float* __restrict__ er,
+                                                               float* __restrict__ exp, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < E; i += (int64_t)gridDim.x * kBlock) {
+    const idx_t eid = eids[i];
+    const float4 a = ld4(el + eid * 4), c = ld4(er + eid * 4);
+    st4(exp + eid * 4, make_float4(leaky_exp(a.x + c.x, slope), leaky_exp(a.y + c.y, slope), leaky_exp(a.z + c.z, slope),
+                                   leaky_exp(a.w + c.w, slope)));
   }
 }
 
@@ -325,6 +411,66 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped(
         float* p = grad_fold_w + ((int64_t)(blockIdx.x % (unsigned)replicas) * R + q) * X + x;
         atomicAdd(p + 0, t.x); atomicAdd(p + 1, t.y); atomicAdd(p + 2, t.z); atomicAdd(p + 3, t.w);
       }
+    }
+  }
+}
+
+
+// Cooperative form of HET_gat_backward_grouped<LPR, false, false> (kind 0, exp / el / er gathered by edge id: the
+// reference-named backward op called on its own): per step of 4 edges per lane group 1 id + 3 scalar loads, 4 feat
+// rows in, 4 gradient rows out and 1-2 scalar stores instead of 32 instructions.
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_gat_backward_grouped_coop(
+    Items it, const int32_t* __restrict__ p_eid, const float* __restrict__ feat, const float* __restrict__ el,
+    const float* __restrict__ er, const float* __restrict__ sum, const float* __restrict__ exp,
+    const float* __restrict__ ret, const float* __restrict__ gradout, float* __restrict__ grad_feat,
+    float* __restrict__ grad_el, float* __restrict__ grad_er, int H, float slope) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= it.n) return;
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
+  int eidn = p_eid[jn];
+  const int64_t v = it.seg_key[seg];
+  const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
+  const float sinv = 1.f / sum[v * H + h];
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int eidv = eidn;
+    const float exv = exp[(int64_t)eidv * H + h];
+    const float zlv = el[(int64_t)eidv * H + h];
+    const float zrv = er[(int64_t)eidv * H + h];
+    int eid[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) eid[u] = head_bcast_i<DL>(eidv, u, lane);
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4_nt(feat + (int64_t)eid[u] * X + x);
+    const bool okq = j0 + dq * EPW < e;
+    jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
+    eidn = p_eid[jn];
+    const float av = exv * sinv;
+    const float adv = av * ((zlv + zrv) > 0.f ? 1.f : slope);
+    float tq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = j0 + u * EPW < e;  // uniform within the lane group
+      const float a = head_bcast<DL>(av, u, lane), ad = head_bcast<DL>(adv, u, lane);
+      float tt = g.x * (f[u].x - r.x) + g.y * (f[u].y - r.y) + g.z * (f[u].z - r.z) + g.w * (f[u].w - r.w);
+#pragma unroll
+      for (int off = DL >> 1; off > 0; off >>= 1) tt += __shfl_xor(tt, off);
+      tq[u] = tt * ad;
+      if (ok) st4_nt(grad_feat + (int64_t)eid[u] * X + x, make_float4(a * g.x, a * g.y, a * g.z, a * g.w));
+    }
+    float ts = tq[0];
+#pragma unroll
+    for (int u = 1; u < U; ++u) ts = d == u ? tq[u] : ts;
+    if (okq && d < U) {  // lane (h, q) owns the (edge q, head h) scalars
+      grad_el[(int64_t)eidv * H + h] = ts;
+      if (grad_er != grad_el) grad_er[(int64_t)eidv * H + h] = ts;
     }
   }
 }
@@ -541,6 +687,25 @@ __global__ __launch_bounds__(kBlock) void HET_gat_backward_src_slot(
     default: { constexpr int LPR = 64; CALL; break; } \
   }
 
+// (lanes per row, lanes per head) pairs the cooperative kernels are built for: rows of 32 / 64 / 128 floats, heads of >= 16
+#define HET_DISPATCH_COOP_G(LPRV, DLV, CALL)                                \
+  switch ((LPRV) * 64 + (DLV)) {                                            \
+    case 8 * 64 + 4: { constexpr int LPR = 8, DL = 4; CALL; break; }        \
+    case 8 * 64 + 8: { constexpr int LPR = 8, DL = 8; CALL; break; }        \
+    case 16 * 64 + 4: { constexpr int LPR = 16, DL = 4; CALL; break; }      \
+    case 16 * 64 + 8: { constexpr int LPR = 16, DL = 8; CALL; break; }      \
+    case 16 * 64 + 16: { constexpr int LPR = 16, DL = 16; CALL; break; }    \
+    case 32 * 64 + 4: { constexpr int LPR = 32, DL = 4; CALL; break; }      \
+    case 32 * 64 + 8: { constexpr int LPR = 32, DL = 8; CALL; break; }      \
+    case 32 * 64 + 16: { constexpr int LPR = 32, DL = 16; CALL; break; }    \
+    default: { constexpr int LPR = 32, DL = 32; CALL; break; }              \
+  }
+static bool gat_coop_shape(int H, int D) {
+  static const bool off = [] { const char* v = getenv("HET_GAT_COOP"); return v && v[0] == '0'; }();  // A/B switch
+  const int lpr = H * D / 4, dl = D / 4;
+  return !off && (lpr == 8 || lpr == 16 || lpr == 32) && dl >= 4 && dl <= lpr && D % 4 == 0;
+}
+
 // Destinations with few in-edges on average: a lane group per item instead of a wave per item (layer path kernels).
 // Same-box A/B on one rank's share of an 8-way ogbn-mag partition (9 in-edges per destination): backward 0.528 -> 0.506 ms,
 // forward unchanged.
@@ -567,7 +732,12 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
   // own workgroup turnover already overlaps the per-item prologues; the pass runs at the rate random 256-byte rows
   // come out of HBM)
   if (!el_sorted) {
-    hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
+    if (m.kind == HET_KIND_DISABLED && H == 4 && ((reinterpret_cast<uintptr_t>(el) | reinterpret_cast<uintptr_t>(er) |
+                                                  reinterpret_cast<uintptr_t>(exp)) & 15) == 0) {
+      hipLaunchKernelGGL(HET_gat_exp_edge_h4, dim3(grid_for(v.E)), dim3(kBlock), 0, s, v.eids, v.E, el, er, exp, slope);
+    } else {
+      hipLaunchKernelGGL(HET_gat_exp_edge, dim3(grid_for(v.E * H)), dim3(kBlock), 0, s, v, m, el, er, exp, H, slope);
+    }
     HET_LAUNCH_CHECK("HET_gat_exp_edge");
   }
   {
@@ -581,6 +751,10 @@ int gat_forward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps&
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, true>), dim3(nb), dim3(kBlock), 0, s,
                                                       it, g->p0, srow, feat, (const float*)nullptr, sum, ret, exp_sorted,
                                                       H, D, el_sorted, er_sorted, exp, slope));
+  } else if (gat_coop_shape(H, D)) {
+    HET_DISPATCH_COOP_G((int)(X / 4), D / 4,
+                        hipLaunchKernelGGL((HET_gat_aggregate_grouped_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
+                                           srow, feat, exp, sum, ret, exp_sorted, H));
   } else {
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL((HET_gat_aggregate_grouped<LPR, false>), dim3(nb), dim3(kBlock), 0, s,
                                                       it, g->p0, srow, feat, exp, sum, ret, exp_sorted, H, D));
@@ -662,6 +836,11 @@ int gat_backward_grouped(const het_grouping* g, const EdgeView& v, const RowMaps
   } else if (fold_w) {
     HET_KTIME("HET_gat_backward_grouped", s);
     if (sorted) { HET_GAT_BWD(true, true); } else { HET_GAT_BWD(false, true); }
+  } else if (!sorted && !grad_el_sorted && grad_el && grad_er && gat_coop_shape(H, D)) {
+    HET_KTIME("HET_gat_backward_grouped", s);
+    HET_DISPATCH_COOP_G((int)(X / 4), D / 4,
+                        hipLaunchKernelGGL((HET_gat_backward_grouped_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, g->p0,
+                                           feat, el, er, sum, ex, ret, gradout, grad_feat, grad_el, grad_er, H, slope));
   } else {
     HET_KTIME("HET_gat_backward_grouped", s);
     if (sorted) { HET_GAT_BWD(true, false); } else { HET_GAT_BWD(false, false); }

@@ -16,6 +16,7 @@
 //             of <= HET_ITEM_MAX edges, lane groups round-robin, one cross-group reduction and store per item.
 #include <stdlib.h>
 
+#include "coop.hip.h"
 #include "fused_gat.hip.h"
 #include "seg_reduce.hip.h"
 
@@ -319,28 +320,6 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
 // per instruction-per-step in both).  Here lane (head h, d) of a lane group fetches the scalar of edge d of the step --
 // one instruction per step and stream instead of one per edge -- and the DL = D/4 lanes of a head exchange the values
 // with DPP quad broadcasts (DL == 4: no LDS, no extra instruction slot) or a bpermute.
-template <int Q>
-__device__ __forceinline__ int quad_bcast_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, Q * 0x55, 0xf, 0xf, false);  // quad_perm:[Q,Q,Q,Q]
-}
-template <int DL>
-__device__ __forceinline__ int head_bcast_i(int v, int q, int lane) {
-  if constexpr (DL == 4) {
-    switch (q) {
-      case 0: return quad_bcast_i<0>(v);
-      case 1: return quad_bcast_i<1>(v);
-      case 2: return quad_bcast_i<2>(v);
-      default: return quad_bcast_i<3>(v);
-    }
-  } else {
-    return __shfl(v, (lane & ~(DL - 1)) | q, 64);
-  }
-}
-template <int DL>
-__device__ __forceinline__ float head_bcast(float v, int q, int lane) {
-  return __int_as_float(head_bcast_i<DL>(__float_as_int(v), q, lane));
-}
-__device__ __forceinline__ float fast_leaky_exp(float z, float slope) { return __expf(z > 0.f ? z : slope * z); }
 
 // Forward, cooperative form of HET_rgat_aggregate_compact (DL = D/4 >= 4 lanes per head, 4 edges per lane group and step).
 // Measured and dropped (same box, ogbn-mag):
