@@ -277,17 +277,21 @@ def main():
     value = E_global / (dt / args.steps) / 1e6
 
     prof_dir = os.path.join(ROOT, "profiles", "r02")
+    prof_tag = args.variant if args.model == "rgat" else args.model  # profiles/r02/{default,compact,...,rgcn,hgt}_pmc.json
 
     def pmc(kernel, field):
         """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/r02/,
         written by profiles/tools/collect.sh on an earlier box): rocprofv3 cannot run inside the timed process, so
         this is not an observation of this run -- the JSON says so (`traffic_source`).  None when no committed
         profile matches this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
-        path = os.path.join(prof_dir, f"{args.variant}_pmc.json")
-        if args.scale != 1.0 or world != 1 or args.model != "rgat" or args.feat != 64 or args.heads != 4 or not os.path.exists(path):
+        path = os.path.join(prof_dir, f"{prof_tag}_pmc.json")
+        if args.scale != 1.0 or world != 1 or args.feat != 64 or args.heads != (8 if args.model == "hgt" else 4) or not os.path.exists(path):
             return None
-        recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in json.load(open(path))["kernels"].items()
-                if k.startswith(kernel) and field in v]
+        kernels = json.load(open(path))["kernels"]
+        if isinstance(kernel, (tuple, list)):  # an op implemented by several launches per step: the sum over them
+            parts = [pmc(k_, field) for k_ in kernel]
+            return None if any(p_ is None for p_ in parts) else sum(parts)
+        recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in kernels.items() if k.startswith(kernel) and field in v]
         return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel
 
     def hbm_view(kernel, k_ms, nbytes, extra=None, pmc_name=None):
@@ -296,7 +300,7 @@ def main():
              "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
              "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(nbytes),
              "traffic": pmc(pmc_name or kernel.split(" ")[0], "hbm_bytes_per_launch")}
-        r["traffic_source"] = (f"profiles/r02/{args.variant}_pmc.json (committed rocprofv3 --pmc passes of this command on "
+        r["traffic_source"] = (f"profiles/r02/{prof_tag}_pmc.json (committed rocprofv3 --pmc passes of this command on "
                                "another box; not measured in this run)") if r["traffic"] else None
         if r["traffic"]:
             r["traffic_rate_GBps"] = round(r["traffic"] / (k_ms * 1e-3) / 1e9, 1)
@@ -327,8 +331,9 @@ def main():
                 req = nb_ + (E_local - S_row) * 4 * X  # one gradout row per edge instead of per source row
                 ex.update(bytes_with_per_edge_row_gather=int(req),
                           frac_with_per_edge_row_gather=round(req / (kt[bname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-            roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {'4: rows of the distinct (relation, node) projections' if S_row else 0})",
-                                kt[bname][2], nb_, ex, pmc_name=bname)
+            pm = ("HET_rgat_backward_src_coop", "HET_rgat_backward_src_long") if bname == "HET_rgat_backward_src" else bname
+            roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {'4: rows of the distinct (relation, node) projections; short + long segment launches' if S_row else 0})",
+                                kt[bname][2], nb_, ex, pmc_name=pm)
         fname = next((n for n in ("HET_rgat_aggregate", "HET_gat_aggregate_grouped") if n in kt), None)
         if fname:
             nf_ = gat_fwd_bytes(E_local, N_local, H, X, S_row, S_col)
@@ -338,7 +343,29 @@ def main():
                 ex.update(bytes_with_per_edge_row_gather=int(req),
                           frac_with_per_edge_row_gather=round(req / (kt[fname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0})",
-                                    kt[fname][2], nf_, ex, pmc_name=fname)
+                                    kt[fname][2], nf_, ex, pmc_name="HET_rgat_aggregate_coop" if fname == "HET_rgat_aggregate" else fname)
+    if args.model == "rgcn" and "HET_segment_sum" in kt and not use_dist:
+        # RGCN (BASELINE.json configs[1]): the step is two gather-sums (x[src] * norm per (relation, destination) forward,
+        # gradout[dst] * norm per (relation, source) backward) + GEMMs on the distinct rows.  a7 / a8 bytes per SURVEY.md 8d
+        # (U_src = distinct source nodes); the gather passes move one 256-byte row per edge like RGAT's
+        sc = g.get_separate_coo_original()
+        U_src = int(torch.unique(sc["row_indices"]).numel())
+        R_ = g.get_num_rels()
+        a7 = E_local * (3 * 8 + 4) + U_src * 4 * K + N_local * 4 * X + 4 * R_ * K * X
+        a8 = E_local * 28 + (U_src + N_local) * 4 * (K + X) + 8 * R_ * K * X
+        ss_ms = kt["HET_segment_sum"][0]  # one launch per op
+        note = ("kernel_ms = the gather-sum launches of one op (average of the forward and the backward one); the op's GEMMs on "
+                "the distinct rows are separate launches (kernel_ms).  requested_bytes counts one row per edge: the rate at "
+                "the kernels' load instructions, part of it served by L2 / Infinity Cache (the [N,64] table is 0.5 GB and "
+                "the degrees are Zipf-skewed), so it may exceed what HBM delivers")
+        pm = ("HET_segment_sum_packed", "HET_segment_sum_long")
+        roofline = hbm_view("HET_segment_sum_packed + _long (backward_rgcn_layer1_separate_coo: gradout rows by (relation, source))",
+                            ss_ms, a8, {"requested_bytes_one_row_per_edge": int(E_local * (4 * X + 12) + a8),
+                                        "requested_rate_GBps": round((E_local * (4 * X + 12) + a8) / (ss_ms * 1e-3) / 1e9, 1),
+                                        "note": note}, pmc_name=pm)
+        roofline_fwd = hbm_view("HET_segment_sum_packed + _long (rgcn_layer1_separate_coo: x rows by (relation, destination))", ss_ms, a7,
+                                {"requested_bytes_one_row_per_edge": int(E_local * (4 * K + 12) + a7),
+                                 "requested_rate_GBps": round((E_local * (4 * K + 12) + a7) / (ss_ms * 1e-3) / 1e9, 1)}, pmc_name=pm)
     kernel_ms = {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}
 
     # the reference-named ops exactly as the reference's model code calls them (kind 0, [E,H,D] feat), each launched a
@@ -363,13 +390,13 @@ def main():
         g_ms = ms / max(1, n)
         flops = 2.0 * E_local * K * X
         tf = flops / (g_ms * 1e-3) / 1e12
-        busy = pmc("HET_seg_gemm_mfma<64, 2, false, false>", "mfma_busy_frac")
+        busy = pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "mfma_busy_frac")
         roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "mfma_busy_frac_pmc": busy,
-                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false>", "hbm_bytes_per_launch"),
-                         "traffic_source": f"profiles/r02/{args.variant}_pmc.json (committed; not measured in this run)" if busy else None}
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "hbm_bytes_per_launch"),
+                         "traffic_source": f"profiles/r02/{prof_tag}_pmc.json (committed; not measured in this run)" if busy else None}
         # a4 / a5 on the per-edge tensor retp just written (feat_src_per_edge), reference argument order
         el = torch.randn(E_local, H, device=dev)
         er = torch.randn(E_local, H, device=dev)
