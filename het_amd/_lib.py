@@ -39,6 +39,8 @@ _SIGNATURES = {
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
+    "het_hgt_aggregate_compact": [P, P, P, P, P, I64, I64, I64, I64, P],
+    "het_hgt_backward_compact": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],
     "het_backward_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P, I64, P],
     "het_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P, I64, INT, P, P],
@@ -80,6 +82,10 @@ def lib() -> C.CDLL:
         L.het_grouping_bytes.restype = I64
         L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
         L.het_rgat_backward_compact_workspace.restype = I64
+        L.het_hgt_backward_compact_workspace.argtypes = [I64, I64]
+        L.het_hgt_backward_compact_workspace.restype = I64
+        L.het_hgt_compact_shape_ok.argtypes = [I64, I64]
+        L.het_hgt_compact_shape_ok.restype = INT
         L.het_kernel_timing_enable.argtypes = [INT]
         L.het_kernel_timing_enable.restype = INT
         L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]

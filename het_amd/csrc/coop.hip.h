@@ -2,6 +2,8 @@
 // 4-edge step and the DL = D/4 lanes of a head exchange the values with DPP quad broadcasts (DL == 4) or a bpermute.
 // See het_amd/csrc/gat_compact.hip and DESIGN.md section 4.1 (the passes were bound by the number of vector-memory
 // instructions, not by bytes).
+// Hazard: a DPP read of a lane that the current branch has switched off returns the `old` operand (0), not the lane's
+// value -- call the broadcasts where all lanes of the quad / head group are active, never inside a per-lane branch.
 #pragma once
 #include "common.hip.h"
 

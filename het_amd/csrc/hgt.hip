@@ -2,6 +2,7 @@
 // aggregation, edge-wise inner products and the fused attention score; forward and backward.
 // The dk x dk per-head products run through the generic segment GEMM kernels (seg_gemm.hip) with
 // per-(edge, head) row scales; the edge-wise parts are the small kernels below.
+#include "coop.hip.h"
 #include "edge_view.hip.h"
 #include "seg_gemm.hip.h"
 #include "seg_gemm_mfma.hip.h"
@@ -278,6 +279,51 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_grad_attn(const idx_t* __restr
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 constexpr int UR = 4;
+__device__ __forceinline__ int quad_bcast_sw(int v, int q) {  // value of lane q of the caller's quad (DPP quad_perm)
+  switch (q) {
+    case 0: return quad_bcast_i<0>(v);
+    case 1: return quad_bcast_i<1>(v);
+    case 2: return quad_bcast_i<2>(v);
+    default: return quad_bcast_i<3>(v);
+  }
+}
+
+// Cooperative form of HET_rows_inner_product for LPR >= 4: lane (sub % 4) of every quad fetches the ids of edge (sub % 4) of
+// the step and the quad shares them with DPP broadcasts -- 3 id instructions per step of 4 edges instead of 12 (the per-edge
+// kernels were bound by the number of vector-memory instructions).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rows_inner_product_coop(const idx_t* __restrict__ eids,
+                                                                       const idx_t* __restrict__ map_a,
+                                                                       const idx_t* __restrict__ ridx, int64_t E,
+                                                                       const float* __restrict__ left,
+                                                                       const float* __restrict__ right,
+                                                                       float* __restrict__ out, int H, int D) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  static_assert(LPR >= 4 && UR == 4, "whole quads per lane group, 4 edges per step");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2, q4 = sub & 3;
+  const int64_t step = (int64_t)gridDim.x * 4 * EPW * UR;
+  for (int64_t base = (int64_t)blockIdx.x * 4 * EPW * UR; base < E; base += step) {
+    // this lane's edge of the step (u = q4), ids as 32-bit values (E, rows < 2^31 are checked by the callers)
+    const int64_t iq = base + (wave * UR + q4) * EPW + slot;
+    const int64_t ic = iq < E ? iq : E - 1;
+    const int eidv = (int)eids[ic], rrv = (int)ridx[ic];
+    const int lrv = map_a ? (int)map_a[eidv] : eidv;
+    float4 l[UR], r[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) l[u] = ld4(left + (int64_t)quad_bcast_sw(lrv, u) * X + x);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) r[u] = ld4(right + (int64_t)quad_bcast_sw(rrv, u) * X + x);
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      float p = l[u].x * r[u].x + l[u].y * r[u].y + l[u].z * r[u].z + l[u].w * r[u].w;
+      for (int off = DL >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
+      const bool ok = base + (wave * UR + u) * EPW + slot < E;
+      const int eu = quad_bcast_sw(eidv, u);  // outside the branch: a DPP read of a lane the branch switched off returns 0
+      if (ok && (sub & (DL - 1)) == 0) out[(int64_t)eu * H + h] = p;
+    }
+  }
+}
 
 // out[eids[i], h] = < left[lrow(i), h, :], right[ridx[i], h, :] >,  lrow = eid or map_a[eid]
 template <int LPR>
@@ -714,6 +760,18 @@ extern "C" int het_rgnn_inner_product_right_node_separatecoo(
   if (kind != HET_KIND_ENABLED && rows_shape_ok(H, D) && (reinterpret_cast<uintptr_t>(left) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(right) & 15) == 0) {
     const unsigned nb = grid_for(num_edges * (H * D / 4));
+    if (H * D / 4 >= 4 && num_edges < (1ll << 31)) {
+      switch ((int)(H * D / 4)) {
+#define HET_IP_COOP(L) case L: hipLaunchKernelGGL(HET_rows_inner_product_coop<L>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, \
+                                                  eids, kind == 2 ? map_a : nullptr, row, num_edges, left, right, out, (int)H, (int)D); break
+        HET_IP_COOP(4); HET_IP_COOP(8); HET_IP_COOP(16); HET_IP_COOP(32);
+        default: hipLaunchKernelGGL(HET_rows_inner_product_coop<64>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, eids,
+                                    kind == 2 ? map_a : nullptr, row, num_edges, left, right, out, (int)H, (int)D); break;
+#undef HET_IP_COOP
+      }
+      HET_LAUNCH_CHECK("HET_rows_inner_product_coop");
+      return HET_OK;
+    }
     HET_HGT_LPR((int)(H * D / 4), hipLaunchKernelGGL(HET_rows_inner_product<LPR>, dim3(nb), dim3(kBlock), 0,
                                                       (hipStream_t)stream, eids, kind == 2 ? map_a : nullptr, row,
                                                       num_edges, left, right, out, (int)H, (int)D));

@@ -604,6 +604,36 @@ def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad
           er_c.shape[0], H, D, float(slope), _p(ws), ws.numel() * 4, _stream(ret))
 
 
+def hgt_compact_shape_ok(H: int, D: int) -> bool:
+    return bool(_lib.lib().het_hgt_compact_shape_ok(int(H), int(D)))
+
+
+def hgt_compact_groupings(col, srow, num_nodes, num_src_rows):
+    """The two groupings of the compact HGT passes (include/het_amd.h: het_hgt_aggregate_compact): by destination and by
+    (relation, source) row.  ``srow`` [E] int64: that row of every edge position."""
+    by_dst = _plan.get_grouping(None, col, num_nodes, srow, None)
+    by_srow = _plan.get_grouping(None, srow, num_src_rows, col, None)
+    return None if by_dst is None or by_srow is None else (by_dst, by_srow)
+
+
+def hgt_aggregate_compact(groupings, kv_c, q, lsum, out):
+    _chk("hgt_aggregate_compact", (kv_c, q, lsum, out))
+    N, H = lsum.shape
+    D = out.numel() // max(1, N * H)
+    _call(out, "het_hgt_aggregate_compact", groupings[0].handle, _p(kv_c), _p(q), _p(lsum), _p(out), N, kv_c.shape[0], H, D,
+          _stream(out))
+
+
+def hgt_backward_compact(groupings, kv_c, q, lsum, out, gradout, grad_kv_c, grad_q):
+    _chk("hgt_backward_compact", (kv_c, q, lsum, out, gradout, grad_kv_c, grad_q))
+    N, H = lsum.shape
+    D = out.numel() // max(1, N * H)
+    nbytes = int(_lib.lib().het_hgt_backward_compact_workspace(N, H))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=out.device)
+    _call(out, "het_hgt_backward_compact", groupings[0].handle, groupings[1].handle, _p(kv_c), _p(q), _p(lsum), _p(out),
+          _p(gradout), _p(grad_kv_c), _p(grad_q), N, kv_c.shape[0], H, D, _p(ws), ws.numel() * 4, _stream(out))
+
+
 def gat_rank_of_position(rel_ptrs, row, col, eids, num_nodes):
     """[E] int64: the rank of every separate-COO position in the destination-grouped order of the kind-0 GAT kernels
     (row j of exp_sorted / grad_el_sorted belongs to the position whose rank is j).  None without groupings."""

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import backend as B
 from .backend import rgat_fused_layer as FL
+from .backend import hgt_fused_layer as _hgt_fused
 
 
 class HET_RelGraphEmbed(nn.Module):
@@ -302,6 +303,14 @@ class HET_HGTLayerHetero(nn.Module):
         offs = G.get_original_node_type_offsets()
         seg_types = G.graph_data["original"].get("node_segment_types") if hasattr(G, "graph_data") else None
         per_run = (lambda w: w) if seg_types is None else (lambda w: w.index_select(0, seg_types))
+        if _hgt_fused.hgt_fused_ok(G, h, self.num_heads, self.d_k):
+            # attention + aggregation as one node on the distinct (relation, source) rows (backend/hgt_fused_layer.py): the
+            # same function of the parameters for every flag combination below, without the per-edge tensors
+            new_h = _hgt_fused.hgt_attention_fused(G, h, offs, self.q_linears, self.k_linears, self.v_linears, self.relation_att,
+                                                   self.relation_msg, self.relation_pri, self.num_heads,
+                                                   self.hgt_fused_attn_score_flag)
+            out = B.rgnn_relational_matmul_no_scatter_gather_list(offs, th.sigmoid(self.skip) * self.a_linears, new_h)
+            return out if num_dst is None else out[:num_dst]
         if self.multiply_among_weights_first_flag:
             return self._forward_weights_first(G, h, offs, per_run, num_dst)
         k = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(self.k_linears), h).view(-1, self.num_heads, self.d_k)

@@ -408,6 +408,31 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
                                                          void* workspace, int64_t workspace_bytes, het_stream stream);
 
 /* ------------------------------------------------------------------------
+ * HGT attention + message aggregation on the distinct (relation, source) rows, without a per-edge float tensor
+ * (layer-level fusion; no reference op of its own).  Inside the one-node HGT layer it replaces the chain
+ * rgnn_relational_matmul (relation_att) -> rgnn_inner_product_right_node -> hgt_full_graph_edge_softmax_ops ->
+ * hgt_full_graph_fused_message_calc_and_mean_aggregation and their backward ops (HGT/models.py:172-262;
+ * OpExport/HGTOps.inc.h, OpExport/HGTOpsEdgeParallel.inc.h; kernels hrt/include/DGLHackKernel/HGT/ *.cu.h): same values,
+ *   a_e[h] = exp(s_e[h]) / SUM_{e' into dst_e} exp(s_e'[h]),  s_e[h] = <k'[srow_e,h,:], q[dst_e,h,:]>,
+ *   out[v,h,:] = SUM_{e into v} a_e[h] * m[srow_e,h,:]
+ * with k' = k . relation_att . (relation_pri / sqrt(dk)) and m = v . relation_msg formed per distinct (relation, source)
+ * row by the caller (one segment GEMM from the layer input when the typed projections are folded into the weights).
+ *   kv_c [S_row, 2, H, D]: k' then m of every (relation, source) row;  q [N,H,D];  lsum [N,H] = SUM exp(s);  out [N,H,D]
+ *   by_dst:  het_grouping_create(NULL, 0, col, E, N, payload0 = (relation, source) row of every position, NULL)
+ *   by_srow: het_grouping_create(NULL, 0, that row of every position, E, S_row, payload0 = col, NULL)
+ * forward overwrites lsum and out (zero rows for destinations without in-edges); backward overwrites grad_kv_c [S_row,2,H,D]
+ * and grad_q [N,H,D].  workspace: het_hgt_backward_compact_workspace(N, H) bytes, 16-byte aligned.
+ * Shapes: H*D in {16, 32, 64, 128}, D a power of two >= 8 (het_hgt_compact_shape_ok); else HET_ERR_UNSUPPORTED. */
+int het_hgt_compact_shape_ok(int64_t H, int64_t D);
+int het_hgt_aggregate_compact(const het_grouping* by_dst, const float* kv_c, const float* q, float* lsum, float* out,
+                              int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, het_stream stream);
+int64_t het_hgt_backward_compact_workspace(int64_t num_nodes, int64_t H);
+int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_srow, const float* kv_c, const float* q,
+                             const float* lsum, const float* out, const float* gradout, float* grad_kv_c, float* grad_q,
+                             int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, void* workspace,
+                             int64_t workspace_bytes, het_stream stream);
+
+/* ------------------------------------------------------------------------
  * RGAT on the distinct (relation, node) rows without a per-edge float tensor (layer-level fusion; no reference op of
  * its own).  Replaces the pair relational_fused_gat_separate_coo / backward_... with CompactAsOfNodeKind 4
  * (OpExport/RGATOps.inc.h:170-245, 465-551; kernels RGAT/RGATKernelsSeparateCOO.cu.h:17-204,

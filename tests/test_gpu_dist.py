@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, compact, outdir):
+def _worker(rank, world, port, compact, outdir, feat=64):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,13 +29,13 @@ def _worker(rank, world, port, compact, outdir):
         dev = torch.device("cuda", 0)
         coo = make_mag_like(scale=4e-3)
         flags = dict(compact_as_of_node_flag=compact, compact_direct_indexing_flag=compact)
-        runner = DistRGAT(coo, 64, 64, 4, dev, **flags)
+        runner = DistRGAT(coo, feat, feat, 4, dev, **flags)
         plan = runner.dl.plan
         lo, hi = int(plan.bounds[rank]), int(plan.bounds[rank + 1])
         mine = plan.node_order[lo:hi].cpu()
         gen = torch.Generator().manual_seed(2)
-        x_full = torch.randn(coo.num_nodes, 64, generator=gen)
-        go_full = torch.randn(coo.num_nodes, 64, generator=gen)
+        x_full = torch.randn(coo.num_nodes, feat, generator=gen)
+        go_full = torch.randn(coo.num_nodes, feat, generator=gen)
         x_own = x_full[mine].to(dev).requires_grad_(True)
         out = runner.dl.forward(x_own)
         out.backward(go_full[mine].to(dev))
@@ -47,15 +47,16 @@ def _worker(rank, world, port, compact, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact", [False, True])
-def test_two_ranks_on_one_gpu_match_single_process(compact):
+@pytest.mark.parametrize("compact,feat", [(False, 64), (True, 64), (False, 128)])
+def test_two_ranks_on_one_gpu_match_single_process(compact, feat):
+    """feat 128 with 4 heads: the layer shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition)."""
     import torch.multiprocessing as mp
     from het_amd.graph import HetGraph
     from het_amd.layers import HET_RGATLayer
     from het_amd.synth import make_mag_like
     world = 2
     with tempfile.TemporaryDirectory() as d:
-        mp.start_processes(_worker, args=(world, _free_port(), compact, d), nprocs=world, join=True, start_method="spawn")
+        mp.start_processes(_worker, args=(world, _free_port(), compact, d, feat), nprocs=world, join=True, start_method="spawn")
         parts = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
     dev = torch.device("cuda", 0)
     coo = make_mag_like(scale=4e-3)
@@ -63,11 +64,11 @@ def test_two_ranks_on_one_gpu_match_single_process(compact):
         setattr(coo, f, getattr(coo, f).to(dev))
     g = HetGraph.from_integrated_coo(coo, full=True)
     torch.manual_seed(0)  # DistRGAT seeds its replicated layer the same way
-    layer = HET_RGATLayer(64, 64, coo.num_rels, 4, self_loop=True, dropout=0.0, compact_as_of_node_flag=compact,
+    layer = HET_RGATLayer(feat, feat, coo.num_rels, 4, self_loop=True, dropout=0.0, compact_as_of_node_flag=compact,
                           compact_direct_indexing_flag=compact).to(dev)
     gen = torch.Generator().manual_seed(2)
-    x = torch.randn(coo.num_nodes, 64, generator=gen).to(dev).requires_grad_(True)
-    go = torch.randn(coo.num_nodes, 64, generator=gen).to(dev)
+    x = torch.randn(coo.num_nodes, feat, generator=gen).to(dev).requires_grad_(True)
+    go = torch.randn(coo.num_nodes, feat, generator=gen).to(dev)
     ref = layer(g, x)
     ref.backward(go)
     assert torch.equal(torch.sort(torch.cat([q["mine"] for q in parts])).values, torch.arange(coo.num_nodes))

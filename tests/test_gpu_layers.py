@@ -199,12 +199,56 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
 
 
 @pytest.mark.parametrize("fused_attn", [False, True])
+@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (1, 64, 64), (4, 64, 64), (2, 32, 64), (1, 32, 32), (4, 128, 128), (2, 64, 16)])
+def test_hgt_layer_fused(fused_attn, H, in_dim, out_dim, monkeypatch):
+    """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
+    (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
+    (BASELINE.json configs[3]: feat 64, heads 8) -- against the fp64 oracle: output and the gradients of the input and of all
+    eight parameters.  A spy checks that the row kernels are what ran."""
+    import het_amd.kernels as k
+    from het_amd.layers import HET_HGTLayerHetero
+    g = mag_graph(1.5e-3)
+    torch.manual_seed(4)
+    N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
+    layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn)
+    with torch.no_grad():
+        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.skip.uniform_(-1, 1)
+    h, go = torch.randn(N, in_dim) * 0.5, torch.randn(N, out_dim)
+    s = g.get_separate_coo_original()
+    names = ["k_linears", "q_linears", "v_linears", "a_linears", "relation_att", "relation_msg", "relation_pri", "skip"]
+    p = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
+    h64 = h.double().requires_grad_(True)
+    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N,
+                       p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
+                       p["relation_pri"], p["skip"], H, fused_attn=fused_attn)
+    grads_ref = torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double())
+    calls = []
+    real_f, real_b = k.hgt_aggregate_compact, k.hgt_backward_compact
+    monkeypatch.setattr(k, "hgt_aggregate_compact", lambda *a, **kw: (calls.append("fwd"), real_f(*a, **kw))[1])
+    monkeypatch.setattr(k, "hgt_backward_compact", lambda *a, **kw: (calls.append("bwd"), real_b(*a, **kw))[1])
+    g.to_(DEV)
+    layer = layer.to(DEV)
+    hd = h.to(DEV).requires_grad_(True)
+    out = layer(g, hd)
+    out.backward(go.to(DEV))
+    g.cpu_()
+    assert calls == ["fwd", "bwd"]
+    assert_close(out, ref, what="out")
+    assert_close(hd.grad, grads_ref[0], what="grad_h")
+    for n, gr in zip(names, grads_ref[1:]):
+        assert_close(getattr(layer, n).grad, gr, what="grad_" + n)
+
+
+@pytest.mark.parametrize("fused_attn", [False, True])
 @pytest.mark.parametrize("H,in_dim,out_dim", [(1, 64, 64), (2, 32, 64), (1, 32, 64)])
-def test_hgt_layer_multiply_among_weights_first(fused_attn, H, in_dim, out_dim):
+def test_hgt_layer_multiply_among_weights_first(fused_attn, H, in_dim, out_dim, monkeypatch):
     """--multiply_among_weights_first_flag of HGT (HGT/models.py:124-151; heads = 1 in the reference's sweep): the typed
     K / Q / V projections folded into the relation weights.  Same function as the layer without the flag, so it is
     checked against the same fp64 oracle: output and the gradients of the input and of all eight parameters."""
     from het_amd.layers import HET_HGTLayerHetero
+    from het_amd.backend import hgt_fused_layer
+    monkeypatch.setattr(hgt_fused_layer, "FUSED", False)  # the op-by-op composition of the flag, not the one-node attention
     g = mag_graph(1.5e-3)  # typed node ranges, relations = canonical edge types
     torch.manual_seed(3)
     N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()

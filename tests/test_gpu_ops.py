@@ -238,6 +238,41 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
         assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
 
 
+@pytest.mark.parametrize("H,D,n,e", [(8, 8, 300, 5000), (1, 64, 300, 5000), (4, 16, 40, 9000), (2, 8, 12, 9000), (4, 32, 300, 700),
+                                     (1, 32, 30, 4000), (2, 32, 300, 3000)])
+def test_hgt_compact_passes(K, H, D, n, e):
+    """het_hgt_aggregate_compact / het_hgt_backward_compact (include/het_amd.h) against their definition in fp64 autograd:
+    a = softmax over the in-edges of <k'[srow], q[dst]> per head (exp without a running maximum, oracle/layers.py hgt_layer),
+    out = SUM a * m[srow].  The layer-level parity with the oracle is tests/test_gpu_layers.py::test_hgt_layer_fused.
+    n = 12 / 30 / 40: hub destinations split over work items and long (relation, source) segments whose pieces add atomically."""
+    import het_amd.kernels as k
+    g = random_graph(seed=29, n=n, r=4, e=e)
+    s = g.get_separate_coo_original()
+    inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    N, S_row, X = g.get_num_nodes(), ss["node_indices_row"].numel(), H * D
+    srow = inv["inverse_indices_row"][s["eids"]].contiguous()  # row of every edge POSITION
+    col = s["col_indices"]
+    gen = torch.Generator().manual_seed(6)
+    kv, q, go = torch.randn(S_row, 2, H, D, generator=gen) * 0.6, torch.randn(N, H, D, generator=gen) * 0.6, torch.randn(N, H, D, generator=gen)
+    kv64, q64 = to64(kv).requires_grad_(True), to64(q).requires_grad_(True)
+    sc = (kv64[srow, 0] * q64[col]).sum(-1)
+    w = torch.exp(sc)
+    den = torch.zeros(N, H, dtype=torch.float64).index_add(0, col, w)
+    out_r = torch.zeros(N, H, D, dtype=torch.float64).index_add(0, col, (w / den[col]).unsqueeze(-1) * kv64[srow, 1])
+    gkv_r, gq_r = torch.autograd.grad(out_r, [kv64, q64], to64(go))
+    grp = k.hgt_compact_groupings(col.to(DEV), srow.to(DEV), N, S_row)
+    kvd, qd = kv.to(DEV), q.to(DEV)
+    lsum, out = torch.full((N, H), 7.0, device=DEV), torch.full((N, X), 7.0, device=DEV)
+    k.hgt_aggregate_compact(grp, kvd, qd, lsum, out)
+    assert_close(lsum, den.detach(), what="lsum")
+    assert_close(out.view(N, H, D), out_r.detach(), what="out")
+    gkv, gq = torch.full_like(kvd, float("nan")), torch.full_like(qd, float("nan"))
+    k.hgt_backward_compact(grp, kvd, qd, lsum, out, go.to(DEV), gkv, gq)
+    assert_close(gq, gq_r, what="grad_q")
+    assert_close(gkv, gkv_r, what="grad_kv")
+
+
 def test_fused_gat_hub_destination(K, plan_mode):
     """One destination with thousands of in-edges (its segment is split over several work
     items), many destinations with none, and eids a non-trivial permutation."""
