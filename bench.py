@@ -264,7 +264,8 @@ def main():
     kt = {}
     for name in ("HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_src", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
                  "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
-                 "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_dw_mfma", "HET_segment_sum"):
+                 "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
+                 "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"):
         ms, n = HL.kernel_timing_read(name)
         if n:
             kt[name] = (ms / n, n / args.steps, ms / args.steps)
@@ -366,6 +367,31 @@ def main():
         roofline_fwd = hbm_view("HET_segment_sum_packed + _long (rgcn_layer1_separate_coo: x rows by (relation, destination))", ss_ms, a7,
                                 {"requested_bytes_one_row_per_edge": int(E_local * (4 * K + 12) + a7),
                                  "requested_rate_GBps": round((E_local * (4 * K + 12) + a7) / (ss_ms * 1e-3) / 1e9, 1)}, pmc_name=pm)
+    if args.model == "hgt" and "HET_hgt_aggregate_rows" in kt and not use_dist:
+        # HGT (BASELINE.json configs[3]): attention + aggregation on the distinct (relation, source) rows (csrc/hgt_compact.hip).
+        # Algorithmic bytes: every tensor of the pass once (kv_c [S_row,2X], q / out / gradout [N,X], per-(node, head) scalars,
+        # two 8-byte indices per edge); the passes gather one 2X-float row (forward, destination side) or two X-float rows
+        # (source side) PER EDGE from tables larger than the Infinity Cache -- bytes_with_per_edge_row_gather counts those.
+        ss = g.get_separate_unique_node_indices_single_sided()
+        S_row = int(ss["node_indices_row"].numel())
+        kvb, nxb, nhb = S_row * 2 * X * 4, N_local * X * 4, N_local * H * 4
+        f_b = kvb + 2 * nxb + nhb + E_local * 16
+        d_b = kvb + 4 * nxb + 3 * nhb + E_local * 16            # reads kv_c, q, gradout, out, lsum; writes grad_q, pack2
+        s_b = 2 * kvb + 2 * nxb + 2 * nhb + E_local * 16        # reads kv_c, q, gradout, pack2; writes grad_kv_c
+        f_req = f_b + (E_local - S_row) * 2 * X * 4
+        d_req = d_b + (E_local - S_row) * 2 * X * 4
+        s_req = s_b + (E_local - N_local) * (2 * X * 4 + 8 * H)
+        b_ms = sum(kt[n][2] for n in ("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long") if n in kt)
+        note = ("requested_bytes counts one gathered row per edge: the rate at the kernels' load instructions, part of it served by "
+                "L2 / Infinity Cache (kv_c is 1.2 GB, q / gradout 0.5 GB each, degrees Zipf-skewed), so it may exceed what HBM "
+                "delivers; `traffic` is what crossed the memory fabric")
+        ex = lambda req, ms: {"S_row": S_row, "requested_bytes_one_row_per_edge": int(req),
+                              "requested_rate_GBps": round(req / (ms * 1e-3) / 1e9, 1), "note": note}
+        roofline = hbm_view("HET_hgt_backward_dst_rows + _src_short + _src_long (het_hgt_backward_compact: softmax + aggregation backward "
+                            "of the HGT layer, three launches)", b_ms, d_b + s_b, ex(d_req + s_req, b_ms),
+                            pmc_name=("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"))
+        roofline_fwd = hbm_view("HET_hgt_aggregate_rows (het_hgt_aggregate_compact: score, edge softmax, message aggregation)",
+                                kt["HET_hgt_aggregate_rows"][2], f_b, ex(f_req, kt["HET_hgt_aggregate_rows"][2]))
     kernel_ms = {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}
 
     # the reference-named ops exactly as the reference's model code calls them (kind 0, [E,H,D] feat), each launched a
