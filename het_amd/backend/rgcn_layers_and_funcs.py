@@ -33,9 +33,36 @@ class RgcnLayer1SeparateCoo(th.autograd.Function):
         return None, None, None, None, None, None, None, None, grad_x, grad_weight, grad_norm, None
 
 
-def rgcn_layer1_separate_coo(graph, x, weight, norm):
+class RgcnLayer1SeparateCooBias(th.autograd.Function):
+    """RgcnLayer1SeparateCoo with the layer's bias (RGCN/RGCN.py:338-340, ``node_repr + h_bias``) inside the node: the op
+    accumulates into ``ret`` (reference contract), so ``ret`` starts from the bias rows instead of zeros -- one fill instead
+    of a fill and an elementwise add; the bias gradient is the column sum of gradout."""
+
+    @staticmethod
+    def forward(ctx, rel_ptrs, eids, row, col, num_nodes, x, weight, norm, bias):
+        ctx.save_for_backward(rel_ptrs, eids, row, col, weight, norm, x)
+        ret = bias.to(weight.dtype).expand(num_nodes, weight.size(2)).contiguous()
+        K.rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, weight, norm, ret)
+        return ret
+
+    @staticmethod
+    def backward(ctx, gradout):
+        rel_ptrs, eids, row, col, weight, norm, x = ctx.saved_tensors
+        gradout = gradout.contiguous()
+        grad_x = th.zeros_like(x, memory_format=th.contiguous_format)
+        grad_weight = th.zeros_like(weight, memory_format=th.contiguous_format)
+        grad_norm = th.zeros_like(norm, memory_format=th.contiguous_format)
+        K.backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, th.transpose(weight, 1, 2).contiguous(), norm,
+                                            grad_norm, grad_x, gradout, grad_weight)
+        return None, None, None, None, None, grad_x, grad_weight, grad_norm, gradout.sum(0)
+
+
+def rgcn_layer1_separate_coo(graph, x, weight, norm, bias=None):
     # reference: rgcn_layers_and_funcs.py:570-601
     s = graph.get_separate_coo_original()
+    if bias is not None:
+        return RgcnLayer1SeparateCooBias.apply(s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], graph.get_num_nodes(),
+                                               x.contiguous(), weight.contiguous(), norm.contiguous(), bias)
     o = graph.get_out_csr()
     ret = th.zeros((graph.get_num_nodes(), weight.size(2)), dtype=weight.dtype, device=weight.device)
     return RgcnLayer1SeparateCoo.apply(s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], o["row_ptrs"],

@@ -584,7 +584,7 @@ extern "C" int het_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, const int64
     MfmaGemmArgs m;
     m.A = ssum; m.a_ld = K; m.B = weights; m.b_rel_stride = K * D; m.C = ret; m.c_ld = D; m.scatter = g->seg_key64;
     m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)K; m.X = (int)D;
-    return launch_rows_gemm(m, s);
+    return launch_rows_gemm_add_unique(m, s);  // the destinations of a relation's segments are distinct
   }
   SegGemmArgs a;
   a.A = x; a.a_ld = K; a.gather = row; a.row_scale = norm; a.scale_idx = eids;
@@ -617,7 +617,7 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
     MfmaGemmArgs m;
     m.A = gsum; m.a_ld = D; m.B = weights_t; m.b_rel_stride = D * K; m.C = grad_x; m.c_ld = K; m.scatter = g->seg_key64;
     m.atomic = 1; m.seg_ptrs = g->seg_rel_ptr64; m.num_segs = (int)num_rels; m.num_rows = g->S; m.K = (int)D; m.X = (int)K;
-    if (int rc = launch_rows_gemm(m, s)) return rc;
+    if (int rc = launch_rows_gemm_add_unique(m, s)) return rc;
     MfmaDwArgs w;
     w.A = x; w.a_ld = K; w.gather = g->seg_key64; w.G = gsum; w.g_ld = D; w.dW = grad_w; w.dw_rel_stride = K * D;
     w.seg_ptrs = g->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = g->S; w.K = (int)K; w.X = (int)D;

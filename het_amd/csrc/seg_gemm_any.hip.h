@@ -26,6 +26,18 @@ inline int launch_rows_gemm(const MfmaGemmArgs& m, hipStream_t s) {
   return launch_seg_gemm(a, s);
 }
 
+// C[scatter[i]] += A[i] . B[r] for lists whose rows are DISTINCT inside every segment (the (relation, key) segments of a
+// grouping, a unique (relation, node) list): segment by segment with plain read-modify-write instead of float atomics
+// when the segments are few (launches are ordered on the stream); else atomics.
+inline int launch_rows_gemm_add_unique(const MfmaGemmArgs& m, hipStream_t s) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(m.A) | reinterpret_cast<uintptr_t>(m.C)) & 15) == 0;
+  if (mfma_shape_supported(m.K, m.X) && aligned && m.num_segs <= kRmwMaxSegments && m.K <= 128 && m.X <= 128 && !m.dot_w && !m.bias)
+    return launch_seg_gemm_mfma_rmw_per_segment(m, s);
+  MfmaGemmArgs a = m;
+  a.atomic = 1;
+  return launch_rows_gemm(a, s);
+}
+
 inline int launch_rows_dw(const MfmaDwArgs& m, hipStream_t s) {
   const bool aligned = ((reinterpret_cast<uintptr_t>(m.A) | reinterpret_cast<uintptr_t>(m.G)) & 15) == 0;
   if (mfma_dw_supported(m.K, m.X) && aligned) return launch_seg_dw_mfma(m, s);

@@ -239,7 +239,13 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
             node_repr = B.rgcn_node_mean_aggregation_compact_as_of_node_separate_coo_single_sided(
                 g, feat_compact.view(feat_compact.shape[0], -1), norm, self.compact_direct_indexing_flag)
         else:
-            node_repr = B.rgcn_layer1_separate_coo(g, x, weight, norm)
+            # (the bias joins the op's output buffer when all rows are kept: backend RgcnLayer1SeparateCooBias)
+            bias_in_op = self.bias and (num_dst is None or num_dst >= g.get_num_nodes())
+            node_repr = B.rgcn_layer1_separate_coo(g, x, weight, norm, self.h_bias if bias_in_op else None)
+            if bias_in_op:
+                if self.activation:
+                    node_repr = self.activation(node_repr)
+                return self.dropout(node_repr)
         if num_dst is not None and num_dst < node_repr.shape[0]:
             node_repr = node_repr[:num_dst]
         if self.bias:
