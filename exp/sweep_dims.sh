@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export PYTHONPATH=$R
 # (the reference's sweep also crosses MulFlag = "" / --multiply_among_weights_first_flag for RGAT and HGT: pass the flag as "$@")
-for m in rgat hgt rgcn; do
+for m in ${MODELS:-rgat hgt rgcn}; do
   for dx in 32 64 128; do
     for dy in 32 64 128; do
       python3 -m het_amd.train --model $m -d mag --num_layers 1 --full_graph_training --num_classes $dx --n_infeat $dy --num_heads 1 -e 4 "$@" 2>/dev/null | tail -1 | python3 -c "
