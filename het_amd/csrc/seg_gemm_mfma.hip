@@ -305,17 +305,25 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
 #pragma unroll
       for (int st = 0; st < SB; ++st) {
         const idx_t i = base + 2 * st + half, ic = i < we ? i : we - 1;
-        const int va = reinterpret_cast<const int*>(gp + (has_g ? ic : 0))[0];
-        const int vg = reinterpret_cast<const int*>(ggp + (has_gg ? ic : 0))[0];
-        A[st] = has_g ? va : (int)ic;
-        G[st] = has_gg ? vg : (int)ic;
+        // the raw loaded words: the choice between them and the row's own index is made where the row is fetched (one
+        // batch later) -- a select here would make the wave wait for the id loads it has just issued, and, the counter
+        // being in-order, for every row load before them (measured: 0.305 -> see DESIGN.md section 4.1)
+        A[st] = reinterpret_cast<const int*>(gp + (has_g ? ic : 0))[0];
+        G[st] = reinterpret_cast<const int*>(ggp + (has_gg ? ic : 0))[0];
       }
     };
     // Operand loads: with two 32-wide tiles along K (or X) a lane fetches the float PAIR (2*col, 2*col + 1) of its row with
     // one 8-byte load -- tile t then holds the features 2*m + t instead of t*32 + m, a relabelling of the product's rows
     // (columns) that the epilogue undoes.  Half the vector-memory instructions of one dword per tile (the kernel was
     // bound by their number).
-    auto load_rows = [&](const int (&A)[SB], const int (&G)[SB], float (&AV)[SB][KT], float (&GV)[SB][NT]) {
+    auto load_rows = [&](idx_t base, const int (&Ai)[SB], const int (&Gi)[SB], float (&AV)[SB][KT], float (&GV)[SB][NT]) {
+      int A[SB], G[SB];
+#pragma unroll
+      for (int st = 0; st < SB; ++st) {
+        const idx_t i = base + 2 * st + half, ic = i < we ? i : we - 1;
+        A[st] = has_g ? Ai[st] : (int)ic;
+        G[st] = has_gg ? Gi[st] : (int)ic;
+      }
 #pragma unroll
       for (int st = 0; st < SB; ++st) {
         if (KT == 2) {
@@ -347,18 +355,33 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
         }
       }
     };
+    // Batches of B = 2*SB rows.  At batch j: the rows of batch j+1 are fetched (their ids were issued TWO batches ago, so
+    // waiting for them leaves the rows of batch j in flight), the ids of batch j+3 are issued, batch j multiplies.  An id
+    // consumed one batch after its issue drained the whole load queue at every batch (the counter is in-order).
+    constexpr int B = 2 * SB;
+    int ar2[SB], gr2[SB];
     load_ids(wb, ar[0], gr[0]);
-    load_ids(wb + 2 * SB, ar[1], gr[1]);
-    load_rows(ar[0], gr[0], av[0], gv[0]);
-    for (idx_t b = wb; b < we; b += 4 * SB) {
-      load_rows(ar[1], gr[1], av[1], gv[1]);
-      load_ids(b + 4 * SB, ar[0], gr[0]);
+    load_ids(wb + B, ar[1], gr[1]);
+    load_ids(wb + 2 * B, ar2, gr2);
+    load_rows(wb, ar[0], gr[0], av[0], gv[0]);
+    auto shift_ids = [&](int (&Anew)[SB], int (&Gnew)[SB]) {  // ring: ar[1] <- ar2 <- Anew (ar[0] is refilled from ar[1] by the caller)
+#pragma unroll
+      for (int st = 0; st < SB; ++st) { ar[1][st] = ar2[st]; gr[1][st] = gr2[st]; ar2[st] = Anew[st]; gr2[st] = Gnew[st]; }
+    };
+    for (idx_t b = wb; b < we; b += 2 * B) {
+      int an[SB], gn[SB];
+      load_rows(b + B, ar[1], gr[1], av[1], gv[1]);
+      load_ids(b + 3 * B, an, gn);
       __builtin_amdgcn_sched_barrier(0);
       mma(b, av[0], gv[0]);
-      load_rows(ar[0], gr[0], av[0], gv[0]);
-      load_ids(b + 6 * SB, ar[1], gr[1]);
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the address arithmetic of the next loads behind the MFMAs)
+      shift_ids(an, gn);                  // ar[1] = ids of batch j+2, ar2 = ids of batch j+3
+      load_rows(b + 2 * B, ar[1], gr[1], av[0], gv[0]);
+      load_ids(b + 4 * B, an, gn);
       __builtin_amdgcn_sched_barrier(0);
-      mma(b + 2 * SB, av[1], gv[1]);
+      mma(b + B, av[1], gv[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      shift_ids(an, gn);
     }
   }
   constexpr int NACC = KT * NT * 16;
