@@ -1,6 +1,8 @@
 // Row-dot kernels (see seg_rowdot.hip.h).  A row of H*K floats is covered by LPR = H*K/4 lanes
 // (one float4 each, fully coalesced); KL = K/4 adjacent lanes share a head and combine their
 // partial dot products with xor-shuffles.  A wave handles 64/LPR rows per step.
+#include <stdlib.h>
+
 #include "seg_rowdot.hip.h"
 
 namespace {
@@ -43,6 +45,8 @@ constexpr int U = 4;  // rows per lane group and step; loads are issued in indep
     _Pragma("unroll") for (int u = 0; u < U; ++u) si[u] = ic[u];                  \
   }
 
+// (fetching the ids of step k+1 before touching the rows of step k was measured on these kernels: no gain -- the lists are
+//  short and the launches small; what they wait for is not the id -> row round trip)
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_rowdot_fwd(RowDotArgs a, int chunk) {
   constexpr int EPW = 64 / LPR;
@@ -236,6 +240,48 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dx(RowDotArgs a, int 
   }
 }
 
+// The read-modify-write form (a.rmw: the launch's rows hit distinct output rows) with a lane group per row: one 16-byte
+// load and store per lane, 64/LPR rows per instruction, the H gradients of a row as one vector load when H == 4.
+template <int LPR, int H>
+__global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dx_rmw(RowDotArgs a, int chunk) {
+  constexpr int EPW = 64 / LPR, K = LPR * 4;
+  int r;
+  idx_t rb, re;
+  if (!tile_to_relation(a.seg_ptrs, a.num_segs, chunk, blockIdx.x, r, rb, re)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4;
+  float4 w[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) w[h] = ld4(a.W + ((int64_t)r * H + h) * K + x);
+  for (idx_t base = rb; base < re; base += 4 * EPW * U) {
+    HET_ROWDOT_ROWS(EPW)
+    float g[U][H];
+    float4 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (H == 4) {
+        const float4 t = ld4(a.go + si[u] * H);
+        g[u][0] = t.x; g[u][1] = t.y; g[u][2] = t.z; g[u][3] = t.w;
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) g[u][h] = a.go[si[u] * H + h];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = ld4(a.out + gi[u] * K + x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        c[u].x = fmaf(g[u][h], w[h].x, c[u].x); c[u].y = fmaf(g[u][h], w[h].y, c[u].y);
+        c[u].z = fmaf(g[u][h], w[h].z, c[u].z); c[u].w = fmaf(g[u][h], w[h].w, c[u].w);
+      }
+      st4(a.out + gi[u] * K + x, c[u]);
+    }
+  }
+}
+
 template <int LPR, int H>
 __global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dw(RowDotArgs a, int chunk) {
   constexpr int EPW = 64 / LPR, K = LPR * 4;
@@ -252,11 +298,22 @@ __global__ __launch_bounds__(kBlock) void HET_rowdot1h_bwd_dw(RowDotArgs a, int 
     float4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = ld4(a.A + gi[u] * K + x);
+    float g[U][H];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (H == 4 && (reinterpret_cast<uintptr_t>(a.go) & 15) == 0) {  // the H gradients of a row as one 16-byte load
+        const float4 t = ld4(a.go + si[u] * H);
+        g[u][0] = t.x; g[u][1 % H] = t.y; g[u][2 % H] = t.z; g[u][3 % H] = t.w;
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) g[u][h] = a.go[si[u] * H + h];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const float gu = ok[u] ? a.go[si[u] * H + h] : 0.f;
+        const float gu = ok[u] ? g[u][h] : 0.f;
         acc[h].x = fmaf(gu, v[u].x, acc[h].x); acc[h].y = fmaf(gu, v[u].y, acc[h].y);
         acc[h].z = fmaf(gu, v[u].z, acc[h].z); acc[h].w = fmaf(gu, v[u].w, acc[h].w);
       }
@@ -331,8 +388,12 @@ int launch_rowdot_bwd_dx(const RowDotArgs& a, hipStream_t s) {
 
 int launch_rowdot_bwd_dw(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
-  int64_t chunk = ceil_div64(a.num_rows, 2048);  // about 2048 workgroups, one atomic flush each
-  if (chunk < 1024) chunk = 1024;
+  // Every workgroup ends with one atomic flush into the SAME H*K floats of its relation, and those serialise (~50 ns per
+  // workgroup): on ogbn-mag (2.4 M rows) 8192 / 4096 / 2048 / 1024 / 512 workgroups take 0.48 / 0.27 / 0.17 / 0.136 / 0.131 ms.
+  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 2048; }();  // A/B switches
+  static const int64_t n_wg = [] { const char* v = getenv("HET_ROWDOT_DW_WGS"); return v ? (int64_t)atoi(v) : 512; }();
+  int64_t chunk = ceil_div64(a.num_rows, n_wg);
+  if (chunk < min_chunk) chunk = min_chunk;
   dim3 grid((unsigned)(ceil_div64(a.num_rows, chunk) + a.num_segs)), block(kBlock);
   HET_ROWDOT_DISPATCH(a.H * a.K / 4, hipLaunchKernelGGL(HET_rowdot_bwd_dw<LPR>, grid, block, 0, s, a, (int)chunk));
   HET_LAUNCH_CHECK("HET_rowdot_bwd_dw");
@@ -364,15 +425,22 @@ int launch_rowdot1h_bwd_dx(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   const int chunk = chunk_for(a.num_rows);
   dim3 grid((unsigned)(ceil_div64(a.num_rows, chunk) + a.num_segs)), block(kBlock);
-  HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dx, a, chunk)
+  const bool vec = ((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.go) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0;
+  if (a.rmw && vec) {
+    HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dx_rmw, a, chunk)
+  } else {
+    HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dx, a, chunk)
+  }
   HET_LAUNCH_CHECK("HET_rowdot1h_bwd_dx");
   return HET_OK;
 }
 
 int launch_rowdot1h_bwd_dw(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
-  int64_t chunk = ceil_div64(a.num_rows, 2048);
-  if (chunk < 1024) chunk = 1024;
+  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 2048; }();  // A/B switches
+  static const int64_t n_wg = [] { const char* v = getenv("HET_ROWDOT_DW_WGS"); return v ? (int64_t)atoi(v) : 512; }();
+  int64_t chunk = ceil_div64(a.num_rows, n_wg);  // see launch_rowdot_bwd_dw
+  if (chunk < min_chunk) chunk = min_chunk;
   dim3 grid((unsigned)(ceil_div64(a.num_rows, chunk) + a.num_segs)), block(kBlock);
   HET_ROWDOT1H_DISPATCH(HET_rowdot1h_bwd_dw, a, (int)chunk)
   HET_LAUNCH_CHECK("HET_rowdot1h_bwd_dw");
