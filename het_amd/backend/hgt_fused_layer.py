@@ -30,11 +30,9 @@ FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
 
 
 def hgt_fused_ok(G, h, num_heads, d_k):
-    """Full graphs with the unique (relation, node) lists (built on demand) and canonical relations, on the GPU, shapes the
-    row kernels are built for."""
+    """Graphs (full, or sampled blocks large enough to keep their groupings) with the unique (relation, node) lists (built on
+    demand) and canonical relations, on the GPU, shapes the row kernels are built for."""
     if not (FUSED and _k._plan.enabled and h.is_cuda and h.dim() == 2 and hasattr(G, "graph_data") and G.get_num_edges() > 0):
-        return False
-    if G.graph_data["original"].get("node_segment_types") is not None:  # sampled block: node types come in runs
         return False
     if not (_has_single_sided_lists(G) or hasattr(G, "generate_separate_unique_node_indices_single_sided_for_each_etype")):
         return False

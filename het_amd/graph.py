@@ -357,7 +357,9 @@ class HetGraph:
             rp = s["rel_ptrs"]
             first = rp[:-1].clamp(max=max(0, s["row_indices"].numel() - 1))
             empty = rp[1:] == rp[:-1]
-            typ = lambda nodes: torch.searchsorted(offs[1:].contiguous(), nodes, right=True).clamp(max=offs.numel() - 2)
+            run = lambda nodes: torch.searchsorted(offs[1:].contiguous(), nodes, right=True).clamp(max=offs.numel() - 2)
+            seg_types = self.graph_data["original"].get("node_segment_types")  # sampled block: runs of equal type (sampling.py)
+            typ = run if seg_types is None else (lambda nodes: seg_types[run(nodes)])
             E = s["row_indices"].numel()
             if E == 0:
                 z = torch.zeros(rp.numel() - 1, dtype=_I64, device=rp.device)
