@@ -228,7 +228,11 @@ def main(argv=None):
                              hgt_fused_attn_score_flag=getattr(args, "hgt_fused_attn_score_flag", False))
     model = model.to(dev)
     labels = th.randint(0, args.num_classes, (N,), device=dev)  # random labels as train_dgl.py:132-148
-    optimizer = th.optim.Adam(list(model.parameters()) + list(embed.parameters()), lr=args.lr)
+    params = list(model.parameters()) + list(embed.parameters())
+    try:  # one kernel per step over all parameters (the [N, in] embedding table dominates); same update rule
+        optimizer = th.optim.Adam(params, lr=args.lr, fused=True)
+    except (RuntimeError, TypeError):
+        optimizer = th.optim.Adam(params, lr=args.lr)
     batches = None
     if not args.full_graph_training:  # sampled blocks, one batch of --batch_size seeds per step ("epoch" = one step here)
         from .sampling import NeighborSampler
