@@ -10,4 +10,4 @@ from .hgt_layers_and_funcs import *  # noqa: F401,F403
 def plan_enabled() -> bool:
     """Whether the cached device-side groupings (het_amd/plan.py) are in use (the fast paths of the ops)."""
     from .. import plan as _plan
-    return bool(_plan.enabled)
+    return bool(_plan.is_enabled())

@@ -22,6 +22,8 @@ import os
 
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from .. import kernels as _k
 from ..kernels import K
 from .rgat_fused_layer import _edge_rows, _has_single_sided_lists
@@ -32,7 +34,7 @@ FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
 def hgt_fused_ok(G, h, num_heads, d_k):
     """Graphs (full, or sampled blocks large enough to keep their groupings) with the unique (relation, node) lists (built on
     demand) and canonical relations, on the GPU, shapes the row kernels are built for."""
-    if not (FUSED and _k._plan.enabled and h.is_cuda and h.dim() == 2 and hasattr(G, "graph_data") and G.get_num_edges() > 0):
+    if not (FUSED and _k._plan.is_enabled() and h.is_cuda and h.dim() == 2 and hasattr(G, "graph_data") and G.get_num_edges() > 0):
         return False
     if not (_has_single_sided_lists(G) or hasattr(G, "generate_separate_unique_node_indices_single_sided_for_each_etype")):
         return False
@@ -58,6 +60,7 @@ def fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, num_h
     return th.cat([flat(wk), flat(wm)], dim=2).unsqueeze(1).contiguous()
 
 
+@_consistent_plan
 class HgtAttentionFunction(th.autograd.Function):
     @staticmethod
     def forward(ctx, G, num_heads, offs, h, w_kv, q_w):

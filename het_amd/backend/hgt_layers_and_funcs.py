@@ -3,6 +3,8 @@
 wrappers :425-503) and the inner-product classes of rgnn_layers_and_funcs.py:192-418, 499-591."""
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from .. import kernels as _k
 from ..kernels import K
 
@@ -15,6 +17,7 @@ __all__ = [
 ]
 
 
+@_consistent_plan
 class HGTFullGraphHeteroAttentionOps(th.autograd.Function):
     # reference: hgt_layers_and_funcs.py:9-121 (the in-CSR arguments are carried for its vertex-parallel dq kernel)
     @staticmethod
@@ -44,6 +47,7 @@ class HGTFullGraphHeteroAttentionOps(th.autograd.Function):
         return None, None, None, None, None, None, None, None, grad_k, grad_q, grad_w
 
 
+@_consistent_plan
 class HGTFullGraphMessageCalcEdgeSoftmaxAndMessageMeanAggregationCOO(th.autograd.Function):
     # reference: hgt_layers_and_funcs.py:124-295
     @staticmethod
@@ -103,6 +107,7 @@ def hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(re
         s["eids"], relation_meg_weight.contiguous(), inputs.contiguous(), score, sum_per_node, mu.contiguous(), m, a, new_h)
 
 
+@_consistent_plan
 class _InnerProduct(th.autograd.Function):
     @staticmethod
     def forward(ctx, kind, map_a, map_b, rel_ptrs, eids, row, col, left, right, ret):

@@ -14,12 +14,15 @@ this path is the drop-in number: ``bench.py`` reports it as ``variants.reference
 """
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from ..kernels import K
 
 __all__ = ["RefRgnnRelationalMatmul", "RefRelationalFusedGatSeparateCOO", "ref_rgnn_relational_matmul",
            "ref_relational_fused_gat_separate_coo", "rgat_layer_reference_sequence"]
 
 
+@_consistent_plan
 class RefRgnnRelationalMatmul(th.autograd.Function):
     @staticmethod
     def forward(ctx, separate_coo_relptrs, separate_coo_node_indices, separate_coo_eids, weights, inputs, ret,
@@ -44,6 +47,7 @@ class RefRgnnRelationalMatmul(th.autograd.Function):
         return None, None, None, grad_weight, grad_input, None, None
 
 
+@_consistent_plan
 class RefRelationalFusedGatSeparateCOO(th.autograd.Function):
     @staticmethod
     def forward(ctx, eids, rel_ptrs, row, col, feat_src, el, er, s, exp, ret, slope):

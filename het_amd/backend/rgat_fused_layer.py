@@ -28,6 +28,8 @@ import os
 
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from .. import kernels as _k
 from ..kernels import K
 
@@ -91,7 +93,7 @@ def _edge_rows(g, ss, direct, rp, row, col, eids):
 def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
     R, H, Kd, D = W.shape
-    if not (_k._plan.enabled and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0
+    if not (_k._plan.is_enabled() and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0
             and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
         return False
     compact, _, mulfirst_eff = effective_flags(g, W, compact, True, mulfirst)
@@ -104,6 +106,7 @@ def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     return _k.matmul_attn_dot_only_ok(by_dst, W, x)
 
 
+@_consistent_plan
 class RgatLayerFunction(th.autograd.Function):
     @staticmethod
     def forward(ctx, g, compact, direct, mulfirst, slope, num_dst, halo, x, W, attn_l, attn_r, loop_w, bias):

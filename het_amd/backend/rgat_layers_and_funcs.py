@@ -3,6 +3,8 @@
 wrappers :651-890)."""
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from .. import kernels as _k
 from ..kernels import K
 
@@ -18,6 +20,7 @@ __all__ = [
 ]
 
 
+@_consistent_plan
 class RelationalFusedGatCSR(th.autograd.Function):
     # reference: rgat_layers_and_funcs.py:8-115
     @staticmethod
@@ -46,6 +49,7 @@ class RelationalFusedGatCSR(th.autograd.Function):
         return (None,) * 10 + (grad_feat_src, grad_el, grad_er, None, None, None, None)
 
 
+@_consistent_plan
 class _FusedGatSeparateCOO(th.autograd.Function):
     """Shared body of the separate-COO classes: ``kind`` and the two dicts select the row maps."""
 
@@ -78,6 +82,7 @@ class _FusedGatSeparateCOO(th.autograd.Function):
         return None, None, None, None, None, None, None, grad_feat_src, grad_el, grad_er, None, None, None, None
 
 
+@_consistent_plan
 class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
     """el = <feat_src, attn_l[r]> (the D_out = 1 segment GEMM of RGAT/models.py:288-296) and the fused GAT op under
     ONE autograd node, so that the two gradients that meet in feat_src are written by one store: the GAT backward
@@ -119,6 +124,7 @@ class _FusedGatSeparateCOOWithAttnL(th.autograd.Function):
         return None, None, None, None, grad_feat_src, grad_attn_l, grad_el, None, None, None, None, None
 
 
+@_consistent_plan
 class _FusedGatCompactWithAttnL(th.autograd.Function):
     """The compact-as-of-node counterpart of _FusedGatSeparateCOOWithAttnL: el_compact = <feat_compact, attn_l[r]> over
     the (relation, source) rows and the fused GAT op (kinds 3 / 4) under one autograd node; the gradient through el is
@@ -151,7 +157,7 @@ class _FusedGatCompactWithAttnL(th.autograd.Function):
 def relational_fused_gat_compact_with_attn_l_ok(g, feat_compact, attn_l, negative_slope):
     """Shapes / state for which the compact GAT backward runs on its groupings (the fold lives there)."""
     H, D = attn_l.shape[1], attn_l.shape[2]
-    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat_compact.is_cuda
+    return (_k._plan.is_enabled() and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat_compact.is_cuda
             and g.get_num_edges() > 0)
 
 
@@ -184,7 +190,7 @@ def relational_fused_gat_separate_coo_with_attn_l_ok(g, feat, attn_l, negative_s
     """Whether the fused node applies: kind 0 shapes of the destination-grouped kernels, slope >= 0."""
     H = attn_l.shape[1]
     D = attn_l.shape[2]
-    return (_k._plan.enabled and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat.is_cuda
+    return (_k._plan.is_enabled() and negative_slope >= 0 and _k.gat_grouped_shape_ok(H, D) and feat.is_cuda
             and g.get_num_edges() > 0)
 
 

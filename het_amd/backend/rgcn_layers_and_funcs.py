@@ -2,6 +2,8 @@
 /root/reference/hrt/python/backend/rgcn_layers_and_funcs.py:481-824."""
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from ..kernels import K
 
 __all__ = [
@@ -11,6 +13,7 @@ __all__ = [
 ]
 
 
+@_consistent_plan
 class RgcnLayer1SeparateCoo(th.autograd.Function):
     # reference: rgcn_layers_and_funcs.py:481-567 (the out-CSR arguments are carried but unused there too)
     @staticmethod
@@ -33,6 +36,7 @@ class RgcnLayer1SeparateCoo(th.autograd.Function):
         return None, None, None, None, None, None, None, None, grad_x, grad_weight, grad_norm, None
 
 
+@_consistent_plan
 class RgcnLayer1SeparateCooBias(th.autograd.Function):
     """RgcnLayer1SeparateCoo with the layer's bias (RGCN/RGCN.py:338-340, ``node_repr + h_bias``) inside the node: the op
     accumulates into ``ret`` (reference contract), so ``ret`` starts from the bias rows instead of zeros -- one fill instead
@@ -70,6 +74,7 @@ def rgcn_layer1_separate_coo(graph, x, weight, norm, bias=None):
                                        norm.contiguous(), ret)
 
 
+@_consistent_plan
 class _RGCNCompactAgg(th.autograd.Function):
     @staticmethod
     def forward(ctx, eids, rel_ptrs, row, col, map_a, map_b, feat_src, enorm, ret, direct):

@@ -6,6 +6,8 @@ transposed-weight / zero-filled-gradient protocol of ``backward`` (:43-73) and
 the wrappers that allocate the outputs (:423-493)."""
 import torch as th
 
+from ..plan import consistent as _consistent_plan
+
 from .. import kernels as _k
 from ..kernels import K
 
@@ -17,6 +19,7 @@ __all__ = [
 ]
 
 
+@_consistent_plan
 class RgnnRelationalMatmul(th.autograd.Function):
     # reference: rgnn_layers_and_funcs.py:8-73
     @staticmethod
@@ -44,6 +47,7 @@ class RgnnRelationalMatmul(th.autograd.Function):
         return None, None, None, grad_weight, grad_input, None, None
 
 
+@_consistent_plan
 class _RgnnRelationalMatmulWithAttnDot(th.autograd.Function):
     """Per-edge projection (RgnnRelationalMatmul, one input head, kind 0) that also returns the attention term
     dot[e, h] = <feat[e, h, :], attn[r, h, :]> from the GEMM epilogue (RGAT/models.py:288-296 forms it with a second
@@ -108,6 +112,7 @@ class _RgnnRelationalMatmulWithAttnDot(th.autograd.Function):
         return None, None, None, grad_weight, grad_input, grad_attn, None
 
 
+@_consistent_plan
 class _RgnnRelationalMatmulAttnDotOnly(th.autograd.Function):
     """dot[e, h] = <x[node(e)] . W[r, h], attn[r, h, :]> per edge WITHOUT the per-edge projection tensor: the S distinct
     (relation, node) rows are projected once and kept ([S,H,D]), only their [S,H] dots are duplicated to the edges.
@@ -157,6 +162,7 @@ def rgnn_relational_matmul_with_attn_dot(arg_tensor_dict, weights, inputs, attn,
         arg_tensor_dict["separate_coo_eids"], weights.contiguous(), inputs.contiguous(), attn.contiguous(), folded)
 
 
+@_consistent_plan
 class RgnnRelationalMatmulNoScatterGatherList(th.autograd.Function):
     # reference: rgnn_layers_and_funcs.py:76-118
     @staticmethod
@@ -176,6 +182,7 @@ class RgnnRelationalMatmulNoScatterGatherList(th.autograd.Function):
         return None, grad_weight, grad_input, None
 
 
+@_consistent_plan
 class RgnnRelationalMatmulCompactAsOfNode(th.autograd.Function):
     # reference: rgnn_layers_and_funcs.py:121-189
     @staticmethod

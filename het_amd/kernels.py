@@ -159,7 +159,7 @@ def rgnn_relational_matmul(args_tensor_dict, IntKind, weights, node_feat, ret, I
     # distinct (relation, node) rows + broadcast: the row-dot shape (D == 1), and projections the matrix-core kernel does
     # not take (e.g. an 8-wide output layer)
     if (IntKind == 0 and InputNumHeadOneFlag and ((D == 1 and H & (H - 1) == 0) or (D > 1 and not mfma and X & (X - 1) == 0 and X <= 256))
-            and _plan.enabled and ret.is_cuda and g.numel() > 0 and g.data_ptr() != s.data_ptr()):
+            and _plan.is_enabled() and ret.is_cuda and g.numel() > 0 and g.data_ptr() != s.data_ptr()):
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
         if grp is not None:
             ws = torch.empty(max(1, grp.num_segments) * X, dtype=torch.float32, device=ret.device)
@@ -177,7 +177,7 @@ def matmul_attn_dot_only_ok(args_tensor_dict, weights, node_feat) -> bool:
     """Whether the attention term can be formed without materialising the per-edge projection (kind 0 lists)."""
     R, H, K, D = weights.shape
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
-    return (_plan.enabled and node_feat.is_cuda and matmul_attn_dot_ok(H, K, D) and H & (H - 1) == 0 and H <= H * D // 4
+    return (_plan.is_enabled() and node_feat.is_cuda and matmul_attn_dot_ok(H, K, D) and H & (H - 1) == 0 and H <= H * D // 4
             and g.numel() > 0 and g.data_ptr() != s.data_ptr())
 
 
@@ -191,7 +191,7 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
          tuple(t for t in (rp, g, s) if t is not None))
     R, H, K, D = weights.shape
     grp = ws = comp = None
-    if IntKind == 0 and _plan.enabled and g.numel() > 0 and g.data_ptr() != s.data_ptr():
+    if IntKind == 0 and _plan.is_enabled() and g.numel() > 0 and g.data_ptr() != s.data_ptr():
         grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)  # the grouping the backward uses as well
         if grp is not None:
             S = max(1, grp.num_segments)
@@ -240,7 +240,7 @@ def matmul_attn_dot_only_backward(args_tensor_dict, weights_transposed, node_fea
     path does not apply (no grouping / shape), leaving the outputs untouched."""
     rp, g, s = _matmul_lists(args_tensor_dict, 0)
     R, H, D, K = weights_transposed.shape
-    if not (_plan.enabled and H & (H - 1) == 0 and D % 4 == 0 and g.numel() > 0):
+    if not (_plan.is_enabled() and H & (H - 1) == 0 and D % 4 == 0 and g.numel() > 0):
         return False
     grp = _plan.get_grouping(rp, g, node_feat.shape[0], s, None)
     if grp is None:
@@ -374,7 +374,7 @@ def _gat_direct(kind, maps, rel_ptrs, row, col, eids):
     kind 4 once per graph (feat / er row of every edge id, cached) -- the maps the kernels read without searching."""
     if kind == 2:
         return 4, maps  # (maps[2] is maps[0]: see _gat_maps)
-    if kind not in (1, 3) or not _plan.enabled or eids.numel() == 0:
+    if kind not in (1, 3) or not _plan.is_enabled() or eids.numel() == 0:
         return kind, maps
 
     def build():
@@ -424,7 +424,7 @@ def _rel_by_position(rel_ptrs, num_positions):
 def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
     """Positions grouped by destination; payload0 = edge id, payload1 = feat row (compact kinds) or the relation
     of the position (kind 0; read by the fold_attn_l backward)."""
-    if not _plan.enabled:
+    if not _plan.is_enabled():
         return None
     p1 = _rel_by_position(rel_ptrs, eids.numel()) if kind == 0 else _src_rows_by_position(kind, maps, rel_ptrs, row, eids)
     return _plan.get_grouping(None, col, num_nodes, eids, p1)
@@ -504,7 +504,7 @@ def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_ro
     g = _by_dst(0, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                 separate_coo_eids, N) if IntKind == 0 else None
     gs = gd = ws = None
-    if IntKind != 0 and _plan.enabled and slope >= 0 and gat_grouped_shape_ok(H, D) and E > 0:
+    if IntKind != 0 and _plan.is_enabled() and slope >= 0 and gat_grouped_shape_ok(H, D) and E > 0:
         srow = _src_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_eids)
         drow = _dst_rows_by_position(IntKind, maps, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
         gs = _plan.get_grouping(None, srow, feat_src.shape[0], separate_coo_eids, separate_coo_col_indices)
@@ -658,7 +658,7 @@ def relational_fused_gat_csr(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr
          (incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes))
     N, E, H = incsr_row_ptr.numel() - 1, incsr_eids.numel(), el.shape[1]
     D = ret.numel() // max(1, N * H)
-    if not CompactAsOfNodeFlag and _plan.enabled and E > 0 and gat_grouped_shape_ok(H, D):
+    if not CompactAsOfNodeFlag and _plan.is_enabled() and E > 0 and gat_grouped_shape_ok(H, D):
         # the in-CSR IS the edge list grouped by destination: same math as the separate-COO op on (eids, src, dst) in
         # CSR order, served by the destination-grouped kernels instead of E*H*D float atomics
         dst, rp1 = _csr_expanded_rows(incsr_row_ptr, E)
@@ -682,7 +682,7 @@ def backward_relational_fused_gat_csr(outcsr_row_ptr, outcsr_col_indices, outcsr
          (outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes))
     N, E, H = outcsr_row_ptr.numel() - 1, outcsr_eids.numel(), el.shape[1]
     D = ret.numel() // max(1, N * H)
-    if not CompactAsOfNodeFlag and _plan.enabled and E > 0 and gat_grouped_shape_ok(H, D) and slope >= 0:
+    if not CompactAsOfNodeFlag and _plan.is_enabled() and E > 0 and gat_grouped_shape_ok(H, D) and slope >= 0:
         # out-CSR rows are the sources: (eids, src, dst) in CSR order through the destination-grouped backward (every
         # gradient row of kind 0 belongs to one edge, so "+=" into the zero-filled buffers equals the stores it does)
         src, rp1 = _csr_expanded_rows(outcsr_row_ptr, E)
@@ -756,7 +756,7 @@ def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate_coo_eids
          + ((b,) if b is not None else ()))
     N = ret.shape[0]
     g = None
-    if _plan.enabled and separate_coo_eids.numel() > 0:
+    if _plan.is_enabled() and separate_coo_eids.numel() > 0:
         crow = _src_rows_by_position(4 if DirectIndexFlag else 3, (a, b, None, None), separate_coo_rel_ptrs,
                                      separate_coo_row_indices, separate_coo_eids)
         g = _plan.get_grouping(None, separate_coo_col_indices, N, crow, separate_coo_eids)
@@ -781,7 +781,7 @@ def backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(separate
          + ((b,) if b is not None else ()))
     N = ret.shape[0]
     g = None
-    if _plan.enabled and separate_coo_eids.numel() > 0:
+    if _plan.is_enabled() and separate_coo_eids.numel() > 0:
         crow = _src_rows_by_position(4 if DirectIndexFlag else 3, (a, b, None, None), separate_coo_rel_ptrs,
                                      separate_coo_row_indices, separate_coo_eids)
         g = _plan.get_grouping(None, crow, grad_feat_src.shape[0], separate_coo_col_indices, separate_coo_eids)
@@ -813,7 +813,7 @@ def _ip_direct(d: Dict[str, Tensor], kind: int, rel_ptrs, col, eids):
     """(kind, map_a, map_b) as handed to the C entry points: the binary-search kind 1 is turned into the direct-index
     kind 2 once per graph (left row of every edge id; cached), which is what the fast row kernels read."""
     a, b = _ip_maps(d, kind)
-    if kind != 1 or not _plan.enabled or eids.numel() == 0:
+    if kind != 1 or not _plan.is_enabled() or eids.numel() == 0:
         return kind, a, b
     def build():
         lrow = _rows_by_search(rel_ptrs, col, a, b)
@@ -876,7 +876,7 @@ def inner_product_backward(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, sepa
     D = right_node_vectors.numel() // max(1, right_node_vectors.shape[0] * H)
     IntKind, a, b = _ip_direct(arg_tensor_dict, IntKind, separate_coo_rel_ptrs, separate_coo_col_indices, separate_coo_eids)
     g = gl = None
-    if IntKind in (0, 2) and _plan.enabled:
+    if IntKind in (0, 2) and _plan.is_enabled():
         if IntKind == 0:
             lrow = separate_coo_eids
         else:

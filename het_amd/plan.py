@@ -12,7 +12,9 @@ entry is alive, and ``_version`` catches in-place edits.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from collections import OrderedDict
 from typing import Optional
 
@@ -22,7 +24,47 @@ from . import _lib
 
 _MAX_ENTRIES = 32
 _cache: "OrderedDict[tuple, Grouping]" = OrderedDict()
-enabled = True  # tests flip this to exercise the atomics kernels
+enabled = True  # process-wide default; tests flip this to exercise the atomics kernels
+_tls = threading.local()  # .force: this thread's override of `enabled` (forced(), sampling.one_shot_graphs)
+
+
+def is_enabled() -> bool:
+    """Whether the ops called from this thread use the cached groupings: the thread's override if one is set (``forced``),
+    else the process-wide default ``enabled``."""
+    f = getattr(_tls, "force", None)
+    return enabled if f is None else f
+
+
+@contextlib.contextmanager
+def forced(value: Optional[bool]):
+    """Run a block with groupings on / off on THIS thread only (None: no override).  Other threads -- a concurrent model, the
+    autograd engine's workers -- are not affected; an autograd node keeps the choice of its forward for its backward
+    through ``consistent`` below, whichever thread runs it."""
+    old = getattr(_tls, "force", None)
+    _tls.force = value
+    try:
+        yield
+    finally:
+        _tls.force = old
+
+
+def consistent(cls):
+    """Class decorator for torch.autograd.Function subclasses: backward runs with the groupings on / off as they were
+    when forward ran (kernel selection in the two passes has to match: several backward passes reuse what the grouped
+    forward built), wherever and on whatever thread autograd calls it."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        ctx._het_plan_on = is_enabled()
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        with forced(getattr(ctx, "_het_plan_on", None)):
+            return bwd(ctx, *grads)
+
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
 
 
 class Grouping:
@@ -59,7 +101,7 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
                  payload0: Optional[torch.Tensor] = None, payload1: Optional[torch.Tensor] = None) -> Optional[Grouping]:
     """Grouping of the positions of ``keys`` by (relation, key) -- by key alone when
     ``rel_ptrs`` is None.  Returns None when groupings are disabled."""
-    if not enabled:
+    if not is_enabled():
         return None
     k = (_ident(rel_ptrs), _ident(keys), int(key_bound), _ident(payload0), _ident(payload1), keys.device.index)
     g = _cache.get(k)

@@ -126,16 +126,14 @@ ONE_SHOT_MIN_EDGES = 1 << 20
 @contextlib.contextmanager
 def one_shot_graphs(blocks: Optional[List[Block]] = None, min_edges: int = ONE_SHOT_MIN_EDGES):
     """Wrap one whole training step on sampled blocks -- forward AND backward -- in this: when every block is small the
-    ops run on their preprocessing-free kernels (het_amd.plan.enabled = False) for the duration."""
+    ops run on their preprocessing-free kernels (het_amd.plan.forced(False)) for the duration."""
     from . import plan
     small = blocks is None or all(b.graph.get_num_edges() < min_edges for b in blocks)
-    old = plan.enabled
-    if small:
-        plan.enabled = False
-    try:
+    # a per-thread override, not a process-wide switch: a full-graph model running elsewhere in the process keeps its
+    # groupings, and every autograd node created here carries the choice into its backward (plan.consistent) -- also when
+    # loss.backward() runs after the block has been left or on an autograd worker thread
+    with plan.forced(False if small else None):
         yield
-    finally:
-        plan.enabled = old
 
 
 def run_blocks(layers, blocks: List[Block], h: torch.Tensor, edge_data: Optional[torch.Tensor] = None):
