@@ -22,7 +22,7 @@ srow, drow = inv["inverse_indices_row"], inv["inverse_indices_col"]
 feat = torch.randn(S_row, H, D, device=dev) * 0.1
 el, er = torch.randn(S_row, H, device=dev) * 0.1, torch.randn(S_col, H, device=dev) * 0.1
 sm, ret = torch.empty(N, H, device=dev), torch.empty(N, H, D, device=dev)
-for fold in (1, 2, 4, 8, 16, 64):
+for fold in (1, 2, 4, 8, 16, 64, 256, 1024, 16384):
     m = (S_row + fold - 1) // fold
     sr = (srow % m).contiguous()
     grp = k.rgat_compact_groupings(s["col_indices"], sr, drow, N, S_row, S_col)

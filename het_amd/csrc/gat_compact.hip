@@ -325,6 +325,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
 // Measured and dropped (same box, ogbn-mag):
 //  * splitting it like the backward (packs of short destination segments per lane group, long ones per wave): 0.94-0.96 ms
 //    against 0.93 ms for this kernel alone -- the pass runs at the memory system's rate either way;
+//  * the edge ids of a step through the scalar cache (they are wave-uniform addresses: s_load instead of two of the eight
+//    vector-memory instructions per step): 0.93 -> 2.45 ms -- scalar loads return out of order, so every step waits for all
+//    of them, and 32 ids per step do not stream through the scalar cache;
 //  * also accumulating P[(r,v),h,:] = SUM_e w_e dl_e feat_c[srow_e] per (relation, destination) here, so that the backward
 //    gets grad_er from S_col rows instead of a per-edge term [E,H] + a segmented sum of 16-byte gathers (0.59 ms, 3 GB):
 //    the per-relation accumulators take the kernel from 53 to 104 VGPRs = 8 -> 4 waves per SIMD and 0.93 -> 1.44-1.81 ms,
