@@ -328,13 +328,15 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
 //  * the edge ids of a step through the scalar cache (they are wave-uniform addresses: s_load instead of two of the eight
 //    vector-memory instructions per step): 0.93 -> 2.45 ms -- scalar loads return out of order, so every step waits for all
 //    of them, and 32 ids per step do not stream through the scalar cache;
+//  * persistent waves that walk the items with a stride and fetch the record and first ids of their next item while the
+//    current one is in flight (an item is 26 edges = 2 steps on average, so a wave per item is one dependent chain item
+//    record -> ids -> rows -> store): 0.92 -> 1.02-1.11 ms with 1024 .. 8192 workgroups;
 //  * also accumulating P[(r,v),h,:] = SUM_e w_e dl_e feat_c[srow_e] per (relation, destination) here, so that the backward
 //    gets grad_er from S_col rows instead of a per-edge term [E,H] + a segmented sum of 16-byte gathers (0.59 ms, 3 GB):
 //    the per-relation accumulators take the kernel from 53 to 104 VGPRs = 8 -> 4 waves per SIMD and 0.93 -> 1.44-1.81 ms,
 //    more than the 0.7 ms it saves in the backward.
 template <int LPR, int DL>
-__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, const int32_t* __restrict__ p_srow,
-                                                                   const int32_t* __restrict__ p_drow,
+__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, const int2* __restrict__ p01,
                                                                    const float* __restrict__ feat,
                                                                    const float* __restrict__ el,
                                                                    const float* __restrict__ er,
@@ -352,22 +354,21 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float ssum = 0.f;
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
-  int srown = p_srow[jn], drown = p_drow[jn];
+  int2 idn = p01[jn];  // {feat row, er row} of the edge: one load (grouping_packed_ids)
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const bool add_h = hio && whole && slot == 0 && v < hio_rows;  // see HET_rgat_aggregate_compact
   float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (add_h) h0 = ld4(hio + v * X + x);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int srowv = srown, drowv = drown;
+    const int srowv = idn.x, drowv = idn.y;
     const float zlv = el[(int64_t)srowv * H + h];
     const float zrv = er[(int64_t)drowv * H + h];
     float4 f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
-    srown = p_srow[jn];
-    drown = p_drow[jn];
+    idn = p01[jn];
     const float wv = j0 + dq * EPW < e ? fast_leaky_exp(zlv + zrv, slope) : 0.f;  // one exp per (edge, head)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
 // Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {1/sum, <gradout, ret>} interleaved.
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
-    Packs pk, const int32_t* __restrict__ p_dst, const int32_t* __restrict__ p_drow, const float* __restrict__ feat,
+    Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat,
     const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack2,
     const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
     float* __restrict__ tbuf, int H, float slope, const float* __restrict__ fold_w,
@@ -428,12 +429,12 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
 #pragma unroll
   for (int i = 0; i < 7; ++i) rp[i] = (fold_w && i + 1 < R) ? (int)fold_row_rel_ptrs[i + 1] : 0x7fffffff;
   int jn = b + dq < e ? b + dq : e - 1;
-  int keyn = pk.key[jn], dstn = p_dst[jn], drown = p_drow[jn];
+  int4 idn = kp01[jn];  // {feat row, destination, er row} of the edge: one load (grouping_packed_ids)
   int prev_key = -1, rel_cur = -1;
   float4 fcur = make_float4(0.f, 0.f, 0.f, 0.f), wcur = fcur, acc = fcur;
   float acc_el = 0.f;
   for (int j0 = b; j0 < e; j0 += U) {
-    const int keyv = keyn, dstv = dstn, drowv = drown;
+    const int keyv = idn.x, dstv = idn.y, drowv = idn.z;
     // scalars of the step: lane (h, q) fetches those of edge q, head h
     const float zrv = er[(int64_t)drowv * H + h];
     const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
@@ -451,9 +452,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     }
     // ids of the next step, in flight while this step's rows arrive
     jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
-    keyn = pk.key[jn];
-    dstn = p_dst[jn];
-    drown = p_drow[jn];
+    idn = kp01[jn];
     // per (edge, head) once: attention weight, its leaky-ReLU branch, the destination's <gradout, ret>
     const float zv = zlv + zrv;
     const float av = j0 + dq < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
       const float t = ad * (dot - gr);  // 0 for the padding edges of the last step (a == 0)
       tq[q] = t;
       acc_el += t;  // identical in the DL lanes of a head
-      const int key_next = q + 1 < U ? key[q + 1] : head_bcast_i<DL>(keyn, 0, lane);
+      const int key_next = q + 1 < U ? key[q + 1] : head_bcast_i<DL>(idn.x, 0, lane);
       if (ok && (j0 + q == e - 1 || key_next != key[q])) {  // the segment (or this pack's piece of it) ends: one store
         const int64_t u = key[q];
         float4 o = acc;
@@ -526,8 +525,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
 // (atomic adds only for the items of a segment longer than HET_ITEM_MAX, whose rows HET_rgat_zero_long_rows cleared).
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
-    Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int32_t* __restrict__ p_dst,
-    const int32_t* __restrict__ p_drow, const float* __restrict__ feat, const float* __restrict__ el,
+    Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int2* __restrict__ p01,
+    const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ pack2, const float* __restrict__ gradout,
     float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, float slope,
     const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
   const int item = long_items[wid];
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
-  int dstn = p_dst[jn], drown = p_drow[jn];
+  int2 idn = p01[jn];
   const int64_t u = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 f = ld4(feat + u * X + x);
@@ -549,15 +548,14 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float acc_el = 0.f;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int dstv = dstn, drowv = drown;
+    const int dstv = idn.x, drowv = idn.y;
     const float zrv = er[(int64_t)drowv * H + h];
     const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
     float4 g[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
-    dstn = p_dst[jn];
-    drown = p_drow[jn];
+    idn = p01[jn];
     const float zv = zl + zrv;
     const float av = j0 + dq * EPW < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
     const float adv = av * (zv > 0.f ? 1.f : slope);
@@ -684,12 +682,14 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
   if (by_dst->E == 0) return HET_OK;
   Items it{by_dst->item_seg, by_dst->item_begin, by_dst->item_end, by_dst->seg_ptr, by_dst->seg_key, by_dst->num_items};
   const unsigned nb = (unsigned)ceil_div64(by_dst->num_items, kBlock / 64);
+  if (coop_shape_ok(H, D))
+    if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
   {
     HET_KTIME("HET_rgat_aggregate", s);
     if (coop_shape_ok(H, D)) {
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_aggregate_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p0,
-                                           by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows));
+                        hipLaunchKernelGGL((HET_rgat_aggregate_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p01,
+                                           feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows));
     } else {
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_aggregate_compact<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
                                                         by_dst->p0, by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (int)D,
@@ -770,11 +770,14 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
   Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   if (coop) {
+    if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;
+    if (by_srow->num_long_items > 0)
+      if (int rc = grouping_packed_ids(by_srow, false, s)) return rc;
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->p0,
-                                           by_srow->p1, feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
+                        hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
+                                           feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
                                            (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels));
     }
     HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
@@ -784,7 +787,7 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
       HET_KTIME("HET_rgat_backward_src_long", s);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
                         hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s, it,
-                                           by_srow->long_items, by_srow->num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c,
+                                           by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
                                            er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
                                            row_rel_ptrs, (int)num_rels));
     }

@@ -146,7 +146,7 @@ struct Scratch {  // frees device temporaries on every exit path
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -166,6 +166,8 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->p1) b += 4 * E;
   if (g->seg_of_rank) b += 4 * E;
   if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
+  if (g->p01) b += 8 * (E > 0 ? E : 1);
+  if (g->kp01) b += 16 * (E + 1);
   return b;
 }
 
@@ -365,5 +367,44 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   g->num_long_items = h_num[1];
   g->num_packs = h_num[0];
   g->pack_ptr = pack_ptr;
+  return HET_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void HET_grouping_pack_ids(const int32_t* __restrict__ key, const int32_t* __restrict__ p0,
+                                                             const int32_t* __restrict__ p1, int64_t E, int2* __restrict__ o2,
+                                                             int4* __restrict__ o4) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j <= E; j += (int64_t)gridDim.x * 256) {
+    const int64_t jc = j < E ? j : (E > 0 ? E - 1 : 0);
+    const int a = p0 ? p0[jc] : 0, b = p1 ? p1[jc] : 0;
+    if (o2 && j < E) o2[j] = make_int2(a, b);
+    if (o4) o4[j] = make_int4(j < E ? key[j] : -1, a, b, 0);
+  }
+}
+}  // namespace
+
+int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s) {
+  if (with_keys)
+    if (int rc = grouping_packs(g, s)) return rc;
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if ((with_keys ? (void*)g->kp01 : (void*)g->p01) || g->E == 0) return HET_OK;
+  const int64_t E = g->E;
+  int2* o2 = nullptr;
+  int4* o4 = nullptr;
+  if (with_keys) {
+    HET_REQUIRE(g->key_of_rank, "grouping_packed_ids: the grouping has no packs (no segments?)");
+    HET_HIP(hipMalloc((void**)&o4, sizeof(int4) * (size_t)(E + 1)));
+  } else {
+    HET_HIP(hipMalloc((void**)&o2, sizeof(int2) * (size_t)E));
+  }
+  hipLaunchKernelGGL(HET_grouping_pack_ids, dim3(blocks_for(E + 1)), dim3(256), 0, s, g->key_of_rank, g->p0, g->p1, E, o2, o4);
+  hipError_t e = hipGetLastError();
+
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete
+  if (e != hipSuccess) {
+    (void)hipFree(o2); (void)hipFree(o4);
+    HET_HIP(e);
+  }
+  if (with_keys) g->kp01 = o4; else g->p01 = o2;
   return HET_OK;
 }
