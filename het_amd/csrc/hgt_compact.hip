@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
 
 // Backward, source side, SHORT segments: lane group per pack of whole (relation, source) segments.
 template <int LPR, int DL>
-__global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, const int32_t* __restrict__ p_dst,
+__global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, const int4* __restrict__ kp01,
                                                                       const float* __restrict__ kv, const float* __restrict__ q,
                                                                       const float* __restrict__ pack2,
                                                                       const float* __restrict__ gradout,
@@ -231,12 +231,12 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
   const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
   if (pb >> 31) return;  // a long segment: HET_hgt_backward_src_long takes its work items
   int jn = b + qd < e ? b + qd : e - 1;
-  int keyn = pk.key[jn], dstn = p_dst[jn];
+  int4 idn = kp01[jn];  // {source row, destination, -, -} of the edge: one load (grouping_packed_ids)
   int prev_key = -1;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 kcur = zero, mcur = zero, acck = zero, accm = zero;
   for (int j0 = b; j0 < e; j0 += U) {
-    const int keyv = keyn, dstv = dstn;
+    const int keyv = idn.x, dstv = idn.y;
     int key[U];
     float4 qr[U], gr[U], kq[U], mq[U];
     float2 p2[U];
@@ -260,9 +260,8 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
       }
     }
     jn = j0 + U + qd < e ? j0 + U + qd : e - 1;
-    keyn = pk.key[jn];
-    dstn = p_dst[jn];
-    const int key_after = quad_bcast_i<0>(keyn);
+    idn = kp01[jn];
+    const int key_after = quad_bcast_i<0>(idn.x);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = j0 + u < e;  // uniform within the lane group
@@ -465,13 +464,13 @@ extern "C" int het_hgt_backward_compact(const het_grouping* by_dst, const het_gr
                                              kv_c, q, lsum, out, gradout, grad_q, pack2, (int)H));
   }
   HET_LAUNCH_CHECK("HET_hgt_backward_dst_rows");
-  if (int rc = grouping_packs(by_srow, s)) return rc;
+  if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;  // (builds the packs as well)
   {
     Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
     const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
     HET_KTIME("HET_hgt_backward_src_short", s);
     HET_DISPATCH_HGT_ROWS((int)(X / 4), (int)(D / 4),
-                          hipLaunchKernelGGL((HET_hgt_backward_src_short<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->p0,
+                          hipLaunchKernelGGL((HET_hgt_backward_src_short<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
                                              kv_c, q, pack2, gradout, grad_kv_c, (int)H));
   }
   HET_LAUNCH_CHECK("HET_hgt_backward_src_short");
