@@ -89,11 +89,14 @@ def _bench_line(cmd, env):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-def test_bench_distributed_flow_one_rank():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_distributed_flow_one_rank(backend):
     """bench.py's multi-GPU code path (DistRGAT: plan, halo exchange inside the layer node, gradient all-reduce) with a
-    process group of one rank on the test box's GPU."""
+    process group of one rank on the test box's GPU.  backend = nccl: the RCCL communicator itself -- init, the asynchronous
+    all_to_all_single of the halo contexts (empty on one rank), the gradient all-reduce and the timing all-reduce run
+    through RCCL; two RCCL ranks cannot share one GPU, so this is as far as a one-GPU box goes."""
     import sys
-    env = dict(os.environ, HET_FORCE_DIST="1", HET_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+    env = dict(os.environ, HET_FORCE_DIST="1", HET_DIST_BACKEND=backend, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = _bench_line([sys.executable, "bench.py", "--gpus", "1", "--scale", "0.02", "--steps", "3", "--warmup", "1",
                        "--no-cpu-baseline", "--no-variants"], env)
