@@ -27,6 +27,7 @@ from ..plan import consistent as _consistent_plan
 from .. import kernels as _k
 from ..kernels import K
 from .rgat_fused_layer import _edge_rows, _has_single_sided_lists
+from .rgnn_layers_and_funcs import rgnn_relational_matmul_no_scatter_gather_list as B_matmul_no_scatter_gather
 
 FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
 
@@ -60,36 +61,54 @@ def fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, num_h
     return th.cat([flat(wk), flat(wm)], dim=2).unsqueeze(1).contiguous()
 
 
+# Destinations WITHOUT in-edges receive nothing: their rows of new_h are zero, and so are their rows of the layer output
+# (the typed output projection has no bias).  When they are many (on the ogbn-mag-like graph 58 % of the nodes), q, lsum,
+# new_h and the output projection live on the S_dst destinations that do have in-edges: the row kernels are agnostic (their
+# "node" is then the rank of the destination in the sorted list of those), the two typed projections run on S_dst rows.
+COMPACT_DST_BELOW = float(os.environ.get("HET_HGT_COMPACT_DST", "0.8"))  # use the lists when S_dst < this fraction of N
+
+
 @_consistent_plan
 class HgtAttentionFunction(th.autograd.Function):
     @staticmethod
-    def forward(ctx, G, num_heads, offs, h, w_kv, q_w):
-        """h [N,in]; w_kv [R,1,in,2X]; q_w [T,1,in,X] typed projection of the destination side (one weight per run of offs)."""
+    def forward(ctx, G, num_heads, offs, h, w_kv, q_w, dst):
+        """h [N,in]; w_kv [R,1,in,2X]; q_w [T,1,in,X] typed projection of the destination side (one weight per run of offs).
+        dst = None: rows of the result are nodes.  dst = (dst_nodes, rank_of_edge, run_ptrs) (kernels.destination_lists):
+        rows are the destinations with in-edges, in that order."""
         h, w_kv, q_w = h.contiguous(), w_kv.contiguous(), q_w.contiguous()
         N, K_in = h.shape
         X = q_w.shape[3]
-        H, D = num_heads, X // num_heads
+        H = num_heads
         s = G.get_separate_coo_original()
         ss = G.get_separate_unique_node_indices_single_sided()
         rp_row, rows_node = ss["rel_ptrs_row"], ss["node_indices_row"]
         S_row = rows_node.numel()
         new = lambda *shape: th.empty(shape, dtype=h.dtype, device=h.device)
-        q = new(N, X)
-        K.rgnn_relational_matmul_no_scatter_gather_list(offs, q_w, h, q)
+        if dst is None:
+            ND, keys = N, s["col_indices"]
+            q = new(ND, X)
+            K.rgnn_relational_matmul_no_scatter_gather_list(offs, q_w, h, q)
+        else:
+            dst_nodes, keys, run_ptrs = dst
+            ND = dst_nodes.numel()
+            q = new(ND, 1, X)
+            K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes},
+                                     1, q_w, h, q, True)
+            q = q.view(ND, X)
         kv_c = new(S_row, 1, 2 * X)
         K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": rp_row, "unique_srcs_and_dests_node_indices": rows_node},
                                  1, w_kv, h, kv_c, True)
         srow, _ = _edge_rows(G, ss, True, s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"])
-        grp = _k.hgt_compact_groupings(s["col_indices"], srow, N, S_row)
-        lsum, out = new(N, H), new(N, X)
+        grp = _k.hgt_compact_groupings(keys, srow, ND, S_row)
+        lsum, out = new(ND, H), new(ND, X)
         _k.hgt_aggregate_compact(grp, kv_c, q, lsum, out)
-        ctx.G, ctx.H, ctx.grp = G, H, grp
-        ctx.save_for_backward(h, w_kv, q_w, offs, q, kv_c, lsum, out)
+        ctx.G, ctx.H, ctx.grp, ctx.compact_dst = G, H, grp, dst is not None
+        ctx.save_for_backward(h, w_kv, q_w, offs, q, kv_c, lsum, out, *(() if dst is None else (dst[0], dst[2])))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        h, w_kv, q_w, offs, q, kv_c, lsum, out = ctx.saved_tensors
+        h, w_kv, q_w, offs, q, kv_c, lsum, out, *lists = ctx.saved_tensors
         G, H = ctx.G, ctx.H
         N, K_in = h.shape
         X = q_w.shape[3]
@@ -98,9 +117,22 @@ class HgtAttentionFunction(th.autograd.Function):
         grad_out = grad_out.contiguous()
         g_kv, g_q = th.empty_like(kv_c), th.empty_like(q)
         _k.hgt_backward_compact(ctx.grp, kv_c, q, lsum, out, grad_out, g_kv, g_q)
-        # one input-gradient buffer: the typed projection writes every row with plain stores, the source-row GEMM adds to it
-        grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)
-        _k.matmul_no_scatter_gather_backward(offs, q_w.transpose(2, 3).contiguous(), h, g_q, grad_h, grad_qw, accumulate=False)
+        # one input-gradient buffer for both consumers of h
+        qwt = q_w.transpose(2, 3).contiguous()
+        if not ctx.compact_dst:  # the typed projection writes every row with plain stores, the source-row GEMM adds to it
+            grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)
+            _k.matmul_no_scatter_gather_backward(offs, qwt, h, g_q, grad_h, grad_qw, accumulate=False)
+        else:
+            dst_nodes, run_ptrs = lists
+            grad_h = th.zeros_like(h)
+            if _k.rows_matmul_backward_split_ok(1, K_in, X):
+                grad_qw = th.empty_like(q_w)
+                _k.rows_matmul_backward_dx(run_ptrs, dst_nodes, qwt, g_q, grad_h, atomic=2)  # distinct nodes
+                _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
+            else:
+                grad_qw = th.zeros_like(q_w)
+                _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes}, 1,
+                                   qwt, h, g_q.view(-1, 1, X), grad_h, grad_qw, True, accumulate=True)
         wt = w_kv.transpose(2, 3).contiguous()
         if _k.rows_matmul_backward_split_ok(1, K_in, 2 * X):
             grad_wkv = th.empty_like(w_kv)
@@ -110,13 +142,53 @@ class HgtAttentionFunction(th.autograd.Function):
             grad_wkv = th.zeros_like(w_kv)
             _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": rp_row, "unique_srcs_and_dests_node_indices": rows_node}, 1, wt, h,
                                g_kv, grad_h, grad_wkv, True, accumulate=True)
-        return None, None, None, grad_h, grad_wkv, grad_qw
+        return None, None, None, grad_h, grad_wkv, grad_qw, None
 
 
-def hgt_attention_fused(G, h, offs, q_w, k_lin, v_lin, rel_att, rel_msg, rel_pri, num_heads, fused_attn):
-    """new_h [N, H*dk] of the HGT layer (before the typed output projection)."""
+@_consistent_plan
+class RowsLinearScatter(th.autograd.Function):
+    """out[rows[i], :] = x_c[i, :] . w[t(i)] for the listed rows, zero elsewhere: a typed projection of compact rows written
+    straight into the dense result (and its gradient read straight from the dense gradient) -- no index_copy / index_select
+    passes.  rows are distinct and sorted, ``run_ptrs`` [T+1] splits them into the runs of ``w`` [T,1,K,X]."""
+
+    @staticmethod
+    def forward(ctx, run_ptrs, rows, num_out_rows, x_c, w):
+        x_c, w = x_c.contiguous(), w.contiguous()
+        out = th.zeros((num_out_rows, w.shape[3]), dtype=w.dtype, device=w.device)
+        # (the "transposed weight" slot of the dX entry point takes [T,1,D_in,K_out]: exactly w)
+        _k.rows_matmul_backward_dx(run_ptrs, rows, w, x_c, out, atomic=False)
+        ctx.save_for_backward(run_ptrs, rows, x_c, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        run_ptrs, rows, x_c, w = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        T, _, K_in, X_out = w.shape
+        g_x = th.empty((x_c.shape[0], 1, K_in), dtype=w.dtype, device=w.device)
+        K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": rows}, 1,
+                                 w.transpose(2, 3).contiguous(), grad_out, g_x, True)  # g_x[i] = grad_out[rows[i]] . w[t]^T
+        g_wt = th.empty((T, 1, X_out, K_in), dtype=w.dtype, device=w.device)
+        _k.rows_matmul_backward_dw(run_ptrs, rows, grad_out, x_c, g_wt, accumulate=False)  # SUM grad_out[rows[i]]^T (x) x_c[i]
+        return None, None, None, g_x.view_as(x_c), g_wt.transpose(2, 3)
+
+
+def hgt_layer_fused(G, h, offs, q_w, a_w, k_lin, v_lin, rel_att, rel_msg, rel_pri, num_heads, fused_attn):
+    """The HGT layer [N, out]: attention + aggregation as one node, then the typed output projection ``a_w`` [T,1,X,out] (one
+    weight per run of offs; the caller folds sigmoid(skip) in) -- on the destinations with in-edges only when those are a
+    minority of the nodes (the other rows of the output are zero by construction)."""
     if not _has_single_sided_lists(G):
         G.generate_separate_unique_node_indices_single_sided_for_each_etype()
     st, _ = G.get_rel_node_types()
     w_kv = fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, st, num_heads, fused_attn)
-    return HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w)
+    N = h.shape[0]
+    col = G.get_separate_coo_original()["col_indices"]
+    dst = _k.destination_lists(col, offs)
+    if dst[0].numel() >= COMPACT_DST_BELOW * N:
+        new_h = HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, None)
+        return B_matmul_no_scatter_gather(offs, a_w, new_h)
+    new_h_c = HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, dst)
+    if _k.rows_matmul_backward_split_ok(1, a_w.shape[3], a_w.shape[2]):
+        return RowsLinearScatter.apply(dst[2], dst[0], N, new_h_c, a_w)
+    out_c = B_matmul_no_scatter_gather(dst[2], a_w, new_h_c)  # rows of a type are a contiguous piece of the sorted list
+    return th.zeros((N, out_c.shape[1]), dtype=out_c.dtype, device=out_c.device).index_copy(0, dst[0], out_c)

@@ -608,6 +608,17 @@ def hgt_compact_shape_ok(H: int, D: int) -> bool:
     return bool(_lib.lib().het_hgt_compact_shape_ok(int(H), int(D)))
 
 
+def destination_lists(col, offsets):
+    """(dst_nodes [S_dst] sorted, rank_of_edge [E], run_ptrs [len(offsets)]) for the destinations that HAVE in-edges: the
+    distinct values of ``col``, the index of every edge's destination in that list, and the list split at the node-type
+    offsets (rows of a node type are a contiguous piece of the sorted list).  Built once per graph (cached)."""
+    def build():
+        nodes, inv = torch.unique(col, return_inverse=True)
+        ptrs = torch.searchsorted(nodes, offsets.to(nodes.dtype)).contiguous()
+        return nodes.contiguous(), inv.contiguous(), ptrs
+    return _derived_get("dst_lists", (col, offsets), build)
+
+
 def hgt_compact_groupings(col, srow, num_nodes, num_src_rows):
     """The two groupings of the compact HGT passes (include/het_amd.h: het_hgt_aggregate_compact): by destination and by
     (relation, source) row.  ``srow`` [E] int64: that row of every edge position."""

@@ -312,10 +312,9 @@ class HET_HGTLayerHetero(nn.Module):
         if _hgt_fused.hgt_fused_ok(G, h, self.num_heads, self.d_k):
             # attention + aggregation as one node on the distinct (relation, source) rows (backend/hgt_fused_layer.py): the
             # same function of the parameters for every flag combination below, without the per-edge tensors
-            new_h = _hgt_fused.hgt_attention_fused(G, h, offs, per_run(self.q_linears), self.k_linears, self.v_linears,
-                                                   self.relation_att, self.relation_msg, self.relation_pri, self.num_heads,
-                                                   self.hgt_fused_attn_score_flag)
-            out = B.rgnn_relational_matmul_no_scatter_gather_list(offs, per_run(th.sigmoid(self.skip) * self.a_linears), new_h)
+            out = _hgt_fused.hgt_layer_fused(G, h, offs, per_run(self.q_linears), per_run(th.sigmoid(self.skip) * self.a_linears),
+                                             self.k_linears, self.v_linears, self.relation_att, self.relation_msg,
+                                             self.relation_pri, self.num_heads, self.hgt_fused_attn_score_flag)
             return out if num_dst is None else out[:num_dst]
         if self.multiply_among_weights_first_flag:
             return self._forward_weights_first(G, h, offs, per_run, num_dst)

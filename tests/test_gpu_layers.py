@@ -198,15 +198,18 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
         assert_close(getattr(layer, n).grad, gr, what="grad_" + n)
 
 
-@pytest.mark.parametrize("fused_attn", [False, True])
+@pytest.mark.parametrize("fused_attn,compact_dst", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (1, 64, 64), (4, 64, 64), (2, 32, 64), (1, 32, 32), (4, 128, 128), (2, 64, 16)])
-def test_hgt_layer_fused(fused_attn, H, in_dim, out_dim, monkeypatch):
+def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch):
     """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
     (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
     (BASELINE.json configs[3]: feat 64, heads 8) -- against the fp64 oracle: output and the gradients of the input and of all
-    eight parameters.  A spy checks that the row kernels are what ran."""
+    eight parameters.  A spy checks that the row kernels are what ran.  compact_dst: q, new_h and the output projection on the
+    destinations that have in-edges only (the other output rows are zero by construction) / on all nodes."""
     import het_amd.kernels as k
+    from het_amd.backend import hgt_fused_layer
     from het_amd.layers import HET_HGTLayerHetero
+    monkeypatch.setattr(hgt_fused_layer, "COMPACT_DST_BELOW", 2.0 if compact_dst else 0.0)
     g = mag_graph(1.5e-3)
     torch.manual_seed(4)
     N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
