@@ -127,7 +127,7 @@ class HgtAttentionFunction(th.autograd.Function):
             grad_h = th.zeros_like(h)
             if _k.rows_matmul_backward_split_ok(1, K_in, X):
                 grad_qw = th.empty_like(q_w)
-                _k.rows_matmul_backward_dx(run_ptrs, dst_nodes, qwt, g_q, grad_h, atomic=2)  # distinct nodes
+                _k.rows_matmul_backward_dx(run_ptrs, dst_nodes, qwt, g_q, grad_h, atomic=False)  # distinct nodes, first writer: "="
                 _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
             else:
                 grad_qw = th.zeros_like(q_w)
