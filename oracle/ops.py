@@ -486,3 +486,21 @@ def backward_hgt_full_graph_hetero_attention_ops_coo(in_row_ptrs, in_col, in_eid
         grad_q.view(q.shape[0], H, do).index_add_(0, col[a0:b0], gs * inner.reshape(-1, H, do)[eids[a0:b0]])
         grad_k.view(k.shape[0], H, dk).index_add_(0, row[a0:b0], torch.einsum("nhd,hdk->nhk", gs * qq, Wt[r]))
         grad_W[r] += torch.einsum("nhk,nhd->hkd", kk, gs * qq)
+
+
+# --------------------------------------------------------------------------
+# HGT attention + aggregation on the distinct (relation, source) rows (no reference op of its own: the chain
+# relation_att product -> inner product -> edge softmax -> message product + aggregation of HGT/models.py:172-262 with its
+# source side pre-multiplied per (relation, source) row; include/het_amd.h het_hgt_aggregate_compact)
+# --------------------------------------------------------------------------
+def hgt_attention_rows(kv_c, q, srow, col, num_nodes):
+    """kv_c [S_row, 2, H, D] (k' then m of every (relation, source) row), q [N, H, D], srow / col [E]: the row and the
+    destination of every edge.  Returns (lsum [N,H], out [N,H,D]); differentiable (autograd gives the backward op's outputs).
+    exp without a running maximum, softmax over ALL in-edges of a destination (layers.hgt_layer)."""
+    H = q.shape[1]
+    s = (kv_c[srow, 0] * q[col]).sum(-1)
+    w = torch.exp(s)
+    lsum = torch.zeros(num_nodes, H, dtype=q.dtype, device=q.device).index_add(0, col, w)
+    out = torch.zeros_like(q[:num_nodes]).index_add(0, col, (w / lsum[col]).unsqueeze(-1) * kv_c[srow, 1])
+    return lsum, out
+

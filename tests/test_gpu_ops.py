@@ -241,9 +241,8 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
 @pytest.mark.parametrize("H,D,n,e", [(8, 8, 300, 5000), (1, 64, 300, 5000), (4, 16, 40, 9000), (2, 8, 12, 9000), (4, 32, 300, 700),
                                      (1, 32, 30, 4000), (2, 32, 300, 3000)])
 def test_hgt_compact_passes(K, H, D, n, e):
-    """het_hgt_aggregate_compact / het_hgt_backward_compact (include/het_amd.h) against their definition in fp64 autograd:
-    a = softmax over the in-edges of <k'[srow], q[dst]> per head (exp without a running maximum, oracle/layers.py hgt_layer),
-    out = SUM a * m[srow].  The layer-level parity with the oracle is tests/test_gpu_layers.py::test_hgt_layer_fused.
+    """het_hgt_aggregate_compact / het_hgt_backward_compact (include/het_amd.h) against oracle/ops.py::hgt_attention_rows in
+    fp64 (backward: its autograd): a = softmax over the in-edges of <k'[srow], q[dst]> per head, out = SUM a * m[srow].  The layer-level parity with the oracle is tests/test_gpu_layers.py::test_hgt_layer_fused.
     n = 12 / 30 / 40: hub destinations split over work items and long (relation, source) segments whose pieces add atomically."""
     import het_amd.kernels as k
     g = random_graph(seed=29, n=n, r=4, e=e)
@@ -256,10 +255,7 @@ def test_hgt_compact_passes(K, H, D, n, e):
     gen = torch.Generator().manual_seed(6)
     kv, q, go = torch.randn(S_row, 2, H, D, generator=gen) * 0.6, torch.randn(N, H, D, generator=gen) * 0.6, torch.randn(N, H, D, generator=gen)
     kv64, q64 = to64(kv).requires_grad_(True), to64(q).requires_grad_(True)
-    sc = (kv64[srow, 0] * q64[col]).sum(-1)
-    w = torch.exp(sc)
-    den = torch.zeros(N, H, dtype=torch.float64).index_add(0, col, w)
-    out_r = torch.zeros(N, H, D, dtype=torch.float64).index_add(0, col, (w / den[col]).unsqueeze(-1) * kv64[srow, 1])
+    den, out_r = O.hgt_attention_rows(kv64, q64, srow, col, N)
     gkv_r, gq_r = torch.autograd.grad(out_r, [kv64, q64], to64(go))
     grp = k.hgt_compact_groupings(col.to(DEV), srow.to(DEV), N, S_row)
     kvd, qd = kv.to(DEV), q.to(DEV)
