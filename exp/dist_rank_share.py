@@ -27,7 +27,7 @@ def timeit(fn, n=20):
 import het_amd.dist as D
 ONLY = os.environ.get("ONLY")  # "world,rank": just that share (for rocprofv3)
 BETAS = [float(t) for t in os.environ.get("BETAS", "12").split(",")]
-WORLDS = [int(t) for t in os.environ.get("WORLDS", "2,4,8").split(",")]
+WORLDS = [int(t) for t in os.environ.get("WORLDS", "2,4,8").split(",") if t]  # WORLDS= (empty) with KERNELS=w,r: only that breakdown
 for world, beta in ([(1, 0.0)] if 1 in WORLDS or "WORLDS" not in os.environ else []) + [(w, b) for w in WORLDS if w > 1 for b in BETAS]:
     D.NODE_WEIGHT = beta
     rows = []
@@ -81,3 +81,33 @@ for world, beta in ([(1, 0.0)] if 1 in WORLDS or "WORLDS" not in os.environ else
     print(f"world {world} node_weight {beta}: compute+pack per rank min {min(ms):.2f} max {max(ms):.2f} ms; "
           f"max rows sent {max(r[4] for r in rows)}, max halo {max(r[3] for r in rows)}; "
           f"=> {coo.num_edges / max(ms) / 1e3:.0f} M edges/s before the exchange", flush=True)
+
+if os.environ.get("KERNELS"):  # per-kernel breakdown of one share: KERNELS="world,rank"
+    from het_amd import _lib as HL
+    world, rank = (int(t) for t in os.environ["KERNELS"].split(","))
+    p = build_plan(coo, rank, world)
+    g = HetGraph.from_integrated_coo(p.local, full=False)
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(64, 64, coo.num_rels, 4, self_loop=True, dropout=0.0).to(dev)
+    n_local = p.n_own + p.n_halo
+    x = (torch.randn(n_local, 64, device=dev) * 0.1).requires_grad_(True)
+    go = torch.randn(p.n_own, 64, device=dev)
+
+    def step():
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        layer(g, x, num_dst=p.n_own).backward(go)
+
+    for _ in range(3):
+        step()
+    HL.kernel_timing(True)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    print(f"kernels of rank {rank} of {world} (ms per step):")
+    for name in ("HET_rgat_aggregate", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_segment_sum", "HET_seg_gemm_mfma<store>",
+                 "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_gemm_mfma<atomic>", "HET_seg_dw_mfma"):
+        ms, n = HL.kernel_timing_read(name)
+        if n:
+            print(f"  {name:32s} {ms / 10:.3f}  ({n / 10:.0f} launches)")
+    HL.kernel_timing(False)

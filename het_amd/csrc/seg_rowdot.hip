@@ -390,7 +390,7 @@ int launch_rowdot_bwd_dw(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
   // Every workgroup ends with one atomic flush into the SAME H*K floats of its relation, and those serialise (~50 ns per
   // workgroup): on ogbn-mag (2.4 M rows) 8192 / 4096 / 2048 / 1024 / 512 workgroups take 0.48 / 0.27 / 0.17 / 0.136 / 0.131 ms.
-  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 2048; }();  // A/B switches
+  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 512; }();  // A/B switches (the minimum only matters for short lists: a rank's share of a partition)
   static const int64_t n_wg = [] { const char* v = getenv("HET_ROWDOT_DW_WGS"); return v ? (int64_t)atoi(v) : 512; }();
   int64_t chunk = ceil_div64(a.num_rows, n_wg);
   if (chunk < min_chunk) chunk = min_chunk;
@@ -437,7 +437,7 @@ int launch_rowdot1h_bwd_dx(const RowDotArgs& a, hipStream_t s) {
 
 int launch_rowdot1h_bwd_dw(const RowDotArgs& a, hipStream_t s) {
   if (a.num_rows == 0) return HET_OK;
-  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 2048; }();  // A/B switches
+  static const int64_t min_chunk = [] { const char* v = getenv("HET_ROWDOT_DW_MIN"); return v ? (int64_t)atoi(v) : 512; }();  // A/B switches (the minimum only matters for short lists: a rank's share of a partition)
   static const int64_t n_wg = [] { const char* v = getenv("HET_ROWDOT_DW_WGS"); return v ? (int64_t)atoi(v) : 512; }();
   int64_t chunk = ceil_div64(a.num_rows, n_wg);  // see launch_rowdot_bwd_dw
   if (chunk < min_chunk) chunk = min_chunk;
