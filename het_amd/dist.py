@@ -40,27 +40,59 @@ from .synth import IntegratedCOO
 NODE_WEIGHT = float(os.environ.get("HET_DIST_NODE_WEIGHT", "12"))  # sweep 0..64 on ogbn-mag: best 8..16 at 2, 4 and 8 ranks
 
 
-def partition_bounds(col: torch.Tensor, num_nodes: int, world: int, node_weight: float = None) -> torch.Tensor:
+# Cost of a halo row (a remote source a rank has to receive, project and return a gradient for), in edges, and the number
+# of refinement rounds of the boundaries against it (the halo of a range is only known once the ranges are: start from the
+# edge + node balance, measure every rank's halo, move the boundaries towards equal edge + node + halo cost, repeat).
+HALO_WEIGHT = float(os.environ.get("HET_DIST_HALO_WEIGHT", "8"))  # sweep 0..24 on ogbn-mag: 8 is best at 2, 4 and 8 ranks
+REFINE_ROUNDS = int(os.environ.get("HET_DIST_REFINE", "4"))
+
+
+def partition_bounds(col: torch.Tensor, num_nodes: int, world: int, node_weight: float = None, row: torch.Tensor = None,
+                     halo_weight: float = None) -> torch.Tensor:
     """Node-id boundaries [world+1] of contiguous destination ranges with ~equal cost = in-edges + node_weight per
-    destination (node_weight 0: equal in-edge counts)."""
+    destination (node_weight 0: equal in-edge counts) + halo_weight per remote source row of the range (needs ``row``)."""
     node_weight = NODE_WEIGHT if node_weight is None else node_weight
+    halo_weight = HALO_WEIGHT if halo_weight is None else halo_weight
+    dev = col.device
     indeg = torch.bincount(col, minlength=num_nodes)
     cost = indeg.to(torch.float64) + node_weight * (indeg > 0).to(torch.float64)
     csum = torch.cumsum(cost, 0)
     total = float(csum[-1]) if num_nodes else 0.0
-    targets = torch.arange(1, world, device=col.device, dtype=torch.float64) * (total / world)
-    cuts = torch.searchsorted(csum, targets, right=False) + 1
-    b = torch.cat([torch.zeros(1, dtype=torch.int64, device=col.device), cuts.clamp(max=num_nodes),
-                   torch.tensor([num_nodes], dtype=torch.int64, device=col.device)])
-    return torch.cummax(b, 0).values
+
+    def bounds_for(shares):
+        targets = torch.cumsum(shares, 0)[:-1] * total
+        cuts = torch.searchsorted(csum, targets, right=False) + 1
+        b = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cuts.clamp(max=num_nodes),
+                       torch.tensor([num_nodes], dtype=torch.int64, device=dev)])
+        return torch.cummax(b, 0).values
+
+    shares = torch.full((world,), 1.0 / world, dtype=torch.float64, device=dev)
+    b = bounds_for(shares)
+    if row is None or world < 2 or halo_weight <= 0 or col.numel() == 0:
+        return b
+    has_in = indeg > 0
+    for _ in range(REFINE_ROUNDS):
+        upper = b[1:].contiguous()
+        own_dst = torch.searchsorted(upper, col, right=True).clamp(max=world - 1)
+        own_src = torch.searchsorted(upper, row, right=True).clamp(max=world - 1)
+        # (sources without in-edges are dealt out evenly afterwards, node_ownership: counted as remote here)
+        remote = (own_dst != own_src) | ~has_in[row]
+        halo = torch.bincount(torch.unique(own_dst[remote] * num_nodes + row[remote]) // num_nodes, minlength=world)
+        base = csum[(b[1:] - 1).clamp(min=0)] * (b[1:] > 0)
+        part = base - torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), base[:-1]])
+        rank_cost = part + halo_weight * halo.to(torch.float64)
+        shares = shares * (rank_cost.mean() / rank_cost.clamp(min=1.0))
+        shares = shares / shares.sum()
+        b = bounds_for(shares)
+    return b
 
 
-def node_ownership(col: torch.Tensor, num_nodes: int, world: int):
+def node_ownership(col: torch.Tensor, num_nodes: int, world: int, row: torch.Tensor = None):
     """(node_order [N] new -> original id, new_id [N] original -> new, bounds [world+1] in new ids).
     Destinations: contiguous original-id ranges with ~equal in-edge counts.  Nodes without in-edges: equal shares."""
     dev = col.device
     indeg = torch.bincount(col, minlength=num_nodes)
-    b = partition_bounds(col, num_nodes, world)
+    b = partition_bounds(col, num_nodes, world, row=row)
     ids = torch.arange(num_nodes, device=dev)
     owner = torch.searchsorted(b[1:].contiguous(), ids, right=True).clamp(max=world - 1)
     free = indeg == 0
@@ -105,7 +137,7 @@ def build_plan(coo: IntegratedCOO, rank: int, world: int) -> DistPlan:
     """Every rank holds the (seeded, identical) global edge list and derives its own share:
     no communication is needed to build the plan."""
     N = coo.num_nodes
-    node_order, new_id, bounds = node_ownership(coo.col, N, world)
+    node_order, new_id, bounds = node_ownership(coo.col, N, world, row=coo.row)
     row, col, rel = new_id[coo.row], new_id[coo.col], coo.rel
     owner_dst = torch.searchsorted(bounds[1:].contiguous(), col, right=True)
     owner_src = torch.searchsorted(bounds[1:].contiguous(), row, right=True)
