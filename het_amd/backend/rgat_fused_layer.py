@@ -58,6 +58,11 @@ def effective_flags(g, W, compact, direct, mulfirst):
     return bool(compact), bool(direct), bool(mulfirst)
 
 
+def _destinations_below(col, nd):
+    """Whether every destination id is < nd (cached per graph: one reduction + host read the first time)."""
+    return col.numel() == 0 or _k._derived_get("col_max", (col,), lambda: int(col.max())) < nd
+
+
 def _lists(g):
     s = g.get_separate_coo_original()
     by_src = {"separate_coo_rel_ptrs": s["rel_ptrs"], "separate_coo_node_indices": s["row_indices"], "separate_coo_eids": s["eids"]}
@@ -220,11 +225,15 @@ class RgatLayerFunction(th.autograd.Function):
                                                  grad_x[:nd], grad_loop.view(1, 1, Kd, X), accumulate=False)
         else:
             grad_x = th.zeros_like(x)
-        if nd == N:
-            go = grad_h.view(N, H, D)
+        # every edge points at one of the first nd nodes (blocks, partitions: checked once per graph)?  then the
+        # per-destination tensors of the distinct-row backward are their first nd rows
+        dst_prefix = ctx.compact and _destinations_below(col, nd)
+        if nd == N or dst_prefix:
+            go = grad_h.view(nd, H, D)
         else:  # rows of non-destination nodes receive no gradient
             go = th.zeros((N, H, D), dtype=x.dtype, device=x.device)
             go.view(N, X)[:nd] = grad_h
+        ndp = nd if dst_prefix else N
         mulfirst = ctx.mulfirst
         if mulfirst:
             wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)  # [R,H,K,1] transposed(2,3): same memory
@@ -238,7 +247,7 @@ class RgatLayerFunction(th.autograd.Function):
             g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
             if ctx.has_bias:  # the bias gradient (column sums of grad_h) from the pass that reads every gradout row anyway
                 grad_bias = th.empty(X, dtype=x.dtype, device=x.device)
-            _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm, ret, go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
+            _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:ndp], ret[:ndp], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                      row_rel_ptrs=ss["rel_ptrs_row"], grad_bias=grad_bias if ctx.has_bias else None, bias_rows=nd)
             grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
             _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
@@ -301,13 +310,12 @@ class RgatLayerFunction(th.autograd.Function):
         grad_x = th.empty_like(x)
         grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
         _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
-        go = grad_h.view(nd, H, D)
-        if nd != N:  # rows of the halo nodes receive no gradient
-            go = th.zeros((N, H, D), dtype=x.dtype, device=x.device)
-            go.view(N, X)[:nd] = grad_h
+        s_coo = g.get_separate_coo_original()
+        assert _destinations_below(s_coo["col_indices"], nd), "a partition's edges point at owned nodes"
+        go = grad_h.view(nd, H, D)  # (so the per-destination tensors of the backward are their first nd rows)
         g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
-        _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm, ret, go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
+        _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
         _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=2)  # rows of a relation: distinct nodes
         halo.start_return(grad_x)
