@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
     const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack,
     const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
     float* __restrict__ tbuf, int H, int D, float slope, const float* __restrict__ fold_w,
-    const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+    const idx_t* __restrict__ fold_row_rel_ptrs, int R, int skip_long) {
   constexpr int EPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
   if (pid >= pk.n) return;
   const uint32_t pb = (uint32_t)pk.ptr[pid];
   const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
-  constexpr bool partial = false;  // (a long segment is one pack here: summed by this lane group alone, stored once)
+  if (skip_long && (pb >> 31)) return;  // a long segment: HET_rgat_backward_src_long_any takes its work items
+  constexpr bool partial = false;  // (without skip_long a long segment is one pack: summed by this lane group alone)
   const int64_t X = (int64_t)H * D;
   const bool head_lane = (sub & (DL - 1)) == 0;
   // ids of the first batch (clamped to the pack); keyn[U] = key of the rank after the batch
@@ -312,6 +313,85 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
   }
 }
 
+
+// The LONG (relation, source) segments for the shapes the cooperative kernels are not built for (heads of 4 or 8 floats, rows
+// of other widths): wave per work item, lane groups round-robin, every lane fetches its own scalars.  Without it a row with
+// 12 000 edges was summed by ONE lane group of the pack kernel above (10.6 ms on ogbn-mag with 8 heads of 8).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long_any(
+    Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int32_t* __restrict__ p_dst,
+    const int32_t* __restrict__ p_drow, const float* __restrict__ feat, const float* __restrict__ el,
+    const float* __restrict__ er, const float* __restrict__ pack, const float* __restrict__ gradout,
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, int D, float slope,
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+  constexpr int EPW = 64 / LPR, U = 4;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const bool head_lane = (sub & (DL - 1)) == 0;
+  const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (wid >= num_long_items) return;
+  const int item = long_items[wid];
+  const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const int64_t u = it.seg_key[seg], X = (int64_t)H * D;
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  const float4 f = ld4(feat + u * X + x);
+  const float zl = el[u * H + h];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc_el = 0.f;
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    int64_t dst[U], drow[U];
+    bool ok[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int j = j0 + q * EPW;
+      ok[q] = j < e;
+      dst[q] = p_dst[ok[q] ? j : e - 1];
+      drow[q] = p_drow[ok[q] ? j : e - 1];
+    }
+    float zr[U], sinv[U], gr[U];
+    float4 g[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) zr[q] = er[drow[q] * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) sinv[q] = pack[dst[q] * 2 * H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) gr[q] = pack[dst[q] * 2 * H + H + h];
+#pragma unroll
+    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + dst[q] * X + x);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const float z = zl + zr[q];
+      const float a = ok[q] ? leaky_exp(z, slope) * sinv[q] : 0.f;
+      acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
+      acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
+      float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
+      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float t = a * (z > 0.f ? 1.f : slope) * (dot - gr[q]);
+      if (ok[q] && head_lane) tbuf[(int64_t)(j0 + q * EPW) * H + h] = t;
+      acc_el += t;  // identical in the DL lanes of a head
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    acc_el += __shfl_xor(acc_el, off);
+  }
+  if (slot != 0) return;
+  if (fold_w) {
+    const float4 w = ld4(fold_w + (int64_t)find_segment(fold_row_rel_ptrs, R, (idx_t)u) * X + x);
+    acc.x = fmaf(acc_el, w.x, acc.x); acc.y = fmaf(acc_el, w.y, acc.y);
+    acc.z = fmaf(acc_el, w.z, acc.z); acc.w = fmaf(acc_el, w.w, acc.w);
+  }
+  float* gp = grad_feat + u * X + x;
+  if (whole) {
+    st4(gp, acc);
+    if (head_lane) grad_el[u * H + h] = acc_el;
+  } else {  // (rows cleared by HET_rgat_zero_long_rows)
+    atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
+    if (head_lane) atomicAdd(&grad_el[u * H + h], acc_el);
+  }
+}
 
 // ---- cooperative scalar loads -------------------------------------------------------------------------------------
 // Both passes were bound by the NUMBER of vector-memory instructions, not by bytes: every per-edge scalar (an index, an
@@ -793,14 +873,28 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
     }
   } else {
     static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
-    HET_KTIME("HET_rgat_backward_src", s);
+    const int skip_long = by_srow->num_long_items > 0 ? 1 : 0;
+    {
+      HET_KTIME("HET_rgat_backward_src_short", s);
 #define HET_BWD_PACKED(UU)                                                                                                 \
   HET_DISPATCH_LPR((int)(X / 4),                                                                                           \
                    hipLaunchKernelGGL((HET_rgat_backward_src_packed<LPR, UU>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->p0, \
                                       by_srow->p1, feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, \
-                                      (int)D, (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels))
-    if (u_rows == 2) { HET_BWD_PACKED(2); } else if (u_rows == 8) { HET_BWD_PACKED(8); } else { HET_BWD_PACKED(4); }
+                                      (int)D, (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels, skip_long))
+      if (u_rows == 2) { HET_BWD_PACKED(2); } else if (u_rows == 8) { HET_BWD_PACKED(8); } else { HET_BWD_PACKED(4); }
 #undef HET_BWD_PACKED
+    }
+    if (skip_long) {
+      HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
+      Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
+      const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
+      HET_KTIME("HET_rgat_backward_src_long", s);
+      HET_DISPATCH_LPR((int)(X / 4),
+                       hipLaunchKernelGGL(HET_rgat_backward_src_long_any<LPR>, dim3(nbl), dim3(kBlock), 0, s, it, by_srow->long_items,
+                                          by_srow->num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c, er_c, pack, gradout,
+                                          grad_feat_c, grad_el_c, tbuf, (int)H, (int)D, (float)slope, fold_attn_l, row_rel_ptrs,
+                                          (int)num_rels));
+    }
   }
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[rank, :]   (segments of by_drow are the er rows in order)
