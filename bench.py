@@ -415,9 +415,9 @@ def main():
         ms, n = HL.kernel_timing_read("HET_seg_gemm_mfma<store>")
         g_ms = ms / max(1, n)
         flops = 2.0 * E_local * K * X
-        tf = flops / (g_ms * 1e-3) / 1e12
+        tf = flops / (g_ms * 1e-3) / 1e12 if n else 0.0  # (n == 0: not a matrix-core shape -- the LDS-tiled FMA kernel ran)
         busy = pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "mfma_busy_frac")
-        roofline_gemm = {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
+        roofline_gemm = None if not n else {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "mfma_busy_frac_pmc": busy,
