@@ -99,12 +99,16 @@ def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     """Shapes / state for which every op of the node runs on its fast path (else use the op-by-op composition)."""
     R, H, Kd, D = W.shape
     if not (_k._plan.is_enabled() and x.is_cuda and x.dim() == 2 and slope >= 0 and g.get_num_edges() > 0
-            and _k.gat_grouped_shape_ok(H, D) and _k.matmul_attn_dot_ok(H, Kd, D)):
+            and _k.gat_grouped_shape_ok(H, D)):
         return False
     compact, _, mulfirst_eff = effective_flags(g, W, compact, True, mulfirst)
     if mulfirst and not _mulfirst_shape_ok(H, Kd):
         return False
     mulfirst = mulfirst_eff
+    if not _k.matmul_attn_dot_ok(H, Kd, D):
+        # widths the matrix-core projection does not take (e.g. the 8 output classes of the reference CLI's defaults): the
+        # distinct-row dataflow with er from the folded weight runs on the any-shape GEMM + a row-dot for el
+        return compact and mulfirst and H & (H - 1) == 0
     if compact or mulfirst:
         return True
     _, _, by_dst = _lists(g)
@@ -161,7 +165,11 @@ class RgatLayerFunction(th.autograd.Function):
                 h = _k.rows_linear_bias(offs, x[:nd], loop_w, None if bias is None else bias.contiguous())
             if halo is not None:
                 halo.finish_push()
-            _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
+            if _k.matmul_attn_dot_ok(H, Kd, D):
+                _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
+            else:  # other widths: any-shape projection, then el_c as a row-dot over the relation-bucketed rows
+                K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
+                K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc.view(-1, H, 1))
             # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
             srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
             grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])

@@ -113,6 +113,23 @@ def test_rgat_layer_one_and_two_heads(H, compact, mulfirst):
               mulfirst=mulfirst)
 
 
+@pytest.mark.parametrize("H,K,X", [(1, 64, 8), (2, 64, 16), (1, 16, 16), (4, 64, 16), (1, 64, 4), (8, 64, 64), (4, 32, 32)])
+@pytest.mark.parametrize("compact,mulfirst", [(False, False), (True, True)])
+def test_rgat_layer_small_and_odd_widths(H, K, X, compact, mulfirst, monkeypatch):
+    """Output widths outside the matrix-core shapes -- 64 -> 8 is the layer of the reference CLI's defaults (--n_infeat 64
+    --num_classes 8 --num_heads 1) -- and heads of 4 / 8 floats: the one-node layer runs them on the distinct-row dataflow
+    (any-shape projection + row-dot, the non-cooperative gather kernels incl. the wave-per-item kernel for long rows); a spy
+    checks that the row kernels ran, not the op-by-op composition.  n = 40: rows with hundreds of edges."""
+    import het_amd.kernels as k
+    calls = []
+    real = k.rgat_aggregate_compact
+    monkeypatch.setattr(k, "rgat_aggregate_compact", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    for n in (320, 40):
+        _run_rgat(random_graph(seed=45, n=n, r=4, e=5000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,
+                  mulfirst=mulfirst)
+    assert len(calls) == 2
+
+
 def test_rgat_layer_heads1_feat128():
     _run_rgat(random_graph(seed=43, n=300, r=5, e=4000, shuffle=False), H=1, K=128, X=128, compact=False, direct=False, mulfirst=False)
 
