@@ -368,7 +368,12 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
   } else {
     a.KA = (int)D; a.a_head_stride = D; a.b_head_stride = D * K; a.c_ld = H * K; a.c_head_stride = K; a.heads_z = (int)H;
   }
-  if (int rc = launch_seg_gemm(a, s)) return rc;
+  // kind 1: a relation's rows are distinct nodes (its unique list) -- relation by relation with plain read-modify-write
+  if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments) {
+    if (int rc = launch_seg_gemm_rmw_per_segment(a, s)) return rc;
+  } else {
+    if (int rc = launch_seg_gemm(a, s)) return rc;
+  }
   // grad_w[r,h] += x[gather]^T (x) gradout[scatter]
   SegDwArgs w;
   w.A = x; w.gather = gather_idx; w.G = gradout; w.g_gather = scatter; w.dW = grad_w;
@@ -540,8 +545,8 @@ extern "C" int het_backward_rgnn_relational_matmul_no_scatter_gather_list(
     q.out = grad_w;
     return launch_rowdot_bwd_dw(q, s);
   }
-  SegGemmArgs a;  // rows are disjoint: plain "+=" without atomics would do, atomics keep one code path
-  a.A = gradout; a.B = weights_t; a.C = grad_x; a.atomic = 1;
+  SegGemmArgs a;  // rows are disjoint (their own gather list): plain stores when overwriting, plain "+=" when accumulating
+  a.A = gradout; a.B = weights_t; a.C = grad_x; a.atomic = accumulate ? 2 : 0;
   a.seg_ptrs = offsets; a.num_segs = (int)num_types; a.num_rows = num_rows;
   a.b_rel_stride = H * D * K; a.a_ld = H * D; a.NB = (int)K;
   if (!x_per_head) {

@@ -10,7 +10,8 @@ namespace {
 
 constexpr int TM = 64, TN = 64, TK = 16, PAD = 4;
 
-template <bool ATOMIC>
+// MODE 0: C row = product; 1: atomic add; 2: plain read-modify-write (rows of the launch are distinct C rows)
+template <int MODE>
 __global__ __launch_bounds__(256) void HET_seg_gemm_generic(SegGemmArgs a) {
   int r;
   idx_t rb, re;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_generic(SegGemmArgs a) {
       const int gn = n0 + tx * 4 + j;
       if (gn < NB) {
         float* p = Cb + cr * a.c_ld + gn;
-        if (ATOMIC) atomicAdd(p, acc[i][j]); else *p = acc[i][j];
+        if (MODE == 1) atomicAdd(p, acc[i][j]); else if (MODE == 2) *p += acc[i][j]; else *p = acc[i][j];
       }
     }
   }
@@ -174,11 +175,27 @@ int launch_seg_gemm(const SegGemmArgs& a, hipStream_t s) {
   const int64_t gx = ceil_div64(a.num_rows, TM) + a.num_segs;
   HET_REQUIRE(gx < (1ll << 31), "segment GEMM: too many row tiles (%lld)", (long long)gx);
   dim3 grid((unsigned)gx, (unsigned)ceil_div64(a.NB, TN), (unsigned)a.heads_z), block(256);
-  if (a.atomic)
-    hipLaunchKernelGGL(HET_seg_gemm_generic<true>, grid, block, 0, s, a);
+  if (a.atomic == 2)
+    hipLaunchKernelGGL(HET_seg_gemm_generic<2>, grid, block, 0, s, a);
+  else if (a.atomic)
+    hipLaunchKernelGGL(HET_seg_gemm_generic<1>, grid, block, 0, s, a);
   else
-    hipLaunchKernelGGL(HET_seg_gemm_generic<false>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(HET_seg_gemm_generic<0>, grid, block, 0, s, a);
   HET_LAUNCH_CHECK("HET_seg_gemm_generic");
+  return HET_OK;
+}
+
+// C[scatter[i]] += A[i] . B[r] for lists whose rows are distinct inside every segment: segment by segment (launches are
+// ordered on the stream) with plain read-modify-write instead of one float atomic per element.
+int launch_seg_gemm_rmw_per_segment(const SegGemmArgs& a, hipStream_t s) {
+  for (int r = 0; r < a.num_segs; ++r) {
+    SegGemmArgs m = a;
+    m.seg_ptrs = a.seg_ptrs + r;  // the one segment [seg_ptrs[r], seg_ptrs[r+1]); row indices stay absolute
+    m.num_segs = 1;
+    m.B = a.B + (int64_t)r * a.b_rel_stride;
+    m.atomic = 2;
+    if (int rc = launch_seg_gemm(m, s)) return rc;
+  }
   return HET_OK;
 }
 

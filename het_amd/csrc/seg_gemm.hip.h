@@ -17,7 +17,7 @@ struct SegGemmArgs {
   int64_t c_ld = 0;
   int64_t c_head_stride = 0;
   const idx_t* scatter = nullptr;  // C row of position i (NULL: i)
-  int atomic = 0;
+  int atomic = 0;                  // 0 "=", 1 atomic "+=", 2 plain "+=" (distinct C rows in the launch)
   const idx_t* seg_ptrs = nullptr;  // [num_segs + 1]
   int num_segs = 0;
   int64_t num_rows = 0;
@@ -27,6 +27,7 @@ struct SegGemmArgs {
   int KA = 0, NB = 0, heads_z = 1;
 };
 int launch_seg_gemm(const SegGemmArgs& a, hipStream_t s);
+int launch_seg_gemm_rmw_per_segment(const SegGemmArgs& a, hipStream_t s);  // atomic-free "+=" for segment-wise distinct rows
 
 // dW_r(k, n) += sum_{i in segment r} scale(i) * A[ga(i), za + k] * G[gg(i), zg + n]
 struct SegDwArgs {

@@ -23,6 +23,7 @@ inline int launch_rows_gemm(const MfmaGemmArgs& m, hipStream_t s) {
     a.KA = m.K; a.NB = m.X; a.heads_z = 1;
     if (m.b_headcat == 1) { a.b_headcat = 1; a.headcat_d = m.headcat_d; }
   }
+  if (m.atomic == 2) return launch_seg_gemm_rmw_per_segment(a, s);  // (segment-wise distinct C rows: the caller's contract)
   return launch_seg_gemm(a, s);
 }
 
@@ -34,7 +35,8 @@ inline int launch_rows_gemm_add_unique(const MfmaGemmArgs& m, hipStream_t s) {
   if (mfma_shape_supported(m.K, m.X) && aligned && m.num_segs <= kRmwMaxSegments && m.K <= 128 && m.X <= 128 && !m.dot_w && !m.bias)
     return launch_seg_gemm_mfma_rmw_per_segment(m, s);
   MfmaGemmArgs a = m;
-  a.atomic = 1;
+  a.atomic = m.num_segs <= kRmwMaxSegments ? 2 : 1;  // the any-shape kernel has the same read-modify-write form
+  if (a.atomic == 2 && mfma_shape_supported(m.K, m.X) && aligned) a.atomic = 1;  // (an MFMA shape that failed the other conditions)
   return launch_rows_gemm(a, s);
 }
 
