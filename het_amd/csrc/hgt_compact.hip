@@ -83,30 +83,42 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_aggregate_rows(Items it, const
                                                                   const float* __restrict__ kv, const float* __restrict__ q,
                                                                   float* __restrict__ lsum, float* __restrict__ out, int H) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
-  static_assert(LPR >= 4 && DL <= LPR, "whole quads per lane group");
+  static_assert(DL <= LPR, "heads inside the lane group");  // (LPR >= 4: ids shared by quads; LPR == 2: every lane loads its ids)
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL, qd = sub & 3;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
-  int jn = b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1;
-  int srown = p_srow[jn];
+  int sidn[U];  // ids of the next step: one per lane and quad-shared (LPR >= 4), or all U in every lane
+  if constexpr (LPR >= 4) {
+    const int jn = b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1;
+    sidn[0] = p_srow[jn];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) sidn[u] = p_srow[b + slot + u * EPW < e ? b + slot + u * EPW : e - 1];
+  }
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 q4 = ld4(q + v * X + x);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float ssum = 0.f;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int srowv = srown;
     float4 kk[U], mm[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* rowp = kv + (int64_t)quad_bcast(srowv, u) * (2 * X) + x;
+      int sid;
+      if constexpr (LPR >= 4) sid = quad_bcast(sidn[0], u); else sid = sidn[u];
+      const float* rowp = kv + (int64_t)sid * (2 * X) + x;
       kk[u] = ld4(rowp);
       mm[u] = ld4(rowp + X);
     }
-    jn = j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1;
-    srown = p_srow[jn];
+    if constexpr (LPR >= 4) {
+      const int jn = j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1;
+      sidn[0] = p_srow[jn];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) sidn[u] = p_srow[j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float s = head_sum<DL>(dot4(kk[u], q4));
@@ -167,14 +179,20 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
                                                                      const float* __restrict__ gradout, float* __restrict__ grad_q,
                                                                      float* __restrict__ pack2, int H) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
-  static_assert(LPR >= 4 && DL <= LPR, "whole quads per lane group");
+  static_assert(DL <= LPR, "heads inside the lane group");  // (LPR >= 4: ids shared by quads; LPR == 2: every lane loads its ids)
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL, qd = sub & 3;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
-  int jn = b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1;
-  int srown = p_srow[jn];
+  int sidn[U];  // ids of the next step: one per lane and quad-shared (LPR >= 4), or all U in every lane
+  if constexpr (LPR >= 4) {
+    const int jn = b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1;
+    sidn[0] = p_srow[jn];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) sidn[u] = p_srow[b + slot + u * EPW < e ? b + slot + u * EPW : e - 1];
+  }
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 q4 = ld4(q + v * X + x), go = ld4(gradout + v * X + x), o4 = ld4(out + v * X + x);
@@ -182,16 +200,22 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
   const float dotn = head_sum<DL>(dot4(go, o4));
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int srowv = srown;
     float4 kk[U], mm[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* rowp = kv + (int64_t)quad_bcast(srowv, u) * (2 * X) + x;
+      int sid;
+      if constexpr (LPR >= 4) sid = quad_bcast(sidn[0], u); else sid = sidn[u];
+      const float* rowp = kv + (int64_t)sid * (2 * X) + x;
       kk[u] = ld4(rowp);
       mm[u] = ld4(rowp + X);
     }
-    jn = j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1;
-    srown = p_srow[jn];
+    if constexpr (LPR >= 4) {
+      const int jn = j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1;
+      sidn[0] = p_srow[jn];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) sidn[u] = p_srow[j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float s = head_sum<DL>(dot4(kk[u], q4));
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
                                                                       const float* __restrict__ gradout,
                                                                       float* __restrict__ grad_kv, int H) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
-  static_assert(LPR >= 4 && DL <= LPR, "whole quads per lane group");
+  static_assert(DL <= LPR, "heads inside the lane group");  // (LPR >= 4: ids shared by quads; LPR == 2: every lane loads its ids)
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, qd = sub & 3;
   const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
@@ -230,21 +254,28 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
   const uint32_t pb = (uint32_t)pk.ptr[pid];
   const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
   if (pb >> 31) return;  // a long segment: HET_hgt_backward_src_long takes its work items
-  int jn = b + qd < e ? b + qd : e - 1;
-  int4 idn = kp01[jn];  // {source row, destination, -, -} of the edge: one load (grouping_packed_ids)
+  int4 idn[U];  // {source row, destination, -, -} of the edges of the next step (grouping_packed_ids): quad-shared or per lane
+  if constexpr (LPR >= 4) {
+    idn[0] = kp01[b + qd < e ? b + qd : e - 1];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) idn[u] = kp01[b + u < e ? b + u : e - 1];
+  }
   int prev_key = -1;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 kcur = zero, mcur = zero, acck = zero, accm = zero;
   for (int j0 = b; j0 < e; j0 += U) {
-    const int keyv = idn.x, dstv = idn.y;
-    int key[U];
+    int key[U], dsti[U];
     float4 qr[U], gr[U], kq[U], mq[U];
     float2 p2[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) key[u] = quad_bcast(keyv, u);
+    for (int u = 0; u < U; ++u) {
+      if constexpr (LPR >= 4) { key[u] = quad_bcast(idn[0].x, u); dsti[u] = quad_bcast(idn[0].y, u); }
+      else { key[u] = idn[u].x; dsti[u] = idn[u].y; }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t dv = quad_bcast(dstv, u);
+      const int64_t dv = dsti[u];
       qr[u] = ld4(q + dv * X + x);
       gr[u] = ld4(gradout + dv * X + x);
       p2[u] = *reinterpret_cast<const float2*>(pack2 + (dv * H + h) * 2);
@@ -259,9 +290,15 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
         mq[u] = ld4(rowp + X);
       }
     }
-    jn = j0 + U + qd < e ? j0 + U + qd : e - 1;
-    idn = kp01[jn];
-    const int key_after = quad_bcast_i<0>(idn.x);
+    int key_after;
+    if constexpr (LPR >= 4) {
+      idn[0] = kp01[j0 + U + qd < e ? j0 + U + qd : e - 1];
+      key_after = quad_bcast_i<0>(idn[0].x);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) idn[u] = kp01[j0 + U + u < e ? j0 + U + u : e - 1];
+      key_after = idn[0].x;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = j0 + u < e;  // uniform within the lane group
@@ -296,32 +333,41 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_long(Items it, co
                                                                      const float* __restrict__ gradout,
                                                                      float* __restrict__ grad_kv, int H) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
-  static_assert(LPR >= 4 && DL <= LPR, "whole quads per lane group");
+  static_assert(DL <= LPR, "heads inside the lane group");  // (LPR >= 4: ids shared by quads; LPR == 2: every lane loads its ids)
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, qd = sub & 3;
   const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (wid >= num_long_items) return;
   const int item = long_items[wid];
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
-  int jn = b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1;
-  int dstn = p_dst[jn];
+  int dstn[U];
+  if constexpr (LPR >= 4) {
+    dstn[0] = p_dst[b + slot + qd * EPW < e ? b + slot + qd * EPW : e - 1];
+  } else {
+#pragma unroll
+    for (int t = 0; t < U; ++t) dstn[t] = p_dst[b + slot + t * EPW < e ? b + slot + t * EPW : e - 1];
+  }
   const int64_t u = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 kcur = ld4(kv + u * (2 * X) + x), mcur = ld4(kv + u * (2 * X) + X + x);
   float4 acck = make_float4(0.f, 0.f, 0.f, 0.f), accm = acck;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int dstv = dstn;
     float4 qr[U], gr[U];
     float2 p2[U];
 #pragma unroll
     for (int t = 0; t < U; ++t) {
-      const int64_t dv = quad_bcast(dstv, t);
+      int64_t dv;
+      if constexpr (LPR >= 4) dv = quad_bcast(dstn[0], t); else dv = dstn[t];
       qr[t] = ld4(q + dv * X + x);
       gr[t] = ld4(gradout + dv * X + x);
       p2[t] = *reinterpret_cast<const float2*>(pack2 + (dv * H + h) * 2);
     }
-    jn = j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1;
-    dstn = p_dst[jn];
+    if constexpr (LPR >= 4) {
+      dstn[0] = p_dst[j0 + (U + qd) * EPW < e ? j0 + (U + qd) * EPW : e - 1];
+    } else {
+#pragma unroll
+      for (int t = 0; t < U; ++t) dstn[t] = p_dst[j0 + (U + t) * EPW < e ? j0 + (U + t) * EPW : e - 1];
+    }
 #pragma unroll
     for (int t = 0; t < U; ++t) {
       const float s = head_sum<DL>(dot4(kcur, qr[t]));
@@ -360,6 +406,7 @@ inline unsigned grid_for(int64_t total) {
 // (lanes per row, lanes per head): rows of 16 .. 128 floats, heads of 8 .. 128
 #define HET_DISPATCH_HGT_ROWS(LPRV, DLV, CALL)                                                                       \
   switch ((LPRV) * 64 + (DLV)) {                                                                                     \
+    case 2 * 64 + 2: { constexpr int LPR = 2, DL = 2; CALL; break; }                                                 \
     case 4 * 64 + 2: { constexpr int LPR = 4, DL = 2; CALL; break; }                                                 \
     case 4 * 64 + 4: { constexpr int LPR = 4, DL = 4; CALL; break; }                                                 \
     case 8 * 64 + 2: { constexpr int LPR = 8, DL = 2; CALL; break; }                                                 \
@@ -379,7 +426,7 @@ inline unsigned grid_for(int64_t total) {
 static bool hgt_rows_shape_ok(int64_t H, int64_t D) {
   const int64_t X = H * D, lpr = X / 4, dl = D / 4;
   const bool p2 = D > 0 && (D & (D - 1)) == 0 && X > 0 && (X & (X - 1)) == 0;
-  return p2 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32) && dl >= 2 && dl <= lpr;
+  return p2 && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32) && dl >= 2 && dl <= lpr;
 }
 
 extern "C" int het_hgt_compact_shape_ok(int64_t H, int64_t D) { return hgt_rows_shape_ok(H, D) ? 1 : 0; }

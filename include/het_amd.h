@@ -422,7 +422,7 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
  *   by_srow: het_grouping_create(NULL, 0, that row of every position, E, S_row, payload0 = col, NULL)
  * forward overwrites lsum and out (zero rows for destinations without in-edges); backward overwrites grad_kv_c [S_row,2,H,D]
  * and grad_q [N,H,D].  workspace: het_hgt_backward_compact_workspace(N, H) bytes, 16-byte aligned.
- * Shapes: H*D in {16, 32, 64, 128}, D a power of two >= 8 (het_hgt_compact_shape_ok); else HET_ERR_UNSUPPORTED. */
+ * Shapes: H*D in {8, 16, 32, 64, 128}, D a power of two >= 8 (het_hgt_compact_shape_ok); else HET_ERR_UNSUPPORTED. */
 int het_hgt_compact_shape_ok(int64_t H, int64_t D);
 int het_hgt_aggregate_compact(const het_grouping* by_dst, const float* kv_c, const float* q, float* lsum, float* out,
                               int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, het_stream stream);

@@ -239,7 +239,7 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
 
 
 @pytest.mark.parametrize("H,D,n,e", [(8, 8, 300, 5000), (1, 64, 300, 5000), (4, 16, 40, 9000), (2, 8, 12, 9000), (4, 32, 300, 700),
-                                     (1, 32, 30, 4000), (2, 32, 300, 3000)])
+                                     (1, 32, 30, 4000), (2, 32, 300, 3000), (1, 8, 300, 5000), (1, 8, 12, 9000)])
 def test_hgt_compact_passes(K, H, D, n, e):
     """het_hgt_aggregate_compact / het_hgt_backward_compact (include/het_amd.h) against oracle/ops.py::hgt_attention_rows in
     fp64 (backward: its autograd): a = softmax over the in-edges of <k'[srow], q[dst]> per head, out = SUM a * m[srow].  The layer-level parity with the oracle is tests/test_gpu_layers.py::test_hgt_layer_fused.
