@@ -39,13 +39,28 @@ def hgt_fused_ok(G, h, num_heads, d_k):
         return False
     if not (_has_single_sided_lists(G) or hasattr(G, "generate_separate_unique_node_indices_single_sided_for_each_etype")):
         return False
-    if not _k.hgt_compact_shape_ok(num_heads, d_k):
+    if not _k.hgt_compact_shape_ok(num_heads, _padded_head(d_k)):
         return False
     try:
         G.get_rel_node_types()
     except ValueError:  # a relation mixes node types: no single K / V projection per relation to fold
         return False
     return True
+
+
+def _padded_head(d_k: int) -> int:
+    """Head width the row kernels run with: a power of two >= 8.  Narrower / odd heads (the 8 classes of the reference CLI's
+    last layer split over 4 heads: d_k = 2) are zero-padded -- zero columns in the folded weights and in the typed projection
+    of q add nothing to a score, and the padded components of the aggregated messages are dropped."""
+    return max(8, 1 << max(0, int(d_k) - 1).bit_length())
+
+
+def _pad_heads(w, num_heads, d_k, d_pad, parts=1):
+    """[..., parts * H * d_k] -> [..., parts * H * d_pad] with zero columns after every head's d_k."""
+    if d_pad == d_k:
+        return w
+    lead = w.shape[:-1]
+    return th.nn.functional.pad(w.reshape(*lead, parts * num_heads, d_k), (0, d_pad - d_k)).reshape(*lead, parts * num_heads * d_pad)
 
 
 def fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, num_heads, fused_attn):
@@ -182,12 +197,16 @@ def hgt_layer_fused(G, h, offs, q_w, a_w, k_lin, v_lin, rel_att, rel_msg, rel_pr
     st, _ = G.get_rel_node_types()
     w_kv = fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, st, num_heads, fused_attn)
     N = h.shape[0]
+    d_k = q_w.shape[3] // num_heads
+    d_pad = _padded_head(d_k)
+    w_kv, q_w = _pad_heads(w_kv, num_heads, d_k, d_pad, parts=2), _pad_heads(q_w, num_heads, d_k, d_pad)
+    unpad = (lambda t: t) if d_pad == d_k else (lambda t: t.view(t.shape[0], num_heads, d_pad)[..., :d_k].reshape(t.shape[0], -1))
     col = G.get_separate_coo_original()["col_indices"]
     dst = _k.destination_lists(col, offs)
     if dst[0].numel() >= COMPACT_DST_BELOW * N:
-        new_h = HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, None)
+        new_h = unpad(HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, None))
         return B_matmul_no_scatter_gather(offs, a_w, new_h)
-    new_h_c = HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, dst)
+    new_h_c = unpad(HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, dst))
     if _k.rows_matmul_backward_split_ok(1, a_w.shape[3], a_w.shape[2]):
         return RowsLinearScatter.apply(dst[2], dst[0], N, new_h_c, a_w)
     out_c = B_matmul_no_scatter_gather(dst[2], a_w, new_h_c)  # rows of a type are a contiguous piece of the sorted list

@@ -217,7 +217,8 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
 
 @pytest.mark.parametrize("fused_attn,compact_dst", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (1, 64, 64), (4, 64, 64), (2, 32, 64), (1, 32, 32), (4, 128, 128), (2, 64, 16),
-                                              (1, 64, 8)])  # 64 -> 8, one head: the layer of the reference CLI's defaults
+                                              (1, 64, 8),   # 64 -> 8, one head: the layer of the reference CLI's defaults
+                                              (4, 64, 8), (2, 64, 10), (1, 64, 4)])  # heads of 2 / 5 / 4 floats: zero-padded to 8
 def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch):
     """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
     (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
