@@ -147,7 +147,7 @@ class HgtAttentionFunction(th.autograd.Function):
             else:
                 grad_qw = th.zeros_like(q_w)
                 _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes}, 1,
-                                   qwt, h, g_q.view(-1, 1, X), grad_h, grad_qw, True, accumulate=True)
+                                   qwt, h, g_q.view(-1, 1, X), grad_h, grad_qw, True, accumulate=True, distinct_rows=True)
         wt = w_kv.transpose(2, 3).contiguous()
         if _k.rows_matmul_backward_split_ok(1, K_in, 2 * X):
             grad_wkv = th.empty_like(w_kv)
@@ -156,7 +156,7 @@ class HgtAttentionFunction(th.autograd.Function):
         else:
             grad_wkv = th.zeros_like(w_kv)
             _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": rp_row, "unique_srcs_and_dests_node_indices": rows_node}, 1, wt, h,
-                               g_kv, grad_h, grad_wkv, True, accumulate=True)
+                               g_kv, grad_h, grad_wkv, True, accumulate=True, distinct_rows=True)
         return None, None, None, grad_h, grad_wkv, grad_qw, None
 
 

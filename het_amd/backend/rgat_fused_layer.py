@@ -260,14 +260,14 @@ class RgatLayerFunction(th.autograd.Function):
             grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
             _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
                                                  grad_attn_l.unsqueeze(-1), accumulate=False)
-            _k.matmul_backward(d_row, 1, Wt, x, g_featc, grad_x, grad_W, True, accumulate=True)
+            _k.matmul_backward(d_row, 1, Wt, x, g_featc, grad_x, grad_W, True, accumulate=True, distinct_rows=True)
             if mulfirst:
-                _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True)
+                _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True, distinct_rows=True)
             else:
                 g_featd = th.empty_like(featd)
                 _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_col"], attn_r.unsqueeze(2), featd, g_erc, g_featd,
                                                      grad_attn_r.unsqueeze(-1), accumulate=False)
-                _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True)
+                _k.matmul_backward(d_col, 1, Wt, x, g_featd, grad_x, grad_W, True, accumulate=True, distinct_rows=True)
         else:
             feat, exs = saved[:2]
             # the edges' grad_el (= grad_er) in the kernel's destination-grouped order: sequential stores, and the
@@ -335,7 +335,7 @@ class RgatLayerFunction(th.autograd.Function):
                                              accumulate=False)
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)
         grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
-        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True)  # owned rows only
+        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True, distinct_rows=True)  # owned rows only
         grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
         grad_attn_r = (W * grad_wa).sum(2)
         grad_own = halo.finish_return(grad_x[:nd])

@@ -204,7 +204,8 @@ class RgnnRelationalMatmulCompactAsOfNode(th.autograd.Function):
         _k.matmul_backward(
             {"unique_srcs_and_dests_rel_ptrs": rel_ptrs, "unique_srcs_and_dests_node_indices": node_indices},
             1, th.transpose(weight, 2, 3).contiguous(), node_feat, gradout.contiguous(), grad_node_feat, grad_weight,
-            ctx.input_num_head_one_flag, accumulate=False)
+            ctx.input_num_head_one_flag, accumulate=False,
+            distinct_rows=True)  # the wrapper's contract (its argument names): a UNIQUE (relation, node) list
         return None, None, grad_weight, grad_node_feat, None, None
 
 

@@ -233,6 +233,12 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
                                                    const het_grouping* by_rel_gather, void* workspace,
                                                    int64_t workspace_bytes, het_stream stream) {
   const char* op = "backward_rgnn_relational_matmul";
+  // HET_ACC_DISTINCT_ROWS: the caller states that gather_idx holds every node at most once per relation (a unique
+  // (relation, node) list); only then may kind 1 add its input gradients with plain read-modify-write, relation by
+  // relation.  Without the bit -- the reference-named op -- any list is valid: float atomics, as the reference's
+  // compact backward (RGNN/my_shmem_sgemm_func.cu.h:711-776).
+  const bool distinct_rows = (accumulate & HET_ACC_DISTINCT_ROWS) != 0;
+  accumulate &= HET_ACC_ADD;
   if (H == 1 && D > 1) in1head = 1;  // as in the forward (the D == 1 row-dot shapes keep their own per-head kernels)
   if (int rc = check_matmul(op, kind, rel_ptrs, num_rels, gather_idx, scatter_idx, num_rows, H, K, D)) return rc;
   HET_REQUIRE(num_rows == 0 || (weights_t && x && gradout && grad_w), "%s: null data pointer", op);
@@ -280,7 +286,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
       q.gather = g->seg_key64; q.scatter = nullptr; q.go = gsum; q.seg_ptrs = g->seg_rel_ptr64; q.num_rows = g->S;
     }
     q.out = grad_x;
-    if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments) {
+    if (kind == HET_KIND_ENABLED && distinct_rows && num_rels <= kRmwMaxSegments) {
       // rows of one relation are distinct nodes: relation by relation, plain read-modify-write instead of atomics
       for (int r = 0; r < (int)num_rels; ++r) {
         RowDotArgs qr = q;
@@ -347,7 +353,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     m.seg_ptrs = rel_ptrs; m.num_segs = (int)num_rels; m.num_rows = num_rows; m.K = (int)(H * D); m.X = (int)K;
     // kind 1: a relation's rows are distinct nodes (its unique list) -- relation by relation the gradient rows are added
     // with plain read-modify-write instead of float atomics (0.52 -> 0.3 ms for the 2.4 M rows of ogbn-mag)
-    if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments && H * D <= 128 && K <= 128) {
+    if (kind == HET_KIND_ENABLED && distinct_rows && num_rels <= kRmwMaxSegments && H * D <= 128 && K <= 128) {
       if (int rc = launch_seg_gemm_mfma_rmw_per_segment(m, s)) return rc;
     } else {
       if (int rc = launch_seg_gemm_mfma(m, s)) return rc;
@@ -369,7 +375,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     a.KA = (int)D; a.a_head_stride = D; a.b_head_stride = D * K; a.c_ld = H * K; a.c_head_stride = K; a.heads_z = (int)H;
   }
   // kind 1: a relation's rows are distinct nodes (its unique list) -- relation by relation with plain read-modify-write
-  if (kind == HET_KIND_ENABLED && num_rels <= kRmwMaxSegments) {
+  if (kind == HET_KIND_ENABLED && distinct_rows && num_rels <= kRmwMaxSegments) {
     if (int rc = launch_seg_gemm_rmw_per_segment(a, s)) return rc;
   } else {
     if (int rc = launch_seg_gemm(a, s)) return rc;

@@ -531,10 +531,12 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
   // K <= 64 into X = 128 (HGT's k' | m rows): two launches of the X = 64 kernel beat the one with four column tiles per
   // wave (0.60 -> 0.55 ms for 2.4 M rows), although the A rows are read twice.  HET_GEMM_XSLAB64=0: A/B switch
   static const bool xslab64 = [] { const char* v = getenv("HET_GEMM_XSLAB64"); return !(v && v[0] == '0'); }();
-  if (xslab64 && a.X == 128 && a.K <= 64 && !a.dot_w && !a.bias && !a.b_n0 && !a.b_k0 && !a.atomic) {
+  if (xslab64 && a.X == 128 && a.K <= 64 && !a.dot_w && !a.bias && !a.atomic) {
     for (int n0 = 0; n0 < 128; n0 += 64) {  // two 64-wide column slabs (the A rows are read twice)
       MfmaGemmArgs w = a;
-      w.X = 64; w.C = a.C + n0; w.b_n0 = n0; w.b_kfull = a.K; w.b_xfull = a.X;
+      // (a may itself be a window of a wider weight -- the 128-wide slabs above: offsets compose, the full size is kept)
+      w.X = 64; w.C = a.C + n0; w.b_n0 = a.b_n0 + n0;
+      w.b_kfull = a.b_kfull ? a.b_kfull : a.K; w.b_xfull = a.b_xfull ? a.b_xfull : a.X;
       if (int rc = launch_seg_gemm_mfma(w, s)) return rc;
     }
     return HET_OK;

@@ -263,8 +263,12 @@ def backward_rgnn_relational_matmul(args_tensor_dict, IntKind, weights_transpose
 
 
 def matmul_backward(args_tensor_dict, IntKind, weights_transposed, node_feat, gradout, grad_node_feat, grad_weights,
-                    InputNumHeadOneFlag, accumulate: bool):
-    """backward_rgnn_relational_matmul with the choice of "+=" (the reference op's contract) or "=" outputs."""
+                    InputNumHeadOneFlag, accumulate: bool, distinct_rows: bool = False):
+    """backward_rgnn_relational_matmul with the choice of "+=" (the reference op's contract) or "=" outputs.
+    distinct_rows (kind 1): the caller guarantees that the unique list holds a node at most once per relation -- the
+    graph's own unique (relation, node) lists -- which lets the input gradients be added relation by relation with plain
+    read-modify-write.  The reference-named op never sets it: any list, duplicates included, is then summed with float
+    atomics as in the reference (include/het_amd.h, a2)."""
     rp, g, s = _matmul_lists(args_tensor_dict, IntKind)
     _chk("backward_rgnn_relational_matmul",
          tuple(t for t in (weights_transposed, node_feat, gradout, grad_node_feat, grad_weights) if t is not None),
@@ -277,7 +281,8 @@ def matmul_backward(args_tensor_dict, IntKind, weights_transposed, node_feat, gr
             ws = torch.empty(max(1, grp.num_segments) * H * D, dtype=torch.float32, device=gradout.device)
     _call(gradout, "het_backward_rgnn_relational_matmul", IntKind, _p(rp), R, _p(g), _p(s), g.numel(),
           node_feat.shape[0], _p(weights_transposed), _p(node_feat), _p(gradout), _p(grad_node_feat), _p(grad_weights),
-          H, K, D, int(InputNumHeadOneFlag), int(accumulate), None if grp is None else grp.handle, _p(ws),
+          H, K, D, int(InputNumHeadOneFlag), int(bool(accumulate)) | (2 if distinct_rows and IntKind == 1 else 0),
+          None if grp is None else grp.handle, _p(ws),
           0 if ws is None else ws.numel() * 4, _stream(gradout))
 
 

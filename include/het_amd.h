@@ -153,7 +153,15 @@ int het_backward_rgnn_relational_matmul_attn_dot_only(const int64_t* rel_ptrs, i
  *   accumulate != 0: "+=" into the caller's buffers as the reference does (its wrapper zero-fills them,
  *   rgnn_layers_and_funcs.py:52-55); accumulate == 0: grad_x and grad_w are overwritten, no pre-zeroing
  *   needed (saves a fill + a read-modify-write pass when every grad_x row has a single writer).
- *   grad_x may be NULL for the per-head D == 1 shape (attention vectors): weight gradient only. */
+ *   grad_x may be NULL for the per-head D == 1 shape (attention vectors): weight gradient only.
+ *   `accumulate` is a bit set: HET_ACC_ADD (1) as above; HET_ACC_DISTINCT_ROWS (2), kind 1 only: the caller GUARANTEES
+ *   that gather_idx holds a node at most once inside every relation (a unique (relation, node) list, what the reference's
+ *   graph builders produce).  Only with that bit are the input gradients of a relation added with plain
+ *   read-modify-write, relation by relation (deterministic, faster); without it -- the reference-named torch op -- any
+ *   list is valid, duplicates included, and the adds are float atomics as in the reference's compact backward
+ *   (RGNN/my_shmem_sgemm_func.cu.h:711-776).  A list with duplicates passed WITH the bit loses contributions. */
+#define HET_ACC_ADD 1
+#define HET_ACC_DISTINCT_ROWS 2
 int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* rel_ptrs, int64_t num_rels,
                                         const int64_t* gather_idx, const int64_t* scatter_idx, int64_t num_rows,
                                         int64_t num_x_rows /* rows of x and grad_x */,

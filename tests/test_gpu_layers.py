@@ -179,7 +179,7 @@ def _run_rgcn(g, compact, direct, K, D, R):
 
 @pytest.mark.parametrize("fused_attn,compact,direct", [(False, False, False), (True, False, False), (False, True, False),
                                                        (False, True, True)])
-@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8), (1, 64, 64), (2, 64, 64), (4, 256, 256), (1, 64, 8)])
+@pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8), (1, 64, 64), (2, 64, 64), (4, 256, 256), (1, 64, 8), (4, 256, 64)])
 def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
     """HGT layer (BASELINE.json configs[3]: feat 64, heads 8) against the plain-PyTorch fp64 oracle."""
     from het_amd.graph import HetGraph
@@ -419,7 +419,8 @@ def test_rgat_mulfirst_op_by_op_and_heads8(compact, monkeypatch):
 
 
 @pytest.mark.parametrize("H,K,X,compact", [(4, 128, 128, False), (8, 64, 64, False), (8, 32, 128, True), (16, 64, 64, True),
-                                           (4, 256, 256, False), (4, 256, 256, True), (1, 64, 8, False), (2, 64, 16, True)])
+                                           (4, 256, 256, False), (4, 256, 256, True), (1, 64, 8, False), (2, 64, 16, True),
+                                           (4, 256, 64, True), (1, 256, 32, False), (2, 256, 128, True)])
 def test_rgat_layer_other_shapes_single_node(H, K, X, compact):
     """feat = 128 (BASELINE.json configs[4]), 8 and 16 heads, K != X: the single-node layer on its other shapes."""
     _run_rgat(random_graph(seed=48, n=260, r=3, e=4000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,

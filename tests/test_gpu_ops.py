@@ -87,6 +87,27 @@ def test_rgnn_relational_matmul_fwd_bwd(K, H, Kd, D, in1head, kind):
     assert_close(gW, gW_ref, what="grad_W")
 
 
+@pytest.mark.parametrize("H,Kd,D", [(4, 64, 16), (4, 64, 1), (3, 7, 5)])
+def test_matmul_backward_kind1_duplicate_rows(K, H, Kd, D):
+    """The reference-named a2 with a kind-1 list that holds a node MORE than once inside a relation: every occurrence
+    contributes (float atomics, as the reference's compact backward, RGNN/my_shmem_sgemm_func.cu.h:711-776).  The plain
+    read-modify-write schedule is only taken when the caller states the list is unique (HET_ACC_DISTINCT_ROWS)."""
+    gen = torch.Generator().manual_seed(8)
+    N, R = 50, 3
+    rp = torch.tensor([0, 300, 300, 700])
+    nodes = torch.randint(0, N, (700,), generator=gen)  # ~6 occurrences of every node per relation
+    d = {"unique_srcs_and_dests_rel_ptrs": rp, "unique_srcs_and_dests_node_indices": nodes}
+    W = torch.randn(R, H, Kd, D, generator=gen)
+    x = torch.randn(N, Kd, generator=gen)
+    go = torch.randn(700, H, D, generator=gen)
+    gx_ref, gW_ref = torch.zeros_like(to64(x)), torch.zeros_like(to64(W))
+    O.backward_rgnn_relational_matmul(d, 1, to64(W).transpose(2, 3).contiguous(), to64(x), to64(go), gx_ref, gW_ref, True)
+    gx, gW = torch.zeros_like(x, device=DEV), torch.zeros_like(W, device=DEV)
+    K.backward_rgnn_relational_matmul(_dev(d), 1, W.transpose(2, 3).contiguous().to(DEV), x.to(DEV), go.to(DEV), gx, gW, True)
+    assert_close(gx, gx_ref, what="grad_x")
+    assert_close(gW, gW_ref, what="grad_W")
+
+
 def test_matmul_gather_equals_scatter_list(K):
     """el = feat_edge . attn with node_indices and eids the SAME tensor
     (the reference dispatches on data_ptr equality, RGNNOps.inc.h:253)."""
@@ -106,7 +127,8 @@ def test_matmul_gather_equals_scatter_list(K):
     assert_close(ret, ref)
 
 
-@pytest.mark.parametrize("H,Kd,D,per_head", [(1, 64, 64, False), (1, 16, 16, False), (4, 16, 1, True), (3, 6, 5, False), (8, 8, 8, True)])
+@pytest.mark.parametrize("H,Kd,D,per_head", [(1, 64, 64, False), (1, 16, 16, False), (4, 16, 1, True), (3, 6, 5, False), (8, 8, 8, True),
+                                             (1, 256, 32, False), (1, 256, 64, False), (2, 256, 32, False), (4, 256, 16, False), (1, 128, 256, False)])
 def test_matmul_no_scatter_gather(K, H, Kd, D, per_head):
     offsets = torch.tensor([0, 130, 130, 131, 700, 1023])
     T, n = 5, 1023
@@ -125,6 +147,14 @@ def test_matmul_no_scatter_gather(K, H, Kd, D, per_head):
     K.backward_rgnn_relational_matmul_no_scatter_gather_list(offsets.to(DEV), W.transpose(2, 3).contiguous().to(DEV), x.to(DEV), go.to(DEV), gx, gW)
     assert_close(gx, gx_ref, what="grad_x")
     assert_close(gW, gW_ref, what="grad_W")
+    # the layers' "=" form of the same op (plain stores into uninitialised buffers; a 256-wide input gradient from a
+    # narrow output runs as column slabs of the weight, which have to compose: ADVICE r2, seg_gemm_mfma.hip)
+    import het_amd.kernels as k
+    gx2, gW2 = torch.full_like(gx, float("nan")), torch.full_like(gW, float("nan"))
+    k.matmul_no_scatter_gather_backward(offsets.to(DEV), W.transpose(2, 3).contiguous().to(DEV), x.to(DEV), go.to(DEV), gx2, gW2,
+                                        accumulate=False)
+    assert_close(gx2, gx_ref, what="grad_x (=)")
+    assert_close(gW2, gW_ref, what="grad_W (=)")
 
 
 def test_matmul_empty(K):
