@@ -38,6 +38,9 @@ _SIGNATURES = {
     "het_rows_matmul_backward_dx": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
+    "het_node_row_map": [P, I64, P, I64, I64, P, P],
+    "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P],
+    "het_rgat_node_backward_dw": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, INT, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_hgt_aggregate_compact": [P, P, P, P, P, I64, I64, I64, I64, P],
     "het_hgt_backward_compact": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
@@ -86,6 +89,8 @@ def lib() -> C.CDLL:
         L.het_hgt_backward_compact_workspace.restype = I64
         L.het_hgt_compact_shape_ok.argtypes = [I64, I64]
         L.het_hgt_compact_shape_ok.restype = INT
+        L.het_rgat_node_gemm_ok.argtypes = [I64, I64, I64, I64]
+        L.het_rgat_node_gemm_ok.restype = INT
         L.het_kernel_timing_enable.argtypes = [INT]
         L.het_kernel_timing_enable.restype = INT
         L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]

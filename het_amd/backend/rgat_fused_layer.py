@@ -37,6 +37,8 @@ from ..kernels import K
 _OFFS = {}
 PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
+NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
+NODE_DW = os.environ.get("HET_RGAT_NODE_DW", "0") == "1"       # ... the weight gradients too (one read of x for all of them)
 
 
 def _mulfirst_shape_ok(H, Kd):
@@ -223,6 +225,8 @@ class RgatLayerFunction(th.autograd.Function):
             return RgatLayerFunction._backward_with_halo(ctx, grad_h)
         grad_bias = grad_h.sum(0) if (ctx.has_bias and not ctx.compact) else None
         Wt = th.transpose(W, 2, 3).contiguous()
+        if ctx.compact and ctx.mulfirst and NODE_GEMM and _k.rgat_node_gemm_ok(R, H, Kd, D) and _destinations_below(col, nd):
+            return RgatLayerFunction._backward_node_major(ctx, grad_h, Wt)
         grad_W = th.zeros_like(W)
         # one input-gradient buffer: the self-loop writes its rows with plain stores, the projections add to it
         grad_loop = None
@@ -299,6 +303,50 @@ class RgatLayerFunction(th.autograd.Function):
             grad_attn_r = (W * grad_wa).sum(2)
         return None, None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
 
+
+    @staticmethod
+    def _backward_node_major(ctx, grad_h, Wt):
+        """The backward on the distinct-row dataflow with every GEMM-side term gathered per NODE (csrc/node_gemm.hip): one
+        pass stores the input gradient (self-loop + relation projections + the folded attention vector), one pass forms all
+        weight gradients from a single read of x -- instead of a self-loop pass, one read-modify-write launch per relation
+        and side, and three weight-gradient launches."""
+        x, W, attn_l, attn_r, loop_w, offs, sm, ex, ret, featc, elc, erc = ctx.saved_tensors
+        g, nd, slope = ctx.g, ctx.nd, ctx.slope
+        N, Kd = x.shape
+        R, H, _, D = W.shape
+        X = H * D
+        ss = g.get_separate_unique_node_indices_single_sided()
+        rp_row = ss["rel_ptrs_row"]
+        row_map = _k.node_row_map(rp_row, ss["node_indices_row"], N)
+        dst_map = _k.node_row_map(ss["rel_ptrs_col"], ss["node_indices_col"], N)
+        go = grad_h.view(nd, H, D)  # every edge points at one of the first nd nodes (checked by the caller)
+        g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
+        grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
+                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
+        grad_attn_l = th.empty_like(attn_l)
+        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                             accumulate=False)
+        wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
+        grad_x = th.empty_like(x)
+        grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
+        grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
+        gh = grad_h if ctx.has_loop else None
+        _k.rgat_node_backward_dx(0, N, nd, gh, loop_w.t().contiguous() if ctx.has_loop else None, g_featc.view(-1, X), Wt, row_map,
+                                 g_erc, wa_t, dst_map, grad_x)
+        if NODE_DW:
+            _k.rgat_node_backward_dw(0, N, nd, x, gh, g_featc.view(-1, X), row_map, g_erc, dst_map, grad_loop, grad_W, grad_wa,
+                                     accumulate=False)
+        else:  # the weight gradients per source (three launches; each reads its own rows of x)
+            if ctx.has_loop:
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+            _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
+            d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+            _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
+                               accumulate=False)
+        grad_W.addcmul_(grad_wa.unsqueeze(-1), attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
+        grad_attn_r = (W * grad_wa.unsqueeze(-1)).sum(2)
+        return None, None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
 
     @staticmethod
     def _backward_with_halo(ctx, grad_h):

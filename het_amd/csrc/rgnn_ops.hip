@@ -251,7 +251,9 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
   const bool rowdot = !in1head && D == 1 && rowdot_supported((int)H, (int)K) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
   // grad_x == NULL: weight gradient only (a caller that folded the input gradient elsewhere); row-dot shape only
-  HET_REQUIRE(num_rows == 0 || grad_x || rowdot, "%s: grad_x may be NULL only for the per-head D == 1 shape", op);
+  const bool rowdot1h = in1head && D == 1 && rowdot1h_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0;
+  HET_REQUIRE(num_rows == 0 || grad_x || rowdot || rowdot1h, "%s: grad_x may be NULL only for the D == 1 shapes", op);
   if (!accumulate) {  // "=" semantics: zero what the kernels below accumulate into
     HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
     // rows of x that no position gathers must read zero; with a unique row-dot list of all rows every
@@ -272,8 +274,7 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
     return launch_rowdot_bwd_dw(q, s);
   }
   const het_grouping* g = by_rel_gather;
-  if (in1head && D == 1 && rowdot1h_supported((int)H, (int)K) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0) {
+  if (rowdot1h) {
     RowDotArgs q;
     q.A = x; q.gather = gather_idx; q.W = weights_t; q.scatter = scatter; q.go = gradout; q.seg_ptrs = rel_ptrs;
     q.num_segs = (int)num_rels; q.num_rows = num_rows; q.H = (int)H; q.K = (int)K;
@@ -286,7 +287,9 @@ extern "C" int het_backward_rgnn_relational_matmul(int64_t kind, const int64_t* 
       q.gather = g->seg_key64; q.scatter = nullptr; q.go = gsum; q.seg_ptrs = g->seg_rel_ptr64; q.num_rows = g->S;
     }
     q.out = grad_x;
-    if (kind == HET_KIND_ENABLED && distinct_rows && num_rels <= kRmwMaxSegments) {
+    if (!grad_x) {
+      // weight gradient only (the caller formed the input gradient elsewhere: csrc/node_gemm.hip)
+    } else if (kind == HET_KIND_ENABLED && distinct_rows && num_rels <= kRmwMaxSegments) {
       // rows of one relation are distinct nodes: relation by relation, plain read-modify-write instead of atomics
       for (int r = 0; r < (int)num_rels; ++r) {
         RowDotArgs qr = q;

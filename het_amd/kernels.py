@@ -581,6 +581,41 @@ def rows_matmul_backward_dw(rel_ptrs, gather_idx, x, gradout, grad_w, accumulate
           _p(grad_w), H, K, D, int(accumulate), _stream(gradout))
 
 
+def rgat_node_gemm_ok(R: int, H: int, K: int, D: int) -> bool:
+    """Shapes of the node-major backward GEMMs (include/het_amd.h: het_rgat_node_backward_dx / _dw)."""
+    return bool(_lib.lib().het_rgat_node_gemm_ok(R, H, K, D))
+
+
+def node_row_map(rel_ptrs, nodes, num_nodes: int):
+    """[R, num_nodes] int32: row of (relation, node) in a unique (relation, node) list, -1 where the node has none.  Built
+    once per list on the device (het_node_row_map) and cached by the identity of the list."""
+    def build():
+        R = rel_ptrs.numel() - 1
+        m = torch.empty((R, num_nodes), dtype=torch.int32, device=nodes.device)
+        _call(nodes, "het_node_row_map", _p(rel_ptrs), R, _p(nodes), nodes.numel(), num_nodes, _p(m), _stream(nodes))
+        return m
+    _chk("node_row_map", (), (rel_ptrs, nodes))
+    return _derived_get(("nodemap", num_nodes), (rel_ptrs, nodes), build)
+
+
+def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weights_t, row_map, g_er, wa_t, dst_map, grad_x):
+    """grad_x rows [n_begin, n_end) of the one-node RGAT layer in one pass over the nodes (include/het_amd.h)."""
+    _chk("rgat_node_backward_dx", tuple(t for t in (grad_h, loop_wt, g_rows, weights_t, g_er, wa_t, grad_x) if t is not None))
+    R, H, D, K = weights_t.shape
+    _call(grad_x, "het_rgat_node_backward_dx", int(n_begin), int(n_end), int(n_loop), grad_x.shape[0], R, _p(grad_h), _p(loop_wt),
+          _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _stream(grad_x))
+
+
+def rgat_node_backward_dw(n_begin, n_end, n_loop, x, grad_h, g_rows, row_map, g_er, dst_map, grad_loop, grad_w, grad_wa,
+                          accumulate: bool):
+    """The weight gradients of the one-node RGAT layer (self-loop, relations, folded attention vector) from one read of the
+    layer input (include/het_amd.h)."""
+    _chk("rgat_node_backward_dw", tuple(t for t in (x, grad_h, g_rows, g_er, grad_loop, grad_w, grad_wa) if t is not None))
+    R, H, K, D = grad_w.shape
+    _call(x, "het_rgat_node_backward_dw", int(n_begin), int(n_end), int(n_loop), x.shape[0], R, _p(x), _p(grad_h), _p(g_rows),
+          _p(row_map), _p(g_er), _p(dst_map), _p(grad_loop), _p(grad_w), _p(grad_wa), H, K, D, int(accumulate), _stream(x))
+
+
 def rows_linear_bias_ok(K: int, X: int) -> bool:
     return K in (32, 64, 128) and X in (32, 64, 128)
 

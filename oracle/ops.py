@@ -14,9 +14,15 @@ or run here (no nvcc, empty third_party/ submodules) and the reference ships no
 arithmetic test vectors, so for the floating-point ops this restatement follows
 the CUDA sources as text (file:line cited per function) and is "parity
 unpinned", except:
-  * layouts (integer, exact) and the ``exp`` / ``sum`` outputs of the fused GAT
-    forward are pinned by golden vectors generated from the reference's own
-    importable Python (tests/golden/make_golden.py).
+  * layouts (integer, exact);
+  * the ``exp`` / ``sum`` outputs of the fused GAT forward (a4), CompactAsOfNodeKind 0 and 4
+    (ref_rgat.py:5-32 and its dual-unique-list wrapper :77-115);
+  * ``grad_feat_src`` of the fused GAT backward (a5; ref_rgat.py:66-75)
+    are pinned by golden vectors generated from the reference's own importable Python
+    (tests/golden/make_golden.py; tests/test_oracle.py::*_golden, tests/test_gpu_ops.py::test_gat_golden_*).
+    NOT pinned, because the reference holds nothing comparable: a4's ``ret`` (ref_rgat.py never writes it), a5's
+    ``grad_el`` / ``grad_er`` (ref_rgat.py:64-65 adds ``slope`` to the leaky-ReLU derivative and drops the dot product
+    over the feature dimension -- it disagrees with the CUDA kernel it mirrors), and every other floating-point op.
 Where the CUDA code deviates from the reference's own stated intent (its DSL
 specs hrt/pyctor/examples/inter-op-dsl/*.inter-op and in-code TODO/FIXMEs) the
 oracle implements the INTENDED semantics; each such position is listed in

@@ -15,7 +15,12 @@ What is pinned:
     loaded by file path (their packages import DGL, which is absent here);
   * the ``exp`` and ``sum`` outputs of the fused GAT forward, computed by
     hrt/python/testing/ref_kernels_lite/ref_rgat.py (its ``ret`` is never
-    written by that file, so ``ret`` is NOT pinned by it).
+    written by that file, so ``ret`` is NOT pinned by it);
+  * the same two outputs through its dual-unique-list compact wrapper
+    (ref_rgat.py:77-115): CompactAsOfNodeKind 4;
+  * ``grad_feat_src`` of its backward (ref_rgat.py:66-75).  Its ``grad_el`` /
+    ``grad_er`` (:64-65) are NOT pinned: they add ``slope`` to the leaky-ReLU
+    derivative and drop the dot product, unlike the CUDA kernel they mirror.
 
 Two graphs: the 4-node toy graph of SURVEY.md section 10 and a slice of the
 only real topology shipped with the reference, hrt/data/ogbn_mag_0.1/*.npy
@@ -84,6 +89,44 @@ def gat_exp_sum(lay, num_nodes, H, seed):
     return {"gat_el": el, "gat_er": er, "gat_exp": exp, "gat_sum": s, "gat_slope": torch.tensor(0.2)}
 
 
+def gat_backward_grad_feat_src(lay, num_nodes, H, D, seed):
+    """grad_feat_src of the reference's own backward (ref_rgat.py:66-75: += gradout[col] * exp / s[col], node-indexed).
+    The function is run UNMODIFIED; its grad_el / grad_er statements (:64-65, wrong by "+ slope" and shaped for D == 1) are
+    fed shapes they do not raise on ([E,H,1] pre-activations, [E,H,D] dummies) and their outputs are discarded."""
+    g = torch.Generator().manual_seed(seed)
+    E = lay["sep_row"].numel()
+    el, er = lay["gat_el"], lay["gat_er"]  # the pre-activations whose exp / sum the forward fixture pins
+    exp, s = lay["gat_exp"], lay["gat_sum"]
+    feat_src = torch.randn(num_nodes, H, D, generator=g)
+    ret = torch.randn(num_nodes, H, D, generator=g)
+    gradout = torch.zeros(num_nodes, H, D)  # random on the destination nodes only (the others are never read): small file
+    dst = torch.unique(lay["sep_col"])
+    gradout[dst] = torch.randn(dst.numel(), H, D, generator=g)
+    grad_feat_src = torch.zeros(num_nodes, H, D)
+    dummy_l, dummy_r = torch.zeros(E, H, D), torch.zeros(E, H, D)
+    ref_rgat.backward_relational_fused_gat_separate_coo(torch.arange(E), lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"],
+                                                       feat_src, el.unsqueeze(-1), er.unsqueeze(-1), s, exp, ret, gradout,
+                                                       grad_feat_src, dummy_l, dummy_r, 0.2)
+    return {"gatb_gradout": gradout, "gatb_grad_feat_src": grad_feat_src}
+
+
+def gat_compact_exp_sum(lay, num_nodes, H, seed):
+    """exp / sum through the reference's dual-unique-list compact wrapper (ref_rgat.py:77-115): el per distinct
+    (relation, source) row, er per distinct (relation, destination) row, expanded with the inverse indices of the
+    single-sided unique lists -- CompactAsOfNodeKind 4 of the fused GAT forward."""
+    g = torch.Generator().manual_seed(seed)
+    E = lay["sep_row"].numel()
+    el_c = torch.randn(lay["ss_node_indices_row"].numel(), H, generator=g)
+    er_c = torch.randn(lay["ss_node_indices_col"].numel(), H, generator=g)
+    feat = torch.randn(num_nodes, H, 2, generator=g)  # feeds the (discarded) ret only
+    s, exp, ret = torch.zeros(num_nodes, H), torch.zeros(E, H), torch.zeros(num_nodes, H, 2)
+    ref_rgat.towrap_relational_fused_gat_kernel_compact_as_of_node_separate_coo_dual_unique_node_list(
+        lay["ss_inverse_indices_row"], lay["ss_inverse_indices_col"], torch.arange(E), lay["sep_rel_ptrs"], lay["sep_row"],
+        lay["sep_col"], lay["ss_rel_ptrs_row"], lay["ss_rel_ptrs_col"], lay["ss_node_indices_row"], lay["ss_node_indices_col"],
+        feat, el_c, er_c, s, exp, ret, 0.2)
+    return {"gatc_el": el_c, "gatc_er": er_c, "gatc_exp": exp, "gatc_sum": s}
+
+
 def save(name, d):
     arrs = {}
     for k, v in d.items():
@@ -101,6 +144,8 @@ def main():
     eids = torch.arange(6)
     lay = layouts(row, col, rel, eids, 2)
     lay.update(gat_exp_sum(lay, 4, 2, seed=1))
+    lay.update(gat_backward_grad_feat_src(lay, 4, 2, 3, seed=11))
+    lay.update(gat_compact_exp_sum(lay, 4, 2, seed=21))
     lay["num_nodes"], lay["num_rels"] = torch.tensor(4), torch.tensor(2)
     save("toy.npz", lay)
 
@@ -119,6 +164,8 @@ def main():
     lay = layouts(row, col, rel, eids, 6)
     n = int(max(row.max(), col.max())) + 1
     lay.update(gat_exp_sum(lay, n, 4, seed=2))
+    lay.update(gat_backward_grad_feat_src(lay, n, 4, 4, seed=12))
+    lay.update(gat_compact_exp_sum(lay, n, 4, seed=22))
     lay["num_nodes"], lay["num_rels"] = torch.tensor(n), torch.tensor(6)
     save("mag01_slice.npz", lay)
 

@@ -4,6 +4,8 @@ closed-form consequence of the op's definition, computed with plain torch ops on
 import pytest
 import torch
 
+from tests.util import rgat_nudge_off_kink
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -116,6 +118,14 @@ def test_rgat_layer_dataflows_agree_at_full_size(heads):
     gen = torch.Generator(device=DEV).manual_seed(11)
     x0 = torch.randn(N, 64, device=DEV, generator=gen) * 0.3
     go = torch.randn(N, 64, device=DEV, generator=gen)
+    # no (edge, head) pre-activation within 2e-6 of the leaky-ReLU kink (tests/util.py): the dataflows round el + er
+    # differently (~3e-7), and an edge that lands on different sides of the kink changes a gradient by a finite amount
+    torch.manual_seed(0)
+    probe = HET_RGATLayer(64, 64, g.get_num_rels(), heads, self_loop=True, dropout=0.0)
+    x0, zmin = rgat_nudge_off_kink(x0, probe.conv_weights.to(DEV), probe.attn_l.to(DEV), probe.attn_r.to(DEV),
+                                   g.get_separate_coo_original())
+    assert zmin >= 2e-6, zmin
+    del probe
     results = []
     for flags in ({}, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True},
                   {"multiply_among_weights_first_flag": True}):
@@ -133,22 +143,23 @@ def test_rgat_layer_dataflows_agree_at_full_size(heads):
             a64, d64 = a.double(), (b.double() - a.double())
             rel_l2 = float(d64.norm() / a64.norm().clamp(min=1e-30))
             worst = float(d64.abs().max() / a64.abs().max().clamp(min=1e-30))
-            # per-node tensors agree to ~1e-7.  A parameter gradient can move by ~1e-3 of its norm when ONE of the 84 M
-            # (edge, head) pre-activations el + er lies within fp32 rounding of the leaky-ReLU kink and the dataflows
-            # (different summation orders inside el / er) land on different sides of it: measured, seed 11 -- with
-            # slope = 1 (no kink) the same comparison gives 4e-7
-            tol_l2, tol_max = (1e-4, 2e-3) if name in ("out", "grad_x") else (5e-3, 1e-2)
+            # per-node tensors agree to ~1e-7, parameter gradients to ~1e-6 (sums over 2 M .. 21 M rows in different orders)
+            tol_l2, tol_max = (2e-5, 1e-3)
             assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
 
 
-@pytest.mark.parametrize("heads,flags", [(4, {}), (1, {}), (4, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True,
-                                                            "multiply_among_weights_first_flag": True}),
-                                         (4, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True}),
-                                         (4, {"multiply_among_weights_first_flag": True})])
-def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, feat=64):
+@pytest.mark.parametrize("heads,flags,slope", [
+    (4, {}, 0.2), (1, {}, 0.2),
+    (4, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True, "multiply_among_weights_first_flag": True}, 0.2),
+    (4, {"compact_as_of_node_flag": True, "compact_direct_indexing_flag": True}, 0.2),
+    (4, {"multiply_among_weights_first_flag": True}, 0.2),
+    (4, {}, 1.0)])  # slope 1: no kink at all
+def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, slope, feat=64, nudge=True):
     """BASELINE.json's RGAT configuration (ogbn-mag shape, feat 64) against oracle/layers.py evaluated in fp64 -- the
     oracle is plain torch, so at this size it runs on the GPU (minutes on the CPU): output, input gradient and every
-    parameter gradient of the HIP layer."""
+    parameter gradient of the HIP layer, all held to relative L2 2e-5 / max 1e-3.  With slope < 1 the input is first moved
+    off the leaky-ReLU kink (no |el + er| below 2e-6 in fp64: tests/util.py::rgat_nudge_off_kink); nudge=False is the
+    explicitly named kink-tolerance test below."""
     from oracle import layers as OL
     from het_amd.graph import HetGraph
     from het_amd.layers import HET_RGATLayer
@@ -163,7 +174,10 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, feat=64):
     x0 = torch.randn(N, feat, device=DEV, generator=gen) * 0.3
     go = torch.randn(N, feat, device=DEV, generator=gen)
     torch.manual_seed(0)
-    layer = HET_RGATLayer(feat, feat, g.get_num_rels(), heads, self_loop=True, dropout=0.0, **flags).to(DEV)
+    layer = HET_RGATLayer(feat, feat, g.get_num_rels(), heads, self_loop=True, dropout=0.0, leaky_relu_slope=slope, **flags).to(DEV)
+    if nudge and slope != 1.0:
+        x0, zmin = rgat_nudge_off_kink(x0, layer.conv_weights, layer.attn_l, layer.attn_r, s)
+        assert zmin >= 2e-6, zmin
     x = x0.clone().requires_grad_(True)
     out = layer(g, x)
     out.backward(go)
@@ -172,7 +186,7 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, feat=64):
     p64 = {k: v.detach().double().requires_grad_(True) for k, v in layer.named_parameters()}
     x64 = x0.double().requires_grad_(True)
     ref = OL.rgat_layer(x64, p64["conv_weights"], p64["attn_l"], p64["attn_r"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
-                        N, 0.2, p64["loop_weight"], p64["h_bias"])
+                        N, slope, p64["loop_weight"], p64["h_bias"])
     ref.backward(go.double())
     want = {"out": ref.detach(), "grad_x": x64.grad, "grad_W": p64["conv_weights"].grad, "grad_attn_l": p64["attn_l"].grad,
             "grad_attn_r": p64["attn_r"].grad, "grad_loop_weight": p64["loop_weight"].grad, "grad_h_bias": p64["h_bias"].grad}
@@ -180,18 +194,26 @@ def test_rgat_layer_matches_the_fp64_oracle_at_full_size(heads, flags, feat=64):
         a, d = want[name], got[name].double() - want[name]
         rel_l2 = float(d.norm() / a.norm().clamp(min=1e-30))
         worst = float(d.abs().max() / a.abs().max().clamp(min=1e-30))
-        # typical: 1.5e-7 (out, grad_x), 1e-6 .. 8e-6 (parameter gradients); the parameter bound leaves room for an edge whose
-        # fp32 pre-activation falls on the other side of the leaky-ReLU kink than the fp64 one (see the test above)
-        tol_l2, tol_max = (2e-5, 1e-3) if name in ("out", "grad_x") else (3e-3, 6e-3)
-        print(f"[full-size vs fp64 oracle] feat={feat} heads={heads} flags={sorted(flags)} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
+        # typical: 1.5e-7 (out, grad_x), 1e-6 .. 8e-6 (parameter gradients).  Without the nudge (kink-tolerance test) a parameter
+        # gradient may move by ~1e-3 of its norm per edge whose fp32 pre-activation falls on the other side of the kink
+        tol_l2, tol_max = (2e-5, 1e-3) if (nudge or slope == 1.0 or name in ("out", "grad_x")) else (3e-3, 6e-3)
+        print(f"[full-size vs fp64 oracle] feat={feat} heads={heads} slope={slope} nudge={nudge} flags={sorted(flags)} {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
         assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+
+def test_rgat_layer_kink_tolerance_at_full_size():
+    """KINK TOLERANCE: the same comparison on the raw random input.  Of its 84 M (edge, head) pre-activations a few hundred
+    lie within 2e-6 of the leaky-ReLU kink; fp32 (these kernels, and the reference's) and fp64 may take different branches
+    there -- a finite gradient difference that is an error of neither side.  Output and input gradient keep the tight
+    bound; the parameter gradients are only held to relative L2 3e-3 here (the nudged runs above hold them to 2e-5)."""
+    test_rgat_layer_matches_the_fp64_oracle_at_full_size(4, {}, 0.2, nudge=False)
 
 
 def test_rgat_feat128_layer_matches_the_fp64_oracle_at_full_size():
     """BASELINE.json configs[4]'s single-GPU shape: RGAT on the full ogbn-mag-shaped graph at feat 128, 4 heads (the fp64
     oracle peaks at 173 GB of the 288 GB here)."""
     torch.cuda.empty_cache()
-    test_rgat_layer_matches_the_fp64_oracle_at_full_size(4, {}, feat=128)
+    test_rgat_layer_matches_the_fp64_oracle_at_full_size(4, {}, 0.2, feat=128)
     torch.cuda.empty_cache()
 
 

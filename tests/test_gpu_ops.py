@@ -370,6 +370,42 @@ def test_gat_golden_exp_sum(K, golden_mag):
     torch.testing.assert_close(cpu(sm), gold["gat_sum"], rtol=1e-5, atol=1e-5)
 
 
+def test_gat_golden_compact_exp_sum(K, plan_mode, golden_mag):
+    """CompactAsOfNodeKind 4 forward: exp / sum against the reference's dual-unique-list wrapper (ref_rgat.py:77-115)."""
+    gold = golden_mag
+    n = int(gold["num_nodes"])
+    el, er = gold["gatc_el"], gold["gatc_er"]
+    E, H = gold["gatc_exp"].shape
+    d = {"edata_idx_to_inverse_idx_row": gold["ss_inverse_indices_row"].to(DEV),
+         "edata_idx_to_inverse_idx_col": gold["ss_inverse_indices_col"].to(DEV)}
+    feat = torch.randn(el.shape[0], H, 4)
+    sm, ex, ret = torch.empty(n, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(n, H, 4, device=DEV)
+    K.relational_fused_gat_separate_coo(torch.arange(E, device=DEV), gold["sep_rel_ptrs"].to(DEV), gold["sep_row"].to(DEV),
+                                        gold["sep_col"].to(DEV), 4, d, feat.to(DEV), el.to(DEV), er.to(DEV), sm, ex, ret,
+                                        float(gold["gat_slope"]))
+    torch.testing.assert_close(cpu(ex), gold["gatc_exp"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cpu(sm), gold["gatc_sum"], rtol=1e-5, atol=1e-5)
+
+
+def test_gat_golden_backward_grad_feat_src(K, plan_mode, golden_mag):
+    """a5's grad_feat_src against the reference's own backward (ref_rgat.py:66-75; per-edge rows summed per source node as
+    that file indexes them -- tests/test_oracle.py::test_gat_backward_grad_feat_src_golden)."""
+    gold = golden_mag
+    n = int(gold["num_nodes"])
+    go = gold["gatb_gradout"]
+    E, H = gold["gat_exp"].shape
+    D = go.shape[2]
+    gen = torch.Generator().manual_seed(4)
+    feat, ret = torch.randn(E, H, D, generator=gen), torch.randn(n, H, D, generator=gen)
+    gf, gl, gr = (torch.zeros(E, H, D, device=DEV), torch.zeros(E, H, device=DEV), torch.zeros(E, H, device=DEV))
+    K.backward_relational_fused_gat_separate_coo(torch.arange(E, device=DEV), gold["sep_rel_ptrs"].to(DEV), gold["sep_row"].to(DEV),
+                                                 gold["sep_col"].to(DEV), 0, {}, feat.to(DEV), gold["gat_el"].to(DEV),
+                                                 gold["gat_er"].to(DEV), gold["gat_sum"].to(DEV), gold["gat_exp"].to(DEV), ret.to(DEV),
+                                                 go.to(DEV), gf, gl, gr, float(gold["gat_slope"]))
+    per_node = torch.zeros(n, H, D, dtype=torch.float64).index_add_(0, gold["sep_row"], cpu(gf).double())
+    torch.testing.assert_close(per_node.float(), gold["gatb_grad_feat_src"], rtol=5e-5, atol=5e-6)  # (fp32 sums of hub sources)
+
+
 # ---------------------------------------------------------------- RGCN
 @pytest.mark.parametrize("Kd,D", [(16, 16), (64, 64), (7, 3)])
 def test_rgcn_layer1(K, plan_mode, Kd, D):
@@ -764,3 +800,85 @@ def test_halo_pack_unpack_rows():
     got = k.rows_scatter_add_(acc.to(DEV), idx.to(DEV), src.to(DEV))
     assert_close(got, ref, what="scatter_add")
     assert k.rows_gather(x.to(DEV), idx[:0].to(DEV)).shape == (0, 64)
+
+
+# ---------------------------------------------------------------- node-major backward GEMMs (layer-level extension)
+@pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 4), (2, 64, 32, 6)])
+@pytest.mark.parametrize("with_loop,with_er,typed", [(True, True, False), (False, True, True), (True, False, True), (True, True, True)])
+def test_rgat_node_backward_gemms(K, H, Kd, D, R, with_loop, with_er, typed):
+    """het_rgat_node_backward_dx / _dw (csrc/node_gemm.hip) against the per-term definition in fp64 (the terms of a2 / a3:
+    RGNNOps.inc.h:946-1010, 660-753): whole range and split ranges, nodes without rows, a self-loop prefix n_loop < N."""
+    import het_amd.kernels as k
+    if not k.rgat_node_gemm_ok(R, H, Kd, D):
+        pytest.skip("shape outside the node-major kernels")
+    gen = torch.Generator().manual_seed(17 + H + R)
+    N, X = 333, H * D
+    n_loop = 301
+
+    def unique_lists(p):
+        ptr, nodes = [0], []
+        for r in range(R):
+            if typed:  # a relation's nodes live in one third of the id range
+                lo = (r % 3) * (N // 3)
+                cand = torch.arange(lo, lo + N // 3)
+            else:
+                cand = torch.arange(N)
+            keep = cand[torch.rand(cand.numel(), generator=gen) < p]
+            nodes.append(keep)
+            ptr.append(ptr[-1] + keep.numel())
+        return torch.tensor(ptr), torch.cat(nodes)
+
+    rp_row, n_row = unique_lists(0.6)
+    rp_col, n_col = unique_lists(0.4)
+    n_col = n_col.clamp(max=n_loop - 1) if False else n_col
+    S_row, S_col = n_row.numel(), n_col.numel()
+    x = torch.randn(N, Kd, generator=gen, dtype=torch.float64)
+    gh = torch.randn(n_loop, X, generator=gen, dtype=torch.float64)
+    g_rows = torch.randn(S_row, X, generator=gen, dtype=torch.float64)
+    g_er = torch.randn(S_col, H, generator=gen, dtype=torch.float64)
+    loop_w = torch.randn(Kd, X, generator=gen, dtype=torch.float64)
+    W = torch.randn(R, H, Kd, D, generator=gen, dtype=torch.float64)
+    wa = torch.randn(R, H, Kd, generator=gen, dtype=torch.float64)
+    # reference, term by term
+    gx = torch.zeros(N, Kd, dtype=torch.float64)
+    g_loop, g_W, g_wa = torch.zeros_like(loop_w), torch.zeros_like(W), torch.zeros_like(wa)
+    if with_loop:
+        gx[:n_loop] += gh @ loop_w.t()
+        g_loop += x[:n_loop].t() @ gh
+    for r in range(R):
+        rows = slice(int(rp_row[r]), int(rp_row[r + 1]))
+        nodes = n_row[rows]
+        Wr = W[r].permute(1, 0, 2).reshape(Kd, X)  # [K, (h, d)]
+        gx.index_add_(0, nodes, g_rows[rows] @ Wr.t())
+        g_W[r] += (x[nodes].t() @ g_rows[rows]).view(Kd, H, D).permute(1, 0, 2)
+        if with_er:
+            rows = slice(int(rp_col[r]), int(rp_col[r + 1]))
+            nodes = n_col[rows]
+            gx.index_add_(0, nodes, g_er[rows] @ wa[r])
+            g_wa[r] += g_er[rows].t() @ x[nodes]
+    f = lambda t: t.float().to(DEV).contiguous()
+    row_map = k.node_row_map(rp_row.to(DEV), n_row.to(DEV), N)
+    dst_map = k.node_row_map(rp_col.to(DEV), n_col.to(DEV), N)
+    ref_map = torch.full((R, N), -1, dtype=torch.int32)
+    for r in range(R):
+        ref_map[r, n_row[int(rp_row[r]):int(rp_row[r + 1])]] = torch.arange(int(rp_row[r]), int(rp_row[r + 1]), dtype=torch.int32)
+    assert torch.equal(row_map.cpu(), ref_map)
+    Wt = f(W.transpose(2, 3))
+    args = (f(gh) if with_loop else None, f(loop_w.t()) if with_loop else None, f(g_rows), Wt, row_map,
+            f(g_er) if with_er else None, f(wa) if with_er else None, dst_map if with_er else None)
+    for ranges in ([(0, N)], [(300, N), (0, 300)], [(0, 31), (31, 64), (64, N)]):
+        out = torch.full((N, Kd), float("nan"), device=DEV)
+        for b, e in ranges:
+            k.rgat_node_backward_dx(b, e, n_loop, *args, out)
+        assert_close(out, gx, what=f"grad_x {ranges}")
+        o_loop = torch.full((Kd, X), float("nan"), device=DEV) if with_loop else None
+        o_W = torch.full((R, H, Kd, D), float("nan"), device=DEV)
+        o_wa = torch.full((R, H, Kd), float("nan"), device=DEV) if with_er else None
+        for i, (b, e) in enumerate(ranges):
+            k.rgat_node_backward_dw(b, e, n_loop, f(x), args[0], args[2], row_map, args[5], args[7], o_loop, o_W, o_wa,
+                                    accumulate=i > 0)
+        assert_close(o_W, g_W, what=f"grad_W {ranges}")
+        if with_loop:
+            assert_close(o_loop, g_loop, what=f"grad_loop {ranges}")
+        if with_er:
+            assert_close(o_wa, g_wa, what=f"grad_wa {ranges}")

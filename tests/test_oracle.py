@@ -39,6 +39,43 @@ def test_gat_exp_sum_golden(which, golden_toy, golden_mag):
     torch.testing.assert_close(tot[has], torch.ones_like(tot[has]), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("which", ["toy", "mag"])
+def test_gat_compact_exp_sum_golden(which, golden_toy, golden_mag):
+    """CompactAsOfNodeKind 4 of the fused GAT forward (el per (relation, source) row, er per (relation, destination) row,
+    inverse indices by edge) against the exp / sum the reference's dual-unique-list wrapper produced (ref_rgat.py:77-115)."""
+    gold = golden_toy if which == "toy" else golden_mag
+    n = int(gold["num_nodes"])
+    el, er = gold["gatc_el"], gold["gatc_er"]
+    E, H = gold["gatc_exp"].shape
+    d = {"edata_idx_to_inverse_idx_row": gold["ss_inverse_indices_row"], "edata_idx_to_inverse_idx_col": gold["ss_inverse_indices_col"]}
+    feat = torch.randn(el.shape[0], H, 3)
+    s, exp, ret = torch.empty(n, H), torch.empty(E, H), torch.empty(n, H, 3)
+    O.relational_fused_gat_separate_coo(torch.arange(E), gold["sep_rel_ptrs"], gold["sep_row"], gold["sep_col"],
+                                        4, d, feat, el, er, s, exp, ret, float(gold["gat_slope"]))
+    torch.testing.assert_close(exp, gold["gatc_exp"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(s, gold["gatc_sum"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["toy", "mag"])
+def test_gat_backward_grad_feat_src_golden(which, golden_toy, golden_mag):
+    """grad_feat_src of the fused GAT backward against the reference's own backward (ref_rgat.py:66-75).  The reference
+    file indexes feat_src by SOURCE NODE, the exported kind-0 op by edge ([E,H,D] rows): the per-edge rows of the op are
+    summed per source node before comparing.  (Its grad_el / grad_er, :64-65, are not comparable: DESIGN.md section 3.)"""
+    gold = golden_toy if which == "toy" else golden_mag
+    n = int(gold["num_nodes"])
+    go = gold["gatb_gradout"]
+    E, H = gold["gat_exp"].shape
+    D = go.shape[2]
+    feat = torch.randn(E, H, D)
+    gf, gl, gr = torch.zeros(E, H, D), torch.zeros(E, H), torch.zeros(E, H)
+    O.backward_relational_fused_gat_separate_coo(torch.arange(E), gold["sep_rel_ptrs"], gold["sep_row"], gold["sep_col"], 0, {},
+                                                 feat, gold["gat_el"], gold["gat_er"], gold["gat_sum"], gold["gat_exp"],
+                                                 torch.randn(n, H, D), go, gf, gl, gr, float(gold["gat_slope"]))
+    per_node = torch.zeros(n, H, D).index_add_(0, gold["sep_row"], gf)
+    # the reference sums a hub source's edges in fp32 in its own order: a few ulp of the largest partial sum
+    torch.testing.assert_close(per_node, gold["gatb_grad_feat_src"], rtol=5e-5, atol=5e-6)
+
+
 def _plain_matmul(rp, gather, scatter, W, x, in1head, nrows_out):
     R, H, K, D = W.shape
     out = torch.zeros(nrows_out, H, D, dtype=W.dtype)
