@@ -38,7 +38,9 @@ _OFFS = {}
 PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
-NODE_DW = os.environ.get("HET_RGAT_NODE_DW", "0") == "1"       # ... the weight gradients too (one read of x for all of them)
+# ... the weight gradients too (one read of x for all of them): correct and tested, but at one wave per SIMD (its accumulators take
+# the register file) the kernel runs 1.02 ms against 0.76 ms for the four per-product launches on ogbn-mag -- off by default
+NODE_DW = os.environ.get("HET_RGAT_NODE_DW", "0") == "1"
 
 
 def _mulfirst_shape_ok(H, Kd):
@@ -324,9 +326,6 @@ class RgatLayerFunction(th.autograd.Function):
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
-        grad_attn_l = th.empty_like(attn_l)
-        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
-                                             accumulate=False)
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
         grad_x = th.empty_like(x)
         grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
@@ -335,9 +334,16 @@ class RgatLayerFunction(th.autograd.Function):
         _k.rgat_node_backward_dx(0, N, nd, gh, loop_w.t().contiguous() if ctx.has_loop else None, g_featc.view(-1, X), Wt, row_map,
                                  g_erc, wa_t, dst_map, grad_x)
         if NODE_DW:
-            _k.rgat_node_backward_dw(0, N, nd, x, gh, g_featc.view(-1, X), row_map, g_erc, dst_map, grad_loop, grad_W, grad_wa,
-                                     accumulate=False)
-        else:  # the weight gradients per source (three launches; each reads its own rows of x)
+            # all weight gradients from one read of x; the gradient of attn_l through grad_wl[r,h,:] = SUM g_el[row,h] * x[node,:]
+            # (feat_c[row] = x[node] . W[r], so SUM g_el[row,h] * feat_c[row,h,:] = grad_wl[r,h,:] . W[r,h]): no pass over feat_c
+            grad_wl = th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
+            _k.rgat_node_backward_dw(0, N, nd, x, gh, g_featc.view(-1, X), row_map, g_erc, dst_map, g_elc, grad_loop, grad_W, grad_wa,
+                                     grad_wl, accumulate=False)
+            grad_attn_l = th.einsum("rhk,rhkd->rhd", grad_wl, W)
+        else:  # the weight gradients per source (four launches; each reads its own rows of x / feat_c)
+            grad_attn_l = th.empty_like(attn_l)
+            _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                                 accumulate=False)
             if ctx.has_loop:
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
             _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)

@@ -803,7 +803,7 @@ def test_halo_pack_unpack_rows():
 
 
 # ---------------------------------------------------------------- node-major backward GEMMs (layer-level extension)
-@pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 4), (2, 64, 32, 6)])
+@pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 2), (2, 64, 32, 6)])
 @pytest.mark.parametrize("with_loop,with_er,typed", [(True, True, False), (False, True, True), (True, False, True), (True, True, True)])
 def test_rgat_node_backward_gemms(K, H, Kd, D, R, with_loop, with_er, typed):
     """het_rgat_node_backward_dx / _dw (csrc/node_gemm.hip) against the per-term definition in fp64 (the terms of a2 / a3:
@@ -836,12 +836,13 @@ def test_rgat_node_backward_gemms(K, H, Kd, D, R, with_loop, with_er, typed):
     gh = torch.randn(n_loop, X, generator=gen, dtype=torch.float64)
     g_rows = torch.randn(S_row, X, generator=gen, dtype=torch.float64)
     g_er = torch.randn(S_col, H, generator=gen, dtype=torch.float64)
+    g_el = torch.randn(S_row, H, generator=gen, dtype=torch.float64)
     loop_w = torch.randn(Kd, X, generator=gen, dtype=torch.float64)
     W = torch.randn(R, H, Kd, D, generator=gen, dtype=torch.float64)
     wa = torch.randn(R, H, Kd, generator=gen, dtype=torch.float64)
     # reference, term by term
     gx = torch.zeros(N, Kd, dtype=torch.float64)
-    g_loop, g_W, g_wa = torch.zeros_like(loop_w), torch.zeros_like(W), torch.zeros_like(wa)
+    g_loop, g_W, g_wa, g_wl = torch.zeros_like(loop_w), torch.zeros_like(W), torch.zeros_like(wa), torch.zeros_like(wa)
     if with_loop:
         gx[:n_loop] += gh @ loop_w.t()
         g_loop += x[:n_loop].t() @ gh
@@ -851,6 +852,7 @@ def test_rgat_node_backward_gemms(K, H, Kd, D, R, with_loop, with_er, typed):
         Wr = W[r].permute(1, 0, 2).reshape(Kd, X)  # [K, (h, d)]
         gx.index_add_(0, nodes, g_rows[rows] @ Wr.t())
         g_W[r] += (x[nodes].t() @ g_rows[rows]).view(Kd, H, D).permute(1, 0, 2)
+        g_wl[r] += g_el[rows].t() @ x[nodes]
         if with_er:
             rows = slice(int(rp_col[r]), int(rp_col[r + 1]))
             nodes = n_col[rows]
@@ -874,11 +876,13 @@ def test_rgat_node_backward_gemms(K, H, Kd, D, R, with_loop, with_er, typed):
         o_loop = torch.full((Kd, X), float("nan"), device=DEV) if with_loop else None
         o_W = torch.full((R, H, Kd, D), float("nan"), device=DEV)
         o_wa = torch.full((R, H, Kd), float("nan"), device=DEV) if with_er else None
+        o_wl = torch.full((R, H, Kd), float("nan"), device=DEV) if with_er else None
         for i, (b, e) in enumerate(ranges):
-            k.rgat_node_backward_dw(b, e, n_loop, f(x), args[0], args[2], row_map, args[5], args[7], o_loop, o_W, o_wa,
-                                    accumulate=i > 0)
+            k.rgat_node_backward_dw(b, e, n_loop, f(x), args[0], args[2], row_map, args[5], args[7], f(g_el) if with_er else None,
+                                    o_loop, o_W, o_wa, o_wl, accumulate=i > 0)
         assert_close(o_W, g_W, what=f"grad_W {ranges}")
         if with_loop:
             assert_close(o_loop, g_loop, what=f"grad_loop {ranges}")
         if with_er:
             assert_close(o_wa, g_wa, what=f"grad_wa {ranges}")
+            assert_close(o_wl, g_wl, what=f"grad_wl {ranges}")
