@@ -23,7 +23,17 @@ from . import _lib, graph as _graph, plan as _plan
 
 Tensor = torch.Tensor
 NAMESPACE = "torch_hrt"
-_libdef = torch.library.Library(NAMESPACE, "DEF")
+# HET_TORCH_HRT_LIB=<path to libtorch_hrt.so>: take the reference-named ops from the COMPILED registration object
+# (csrc/torch_export.cpp, `make -C het_amd/csrc torch_hrt`; loaded as the reference loads its own library,
+# hrt/python/kernels/__init__.py:4-16) instead of defining them here.  The functions below then only serve this package's
+# own callers (layers, backend); K.<op> goes through the compiled dispatcher entry.
+import os as _os
+COMPILED_LIB = _os.environ.get("HET_TORCH_HRT_LIB") or None
+if COMPILED_LIB:
+    torch.ops.load_library(COMPILED_LIB)
+    _libdef = None
+else:
+    _libdef = torch.library.Library(NAMESPACE, "DEF")
 _registered: List[str] = []
 
 
@@ -49,8 +59,11 @@ def _op(schema: str):
     name = schema.split("(")[0]
 
     def deco(fn):
-        _libdef.define(schema)
-        _libdef.impl(name, fn, "CompositeExplicitAutograd")
+        if _libdef is not None:
+            _libdef.define(schema)
+            _libdef.impl(name, fn, "CompositeExplicitAutograd")
+        elif not hasattr(getattr(torch.ops, NAMESPACE), name):
+            raise _lib.HetError(f"{COMPILED_LIB} does not register torch_hrt.{name}")
         _registered.append(name)
         return fn
 

@@ -93,3 +93,20 @@ def test_layout_ops_run_on_cpu(golden_toy):
     assert torch.equal(rp, g["sep_rel_ptrs"]) and torch.equal(r, g["sep_row"]) and torch.equal(e, g["sep_eids"])
     ptr, col, eid, rel = k.K.transpose_csr(g["csr_row_ptrs"], g["csr_col"], g["csr_eids"], g["csr_rel"])
     assert torch.equal(ptr, g["tcsr_row_ptrs"])
+
+
+def test_compiled_registration_object_lists_every_op():
+    """libtorch_hrt.so (csrc/torch_export.cpp) loaded the reference's way -- torch.ops.load_library in an interpreter that never
+    imports het_amd -- registers every op the Python registration defines (no GPU needed to load it)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "het_amd", "libtorch_hrt.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("libtorch_hrt.so not built (make -C het_amd/csrc torch_hrt)")
+    import het_amd.kernels as k
+    code = ("import sys, torch; torch.ops.load_library(%r); K = torch.ops.torch_hrt; assert 'het_amd' not in sys.modules; "
+            "print(' '.join(n for n in %r if not hasattr(K, n)))" % (lib, list(k.REGISTERED_OPS)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == "", "ops missing from libtorch_hrt.so: " + r.stdout
