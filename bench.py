@@ -160,6 +160,21 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
 
 
 def main():
+    """Any failure of a rank -- an RCCL / HIP error included -- is printed with the rank and the failing call's traceback and
+    ends the process with a non-zero exit code (torch.distributed.run then stops the other ranks): no retry, no fallback."""
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as ex:  # noqa: BLE001
+        import traceback
+        sys.stderr.write(f"[bench.py rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')}] FAILED: "
+                         f"{type(ex).__name__}: {ex}\n{traceback.format_exc()}")
+        sys.stderr.flush()
+        os._exit(1)  # (a rank stuck in a collective would keep a normal interpreter shutdown waiting)
+
+
+def _main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -471,6 +486,34 @@ def main():
         per_op = {k[4:]: round(v, 3) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}
         per_op["(sum of C-ABI calls)"] = round(sum(acc.values()), 3)
 
+    dist_info = None
+    if use_dist:
+        # what every rank moved and waited for: a few more steps with the halo contexts' wait timers on
+        import torch.distributed as dist
+        halo = runner.dl.halo
+        halo.timing = []
+        tsteps = max(1, min(args.steps, 5))
+        for _ in range(tsteps):
+            step()
+        barrier()
+        waits = {}
+        for what, a, b in halo.timing:
+            waits[what] = waits.get(what, 0.0) + a.elapsed_time(b) / tsteps
+        halo.timing = None
+        p_ = runner.dl.plan
+        mine = {"rank": rank, "owned_nodes": int(p_.n_own), "halo_rows_received": int(p_.n_halo), "halo_rows_sent": int(p_.send_idx.numel()),
+                "halo_MB_sent_per_exchange": round(int(p_.send_idx.numel()) * K * 4 / 1e6, 2),
+                "halo_MB_received_per_exchange": round(int(p_.n_halo) * K * 4 / 1e6, 2), "local_edges": int(E_local),
+                "exposed_wait_ms": {k_: round(v_, 4) for k_, v_ in waits.items()}}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        dist_info = {"ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+                     "overlap": os.environ.get("HET_DIST_OVERLAP", "1") == "1",
+                     "exchange": "x[halo] forward and grad_x[halo] backward, one all_to_all_single each per step; "
+                                 "exposed_wait_ms = time the launch stream waited for it (0 when hidden or synchronous)",
+                     "per_rank": allr,
+                     "max_exposed_wait_ms": round(max(sum(r_["exposed_wait_ms"].values()) for r_ in allr), 4)}
+
     from het_amd import plan as HP
     plan_bytes = HP.cached_bytes()
     if rank == 0:
@@ -492,6 +535,7 @@ def main():
             "roofline_reference_named_ops": roofline_ops,
             "kernel_ms": kernel_ms,
             "per_op_ms": per_op,
+            "dist": dist_info,
             # torch's allocator peak + the groupings (hipMalloc'ed by the library at plan time, outside torch's statistics)
             "peak_memory_GB": round((torch.cuda.max_memory_allocated(dev) + plan_bytes) / 2**30, 2),
             "peak_memory_detail_GB": {"torch_allocator_peak": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),

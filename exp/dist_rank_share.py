@@ -58,6 +58,21 @@ for world, beta in ([(1, 0.0)] if 1 in WORLDS or "WORLDS" not in os.environ else
             return send
 
         ms = timeit(step)
+        if os.environ.get("GRAPH") and world > 1:  # the same share replayed as ONE HIP graph: what launch / host overhead costs
+            xs = torch.randn(p.n_own + p.n_halo, 64, device=dev).mul_(0.1).requires_grad_(True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    layer.zero_grad(set_to_none=True); xs.grad = None
+                    layer(g, xs, num_dst=p.n_own).backward(go)
+            torch.cuda.current_stream().wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            layer.zero_grad(set_to_none=True); xs.grad = None
+            with torch.cuda.graph(cg):
+                layer(g, xs, num_dst=p.n_own).backward(go)
+            eager = timeit(lambda: (layer.zero_grad(set_to_none=True), layer(g, xs, num_dst=p.n_own).backward(go)))
+            print(f"world {world} rank {rank}: layer fwd+bwd eager {eager:.3f} ms, as one HIP graph {timeit(cg.replay):.3f} ms", flush=True)
         if os.environ.get("PROFILE_RANK") and world == 8 and rank == 7 and beta > 0:
             torch.cuda.synchronize()
             from het_amd import kernels as _k

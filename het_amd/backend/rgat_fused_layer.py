@@ -369,27 +369,43 @@ class RgatLayerFunction(th.autograd.Function):
         rp_row, rows_node = ss["rel_ptrs_row"], ss["node_indices_row"]
         d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
         Wt = th.transpose(W, 2, 3).contiguous()
-        grad_x = th.empty_like(x)
-        grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
-        _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
         s_coo = g.get_separate_coo_original()
         assert _destinations_below(s_coo["col_indices"], nd), "a partition's edges point at owned nodes"
         go = grad_h.view(nd, H, D)  # (so the per-destination tensors of the backward are their first nd rows)
         g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)
+        grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
+        grad_x = th.empty_like(x)
+        node_major = NODE_GEMM and _k.rgat_node_gemm_ok(R, H, Kd, D)
+        if not node_major:
+            grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
+            _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
-        _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=2)  # rows of a relation: distinct nodes
-        halo.start_return(grad_x)
+        if node_major:
+            # one pass per node range (csrc/node_gemm.hip): the halo rows first -- only the (relation, source) projections reach
+            # them -- so that they leave with the all-to-all while the owned rows (self-loop + projections + folded attention
+            # vector, every term in one store) and the weight gradients are formed
+            row_map = _k.node_row_map(rp_row, rows_node, N)
+            dst_map = _k.node_row_map(ss["rel_ptrs_col"], ss["node_indices_col"], N)
+            loop_wt = loop_w.t().contiguous()
+            args = (grad_h, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t.view(R, H, Kd), dst_map, grad_x)
+            _k.rgat_node_backward_dx(nd, N, nd, *args)
+            halo.start_return(grad_x)
+            _k.rgat_node_backward_dx(0, nd, nd, *args)
+        else:
+            _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=2)  # rows of a relation: distinct nodes
+            halo.start_return(grad_x)
         grad_W, grad_loop = th.empty_like(W), th.empty_like(loop_w)
         _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)
         _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
         grad_attn_l = th.empty_like(attn_l)
         _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
                                              accumulate=False)
-        wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)
-        grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
-        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True, distinct_rows=True)  # owned rows only
+        # the er side's weight gradient (and, on the per-relation path, its input gradient: owned rows only)
+        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), None if node_major else grad_x, grad_wa, True, accumulate=True,
+                           distinct_rows=True)
         grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
         grad_attn_r = (W * grad_wa).sum(2)
         grad_own = halo.finish_return(grad_x[:nd])

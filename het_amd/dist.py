@@ -214,19 +214,43 @@ class HaloContext:
 
     def __init__(self, plan: DistPlan, group):
         self.plan, self.group = plan, group
-        self._work = self._keep = None
+        self._work = self._keep = self._back = None
+        # exposed wait of the launch stream for the two exchanges of a step (bench.py: `timing = []` switches it on):
+        # (what, event recorded when the launch stream reaches the wait, event recorded when it resumes)
+        self.timing = None
 
     def _a2a(self, recv, send, recv_counts, send_counts):
+        # one exchange in flight per context: an unpaired start_* (an exception between start and finish, a re-entered layer)
+        # would silently drop the handle of a collective that is still writing `recv`
+        if self._work is not None:
+            raise RuntimeError("HaloContext: an exchange is still in flight (start_* without its finish_*)")
         if send.is_cuda and dist.get_backend(self.group) != "gloo":
             self._work = dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group, async_op=True)
             self._keep = (recv, send)  # alive until the collective has finished
         else:
             _all_to_all(recv, send, recv_counts, send_counts, self.group)
 
-    def _wait(self):
+    def _wait(self, what="exchange"):
         if self._work is not None:
-            self._work.wait()
-            self._work = self._keep = None
+            ev = None
+            if self.timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            try:
+                self._work.wait()
+            finally:
+                self._work = self._keep = None
+            if ev is not None:
+                ev[1].record()
+                self.timing.append((what, ev[0], ev[1]))
+
+    def abort(self):
+        """Wait for an exchange a failed step left in flight (exception between start_* and finish_*), so that its buffers may
+        be freed and the context reused."""
+        try:
+            self._wait("abort")
+        finally:
+            self._back = None
 
     def start_push(self, x_own):
         p = self.plan
@@ -237,7 +261,7 @@ class HaloContext:
         return x_local
 
     def finish_push(self):
-        self._wait()
+        self._wait("push")
 
     def start_return(self, grad_local):
         p = self.plan
@@ -245,7 +269,7 @@ class HaloContext:
         self._a2a(self._back, grad_local[p.n_own:], p.send_counts, p.recv_counts)
 
     def finish_return(self, grad_own):
-        self._wait()
+        self._wait("return")
         _scatter_add_rows(grad_own, self.plan.send_idx, self._back)
         self._back = None
         return grad_own
@@ -296,7 +320,11 @@ class DistLayer:
 
     def forward(self, x_own: torch.Tensor) -> torch.Tensor:
         if self.halo_layer_fn is not None:
-            out = self.halo_layer_fn(self.graph, x_own, self.halo)
+            try:
+                out = self.halo_layer_fn(self.graph, x_own, self.halo)
+            except BaseException:
+                self.halo.abort()  # (no exchange may stay in flight behind a failed step)
+                raise
             if out is not None:
                 return out
         x_local = HaloExchange.apply(x_own, self.plan, self.group)

@@ -115,3 +115,68 @@ def test_bench_two_ranks_through_torchrun():
                        "3", "--warmup", "1", "--no-cpu-baseline"], env)
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert "RCCL all-to-all" in out["config"]["parallelism"]
+
+
+def _nccl_worker_script():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "dist_nccl_worker.py")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_ranks_match_single_process(world):
+    """The real thing where the box has the GPUs: `world` ranks, one GPU each, backend nccl (= RCCL over xGMI), launched the
+    driver's way (python -m torch.distributed.run); the asynchronous all_to_all_single of the halo contexts with uneven splits,
+    device_id binding and the gradient all-reduce -- outputs, input and weight gradients against the single-process layer.
+    Skips on a one-GPU box (two RCCL ranks cannot share a GPU)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HET_FORCE_DIST", "HET_DIST_BACKEND"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                            "127.0.0.1", "--master-port", str(_free_port()), _nccl_worker_script(), d], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        parts = [torch.load(os.path.join(d, f"r{q}.pt")) for q in range(world)]
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    dev = torch.device("cuda", 0)
+    feat = 64
+    coo = make_mag_like(scale=4e-3)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    g = HetGraph.from_integrated_coo(coo, full=True)
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(feat, feat, coo.num_rels, 4, self_loop=True, dropout=0.0).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(coo.num_nodes, feat, generator=gen).to(dev).requires_grad_(True)
+    go = torch.randn(coo.num_nodes, feat, generator=gen).to(dev)
+    ref = layer(g, x)
+    ref.backward(go)
+    assert torch.equal(torch.sort(torch.cat([q["mine"] for q in parts])).values, torch.arange(coo.num_nodes))
+    for q in parts:
+        assert q["async_exchanges"] > 0, "the halo contexts took the synchronous branch"
+        torch.testing.assert_close(q["out"], ref.detach().cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(q["gx"], x.grad.cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
+        for n, p in layer.named_parameters():
+            torch.testing.assert_close(q["grads"][n], p.grad.cpu(), rtol=5e-4, atol=1e-4)
+
+
+def test_bench_rccl_two_ranks():
+    """bench.py --gpus 2 over RCCL through the driver's launch line (needs two GPUs): the JSON line carries the rank count, the
+    halo volume of every rank and the exposed exchange time."""
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HET_FORCE_DIST", "HET_DIST_BACKEND"):
+        env.pop(k, None)
+    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                       "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--scale", "0.05", "--steps",
+                       "3", "--warmup", "1", "--no-cpu-baseline"], env)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["dist"]["ranks"] == 2 and "RCCL" in out["dist"]["backend"]
+    assert len(out["dist"]["per_rank"]) == 2 and all(r["halo_rows_sent"] > 0 for r in out["dist"]["per_rank"])
