@@ -34,7 +34,7 @@ _SIGNATURES = {
     "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P, P],
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
-    "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P],
+    "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, I64, P],
     "het_rows_matmul_backward_dx": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         L.het_grouping_num_segments.restype = I64
         L.het_grouping_bytes.argtypes = [P]
         L.het_grouping_bytes.restype = I64
+        L.het_rgat_aggregate_compact_workspace.argtypes = [P, I64, I64]
+        L.het_rgat_aggregate_compact_workspace.restype = I64
         L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
         L.het_rgat_backward_compact_workspace.restype = I64
         L.het_hgt_backward_compact_workspace.argtypes = [I64, I64]

@@ -32,27 +32,40 @@ struct Items {
   int64_t n;
 };
 
+// Softmax WITHOUT overflow inside the one-node layer.  The reference's kernels exponentiate the raw pre-activation
+// (gatLeakyReluExp, GAT/FusedGAT.cu.h:23-26: exp(leaky_relu(el + er)), no maximum subtracted -- SURVEY.md Q2), which the
+// reference-named ops keep because exp / sum are API tensors there.  Here neither is visible to the caller, so every pass
+// works with s = leaky_relu(el + er) relative to a maximum: the forward keeps a running maximum per (destination, head) and
+// rescales its partial sums when it grows (online softmax), stores lse[v,h] = max + log(SUM exp(s - max)) where the
+// reference stores the sum, and the backward forms the attention weight as exp(s - lse[v,h]).  Same value as
+// exp(s) / SUM exp(s) wherever the reference's formula is finite; finite everywhere else too (|el + er| of 100 and more).
+__device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
+
 // ret[v,h,:] = SUM_e w_e * feat[srow_e,h,:] / SUM_e w_e,  w_e = exp(leaky(el[srow_e,h] + er[drow_e,h])); sum[v,h] = SUM_e w_e
 // Same schedule as HET_gat_aggregate_grouped (fused_gat_grouped.hip): 64/LPR lane groups take the item's edges
 // round-robin, U rows per group in flight, ids of the next step prefetched.
+// A whole segment is finished here (running maximum, one store).  An item of a split (hub) destination parks its partial
+// result {acc[X], max[H], sum[H]} in part[item]; HET_rgat_finish_split brings the items of a destination to their common maximum.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, const int32_t* __restrict__ p_srow,
                                                                       const int32_t* __restrict__ p_drow,
                                                                       const float* __restrict__ feat,
                                                                       const float* __restrict__ el,
                                                                       const float* __restrict__ er,
-                                                                      float* __restrict__ sum, float* __restrict__ ret,
+                                                                      float* __restrict__ lse, float* __restrict__ ret,
                                                                       int H, int D, float slope, float* __restrict__ hio,
-                                                                      int64_t hio_rows) {
+                                                                      int64_t hio_rows, float* __restrict__ part) {
   constexpr int EPW = 64 / LPR, U = 4;
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const int64_t X = (int64_t)H * D;
+  const int64_t v = it.seg_key[seg];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float ssum = 0.f;
+  float ssum = 0.f, m = -INFINITY;
   int jn[U];
   int64_t srown[U], drown[U];
 #pragma unroll
@@ -61,15 +74,13 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
   for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
 #pragma unroll
   for (int u = 0; u < U; ++u) drown[u] = p_drow[jn[u]];
-  const int64_t v = it.seg_key[seg];
-  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   // hio (optional): the layer output so far (self-loop + bias rows); the aggregated row is added to it in place.  Its row
   // is requested here so that the read-modify-write at the end of the item does not wait for it
   const bool add_h = hio && whole && slot == 0 && v < hio_rows;
   float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (add_h) h0 = ld4(hio + v * X + x);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    float zl[U], zr[U];
+    float zl[U], zr[U], sv[U];
     float4 f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) zl[u] = el[srown[u] * H + h];
@@ -83,15 +94,34 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
     for (int u = 0; u < U; ++u) srown[u] = p_srow[jn[u]];
 #pragma unroll
     for (int u = 0; u < U; ++u) drown[u] = p_drow[jn[u]];
+    float mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float w = j0 + u * EPW < e ? leaky_exp(zl[u] + zr[u], slope) : 0.f;
+      sv[u] = j0 + u * EPW < e ? lrelu(zl[u] + zr[u], slope) : -INFINITY;
+      mn = fmaxf(mn, sv[u]);
+    }
+    {  // (the first edge of a step exists: mn is finite)
+      const float c = __expf(m - mn);
+      acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+      m = mn;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = __expf(sv[u] - m);  // exp(-inf) = 0 for the padding edges
       acc.x = fmaf(w, f[u].x, acc.x);
       acc.y = fmaf(w, f[u].y, acc.y);
       acc.z = fmaf(w, f[u].z, acc.z);
       acc.w = fmaf(w, f[u].w, acc.w);
       ssum += w;
     }
+  }
+  {  // the lane groups of the wave saw different edges: bring their sums to the common maximum
+    float M = m;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float c = m == -INFINITY ? 0.f : __expf(m - M);
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+    m = M;
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -102,50 +132,73 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
     ssum += __shfl_xor(ssum, off);
   }
   if (slot != 0) return;
-  float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    st4(rp, r4);
+    st4(ret + v * X + x, r4);
     if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (x % D == 0) sum[v * H + h] = ssum;
-  } else {  // hub destination: unnormalised partials, normalised by HET_rgat_normalize_split
-    atomicAdd(rp + 0, acc.x);
-    atomicAdd(rp + 1, acc.y);
-    atomicAdd(rp + 2, acc.z);
-    atomicAdd(rp + 3, acc.w);
-    if (x % D == 0) atomicAdd(&sum[v * H + h], ssum);
+    if (x % D == 0) lse[v * H + h] = m + __logf(ssum);
+  } else {  // a piece of a hub destination: parked for HET_rgat_finish_split
+    float* pp = part + item * (X + 2 * H);
+    st4(pp + x, acc);
+    if (x % D == 0) { pp[X + h] = m; pp[X + H + h] = ssum; }
   }
 }
 
-__global__ __launch_bounds__(kBlock) void HET_rgat_normalize_split(const int32_t* __restrict__ split_seg,
-                                                                    const int32_t* __restrict__ seg_key,
-                                                                    int64_t num_split, const float* __restrict__ sum,
-                                                                    float* __restrict__ ret, int H, int D,
-                                                                    float* __restrict__ hio, int64_t hio_rows) {
-  const int64_t X = (int64_t)H * D, total = num_split * X;
-  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-    const int64_t k = t / X;
-    const int x = (int)(t - k * X);
-    const int64_t v = seg_key[split_seg[k]];
-    const float r = ret[v * X + x] / sum[v * H + x / D];
-    ret[v * X + x] = r;
-    if (hio && v < hio_rows) hio[v * X + x] += r;
+// One wave per split (hub) destination: its work items parked {acc[X], max[H], sum[H]} each (part[item]); the lane groups of
+// the wave take them round-robin (the largest hub of ogbn-mag has ~400), are brought to the common maximum, divided, and the
+// row is stored (ret, lse) and added to the layer output.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_finish_split(const int32_t* __restrict__ split_seg, int64_t num_split, Items it,
+                                                                 const float* __restrict__ part, float* __restrict__ lse,
+                                                                 float* __restrict__ ret, int H, int D, float* __restrict__ hio,
+                                                                 int64_t hio_rows) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= num_split) return;
+  const int seg = split_seg[k];
+  const int64_t X = (int64_t)H * D, v = it.seg_key[seg];
+  int64_t lo = 0, hi = it.n;  // first work item of the segment (items are in segment order)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (it.seg[mid] < seg) lo = mid + 1; else hi = mid;
   }
+  const int64_t n_items = (it.seg_ptr[seg + 1] - it.seg_ptr[seg] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f, m = -INFINITY;
+  for (int64_t i = slot; i < n_items; i += EPW) {
+    const float* pp = part + (lo + i) * (X + 2 * H);
+    const float mi = pp[X + h], si = pp[X + H + h];
+    const float4 a = ld4(pp + x);
+    const float mn = fmaxf(m, mi), c = __expf(m - mn), ci = __expf(mi - mn);
+    acc.x = acc.x * c + a.x * ci; acc.y = acc.y * c + a.y * ci; acc.z = acc.z * c + a.z * ci; acc.w = acc.w * c + a.w * ci;
+    ssum = ssum * c + si * ci;
+    m = mn;
+  }
+  float M = m;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+  const float c = m == -INFINITY ? 0.f : __expf(m - M);
+  acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  const float inv = 1.f / ssum;
+  const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  st4(ret + v * X + x, r4);
+  if (hio && v < hio_rows) {
+    const float4 h0 = ld4(hio + v * X + x);
+    st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
+  }
+  if (x % D == 0) lse[v * H + h] = M + __logf(ssum);
 }
 
-// rows of the split (hub) destinations start from zero: their work items add unnormalised partial sums atomically
-__global__ __launch_bounds__(kBlock) void HET_rgat_zero_split_rows(const int32_t* __restrict__ split_seg,
-                                                                    const int32_t* __restrict__ seg_key,
-                                                                    int64_t num_split, float* __restrict__ ret, int X) {
-  const int64_t total = num_split * X;
-  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-    const int64_t k = t / X;
-    ret[(int64_t)seg_key[split_seg[k]] * X + (t - k * X)] = 0.f;
-  }
-}
-
-// pack[v] = { 1/sum[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }, or interleaved per head ([N,H,2]); bias_part (optional, [gridDim.x * waves, X]):
+// pack[v] = { lse[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }, or interleaved per head ([N,H,2]); bias_part (optional, [gridDim.x * waves, X]):
 // per-wave column sums of gradout over the nodes the wave visited (the bias gradient, reduced by HET_rgat_colsum_finish).
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_rgat_dst_pack(const float* __restrict__ sum, const float* __restrict__ ret,
@@ -165,9 +218,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_dst_pack(const float* __restr
     for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
     if ((sub & (DL - 1)) == 0) {
       if (interleaved) {
-        *reinterpret_cast<float2*>(pack + (v * H + h) * 2) = make_float2(1.f / sum[v * H + h], dot);
+        *reinterpret_cast<float2*>(pack + (v * H + h) * 2) = make_float2(sum[v * H + h], dot);
       } else {
-        pack[v * 2 * H + h] = 1.f / sum[v * H + h];
+        pack[v * 2 * H + h] = sum[v * H + h];
         pack[v * 2 * H + H + h] = dot;
       }
     }
@@ -205,7 +258,7 @@ struct Packs {
 };
 
 // Lane group per pack of the grouping by feat row u (payload0 = destination, payload1 = er row):
-//   a_e = exp(leaky(el[u,h] + er[drow_e,h])) / sum[dst_e,h];  dl_e = (el + er > 0) ? 1 : slope
+//   a_e = exp(leaky(el[u,h] + er[drow_e,h]) - lse[dst_e,h]);  dl_e = (el + er > 0) ? 1 : slope
 //   grad_feat[u,h,:] = SUM_e a_e * gradout[dst_e,h,:]  (+ grad_el[u,h] * fold_w[r(u),h,:])
 //   t_e = a_e * dl_e * (<gradout[dst_e,h,:], feat[u,h,:]> - <gradout, ret>[dst_e,h]);   grad_el[u,h] = SUM_e t_e
 //   tbuf[j,h] = t_e for the edge at sorted rank j   (summed per er row by a segmented pass over the grouping by er row)
@@ -280,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_packed(
       const bool start = ok && key[q] != (q == 0 ? prev_key : key[q - 1]);
       if (start) { fcur = fq[q]; zlcur = zlq[q]; }
       const float z = zlcur + zr[q];
-      const float a = ok ? leaky_exp(z, slope) * sinv[q] : 0.f;
+      const float a = ok ? __expf(lrelu(z, slope) - sinv[q]) : 0.f;  // (sinv: lse of the destination)
       acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
       acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
       float dot = g[q].x * fcur.x + g[q].y * fcur.y + g[q].z * fcur.z + g[q].w * fcur.w;
@@ -361,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long_any(
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const float z = zl + zr[q];
-      const float a = ok[q] ? leaky_exp(z, slope) * sinv[q] : 0.f;
+      const float a = ok[q] ? __expf(lrelu(z, slope) - sinv[q]) : 0.f;  // (sinv: lse of the destination)
       acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
       acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
       float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
@@ -420,9 +473,9 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
                                                                    const float* __restrict__ feat,
                                                                    const float* __restrict__ el,
                                                                    const float* __restrict__ er,
-                                                                   float* __restrict__ sum, float* __restrict__ ret,
+                                                                   float* __restrict__ lse, float* __restrict__ ret,
                                                                    int H, float slope, float* __restrict__ hio,
-                                                                   int64_t hio_rows) {
+                                                                   int64_t hio_rows, float* __restrict__ part) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
@@ -431,12 +484,12 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
   const int64_t item = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= it.n) return;
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
+  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
+  const int64_t v = it.seg_key[seg];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float ssum = 0.f;
+  float ssum = 0.f, m = -INFINITY;
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
   int2 idn = p01[jn];  // {feat row, er row} of the edge: one load (grouping_packed_ids)
-  const int64_t v = it.seg_key[seg];
-  const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const bool add_h = hio && whole && slot == 0 && v < hio_rows;  // see HET_rgat_aggregate_compact
   float4 h0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (add_h) h0 = ld4(hio + v * X + x);
@@ -449,7 +502,17 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
     idn = p01[jn];
-    const float wv = j0 + dq * EPW < e ? fast_leaky_exp(zlv + zrv, slope) : 0.f;  // one exp per (edge, head)
+    // s of this lane's edge; the running maximum of the head over the U edges of the step (lanes d >= U repeat edge U - 1)
+    const float sv = j0 + dq * EPW < e ? lrelu(zlv + zrv, slope) : -INFINITY;
+    {
+      float mn = m;
+#pragma unroll
+      for (int u = 0; u < U; ++u) mn = fmaxf(mn, head_bcast<DL>(sv, u, lane));
+      const float c = __expf(m - mn);  // (the first edge of a step exists: mn is finite; exp(-inf) = 0 the first time)
+      acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+      m = mn;
+    }
+    const float wv = __expf(sv - m);  // one exp per (edge, head); 0 for the padding edges
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float w = head_bcast<DL>(wv, u, lane);
@@ -460,6 +523,14 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
       ssum += w;
     }
   }
+  {  // the lane groups of the wave saw different edges: bring their sums to the common maximum
+    float M = m;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float c = m == -INFINITY ? 0.f : __expf(m - M);
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+    m = M;
+  }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
     acc.x += __shfl_xor(acc.x, off);
@@ -469,23 +540,20 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
     ssum += __shfl_xor(ssum, off);
   }
   if (slot != 0) return;
-  float* rp = ret + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    st4(rp, r4);
+    st4(ret + v * X + x, r4);
     if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (d == 0) sum[v * H + h] = ssum;
-  } else {
-    atomicAdd(rp + 0, acc.x);
-    atomicAdd(rp + 1, acc.y);
-    atomicAdd(rp + 2, acc.z);
-    atomicAdd(rp + 3, acc.w);
-    if (d == 0) atomicAdd(&sum[v * H + h], ssum);
+    if (d == 0) lse[v * H + h] = m + __logf(ssum);
+  } else {  // a piece of a hub destination: parked for HET_rgat_finish_split
+    float* pp = part + item * (X + 2 * H);
+    st4(pp + x, acc);
+    if (d == 0) { pp[X + h] = m; pp[X + H + h] = ssum; }
   }
 }
 
-// Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {1/sum, <gradout, ret>} interleaved.
+// Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {lse, <gradout, ret>} interleaved.
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat,
@@ -535,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     idn = kp01[jn];
     // per (edge, head) once: attention weight, its leaky-ReLU branch, the destination's <gradout, ret>
     const float zv = zlv + zrv;
-    const float av = j0 + dq < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
+    const float av = j0 + dq < e ? __expf(lrelu(zv, slope) - pkv.x) : 0.f;  // pkv.x: lse of the destination
     const float adv = av * (zv > 0.f ? 1.f : slope);
     float tq[U];
 #pragma unroll
@@ -637,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
     idn = p01[jn];
     const float zv = zl + zrv;
-    const float av = j0 + dq * EPW < e ? fast_leaky_exp(zv, slope) * pkv.x : 0.f;
+    const float av = j0 + dq * EPW < e ? __expf(lrelu(zv, slope) - pkv.x) : 0.f;  // pkv.x: lse of the destination
     const float adv = av * (zv > 0.f ? 1.f : slope);
     float tq[U];
 #pragma unroll
@@ -739,29 +807,35 @@ static bool compact_shape_ok(int64_t H, int64_t D) {
   return is_pow2(D) && D >= 4 && is_pow2(X) && X / 4 <= 64 && H <= X / 4;
 }
 
+// bytes of het_rgat_aggregate_compact's workspace: one {acc[H*D], max[H], sum[H]} record per work item when the grouping has
+// destinations that are split over several work items (more than HET_ITEM_MAX in-edges); only the records of those items are touched
+extern "C" int64_t het_rgat_aggregate_compact_workspace(const het_grouping* by_dst, int64_t H, int64_t D) {
+  if (!by_dst || by_dst->num_split == 0) return 0;
+  return (int64_t)sizeof(float) * by_dst->num_items * (H * D + 2 * H);
+}
+
 extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c,
                                           const float* er_c, float* sum, float* ret, int64_t num_nodes, int64_t H,
-                                          int64_t D, double slope, float* h_inout, int64_t h_rows, het_stream stream) {
+                                          int64_t D, double slope, float* h_inout, int64_t h_rows, void* workspace,
+                                          int64_t workspace_bytes, het_stream stream) {
   const char* op = "het_rgat_aggregate_compact";
   hipStream_t s = (hipStream_t)stream;
   HET_REQUIRE(by_dst && sum && ret && num_nodes >= 0, "%s: null argument", op);
   if (!compact_shape_ok(H, D)) { het_set_error("%s: unsupported shape H=%lld D=%lld", op, (long long)H, (long long)D); return HET_ERR_UNSUPPORTED; }
   HET_REQUIRE(by_dst->R == 0 && by_dst->key_bound <= num_nodes && (by_dst->E == 0 || (by_dst->p0 && by_dst->p1 && feat_c && el_c && er_c)),
               "%s: by_dst must group the positions by destination with payload0 = feat row and payload1 = er row", op);
+  const int64_t need = het_rgat_aggregate_compact_workspace(by_dst, H, D);
+  HET_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0),
+              "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_aggregate_compact_workspace)", op, (long long)need);
   const int64_t X = H * D;
-  HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));  // destinations without in-edges; split hubs add atomically
+  HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));  // destinations without in-edges (never read by an edge)
   // ret: zero rows for destinations without in-edges -- unless the caller takes the layer output through h_inout and
-  // reads ret only where edges point (the backward): then only the split hubs' rows are cleared (0.5 GB less to fill)
-  if (!h_inout) {
-    HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
-  } else if (by_dst->num_split > 0) {
-    hipLaunchKernelGGL(HET_rgat_zero_split_rows, dim3(grid_for(by_dst->num_split * X)), dim3(kBlock), 0, s, by_dst->split_seg,
-                       by_dst->seg_key, by_dst->num_split, ret, (int)X);
-    HET_LAUNCH_CHECK("HET_rgat_zero_split_rows");
-  }
+  // reads ret only where edges point (the backward): then nothing is filled (0.5 GB less)
+  if (!h_inout) HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
   if (by_dst->E == 0) return HET_OK;
   Items it{by_dst->item_seg, by_dst->item_begin, by_dst->item_end, by_dst->seg_ptr, by_dst->seg_key, by_dst->num_items};
   const unsigned nb = (unsigned)ceil_div64(by_dst->num_items, kBlock / 64);
+  float* part = static_cast<float*>(workspace);
   if (coop_shape_ok(H, D))
     if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
   {
@@ -769,18 +843,19 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
     if (coop_shape_ok(H, D)) {
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
                         hipLaunchKernelGGL((HET_rgat_aggregate_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p01,
-                                           feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows));
+                                           feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows, part));
     } else {
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_aggregate_compact<LPR>, dim3(nb), dim3(kBlock), 0, s, it,
                                                         by_dst->p0, by_dst->p1, feat_c, el_c, er_c, sum, ret, (int)H, (int)D,
-                                                        (float)slope, h_inout, h_rows));
+                                                        (float)slope, h_inout, h_rows, part));
     }
   }
   HET_LAUNCH_CHECK("HET_rgat_aggregate_compact");
-  if (by_dst->num_split > 0) {
-    hipLaunchKernelGGL(HET_rgat_normalize_split, dim3(grid_for(by_dst->num_split * X)), dim3(kBlock), 0, s, by_dst->split_seg,
-                       by_dst->seg_key, by_dst->num_split, sum, ret, (int)H, (int)D, h_inout, h_rows);
-    HET_LAUNCH_CHECK("HET_rgat_normalize_split");
+  if (by_dst->num_split > 0) {  // the pieces of the hub destinations: common maximum, division, lse
+    const unsigned nbs = (unsigned)ceil_div64(by_dst->num_split, kBlock / 64);
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_split<LPR>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg,
+                                                      by_dst->num_split, it, part, sum, ret, (int)H, (int)D, h_inout, h_rows));
+    HET_LAUNCH_CHECK("HET_rgat_finish_split");
   }
   return HET_OK;
 }

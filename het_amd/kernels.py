@@ -563,12 +563,15 @@ def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_row
 
 
 def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None):
-    """h_inout [rows, H*D] (optional): ret's rows are also added into it in place (include/het_amd.h)."""
+    """h_inout [rows, H*D] (optional): ret's rows are also added into it in place (include/het_amd.h).  ``sum`` receives the
+    log-sum-exp of every (destination, head) -- these two entry points subtract a running maximum (no overflow for any el + er)."""
     _chk("rgat_aggregate_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, h_inout) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
+    nbytes = int(_lib.lib().het_rgat_aggregate_compact_workspace(groupings[0].handle, H, D))  # (hub destinations only)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device) if nbytes else None
     _call(ret, "het_rgat_aggregate_compact", groupings[0].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), N, H, D,
-          float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0], _stream(ret))
+          float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0], _p(ws), nbytes, _stream(ret))
 
 
 def rows_matmul_backward_split_ok(H: int, K: int, D: int) -> bool:

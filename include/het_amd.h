@@ -451,7 +451,14 @@ int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_
  *   by_srow: het_grouping_create(NULL, 0, feat row of every position, E, S_row, payload0 = col, payload1 = er row)
  *   by_drow: het_grouping_create(NULL, 0, er row of every position, E, S_col, payload0 = rank of the position in by_srow
  *            (het_grouping_rank_of_position), NULL)
- * forward:  sum [N,H], ret [N,H,D] are overwritten (a4's outputs; exp is not produced).  h_inout [h_rows, H*D] (optional):
+ * Softmax without overflow: the reference exponentiates the raw pre-activation (gatLeakyReluExp, GAT/FusedGAT.cu.h:23-26; the
+ *   reference-named a4 / a5 keep that because exp and sum are API tensors there).  These two entry points subtract a running
+ *   maximum per (destination, head): `sum` receives lse[v,h] = log(SUM_e exp(leaky_relu(el + er))) instead of the sum itself and
+ *   the backward forms the attention weight as exp(leaky_relu(el + er) - lse[v,h]) -- the reference's value wherever its formula
+ *   is finite, finite for any pre-activation.  workspace (forward): het_rgat_aggregate_compact_workspace(by_dst, H, D) bytes,
+ *   16-byte aligned (0 unless a destination has more than 256 in-edges: its work items park their partial sums there and a
+ *   finishing pass brings them to one maximum -- no float atomics).
+ * forward:  sum [N,H] (= lse), ret [N,H,D] are overwritten (a4's ret; exp is not produced).  h_inout [h_rows, H*D] (optional):
  *   the layer output so far (self-loop + bias, het_rows_linear_bias); ret's row is added to it in place for every
  *   destination < h_rows, and ret is then defined only for destinations WITH in-edges (no 0.5 GB zero fill).
  * backward: grad_feat_c, grad_el_c, grad_er_c are overwritten (a5's outputs on the compact rows).  fold_attn_l [R,H,D]
@@ -461,7 +468,8 @@ int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_
  *   workspace: het_rgat_backward_compact_workspace(N, E, H, D, grad_bias != NULL) bytes, 16-byte aligned. */
 int het_rgat_aggregate_compact(const het_grouping* by_dst, const float* feat_c, const float* el_c, const float* er_c,
                                float* sum, float* ret, int64_t num_nodes, int64_t H, int64_t D, double slope,
-                               float* h_inout, int64_t h_rows, het_stream stream);
+                               float* h_inout, int64_t h_rows, void* workspace, int64_t workspace_bytes, het_stream stream);
+int64_t het_rgat_aggregate_compact_workspace(const het_grouping* by_dst, int64_t H, int64_t D);
 int64_t het_rgat_backward_compact_workspace(int64_t num_nodes, int64_t num_edges, int64_t H, int64_t D, int with_bias);
 int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
                               const float* el_c, const float* er_c, const float* sum, const float* ret,

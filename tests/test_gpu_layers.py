@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0, **layer_kw):
+def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0, attn_scale=1.0, **layer_kw):
     from het_amd.layers import HET_RGATLayer
     torch.manual_seed(seed)
     R, N = g.get_num_rels(), g.get_num_nodes()
@@ -21,6 +21,8 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0,
                           gat_edge_parallel_flag=edge_parallel, dropout=0.0, **layer_kw)
     with torch.no_grad():
         layer.h_bias.uniform_(-0.1, 0.1)
+        layer.attn_l.mul_(attn_scale)
+        layer.attn_r.mul_(attn_scale)
     x = torch.randn(N, K) * 0.5
     go = torch.randn(N, X)
     # oracle (fp64, autograd)
@@ -52,6 +54,29 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0,
                                                      (True, True, False), (True, True, True), (True, False, True)])
 def test_rgat_layer_variants(compact, direct, mulfirst):
     _run_rgat(random_graph(seed=41, n=400, r=4, e=6000, shuffle=False), H=4, K=64, X=64, compact=compact, direct=direct, mulfirst=mulfirst)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgat_layer_large_preactivations_stay_finite(compact):
+    """Pre-activations el + er of +-100 and more: exp() of them overflows fp32 (the reference's kernels, and the
+    reference-named a4 here, would return inf / inf); the one-node layer subtracts a running maximum per (destination, head)
+    and must agree with the fp64 oracle (whose raw exp is finite up to 709).  Graphs with and without destinations of more than
+    256 in-edges (several work items that have to agree on one maximum)."""
+    from tests.util import rgat_min_abs_preactivation
+    for g in (mag_graph(scale=5e-3), random_graph(seed=44, n=300, r=4, e=5000, shuffle=False)):
+        s = g.get_separate_coo_original()
+        _run_rgat(g, H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=False, attn_scale=300.0, seed=5)
+    # the scale really produces such values
+    from het_amd.layers import HET_RGATLayer
+    torch.manual_seed(5)
+    layer = HET_RGATLayer(64, 64, g.get_num_rels(), 4, self_loop=True, dropout=0.0)
+    x = torch.randn(g.get_num_nodes(), 64) * 0.5
+    R = layer.conv_weights.shape[0]
+    rel = torch.repeat_interleave(torch.arange(R), s["rel_ptrs"][1:] - s["rel_ptrs"][:-1])
+    wl = torch.einsum("rhkd,rhd->rhk", layer.conv_weights.detach(), layer.attn_l.detach() * 300)
+    wr = torch.einsum("rhkd,rhd->rhk", layer.conv_weights.detach(), layer.attn_r.detach() * 300)
+    z = torch.einsum("ek,ehk->eh", x[s["row_indices"]], wl[rel]) + torch.einsum("ek,ehk->eh", x[s["col_indices"]], wr[rel])
+    assert float(z.max()) > 90.0, float(z.max())
 
 
 @pytest.mark.parametrize("literal_er", [False, True])
