@@ -888,13 +888,15 @@ int gat_backward_compact_grouped(const het_grouping* by_srow, const het_grouping
                                         fold_row_rel_ptrs, v.R));
     HET_LAUNCH_CHECK("HET_gat_backward_src_grouped");
   }
-  // grad_er[w, :] = SUM over the edges of er row w of tbuf[eid, :]   (segments of by_drow are the er rows in order)
-  return launch_segment_sum(by_drow, tbuf, grad_er, H, nullptr, s);
+  // grad_er[w, :] = SUM over the edges of er row w of tbuf[eid, :]   (segments of by_drow are the er rows in order; when some
+  // er rows have no edge -- a two-sided unique list: rows that are sources only -- every segment lands in the row of its key
+  // and the others read zero)
+  return launch_segment_sum(by_drow, tbuf, grad_er, H, nullptr, s, 0, by_drow->S == n_dst_rows ? -1 : n_dst_rows);
 }
 
 bool gat_backward_compact_supported(const het_grouping* by_srow, const het_grouping* by_drow, int64_t E,
                                     int64_t n_dst_rows, int H, int D, float slope) {
   return by_srow && by_drow && grouped_shape_ok(H, D) && segment_rows_supported(H) && slope >= 0.f && by_srow->E == E &&
          by_drow->E == E && by_srow->R == 0 && by_drow->R == 0 && by_srow->p0 && by_srow->p1 && by_drow->p0 &&
-         by_drow->S == n_dst_rows;
+         by_drow->S <= n_dst_rows && by_drow->key_bound <= n_dst_rows;
 }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_narrow(const int32_t* 
                                                                  const int32_t* __restrict__ seg_ptr, int64_t num_items,
                                                                  const int32_t* __restrict__ p_row, int X,
                                                                  const float* __restrict__ in, float* __restrict__ out,
-                                                                 int accumulate) {
+                                                                 int accumulate, const int32_t* __restrict__ out_row) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= num_items * X) return;
   const int64_t item = t / X;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_narrow(const int32_t* 
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
   float acc = 0.f;
   for (int j = b; j < e; ++j) acc += in[(int64_t)p_row[j] * X + c];
-  float* p = out + (int64_t)seg * X + c;
+  float* p = out + (int64_t)(out_row ? out_row[seg] : seg) * X + c;
   if (b == seg_ptr[seg] && e == seg_ptr[seg + 1]) *p = accumulate ? *p + acc : acc;
   else atomicAdd(p, acc);
 }
@@ -327,11 +327,15 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
                        int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0, int nt_in) {
   HET_REQUIRE(segment_rows_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
   if (X < 4) {
-    HET_REQUIRE(!scale && scatter_rows < 0, "segment sum: rows of fewer than 4 floats take no scale / scatter");
-    if (!accumulate && g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+    HET_REQUIRE(!scale, "segment sum: rows of fewer than 4 floats take no scale");
+    if (!accumulate) {
+      if (scatter_rows >= 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * scatter_rows * X, s));
+      else if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+    }
     if (g->S == 0) return HET_OK;
     hipLaunchKernelGGL(HET_segment_sum_narrow, dim3((unsigned)ceil_div64(g->num_items * X, kBlock)), dim3(kBlock), 0, s,
-                       g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->num_items, g->p0, X, in, out, accumulate);
+                       g->item_seg, g->item_begin, g->item_end, g->seg_ptr, g->num_items, g->p0, X, in, out, accumulate,
+                       scatter_rows >= 0 ? g->seg_key : nullptr);
     HET_LAUNCH_CHECK("HET_segment_sum_narrow");
     return HET_OK;
   }

@@ -424,6 +424,28 @@ def _dst_rows_by_position(kind, maps, rel_ptrs, col, eids):
     return _derived_get("drow", (ca, cb, rel_ptrs, col), lambda: _rows_by_search(rel_ptrs, col, ca, cb))
 
 
+def _csr_compact_maps(row_ptrs, col, eids, reltypes, uniq_rel_ptrs, uniq_nodes, rows_are_dst: bool):
+    """CompactAsOfNodeFlag of the CSR GAT pair (RGATOps.inc.h:251-277, 430-460): feat / el / er live on the rows of ONE
+    unique (relation, node) list and every edge end is looked up by (relation of the edge, node).  Turned once per graph
+    (cached) into the direct-index maps of kind 4 -- feat row and er row of every EDGE ID -- which the destination-grouped
+    kernels read without searching: (rows of the CSR expanded per position, {edata idx -> row} dict)."""
+    def build():
+        E = eids.numel()
+        rows = _graph.csr_to_coo_rows(row_ptrs).contiguous()
+        src, dst = (col, rows) if rows_are_dst else (rows, col)
+        R = uniq_rel_ptrs.numel() - 1
+        bound = int(max(int(row_ptrs.numel()) - 1, int(uniq_nodes.max().item()) + 1 if uniq_nodes.numel() else 1))
+        rel_u = torch.repeat_interleave(torch.arange(R, device=col.device), uniq_rel_ptrs[1:] - uniq_rel_ptrs[:-1])
+        keys = rel_u * bound + uniq_nodes
+        n = int(eids.max().item()) + 1 if E else 0
+        mr = torch.empty(n, dtype=torch.int64, device=col.device)
+        mc = torch.empty(n, dtype=torch.int64, device=col.device)
+        mr[eids] = torch.searchsorted(keys, reltypes * bound + src)
+        mc[eids] = torch.searchsorted(keys, reltypes * bound + dst)
+        return rows, {"edata_idx_to_inverse_idx_row": mr, "edata_idx_to_inverse_idx_col": mc}
+    return _derived_get(("csrcompact", rows_are_dst), (row_ptrs, col, eids, reltypes, uniq_rel_ptrs, uniq_nodes), build)
+
+
 def _csr_expanded_rows(row_ptrs, num_edges):
     """(row id of every CSR position, a one-relation rel_ptrs [0, E]) -- cached per CSR."""
     return _derived_get(("csr", num_edges), (row_ptrs,),
@@ -732,6 +754,14 @@ def relational_fused_gat_csr(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr
         dst, rp1 = _csr_expanded_rows(incsr_row_ptr, E)
         fused_gat_forward(incsr_eids, rp1, incsr_col_indices, dst, 0, {}, feat_src, el, er, sum, exp, ret, slope, None)
         return
+    if CompactAsOfNodeFlag and _plan.is_enabled() and E > 0 and gat_grouped_shape_ok(H, D):
+        # compact rows: the same op as the separate-COO pair with CompactAsOfNodeKind 4 once every edge id knows its feat
+        # row and er row (cached per graph) -- destination-grouped kernels instead of float atomics
+        dst, maps = _csr_compact_maps(incsr_row_ptr, incsr_col_indices, incsr_eids, incsr_reltypes,
+                                      unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, True)
+        _, rp1 = _csr_expanded_rows(incsr_row_ptr, E)
+        fused_gat_forward(incsr_eids, rp1, incsr_col_indices, dst, 4, maps, feat_src, el, er, sum, exp, ret, slope, None)
+        return
     _call(ret, "het_relational_fused_gat_csr", _p(incsr_row_ptr), _p(incsr_col_indices), _p(incsr_eids),
           _p(incsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),
           max(0, unique_srcs_and_dests_rel_ptrs.numel() - 1), _p(feat_src), _p(el), _p(er), _p(sum), _p(exp), _p(ret),
@@ -756,6 +786,18 @@ def backward_relational_fused_gat_csr(outcsr_row_ptr, outcsr_col_indices, outcsr
         src, rp1 = _csr_expanded_rows(outcsr_row_ptr, E)
         fused_gat_backward(outcsr_eids, rp1, src, outcsr_col_indices, 0, {}, feat_src, el, er, sum, exp, ret, gradout,
                            grad_feat_src, grad_el, grad_er, slope, None)
+        return
+    if CompactAsOfNodeFlag and _plan.is_enabled() and E > 0 and gat_grouped_shape_ok(H, D) and slope >= 0:
+        src, maps = _csr_compact_maps(outcsr_row_ptr, outcsr_col_indices, outcsr_eids, outcsr_reltypes,
+                                      unique_srcs_and_dests_rel_ptrs, unique_srcs_and_dests_node_indices, False)
+        _, rp1 = _csr_expanded_rows(outcsr_row_ptr, E)
+        # "+=" contract of the reference-named op: the kind-4 kernels overwrite, so they run into temporaries that are added
+        gf, gl, gr = torch.zeros_like(grad_feat_src), torch.zeros_like(grad_el), torch.zeros_like(grad_er)
+        fused_gat_backward(outcsr_eids, rp1, src, outcsr_col_indices, 4, maps, feat_src, el, er, sum, exp, ret, gradout,
+                           gf, gl, gr, slope, None)
+        grad_feat_src += gf
+        grad_el += gl
+        grad_er += gr
         return
     _call(ret, "het_backward_relational_fused_gat_csr", _p(outcsr_row_ptr), _p(outcsr_col_indices), _p(outcsr_eids),
           _p(outcsr_reltypes), N, E, _p(unique_srcs_and_dests_rel_ptrs), _p(unique_srcs_and_dests_node_indices),

@@ -245,7 +245,12 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
     f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
     sm, ret = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
     k.rgat_aggregate_compact(grp, f, l, r_, sm, ret, slope)
-    assert_close(sm, sm_r, what="sum")
+    # `sum` of this entry point is the log-sum-exp of the destination (running-maximum softmax: include/het_amd.h); destinations
+    # without in-edges keep 0
+    has_in = torch.zeros(N, dtype=torch.bool)
+    has_in[s["col_indices"]] = True
+    assert_close(sm[has_in.to(DEV)], torch.log(sm_r[has_in]), what="log-sum-exp")
+    assert float(sm[(~has_in).to(DEV)].abs().max() if (~has_in).any() else 0.0) == 0.0
     assert_close(ret, ret_r, what="ret")
     # h_inout: the rows are also added into a caller tensor (the first nh destinations), ret untouched elsewhere
     nh = N - 2
@@ -253,8 +258,6 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
     hio, ret2 = h0.to(DEV), torch.full((N, H, D), 7.0, device=DEV)
     k.rgat_aggregate_compact(grp, f, l, r_, sm, ret2, slope, h_inout=hio)
     assert_close(hio, h0.double() + ret_r.view(N, -1)[:nh], what="h_inout")
-    has_in = torch.zeros(N, dtype=torch.bool)
-    has_in[s["col_indices"]] = True
     assert_close(ret2[has_in.to(DEV)], ret_r[has_in], what="ret (destinations with in-edges)")
     gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
     gb = torch.full((H * D,), float("nan"), device=DEV) if bias else None
@@ -342,6 +345,8 @@ def test_fused_gat_csr(K, plan_mode, compact):
     D_ = lambda d, ks: [d[k].to(DEV) for k in ks]
     sm, ex, ret = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(N, H, D, device=DEV)
     f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
+    from het_amd import _lib as HL
+    HL.kernel_timing(True)
     K.relational_fused_gat_csr(*D_(i, ["row_ptrs", "col_indices", "eids", "rel_types"]), *D_(u, ["rel_ptrs", "node_indices"]),
                                f, l, r_, sm, ex, ret, slope, compact)
     assert_close(sm, sm_r, what="sum")
@@ -353,6 +358,15 @@ def test_fused_gat_csr(K, plan_mode, compact):
     assert_close(gf, gf_r, what="grad_feat")
     assert_close(gl, gl_r, what="grad_el")
     assert_close(gr, gr_r, what="grad_er")
+    # with groupings the CSR pair -- compact rows included -- is served by the destination- / row-grouped kernels, not by the
+    # float-atomics edge kernels (the library's kernel timers name the grouped launches)
+    fwd_grouped = HL.kernel_timing_read("HET_gat_aggregate_grouped")[1]
+    bwd_grouped = HL.kernel_timing_read("HET_gat_backward_grouped")[1] + HL.kernel_timing_read("HET_gat_backward_src")[1]
+    HL.kernel_timing(False)
+    if plan_mode:
+        assert fwd_grouped >= 1 and bwd_grouped >= 1, (fwd_grouped, bwd_grouped)
+    else:
+        assert fwd_grouped == 0 and bwd_grouped == 0
 
 
 def test_gat_golden_exp_sum(K, golden_mag):
