@@ -124,16 +124,23 @@ def other_variants(args, coo, dev, steps, default_ms, default_value):
     flag_names = {"reference_op_sequence": "default flags, the reference's op sequence literally: only reference-named torch_hrt "
                                            "ops with the reference wrappers' zero-filled buffers (het_amd/backend/"
                                            "reference_protocol.py = RGAT/models.py:265-385 after the kernels/__init__.py swap)",
+                  "op_by_op": "default flags, the reference's model code line by line (RGAT/models.py:265-385) on this package's "
+                              "backend wrappers (het_amd.backend in place of hrt/python/backend: no fills, '=' gradients) -- "
+                              "no one-node layer",
+                  "op_by_op_compact": "--compact_as_of_node_flag --compact_direct_indexing_flag, the reference's model code line by "
+                                      "line (RGAT/models.py:152-263) on this package's backend wrappers -- no one-node layer",
                   "compact": "--compact_as_of_node_flag --compact_direct_indexing_flag",
                   "mulfirst": "--multiply_among_weights_first_flag",
                   "compact_mulfirst": "--compact_as_of_node_flag --compact_direct_indexing_flag --multiply_among_weights_first_flag"}
-    for variant in ("reference_op_sequence", "compact", "mulfirst", "compact_mulfirst"):
+    for variant in ("reference_op_sequence", "op_by_op", "op_by_op_compact", "compact", "mulfirst", "compact_mulfirst"):
         torch.manual_seed(0)
-        if variant == "reference_op_sequence" and torch.cuda.mem_get_info(dev)[0] < 80 * 2**30 * args.scale:
+        if variant in ("reference_op_sequence", "op_by_op") and torch.cuda.mem_get_info(dev)[0] < 80 * 2**30 * args.scale:
             continue  # needs about ten [E,H,D] tensors (54 GB on ogbn-mag)
+        flags = {"reference_op_sequence": {}, "op_by_op": {}, "op_by_op_compact": layer_flags("compact")}.get(variant)
         layer = HET_RGATLayer(args.feat, args.feat, g.get_num_rels(), args.heads, self_loop=True, dropout=0.0,
                               reference_op_sequence=variant == "reference_op_sequence",
-                              **(layer_flags(variant) if variant != "reference_op_sequence" else {})).to(dev)
+                              **(layer_flags(variant) if flags is None else flags)).to(dev)
+        layer.op_by_op = variant.startswith("op_by_op")
         embed = torch.nn.Parameter(torch.empty(N, args.feat, device=dev))
         torch.nn.init.xavier_uniform_(embed)
         go = torch.randn(N, args.feat, device=dev)

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch as th
 import torch.nn as nn
 
@@ -51,6 +53,10 @@ class HET_RGATLayer(nn.Module):
         # zero-filled "+=" buffers; het_amd/backend/reference_protocol.py) -- the drop-in path bench.py times as
         # variants.reference_op_sequence.  Non-compact flags, full graph.
         self.reference_op_sequence = reference_op_sequence
+        # True (or HET_RGAT_FUSED=0): the reference's model code line by line on this package's backend wrappers (het_amd.backend:
+        # same function names as hrt/python/backend, buffers allocated without fills, "=" gradients) instead of the one-node layer --
+        # what a reference checkout gets when it imports het_amd.backend in place of its own backend package
+        self.op_by_op = os.environ.get("HET_RGAT_FUSED", "1") == "0"
         self.conv_weights = nn.Parameter(th.Tensor(num_rels, num_heads, in_feat, out_feat // num_heads))
         self.attn_l = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
         self.attn_r = nn.Parameter(th.Tensor(num_rels, num_heads, out_feat // num_heads))
@@ -100,7 +106,7 @@ class HET_RGATLayer(nn.Module):
             assert not self.compact_as_of_node_flag and num_dst is None and self.gat_edge_parallel_flag
             from .backend.reference_protocol import rgat_layer_reference_sequence
             return rgat_layer_reference_sequence(self, g, inputs)
-        if (self.gat_edge_parallel_flag and
+        if (self.gat_edge_parallel_flag and not self.op_by_op and
                 FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                        self.multiply_among_weights_first_flag)):
             # the whole layer as one autograd node (het_amd/backend/rgat_fused_layer.py): same ops and values as the
