@@ -81,7 +81,8 @@ struct Packs {
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_hgt_aggregate_rows(Items it, const int32_t* __restrict__ p_srow,
                                                                   const float* __restrict__ kv, const float* __restrict__ q,
-                                                                  float* __restrict__ lsum, float* __restrict__ out, int H) {
+                                                                  float* __restrict__ lsum, float* __restrict__ out, int H,
+                                                                  float* __restrict__ part) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL <= LPR, "heads inside the lane group");  // (LPR >= 4: ids shared by quads; LPR == 2: every lane loads its ids)
   const int lane = threadIdx.x & 63;
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_aggregate_rows(Items it, const
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 q4 = ld4(q + v * X + x);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float ssum = 0.f;
+  // softmax relative to a running maximum of the scores (the reference exponentiates the raw score, HGT/models.py via
+  // hgt_full_graph_edge_softmax_ops: exp(score * mu) -- finite only while |score| < 88): rescale when it grows, keep
+  // lse = max + log(sum) where the reference-named op keeps the sum
+  float ssum = 0.f, m = -INFINITY;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     float4 kk[U], mm[U];
 #pragma unroll
@@ -119,13 +123,29 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_aggregate_rows(Items it, const
 #pragma unroll
       for (int u = 0; u < U; ++u) sidn[u] = p_srow[j0 + (U + u) * EPW < e ? j0 + (U + u) * EPW : e - 1];
     }
+    float sc[U], mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float s = head_sum<DL>(dot4(kk[u], q4));
-      const float w = j0 + u * EPW < e ? __expf(s) : 0.f;  // (uniform within the lane group)
+      sc[u] = j0 + u * EPW < e ? head_sum<DL>(dot4(kk[u], q4)) : -INFINITY;  // (uniform within the lanes of a head)
+      mn = fmaxf(mn, sc[u]);
+    }
+    const float c = __expf(m - mn);  // (the first edge of a step exists: mn is finite; exp(-inf) = 0 the first time)
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+    m = mn;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = __expf(sc[u] - m);  // 0 for the padding edges
       fma4(acc, w, mm[u]);
       ssum += w;
     }
+  }
+  {  // the lane groups of the wave saw different edges: bring their sums to the common maximum
+    float M = m;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float c = m == -INFINITY ? 0.f : __expf(m - M);
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+    m = M;
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -134,15 +154,60 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_aggregate_rows(Items it, const
     ssum += __shfl_xor(ssum, off);
   }
   if (slot != 0) return;
-  float* rp = out + v * X + x;
   if (whole) {
     const float inv = 1.f / ssum;
-    st4(rp, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
-    if (d == 0) lsum[v * H + h] = ssum;
-  } else {  // a hub split into several items: HET_hgt_normalize_rows divides once all have added
-    atomic_add4(rp, acc);
-    if (d == 0) atomicAdd(&lsum[v * H + h], ssum);
+    st4(out + v * X + x, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    if (d == 0) lsum[v * H + h] = m + __logf(ssum);
+  } else {  // a piece of a hub destination: parked {acc[X], max[H], sum[H]} for HET_hgt_finish_split
+    float* pp = part + item * (X + 2 * H);
+    st4(pp + x, acc);
+    if (d == 0) { pp[X + h] = m; pp[X + H + h] = ssum; }
   }
+}
+
+// One wave per split (hub) destination: its work items' parked partial sums brought to the common maximum, divided, stored.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_hgt_finish_split(const int32_t* __restrict__ split_seg, int64_t num_split, Items it,
+                                                                const float* __restrict__ part, float* __restrict__ lse,
+                                                                float* __restrict__ out, int H, int D) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= num_split) return;
+  const int seg = split_seg[k];
+  const int64_t X = (int64_t)H * D, v = it.seg_key[seg];
+  int64_t lo = 0, hi = it.n;  // first work item of the segment (items are in segment order)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (it.seg[mid] < seg) lo = mid + 1; else hi = mid;
+  }
+  const int64_t n_items = (it.seg_ptr[seg + 1] - it.seg_ptr[seg] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f, m = -INFINITY;
+  for (int64_t i = slot; i < n_items; i += EPW) {
+    const float* pp = part + (lo + i) * (X + 2 * H);
+    const float mi = pp[X + h], si = pp[X + H + h];
+    const float4 a = ld4(pp + x);
+    const float mn = fmaxf(m, mi), c = __expf(m - mn), ci = __expf(mi - mn);
+    acc.x = acc.x * c + a.x * ci; acc.y = acc.y * c + a.y * ci; acc.z = acc.z * c + a.z * ci; acc.w = acc.w * c + a.w * ci;
+    ssum = ssum * c + si * ci;
+    m = mn;
+  }
+  float M = m;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+  const float c = m == -INFINITY ? 0.f : __expf(m - M);
+  acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  if (slot != 0) return;
+  const float inv = 1.f / ssum;
+  st4(out + v * X + x, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+  if (x % D == 0) lse[v * H + h] = M + __logf(ssum);
 }
 
 // rows[key of segment list[k]] (row_floats wide) = 0: the rows several work items add to
@@ -196,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
   const int64_t v = it.seg_key[seg];
   const bool whole = b == it.seg_ptr[seg] && e == it.seg_ptr[seg + 1];
   const float4 q4 = ld4(q + v * X + x), go = ld4(gradout + v * X + x), o4 = ld4(out + v * X + x);
-  const float invl = 1.f / lsum[v * H + h];
+  const float lse_v = lsum[v * H + h];  // log-sum-exp of the destination (forward)
   const float dotn = head_sum<DL>(dot4(go, o4));
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
@@ -219,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float s = head_sum<DL>(dot4(kk[u], q4));
-      const float a = j0 + u * EPW < e ? __expf(s) * invl : 0.f;
+      const float a = j0 + u * EPW < e ? __expf(s - lse_v) : 0.f;
       const float ga = head_sum<DL>(dot4(go, mm[u]));
       fma4(acc, a * (ga - dotn), kk[u]);
     }
@@ -235,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
   } else {
     atomic_add4(grad_q + v * X + x, acc);
   }
-  if (d == 0) *reinterpret_cast<float2*>(pack2 + (v * H + h) * 2) = make_float2(invl, dotn);  // (the same from every item of v)
+  if (d == 0) *reinterpret_cast<float2*>(pack2 + (v * H + h) * 2) = make_float2(lse_v, dotn);  // (the same from every item of v)
 }
 
 // Backward, source side, SHORT segments: lane group per pack of whole (relation, source) segments.
@@ -307,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
         mcur = mq[u];
       }
       const float s = head_sum<DL>(dot4(kcur, qr[u]));
-      const float a = ok ? __expf(s) * p2[u].x : 0.f;
+      const float a = ok ? __expf(s - p2[u].x) : 0.f;  // p2.x: lse of the destination
       const float ga = head_sum<DL>(dot4(gr[u], mcur));
       fma4(acck, a * (ga - p2[u].y), qr[u]);
       fma4(accm, a, gr[u]);
@@ -371,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_long(Items it, co
 #pragma unroll
     for (int t = 0; t < U; ++t) {
       const float s = head_sum<DL>(dot4(kcur, qr[t]));
-      const float a = j0 + t * EPW < e ? __expf(s) * p2[t].x : 0.f;
+      const float a = j0 + t * EPW < e ? __expf(s - p2[t].x) : 0.f;  // p2.x: lse of the destination
       const float ga = head_sum<DL>(dot4(gr[t], mcur));
       fma4(acck, a * (ga - p2[t].y), qr[t]);
       fma4(accm, a, gr[t]);
@@ -431,37 +496,49 @@ static bool hgt_rows_shape_ok(int64_t H, int64_t D) {
 
 extern "C" int het_hgt_compact_shape_ok(int64_t H, int64_t D) { return hgt_rows_shape_ok(H, D) ? 1 : 0; }
 
+// bytes of het_hgt_aggregate_compact's workspace: one {acc[H*D], max[H], sum[H]} record per work item when destinations are split
+// over several work items (more than HET_ITEM_MAX in-edges); only the records of those items are touched
+extern "C" int64_t het_hgt_aggregate_compact_workspace(const het_grouping* by_dst, int64_t H, int64_t D) {
+  if (!by_dst || by_dst->num_split == 0) return 0;
+  return (int64_t)sizeof(float) * by_dst->num_items * (H * D + 2 * H);
+}
+
 extern "C" int het_hgt_aggregate_compact(const het_grouping* by_dst, const float* kv_c, const float* q, float* lsum, float* out,
-                                         int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, het_stream stream) {
+                                         int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, void* workspace,
+                                         int64_t workspace_bytes, het_stream stream) {
   const char* op = "het_hgt_aggregate_compact";
   hipStream_t s = (hipStream_t)stream;
   HET_REQUIRE(by_dst && lsum && out && num_nodes >= 0, "%s: null argument", op);
   if (!hgt_rows_shape_ok(H, D)) { het_set_error("%s: unsupported shape H=%lld D=%lld", op, (long long)H, (long long)D); return HET_ERR_UNSUPPORTED; }
   HET_REQUIRE(by_dst->R == 0 && by_dst->key_bound <= num_nodes && num_src_rows >= 0 && (by_dst->E == 0 || (by_dst->p0 && kv_c && q)),
               "%s: by_dst must group the positions by destination with payload0 = the (relation, source) row", op);
+  const int64_t need = het_hgt_aggregate_compact_workspace(by_dst, H, D);
+  HET_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0),
+              "%s: a 16-byte aligned workspace of %lld bytes is needed (het_hgt_aggregate_compact_workspace)", op, (long long)need);
   const int64_t X = H * D;
   HET_HIP(hipMemsetAsync(lsum, 0, sizeof(float) * num_nodes * H, s));
-  if (by_dst->S != num_nodes) {  // destinations without in-edges: zero rows
-    HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * num_nodes * X, s));
-  } else if (by_dst->num_split > 0) {
-    hipLaunchKernelGGL(HET_hgt_zero_rows, dim3(grid_for(by_dst->num_split * (X / 4))), dim3(kBlock), 0, s, by_dst->split_seg,
-                       by_dst->seg_key, by_dst->num_split, out, (int)X);
-    HET_LAUNCH_CHECK("HET_hgt_zero_rows");
-  }
+  if (by_dst->S != num_nodes) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * num_nodes * X, s));  // destinations without in-edges: zero rows
   if (by_dst->E == 0) return HET_OK;
   Items it{by_dst->item_seg, by_dst->item_begin, by_dst->item_end, by_dst->seg_ptr, by_dst->seg_key, by_dst->num_items};
   const unsigned nb = (unsigned)ceil_div64(by_dst->num_items, kBlock / 64);
+  float* part = static_cast<float*>(workspace);
   {
     HET_KTIME("HET_hgt_aggregate_rows", s);
     HET_DISPATCH_HGT_ROWS((int)(X / 4), (int)(D / 4),
                           hipLaunchKernelGGL((HET_hgt_aggregate_rows<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, it, by_dst->p0, kv_c,
-                                             q, lsum, out, (int)H));
+                                             q, lsum, out, (int)H, part));
   }
   HET_LAUNCH_CHECK("HET_hgt_aggregate_rows");
   if (by_dst->num_split > 0) {
-    hipLaunchKernelGGL(HET_hgt_normalize_rows, dim3(grid_for(by_dst->num_split * (X / 4))), dim3(kBlock), 0, s, by_dst->split_seg,
-                       by_dst->seg_key, by_dst->num_split, lsum, out, (int)H, (int)D);
-    HET_LAUNCH_CHECK("HET_hgt_normalize_rows");
+    const unsigned nbs = (unsigned)ceil_div64(by_dst->num_split, kBlock / 64);
+    switch ((int)(X / 4)) {
+      case 2: hipLaunchKernelGGL(HET_hgt_finish_split<2>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg, by_dst->num_split, it, part, lsum, out, (int)H, (int)D); break;
+      case 4: hipLaunchKernelGGL(HET_hgt_finish_split<4>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg, by_dst->num_split, it, part, lsum, out, (int)H, (int)D); break;
+      case 8: hipLaunchKernelGGL(HET_hgt_finish_split<8>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg, by_dst->num_split, it, part, lsum, out, (int)H, (int)D); break;
+      case 16: hipLaunchKernelGGL(HET_hgt_finish_split<16>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg, by_dst->num_split, it, part, lsum, out, (int)H, (int)D); break;
+      default: hipLaunchKernelGGL(HET_hgt_finish_split<32>, dim3(nbs), dim3(kBlock), 0, s, by_dst->split_seg, by_dst->num_split, it, part, lsum, out, (int)H, (int)D); break;
+    }
+    HET_LAUNCH_CHECK("HET_hgt_finish_split");
   }
   return HET_OK;
 }

@@ -710,8 +710,10 @@ def hgt_aggregate_compact(groupings, kv_c, q, lsum, out):
     _chk("hgt_aggregate_compact", (kv_c, q, lsum, out))
     N, H = lsum.shape
     D = out.numel() // max(1, N * H)
+    nbytes = int(_lib.lib().het_hgt_aggregate_compact_workspace(groupings[0].handle, H, D))  # (hub destinations only)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=out.device) if nbytes else None
     _call(out, "het_hgt_aggregate_compact", groupings[0].handle, _p(kv_c), _p(q), _p(lsum), _p(out), N, kv_c.shape[0], H, D,
-          _stream(out))
+          _p(ws), nbytes, _stream(out))
 
 
 def hgt_backward_compact(groupings, kv_c, q, lsum, out, gradout, grad_kv_c, grad_q):

@@ -425,15 +425,19 @@ int het_backward_hgt_full_graph_hetero_attention_ops_coo(const int64_t* row, con
  *   out[v,h,:] = SUM_{e into v} a_e[h] * m[srow_e,h,:]
  * with k' = k . relation_att . (relation_pri / sqrt(dk)) and m = v . relation_msg formed per distinct (relation, source)
  * row by the caller (one segment GEMM from the layer input when the typed projections are folded into the weights).
- *   kv_c [S_row, 2, H, D]: k' then m of every (relation, source) row;  q [N,H,D];  lsum [N,H] = SUM exp(s);  out [N,H,D]
+ *   kv_c [S_row, 2, H, D]: k' then m of every (relation, source) row;  q [N,H,D];  out [N,H,D];
+ *   lsum [N,H] = log SUM exp(s) (the softmax subtracts a running maximum: finite for any score, unlike the reference's raw exp)
  *   by_dst:  het_grouping_create(NULL, 0, col, E, N, payload0 = (relation, source) row of every position, NULL)
  *   by_srow: het_grouping_create(NULL, 0, that row of every position, E, S_row, payload0 = col, NULL)
  * forward overwrites lsum and out (zero rows for destinations without in-edges); backward overwrites grad_kv_c [S_row,2,H,D]
- * and grad_q [N,H,D].  workspace: het_hgt_backward_compact_workspace(N, H) bytes, 16-byte aligned.
+ * and grad_q [N,H,D].  workspace (backward): het_hgt_backward_compact_workspace(N, H) bytes, 16-byte aligned; (forward):
+ * het_hgt_aggregate_compact_workspace(by_dst, H, D) bytes (0 unless a destination has more than 256 in-edges).
  * Shapes: H*D in {8, 16, 32, 64, 128}, D a power of two >= 8 (het_hgt_compact_shape_ok); else HET_ERR_UNSUPPORTED. */
 int het_hgt_compact_shape_ok(int64_t H, int64_t D);
 int het_hgt_aggregate_compact(const het_grouping* by_dst, const float* kv_c, const float* q, float* lsum, float* out,
-                              int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, het_stream stream);
+                              int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, void* workspace,
+                              int64_t workspace_bytes, het_stream stream);
+int64_t het_hgt_aggregate_compact_workspace(const het_grouping* by_dst, int64_t H, int64_t D);
 int64_t het_hgt_backward_compact_workspace(int64_t num_nodes, int64_t H);
 int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_srow, const float* kv_c, const float* q,
                              const float* lsum, const float* out, const float* gradout, float* grad_kv_c, float* grad_q,

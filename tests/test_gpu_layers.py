@@ -245,6 +245,17 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
                                               (1, 64, 8),   # 64 -> 8, one head: the layer of the reference CLI's defaults
                                               (4, 64, 8), (2, 64, 10), (1, 64, 4)])  # heads of 2 / 5 / 4 floats: zero-padded to 8
 def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch):
+    _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch)
+
+
+def test_hgt_layer_large_scores_stay_finite(monkeypatch):
+    """Attention scores of +-100 and more (relation_pri scaled up): exp() of them overflows fp32; the row kernels subtract a
+    running maximum per (destination, head) and must agree with the fp64 oracle (raw exp, finite up to 709)."""
+    _run_hgt_fused(False, True, 8, 64, 64, monkeypatch, pri=(150.0, 300.0))
+    _run_hgt_fused(True, False, 4, 64, 64, monkeypatch, pri=(150.0, 300.0))
+
+
+def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri=(0.5, 1.5)):
     """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
     (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
     (BASELINE.json configs[3]: feat 64, heads 8) -- against the fp64 oracle: output and the gradients of the input and of all
@@ -259,7 +270,7 @@ def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatc
     N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
     layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn)
     with torch.no_grad():
-        layer.relation_pri.uniform_(0.5, 1.5)
+        layer.relation_pri.uniform_(*pri)
         layer.skip.uniform_(-1, 1)
     h, go = torch.randn(N, in_dim) * 0.5, torch.randn(N, out_dim)
     s = g.get_separate_coo_original()
@@ -270,6 +281,7 @@ def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatc
                        p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
                        p["relation_pri"], p["skip"], H, fused_attn=fused_attn)
     grads_ref = torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double())
+    assert bool(torch.isfinite(ref).all())
     calls = []
     real_f, real_b = k.hgt_aggregate_compact, k.hgt_backward_compact
     monkeypatch.setattr(k, "hgt_aggregate_compact", lambda *a, **kw: (calls.append("fwd"), real_f(*a, **kw))[1])
