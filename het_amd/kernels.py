@@ -358,6 +358,8 @@ def _gat_maps(kind: int, d: Dict[str, Tensor], backward: bool):
 
 _derived: "OrderedDict[tuple, tuple]" = OrderedDict()
 _DERIVED_MAX = 64
+import threading as _threading
+_derived_lock = _threading.RLock()
 
 
 def _derived_get(tag, tensors, build):
@@ -367,15 +369,16 @@ def _derived_get(tag, tensors, build):
     returning stale rows.  The entry keeps the source tensors alive, which pins their storage (a data_ptr cannot be
     recycled for other contents while the entry lives).  Least recently used entries go first."""
     key = (tag,) + tuple(_plan._ident(t) for t in tensors)
-    hit = _derived.get(key)
-    if hit is None:
-        hit = (build(), tensors)
-        _derived[key] = hit
-        while len(_derived) > _DERIVED_MAX:
-            _derived.popitem(last=False)
-    else:
-        _derived.move_to_end(key)
-    return hit[0]
+    with _derived_lock:  # (model threads and autograd workers share the cache: lookup, build and eviction under one lock)
+        hit = _derived.get(key)
+        if hit is None:
+            hit = (build(), tensors)
+            _derived[key] = hit
+            while len(_derived) > _DERIVED_MAX:
+                _derived.popitem(last=False)
+        else:
+            _derived.move_to_end(key)
+        return hit[0]
 
 
 def _rows_by_search(rel_ptrs, nodes, ua, ub):

@@ -24,6 +24,7 @@ from . import _lib
 
 _MAX_ENTRIES = 32
 _cache: "OrderedDict[tuple, Grouping]" = OrderedDict()
+_cache_lock = threading.RLock()  # lookups, inserts and evictions of _cache (model threads, the autograd engine's workers)
 enabled = True  # process-wide default; tests flip this to exercise the atomics kernels
 _tls = threading.local()  # .force: this thread's override of `enabled` (forced(), sampling.one_shot_graphs)
 
@@ -104,29 +105,35 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
     if not is_enabled():
         return None
     k = (_ident(rel_ptrs), _ident(keys), int(key_bound), _ident(payload0), _ident(payload1), keys.device.index)
-    g = _cache.get(k)
-    if g is not None:
-        _cache.move_to_end(k)
+    # One lock around lookup, build and eviction: two threads asking for the same grouping get the same object, and an entry is
+    # never evicted between its lookup and its return.  (The caller keeps the returned Grouping alive while it uses it: an
+    # eviction by another thread only drops the cache's reference.)
+    with _cache_lock:
+        g = _cache.get(k)
+        if g is not None:
+            _cache.move_to_end(k)
+            return g
+        for t in (rel_ptrs, keys, payload0, payload1):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+                raise _lib.HetError("groupings need contiguous int64 tensors on the GPU")
+        out = C.c_void_p()
+        stream = C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream)
+        with torch.cuda.device(keys.device):
+            _lib.call("het_grouping_create", _ptr(rel_ptrs), 0 if rel_ptrs is None else rel_ptrs.numel() - 1,
+                      _ptr(keys), keys.numel(), int(key_bound), _ptr(payload0), _ptr(payload1), stream, C.byref(out))
+        g = Grouping(out, (rel_ptrs, keys, payload0, payload1))
+        _cache[k] = g
+        while len(_cache) > _MAX_ENTRIES:
+            _cache.popitem(last=False)
         return g
-    for t in (rel_ptrs, keys, payload0, payload1):
-        if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
-            raise _lib.HetError("groupings need contiguous int64 tensors on the GPU")
-    out = C.c_void_p()
-    stream = C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream)
-    with torch.cuda.device(keys.device):
-        _lib.call("het_grouping_create", _ptr(rel_ptrs), 0 if rel_ptrs is None else rel_ptrs.numel() - 1,
-                  _ptr(keys), keys.numel(), int(key_bound), _ptr(payload0), _ptr(payload1), stream, C.byref(out))
-    g = Grouping(out, (rel_ptrs, keys, payload0, payload1))
-    _cache[k] = g
-    while len(_cache) > _MAX_ENTRIES:
-        _cache.popitem(last=False)
-    return g
 
 
 def cached_bytes() -> int:
     """Device bytes of all cached groupings (add to torch.cuda.max_memory_allocated for a true footprint)."""
-    return sum(g.nbytes for g in _cache.values())
+    with _cache_lock:
+        return sum(g.nbytes for g in _cache.values())
 
 
 def clear():
-    _cache.clear()
+    with _cache_lock:
+        _cache.clear()
