@@ -294,7 +294,7 @@ def _main():
     for name in ("HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_src", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
                  "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
                  "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
-                 "HET_rows4_chunk_permute", "HET_rows4_block_sum", "HET_node_dx", "HET_node_dw", "HET_node_forward",
+                 "HET_node_dx", "HET_node_dw_rows", "HET_node_dw_narrow", "HET_node_forward",
                  "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"):
         ms, n = HL.kernel_timing_read(name)
         if n:

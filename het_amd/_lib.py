@@ -40,7 +40,6 @@ _SIGNATURES = {
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_node_row_map": [P, I64, P, I64, I64, P, P],
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P],
-    "het_rgat_node_backward_dw": [I64, I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, INT, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_hgt_aggregate_compact": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
     "het_hgt_backward_compact": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, I64, P],

@@ -38,9 +38,6 @@ _OFFS = {}
 PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
-# ... the weight gradients too (one read of x for all of them): correct and tested, but at one wave per SIMD (its accumulators take
-# the register file) the kernel runs 1.02 ms against 0.76 ms for the four per-product launches on ogbn-mag -- off by default
-NODE_DW = os.environ.get("HET_RGAT_NODE_DW", "0") == "1"
 
 
 def _mulfirst_shape_ok(H, Kd):
@@ -308,10 +305,9 @@ class RgatLayerFunction(th.autograd.Function):
 
     @staticmethod
     def _backward_node_major(ctx, grad_h, Wt):
-        """The backward on the distinct-row dataflow with every GEMM-side term gathered per NODE (csrc/node_gemm.hip): one
-        pass stores the input gradient (self-loop + relation projections + the folded attention vector), one pass forms all
-        weight gradients from a single read of x -- instead of a self-loop pass, one read-modify-write launch per relation
-        and side, and three weight-gradient launches."""
+        """The backward on the distinct-row dataflow with every term of the INPUT gradient gathered per node
+        (csrc/node_gemm.hip): one pass stores grad_x (self-loop + relation projections + the folded attention vector) -- instead
+        of a self-loop pass and one read-modify-write launch per relation and side."""
         x, W, attn_l, attn_r, loop_w, offs, sm, ex, ret, featc, elc, erc = ctx.saved_tensors
         g, nd, slope = ctx.g, ctx.nd, ctx.slope
         N, Kd = x.shape
@@ -333,23 +329,18 @@ class RgatLayerFunction(th.autograd.Function):
         gh = grad_h if ctx.has_loop else None
         _k.rgat_node_backward_dx(0, N, nd, gh, loop_w.t().contiguous() if ctx.has_loop else None, g_featc.view(-1, X), Wt, row_map,
                                  g_erc, wa_t, dst_map, grad_x)
-        if NODE_DW:
-            # all weight gradients from one read of x; the gradient of attn_l through grad_wl[r,h,:] = SUM g_el[row,h] * x[node,:]
-            # (feat_c[row] = x[node] . W[r], so SUM g_el[row,h] * feat_c[row,h,:] = grad_wl[r,h,:] . W[r,h]): no pass over feat_c
-            grad_wl = th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
-            _k.rgat_node_backward_dw(0, N, nd, x, gh, g_featc.view(-1, X), row_map, g_erc, dst_map, g_elc, grad_loop, grad_W, grad_wa,
-                                     grad_wl, accumulate=False)
-            grad_attn_l = th.einsum("rhk,rhkd->rhd", grad_wl, W)
-        else:  # the weight gradients per source (four launches; each reads its own rows of x / feat_c)
-            grad_attn_l = th.empty_like(attn_l)
-            _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
-                                                 accumulate=False)
-            if ctx.has_loop:
-                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
-            _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
-            d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
-            _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
-                               accumulate=False)
+        # the weight gradients per product (four launches; each reads its own rows of x / feat_c -- a node-major pass that reads x
+        # once was measured in five forms and lost: it multiplies zero rows wherever a node has no row in a relation,
+        # exp/node_dw.hip.txt)
+        grad_attn_l = th.empty_like(attn_l)
+        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                             accumulate=False)
+        if ctx.has_loop:
+            _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+        _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
+        d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
+        _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
+                           accumulate=False)
         grad_W.addcmul_(grad_wa.unsqueeze(-1), attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
         grad_attn_r = (W * grad_wa.unsqueeze(-1)).sum(2)
         return None, None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias

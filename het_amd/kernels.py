@@ -623,7 +623,7 @@ def rows_matmul_backward_dw(rel_ptrs, gather_idx, x, gradout, grad_w, accumulate
 
 
 def rgat_node_gemm_ok(R: int, H: int, K: int, D: int) -> bool:
-    """Shapes of the node-major backward GEMMs (include/het_amd.h: het_rgat_node_backward_dx / _dw)."""
+    """Shapes of the node-major input-gradient pass (include/het_amd.h: het_rgat_node_backward_dx)."""
     return bool(_lib.lib().het_rgat_node_gemm_ok(R, H, K, D))
 
 
@@ -645,17 +645,6 @@ def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weigh
     R, H, D, K = weights_t.shape
     _call(grad_x, "het_rgat_node_backward_dx", int(n_begin), int(n_end), int(n_loop), grad_x.shape[0], R, _p(grad_h), _p(loop_wt),
           _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _stream(grad_x))
-
-
-def rgat_node_backward_dw(n_begin, n_end, n_loop, x, grad_h, g_rows, row_map, g_er, dst_map, g_el, grad_loop, grad_w, grad_wa,
-                          grad_wl, accumulate: bool):
-    """The weight gradients of the one-node RGAT layer (self-loop, relations, and the two attention-vector products grad_wa /
-    grad_wl) from ONE read of the layer input (include/het_amd.h)."""
-    _chk("rgat_node_backward_dw", tuple(t for t in (x, grad_h, g_rows, g_er, g_el, grad_loop, grad_w, grad_wa, grad_wl) if t is not None))
-    R, H, K, D = grad_w.shape
-    _call(x, "het_rgat_node_backward_dw", int(n_begin), int(n_end), int(n_loop), x.shape[0], R, g_rows.shape[0], _p(x), _p(grad_h),
-          _p(g_rows), _p(row_map), _p(g_er), _p(dst_map), _p(g_el), _p(grad_loop), _p(grad_w), _p(grad_wa), _p(grad_wl), H, K, D,
-          int(accumulate), _stream(x))
 
 
 def rows_linear_bias_ok(K: int, X: int) -> bool:

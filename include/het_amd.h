@@ -498,23 +498,18 @@ int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const
                                 int64_t D, int accumulate, het_stream stream);
 
 /* ------------------------------------------------------------------------
- * Node-major backward GEMMs of the one-node RGAT layer (layer-level fusion; no reference op of their own).  They
- * replace, inside het_amd/backend/rgat_fused_layer.py, the per-relation input- and weight-gradient passes of a2
- * (backward_rgnn_relational_matmul with CompactAsOfNodeKind 1, OpExport/RGNNOps.inc.h:946-1010 -> kernels
- * RGNN/my_shmem_sgemm_func.cu.h:711-776), the self-loop's a3 backward (RGNNOps.inc.h:660-753) and the D_out = 1
- * products of the attention-vector side: ONE pass over the nodes forms
+ * Node-major input gradient of the one-node RGAT layer (layer-level fusion; no reference op of its own).  It replaces,
+ * inside het_amd/backend/rgat_fused_layer.py, the per-relation input-gradient passes of a2 (backward_rgnn_relational_matmul
+ * with CompactAsOfNodeKind 1, OpExport/RGNNOps.inc.h:946-1010 -> kernels RGNN/my_shmem_sgemm_func.cu.h:711-776), the self-loop's
+ * a3 backward (RGNNOps.inc.h:660-753) and the D_out = 1 product of the attention-vector side: ONE pass over the nodes forms
  *   grad_x[n,:]  = grad_h[n,:] . loop_wt  +  SUM_r g_rows[row_map[r,n],:] . weights_t[r]  +  SUM_r,h g_er[dst_map[r,n],h] * wa_t[r,h,:]
- *   grad_loop   += x[n,:]^T (x) grad_h[n,:];   grad_w[r] += x[n,:]^T (x) g_rows[row_map[r,n],:];
- *   grad_wa[r,h,:] += g_er[dst_map[r,n],h] * x[n,:];   grad_wl[r,h,:] += g_el[row_map[r,n],h] * x[n,:]
- *   (g_el [S_row, H], optional: the gradient of el = <feat_c, attn_l>.  With grad_wl the caller gets the gradient of attn_l
- *   without a pass over feat_c: grad_attn_l[r,h,d] = SUM_k grad_wl[r,h,k] * W[r,h,k,d], because feat_c[row_r(n)] = x[n] . W[r])
- * for the nodes n in [n_begin, n_end); terms whose map entry is -1 (and the grad_h term for n >= n_loop) are absent.
+ * for the nodes n in [n_begin, n_end) and stores the row once; terms whose map entry is -1 (and the grad_h term for
+ * n >= n_loop) are absent.
  *   row_map / dst_map [R, num_nodes] int32: row of (relation, node) in the unique (relation, source) / (relation,
  *   destination) list, -1 if the node has none (het_node_row_map);  grad_h [n_loop, H*D];  g_rows [S_row, H*D];
- *   g_er [S_col, H] (NULL: no such term);  loop_wt [H*D, K] (= loop_weight^T);  weights_t [R,H,D,K];  wa_t [R,H,K];
- *   grad_loop [K, H*D];  grad_w [R,H,K,D];  grad_wa, grad_wl [R,H,K].   dx stores grad_x rows ("="); dw adds (accumulate != 0)
- *   or overwrites.  Shapes: K and H*D in {32, 64}, H in {1,2,4,8}, R*H <= 16, all 1 + R weights resident in LDS
- *   (het_rgat_node_gemm_ok); HET_ERR_INVALID_ARG otherwise -- callers fall back to the per-relation entry points. */
+ *   g_er [S_col, H] (NULL: no such term);  loop_wt [H*D, K] (= loop_weight^T);  weights_t [R,H,D,K];  wa_t [R,H,K].
+ *   Shapes: K and H*D in {32, 64}, H in {1,2,4,8}, R*H <= 32, all 1 + R weights resident in LDS (het_rgat_node_gemm_ok);
+ *   HET_ERR_INVALID_ARG otherwise -- callers fall back to the per-relation entry points. */
 int het_rgat_node_gemm_ok(int64_t num_rels, int64_t H, int64_t K, int64_t D);
 int het_node_row_map(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* nodes, int64_t num_rows, int64_t num_nodes,
                      int32_t* map, het_stream stream);
@@ -522,11 +517,6 @@ int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t n_loop, in
                               const float* grad_h, const float* loop_wt, const float* g_rows, const float* weights_t,
                               const int32_t* row_map, const float* g_er, const float* wa_t, const int32_t* dst_map,
                               float* grad_x, int64_t H, int64_t K, int64_t D, het_stream stream);
-int het_rgat_node_backward_dw(int64_t n_begin, int64_t n_end, int64_t n_loop, int64_t num_nodes, int64_t num_rels,
-                              int64_t num_src_rows, const float* x, const float* grad_h, const float* g_rows,
-                              const int32_t* row_map, const float* g_er, const int32_t* dst_map, const float* g_el,
-                              float* grad_loop, float* grad_w, float* grad_wa, float* grad_wl, int64_t H, int64_t K, int64_t D,
-                              int accumulate, het_stream stream);
 
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.
