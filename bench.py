@@ -45,7 +45,7 @@ def parse():
                    help="rgat = the BASELINE.json metric; rgcn / hgt time BASELINE.json configs[1] / configs[3] (single GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
-    p.add_argument("--cpu-scale", type=float, default=0.05, help="graph scale of the CPU-baseline sample (1.0 = the full workload: "
+    p.add_argument("--cpu-scale", type=float, default=0.25, help="graph scale of the CPU-baseline sample (1.0 = the full workload: "
                    "one warm-up + one timed iteration, about 3 minutes of host time -- outside the default run)")
     a = p.parse_args()
     if a.heads is None:
@@ -97,7 +97,7 @@ def cpu_baseline(args):
     lw = (torch.randn(K, K) * 0.1).requires_grad_(True)
     go = torch.randn(N, K)
     times = []
-    for it in range(2 if args.cpu_scale >= 0.5 else 4):
+    for it in range(2 if args.cpu_scale >= 0.2 else 4):  # (a quarter of the workload: ~14 s per step on the 128 host threads)
         t0 = time.perf_counter()
         out = OL.rgat_layer(x, W, al, ar, s["rel_ptrs"], s["row_indices"], s["col_indices"], N, 0.2, lw, None)
         torch.autograd.grad(out, [x, W, al, ar, lw], go)
@@ -307,18 +307,33 @@ def _main():
     ms_per_step = dt / args.steps * 1e3
     value = E_global / (dt / args.steps) / 1e6
 
-    prof_dir = os.path.join(ROOT, "profiles", "r02")
-    prof_tag = args.variant if args.model == "rgat" else args.model  # profiles/r02/{default,compact,...,rgcn,hgt}_pmc.json
+    prof_dir = os.path.join(ROOT, "profiles", "r03")
+    prof_tag = args.variant if args.model == "rgat" else args.model  # profiles/r03/{default,rgcn,hgt}_pmc.json
+
+    def kernel_source_sha16():
+        """Digest of het_amd/csrc/* (as profiles/tools/summarize.py records it with the counters)."""
+        import hashlib
+        root = os.path.join(ROOT, "het_amd", "csrc")
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".hip", ".h", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(root, f), "rb").read())
+        return h.hexdigest()[:16]
+    tree_sha = kernel_source_sha16()
 
     def pmc(kernel, field):
-        """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/r02/,
+        """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/r03/,
         written by profiles/tools/collect.sh on an earlier box): rocprofv3 cannot run inside the timed process, so
         this is not an observation of this run -- the JSON says so (`traffic_source`).  None when no committed
         profile matches this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
         path = os.path.join(prof_dir, f"{prof_tag}_pmc.json")
         if args.scale != 1.0 or world != 1 or args.feat != 64 or args.heads != (8 if args.model == "hgt" else 4) or not os.path.exists(path):
             return None
-        kernels = json.load(open(path))["kernels"]
+        prof = json.load(open(path))
+        if prof.get("kernel_source_sha16") != tree_sha:
+            return None  # the kernels changed since those counters were collected: a stale figure is worse than none
+        kernels = prof["kernels"]
         if isinstance(kernel, (tuple, list)):  # an op implemented by several launches per step: the sum over them
             parts = [pmc(k_, field) for k_ in kernel]
             return None if any(p_ is None for p_ in parts) else sum(parts)
@@ -331,7 +346,7 @@ def _main():
              "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
              "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(nbytes),
              "traffic": pmc(pmc_name or kernel.split(" ")[0], "hbm_bytes_per_launch")}
-        r["traffic_source"] = (f"profiles/r02/{prof_tag}_pmc.json (committed rocprofv3 --pmc passes of this command on "
+        r["traffic_source"] = (f"profiles/r03/{prof_tag}_pmc.json (committed rocprofv3 --pmc passes of this command on "
                                "another box; not measured in this run)") if r["traffic"] else None
         if r["traffic"]:
             r["traffic_rate_GBps"] = round(r["traffic"] / (k_ms * 1e-3) / 1e9, 1)
@@ -452,7 +467,7 @@ def _main():
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "mfma_busy_frac_pmc": busy,
                          "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "hbm_bytes_per_launch"),
-                         "traffic_source": f"profiles/r02/{prof_tag}_pmc.json (committed; not measured in this run)" if busy else None}
+                         "traffic_source": f"profiles/r03/{prof_tag}_pmc.json (committed; not measured in this run)" if busy else None}
         # a4 / a5 on the per-edge tensor retp just written (feat_src_per_edge), reference argument order
         el = torch.randn(E_local, H, device=dev)
         er = torch.randn(E_local, H, device=dev)

@@ -39,8 +39,22 @@ if st:
         print(f"{short(r['Name']):45s} calls={int(r['Calls']):5d} avg_ms={float(r['AverageNs'])/1e6:8.3f} "
               f"total_ms={float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):5.1f}%")
 
+def kernel_source_sha16():
+    """Digest of the kernel sources the profiled library was built from (het_amd/csrc/*): bench.py quotes a counter of this
+    file only while the tree's digest is the same, i.e. while no kernel changed since the counters were collected."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "het_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 fe, wr, mf = counters("fetch"), counters("write"), counters("mfma")
-out = {"_how": "profiles/tools/collect.sh; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (mean over launches); "
+out = {"kernel_source_sha16": kernel_source_sha16(),
+       "_how": "profiles/tools/collect.sh; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (mean over launches); "
                "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): GRBM_GUI_ACTIVE is summed "
                "over the 8 XCDs (it equals 8 * kernel duration * ~2.0 GHz here) and one f32 32x32x2 MFMA holds its SIMD's "
                "matrix pipe for 64 cycles (measured: busy cycles / MFMAs issued = 64.0)",
