@@ -37,6 +37,7 @@ from ..kernels import K
 _OFFS = {}
 PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
+RUN_SUMS = os.environ.get("HET_RGAT_RUN_SUMS", "1") != "0"  # A/B switch: grad_er from the forward's run sums
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
 
 
@@ -173,8 +174,11 @@ class RgatLayerFunction(th.autograd.Function):
                 K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc.view(-1, H, 1))
             # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
             srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
-            grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0])
-            _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h)
+            # (run sums: grad_er from S_col rows the forward leaves instead of a per-edge term -- csrc/gat_compact.hip)
+            run_sums = RUN_SUMS and _k.rgat_runs_shape_ok(H, D)
+            grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0], rel_ptrs=rp if run_sums else None,
+                                            drow_nodes=ss["node_indices_col"], drow_rel_ptrs=ss["rel_ptrs_col"])
+            ctx.runs = _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h, num_rels=R)
             ctx.grp = grp
             ex = x.new_empty(0)
         else:
@@ -259,7 +263,8 @@ class RgatLayerFunction(th.autograd.Function):
             if ctx.has_bias:  # the bias gradient (column sums of grad_h) from the pass that reads every gradout row anyway
                 grad_bias = th.empty(X, dtype=x.dtype, device=x.device)
             _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:ndp], ret[:ndp], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
-                                     row_rel_ptrs=ss["rel_ptrs_row"], grad_bias=grad_bias if ctx.has_bias else None, bias_rows=nd)
+                                     row_rel_ptrs=ss["rel_ptrs_row"], grad_bias=grad_bias if ctx.has_bias else None, bias_rows=nd,
+                                     runs=ctx.runs, drow_nodes=ss["node_indices_col"])
             grad_attn_l, grad_attn_r = th.empty_like(attn_l), th.empty_like(attn_r)
             _k.matmul_no_scatter_gather_backward(ss["rel_ptrs_row"], attn_l.unsqueeze(2), featc, g_elc, None,
                                                  grad_attn_l.unsqueeze(-1), accumulate=False)
@@ -321,7 +326,8 @@ class RgatLayerFunction(th.autograd.Function):
         g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
-                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
+                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
+                                 drow_nodes=ss["node_indices_col"])
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
         grad_x = th.empty_like(x)
         grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
@@ -373,7 +379,8 @@ class RgatLayerFunction(th.autograd.Function):
             grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
             _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
-                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd)
+                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
+                                 drow_nodes=ss["node_indices_col"])
         if node_major:
             # one pass per node range (csrc/node_gemm.hip): the halo rows first -- only the (relation, source) projections reach
             # them -- so that they leave with the all-to-all while the owned rows (self-loop + projections + folded attention

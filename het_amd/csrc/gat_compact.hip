@@ -553,6 +553,294 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
   }
 }
 
+// ---- grad_er without a per-edge term ------------------------------------------------------------------------------
+// grad_er[(r,v),h] = SUM over the edges e of the RUN (relation r, destination v) of a_e dl_e (<gradout[v,h,:], feat[srow_e,h,:]> -
+// <gradout, ret>[v,h]).  gradout[v] is the same for the whole run, so with
+//     Q[(r,v),h,:] = SUM_e w_e dl_e feat[srow_e,h,:],   q[(r,v),h] = SUM_e w_e dl_e,   w_e = exp(s_e - ref[(r,v),h])
+// it is exp(ref - lse[v,h]) (<gradout[v,h,:], Q> - <gradout, ret>[v,h] q): S_col rows instead of a per-edge tensor [E,H] written
+// in (relation, source) order and summed in (relation, destination) order (16-byte gathers: 0.58 ms + 0.34 GB of stores on
+// ogbn-mag).  The forward visits the feat rows of a run anyway; what made this lose in round 2 (note above: one accumulator
+// per relation, 104 VGPRs) is avoided by walking a destination's edges IN ORDER -- the grouping by destination is a stable
+// sort of relation-major positions, so the runs of a destination are contiguous -- with ONE run accumulator:
+//   destinations of <= hub_min in-edges: lane group per pack of whole destinations (or per destination), edges in order,
+//     running maximum per destination, run sums stored where the run ends with the maximum of that moment as `ref`;
+//   hubs (54 % of the edges of ogbn-mag at 256): wave per work item of the grouping by (destination, relation) -- same sorted
+//     order, items never cross a run -- partial {O[X], Q[X], max[H], sum[H], q[H]} parked; one wave per hub then finishes
+//     ret / lse and every run of the hub (ref = lse).
+
+// one edge joins the running sums of its destination (acc, ssum) and of its run (accq, sq); all relative to the running maximum m
+__device__ __forceinline__ void online_edge(float s, float dl, const float4& f, float& m, float4& acc, float& ssum, float4& accq,
+                                            float& sq) {
+  const float t = __expf(-fabsf(s - m));  // (m = -inf before the first edge: t = 0, the old sums are dropped)
+  const bool grow = s > m;
+  const float c = grow ? t : 1.f, w = grow ? 1.f : t, wd = w * dl;
+  m = grow ? s : m;
+  acc.x = fmaf(acc.x, c, w * f.x); acc.y = fmaf(acc.y, c, w * f.y); acc.z = fmaf(acc.z, c, w * f.z); acc.w = fmaf(acc.w, c, w * f.w);
+  accq.x = fmaf(accq.x, c, wd * f.x); accq.y = fmaf(accq.y, c, wd * f.y); accq.z = fmaf(accq.z, c, wd * f.z); accq.w = fmaf(accq.w, c, wd * f.w);
+  ssum = fmaf(ssum, c, w);
+  sq = fmaf(sq, c, wd);
+}
+
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
+    Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat, const float* __restrict__ el,
+    const float* __restrict__ er, float* __restrict__ lse, float* __restrict__ ret, int H, float slope, float* __restrict__ hio,
+    int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum, float* __restrict__ qref, int hub_min) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
+  if (pid >= pk.n) return;
+  const uint32_t pb = (uint32_t)pk.ptr[pid];
+  const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
+  if ((pb >> 31) && e - b > hub_min) return;  // a hub (a pack of its own): HET_rgat_aggregate_hub_items + HET_rgat_finish_hubs
+  int jn = b + dq < e ? b + dq : e - 1;
+  int4 idn = kp01[jn];  // {destination, feat row, er row} of the edge
+  int cur_dst = -1, cur_drow = -1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accq = acc, h0 = acc;
+  float ssum = 0.f, sq = 0.f, m = -INFINITY;
+  for (int j0 = b; j0 < e; j0 += U) {
+    const int dstv = idn.x, srowv = idn.y, drowv = idn.z;
+    const float zlv = el[(int64_t)srowv * H + h];
+    const float zrv = er[(int64_t)drowv * H + h];
+    float4 f[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) f[q] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, q, lane) * X + x);
+    jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
+    idn = kp01[jn];
+    const float zv = zlv + zrv, sv = lrelu(zv, slope), dlv = zv > 0.f ? 1.f : slope;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if (j0 + q < e) {  // (uniform within the lane group, like everything below)
+        const int dstq = head_bcast_i<DL>(dstv, q, lane), drowq = head_bcast_i<DL>(drowv, q, lane);
+        if (drowq != cur_drow) {  // a run starts (an er row belongs to one destination: a new destination is a new run too)
+          if (cur_drow >= 0) {
+            st4(qrow + (int64_t)cur_drow * X + x, accq);
+            if (d == 0) { qsum[(int64_t)cur_drow * H + h] = sq; qref[(int64_t)cur_drow * H + h] = m; }
+          }
+          if (dstq != cur_dst) {
+            if (cur_dst >= 0) {
+              const float inv = 1.f / ssum;
+              const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+              st4(ret + (int64_t)cur_dst * X + x, r4);
+              if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
+              if (d == 0) lse[(int64_t)cur_dst * H + h] = m + __logf(ssum);
+            }
+            cur_dst = dstq;
+            if (hio && dstq < hio_rows) h0 = ld4(hio + (int64_t)dstq * X + x);  // needed when the destination ends
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            ssum = 0.f;
+            m = -INFINITY;
+          }
+          cur_drow = drowq;
+          accq = make_float4(0.f, 0.f, 0.f, 0.f);
+          sq = 0.f;
+        }
+        online_edge(head_bcast<DL>(sv, q, lane), head_bcast<DL>(dlv, q, lane), f[q], m, acc, ssum, accq, sq);
+      }
+    }
+  }
+  if (cur_drow >= 0) {
+    st4(qrow + (int64_t)cur_drow * X + x, accq);
+    if (d == 0) { qsum[(int64_t)cur_drow * H + h] = sq; qref[(int64_t)cur_drow * H + h] = m; }
+    const float inv = 1.f / ssum;
+    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    st4(ret + (int64_t)cur_dst * X + x, r4);
+    if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
+    if (d == 0) lse[(int64_t)cur_dst * H + h] = m + __logf(ssum);
+  }
+}
+
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Hubs: wave per hub work item of the grouping by (destination, relation) `it` (keys destination * R + relation; same sorted
+// order as the grouping by destination whose packed ids p01 it reads; hub_items: grouping_hub_items -- a wave per item of
+// that grouping with a test for "hub" spent 1.7 ms on 1.3 M early exits).  part[k] = {O[X], Q[X], max[H], sum[H], q[H]}.
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
+    Items it, const int32_t* __restrict__ hub_items, int64_t num_hub_items, const int2* __restrict__ p01,
+    const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er, int H, float slope,
+    float* __restrict__ part) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  static_assert(DL >= U, "a head needs at least U lanes");
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int dq = d < U ? d : U - 1;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= num_hub_items) return;
+  const int item = hub_items[k];
+  const int b = it.begin[item], e = it.end[item];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accq = acc;
+  float ssum = 0.f, sq = 0.f, m = -INFINITY;
+  int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
+  int2 idn = p01[jn];
+  for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
+    const int srowv = idn.x, drowv = idn.y;
+    const float zlv = el[(int64_t)srowv * H + h];
+    const float zrv = er[(int64_t)drowv * H + h];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
+    jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
+    idn = p01[jn];
+    const float zv = zlv + zrv;
+    const float sv = j0 + dq * EPW < e ? lrelu(zv, slope) : -INFINITY;
+    {
+      float mn = m;
+#pragma unroll
+      for (int u = 0; u < U; ++u) mn = fmaxf(mn, head_bcast<DL>(sv, u, lane));
+      const float c = __expf(m - mn);
+      acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+      accq.x *= c; accq.y *= c; accq.z *= c; accq.w *= c; sq *= c;
+      m = mn;
+    }
+    const float wv = __expf(sv - m), wdv = wv * (zv > 0.f ? 1.f : slope);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = head_bcast<DL>(wv, u, lane), wd = head_bcast<DL>(wdv, u, lane);
+      acc.x = fmaf(w, f[u].x, acc.x); acc.y = fmaf(w, f[u].y, acc.y); acc.z = fmaf(w, f[u].z, acc.z); acc.w = fmaf(w, f[u].w, acc.w);
+      accq.x = fmaf(wd, f[u].x, accq.x); accq.y = fmaf(wd, f[u].y, accq.y); accq.z = fmaf(wd, f[u].z, accq.z); accq.w = fmaf(wd, f[u].w, accq.w);
+      ssum += w;
+      sq += wd;
+    }
+  }
+  {
+    float M = m;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+    const float c = m == -INFINITY ? 0.f : __expf(m - M);
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+    accq.x *= c; accq.y *= c; accq.z *= c; accq.w *= c; sq *= c;
+    m = M;
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    accq.x += __shfl_xor(accq.x, off); accq.y += __shfl_xor(accq.y, off); accq.z += __shfl_xor(accq.z, off); accq.w += __shfl_xor(accq.w, off);
+    ssum += __shfl_xor(ssum, off);
+    sq += __shfl_xor(sq, off);
+  }
+  if (slot != 0) return;
+  float* pp = part + k * (2 * X + 3 * H);
+  st4(pp + x, acc);
+  st4(pp + X + x, accq);
+  if (d == 0) { pp[2 * X + h] = m; pp[2 * X + H + h] = ssum; pp[2 * X + 2 * H + h] = sq; }
+}
+
+// One wave per hub (hub_segs: segments of the grouping by destination): its runs are the segments of `it` with keys in
+// [v * R, (v + 1) * R), its work items are consecutive.  First ret / lse over all items, then the sums of every run relative to lse.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
+    const int32_t* __restrict__ hub_segs, int64_t num_hubs, const int32_t* __restrict__ dseg_key, Items it, int64_t S2, int R,
+    const int32_t* __restrict__ hub_items, int64_t num_hub_items, const int32_t* __restrict__ p_drow,
+    const float* __restrict__ part, float* __restrict__ lse, float* __restrict__ ret, int H,
+    int D, float* __restrict__ hio, int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum,
+    float* __restrict__ qref) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (k >= num_hubs) return;
+  const int64_t X = (int64_t)H * D, v = dseg_key[hub_segs[k]], rec = 2 * X + 3 * H;
+  const int64_t s_lo = lower_bound_i32(it.seg_key, S2, v * R), s_hi = lower_bound_i32(it.seg_key, S2, (v + 1) * R);
+  // the hub's work items are consecutive, and so are their records (hub_items is ascending): record of item i = i_lo + (i - item_lo)
+  const int64_t item_lo = lower_bound_i32(it.seg, it.n, s_lo), item_hi = lower_bound_i32(it.seg, it.n, s_hi);
+  const int64_t i_lo = lower_bound_i32(hub_items, num_hub_items, item_lo), i_hi = i_lo + (item_hi - item_lo);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ssum = 0.f, m = -INFINITY;
+  for (int64_t i = i_lo + slot; i < i_hi; i += EPW) {
+    const float* pp = part + i * rec;
+    const float mi = pp[2 * X + h], si = pp[2 * X + H + h];
+    const float4 a = ld4(pp + x);
+    const float mn = fmaxf(m, mi), c = __expf(m - mn), ci = __expf(mi - mn);
+    acc.x = acc.x * c + a.x * ci; acc.y = acc.y * c + a.y * ci; acc.z = acc.z * c + a.z * ci; acc.w = acc.w * c + a.w * ci;
+    ssum = ssum * c + si * ci;
+    m = mn;
+  }
+  float M = m;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off));
+  {
+    const float c = m == -INFINITY ? 0.f : __expf(m - M);
+    acc.x *= c; acc.y *= c; acc.z *= c; acc.w *= c; ssum *= c;
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    ssum += __shfl_xor(ssum, off);
+  }
+  const float L = M + __logf(ssum);  // (every lane group holds the totals of its head)
+  if (slot == 0) {
+    const float inv = 1.f / ssum;
+    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    st4(ret + v * X + x, r4);
+    if (hio && v < hio_rows) {
+      const float4 h0 = ld4(hio + v * X + x);
+      st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
+    }
+    if (x % D == 0) lse[v * H + h] = L;
+  }
+  int64_t i0 = i_lo;
+  for (int64_t s2 = s_lo; s2 < s_hi; ++s2) {
+    const int64_t n_items = (it.seg_ptr[s2 + 1] - it.seg_ptr[s2] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
+    float4 aq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sq = 0.f;
+    for (int64_t i = i0 + slot; i < i0 + n_items; i += EPW) {
+      const float* pp = part + i * rec;
+      const float ci = __expf(pp[2 * X + h] - L);
+      const float4 a = ld4(pp + X + x);
+      aq.x = fmaf(a.x, ci, aq.x); aq.y = fmaf(a.y, ci, aq.y); aq.z = fmaf(a.z, ci, aq.z); aq.w = fmaf(a.w, ci, aq.w);
+      sq = fmaf(pp[2 * X + 2 * H + h], ci, sq);
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      aq.x += __shfl_xor(aq.x, off); aq.y += __shfl_xor(aq.y, off);
+      aq.z += __shfl_xor(aq.z, off); aq.w += __shfl_xor(aq.w, off);
+      sq += __shfl_xor(sq, off);
+    }
+    if (slot == 0) {
+      const int64_t w = p_drow[it.seg_ptr[s2]];  // er row of the run
+      st4(qrow + w * X + x, aq);
+      if (x % D == 0) { qsum[w * H + h] = sq; qref[w * H + h] = L; }
+    }
+    i0 += n_items;
+  }
+}
+
+// grad_er[w,h] = exp(ref[w,h] - lse[v,h]) (<gradout[v,h,:], Q[w,h,:]> - <gradout, ret>[v,h] q[w,h]),  v = drow_nodes[w];
+// pack2 [N,H,2] = {lse, <gradout, ret>}.  An er row without edges (q == 0, rows never written) gets 0.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_grad_er_runs(const float* __restrict__ qrow, const float* __restrict__ qsum,
+                                                                 const float* __restrict__ qref, const int64_t* __restrict__ drow_nodes,
+                                                                 const float* __restrict__ pack2, const float* __restrict__ gradout,
+                                                                 float* __restrict__ grad_er, int64_t n_rows, int H, int D) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D, DL = D >> 2;
+  const int64_t step = (int64_t)gridDim.x * (kBlock / 64) * EPW;
+  for (int64_t w0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * EPW; w0 < n_rows; w0 += step) {
+    const bool ok = w0 + slot < n_rows;
+    const int64_t w = ok ? w0 + slot : n_rows - 1;
+    const int64_t v = drow_nodes[w];
+    const float sq = qsum[w * H + h];
+    const float4 g = ld4(gradout + v * X + x), q = ld4(qrow + w * X + x);
+    const float2 pkv = *reinterpret_cast<const float2*>(pack2 + (v * H + h) * 2);
+    const float ref = qref[w * H + h];
+    float dot = g.x * q.x + g.y * q.y + g.z * q.z + g.w * q.w;
+    for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if (ok && (sub & (DL - 1)) == 0) grad_er[w * H + h] = sq == 0.f ? 0.f : __expf(ref - pkv.x) * (dot - pkv.y * sq);
+  }
+}
+
 // Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {lse, <gradout, ret>} interleaved.
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
@@ -661,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
     // (writing tbuf in the order of the grouping by er row instead -- scattered 16-byte stores, a streaming segmented
     //  sum afterwards -- was measured: +0.38 ms here and in the long-segment kernel, -0.40 ms there)
-    if (d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;
+    if (tbuf && d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;  // (NULL: grad_er comes from the run sums)
     prev_key = key[U - 1];
   }
 }
@@ -722,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     float ts = tq[0];
 #pragma unroll
     for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
-    if (d < U && j0 + d * EPW < e) tbuf[(int64_t)(j0 + d * EPW) * H + h] = ts;
+    if (tbuf && d < U && j0 + d * EPW < e) tbuf[(int64_t)(j0 + d * EPW) * H + h] = ts;
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -860,41 +1148,124 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
   return HET_OK;
 }
 
+// ---- forward that also leaves the run sums (see "grad_er without a per-edge term" above) ----
+// Destinations with more in-edges than this go to the wave-per-item hub path (parked partial sums), the others are walked in
+// order by one lane group.  At least HET_PACK_T (shorter destinations share a pack); measured on ogbn-mag: see DESIGN.md 4.1.
+static int rgat_hub_min() {
+  static const int v = [] {
+    const char* e = getenv("HET_RGAT_HUB_MIN");
+    const int t = e ? atoi(e) : 256;
+    return t < HET_PACK_T ? HET_PACK_T : t;
+  }();
+  return v;
+}
+
+extern "C" int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel,
+                                                             int64_t num_rels, int64_t H, int64_t D, het_stream stream) {
+  if (!by_dst || !by_dst_rel || num_rels <= 0) return -1;
+  if (grouping_hub_items(by_dst_rel, by_dst, (int)num_rels, rgat_hub_min(), (hipStream_t)stream) != HET_OK) return -1;  // (built on first use)
+  return (int64_t)sizeof(float) * by_dst_rel->num_hub_items * (2 * H * D + 3 * H);
+}
+
+extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
+                                               const float* feat_c, const float* el_c, const float* er_c, float* sum, float* ret,
+                                               int64_t num_nodes, int64_t H, int64_t D, double slope, float* h_inout,
+                                               int64_t h_rows, float* q_rows, float* q_sum, float* q_ref, int64_t num_dst_rows,
+                                               void* workspace, int64_t workspace_bytes, het_stream stream) {
+  const char* op = "het_rgat_aggregate_compact_runs";
+  hipStream_t s = (hipStream_t)stream;
+  HET_REQUIRE(by_dst && by_dst_rel && sum && ret && q_rows && q_sum && q_ref && num_nodes >= 0 && num_rels > 0, "%s: null argument", op);
+  if (!compact_shape_ok(H, D) || !coop_shape_ok(H, D)) {
+    het_set_error("%s: unsupported shape H=%lld D=%lld", op, (long long)H, (long long)D);
+    return HET_ERR_UNSUPPORTED;
+  }
+  HET_REQUIRE(by_dst->R == 0 && by_dst->key_bound <= num_nodes && (by_dst->E == 0 || (by_dst->p0 && by_dst->p1 && feat_c && el_c && er_c)),
+              "%s: by_dst must group the positions by destination with payload0 = feat row and payload1 = er row", op);
+  HET_REQUIRE(by_dst_rel->R == 0 && by_dst_rel->E == by_dst->E && by_dst_rel->key_bound <= num_nodes * num_rels,
+              "%s: by_dst_rel must group the same positions by destination * num_rels + relation", op);
+  const int64_t need = het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream);
+  if (need < 0) return HET_ERR_INVALID_ARG;
+  HET_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0),
+              "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_aggregate_compact_runs_workspace)", op, (long long)need);
+  const int64_t X = H * D;
+  HET_HIP(hipMemsetAsync(sum, 0, sizeof(float) * num_nodes * H, s));
+  HET_HIP(hipMemsetAsync(q_sum, 0, sizeof(float) * num_dst_rows * H, s));  // er rows without edges: q == 0 marks them
+  if (!h_inout) HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
+  if (by_dst->E == 0) return HET_OK;
+  if (int rc = grouping_packed_ids(by_dst, true, s)) return rc;  // (builds the packs too)
+  float* part = static_cast<float*>(workspace);
+  {
+    HET_KTIME("HET_rgat_aggregate", s);
+    Packs pk{by_dst->pack_ptr, by_dst->key_of_rank, by_dst->num_packs};
+    const unsigned nb = (unsigned)ceil_div64(by_dst->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+    HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                      hipLaunchKernelGGL((HET_rgat_aggregate_runs_packed<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_dst->kp01,
+                                         feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows, q_rows, q_sum, q_ref,
+                                         rgat_hub_min()));
+  }
+  HET_LAUNCH_CHECK("HET_rgat_aggregate_runs_packed");
+  if (by_dst_rel->num_hub_items > 0) {
+    if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
+    Items it{by_dst_rel->item_seg, by_dst_rel->item_begin, by_dst_rel->item_end, by_dst_rel->seg_ptr, by_dst_rel->seg_key,
+             by_dst_rel->num_items};
+    const int64_t n_hub = by_dst_rel->num_hub_items;
+    {
+      HET_KTIME("HET_rgat_hub_items", s);
+      const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
+      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                        hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s, it,
+                                           by_dst_rel->hub_items, n_hub, by_dst->p01, feat_c, el_c, er_c, (int)H, (float)slope, part));
+    }
+    HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
+    const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s, by_dst_rel->hub_segs,
+                                                      by_dst_rel->num_hub_segs, by_dst->seg_key, it, by_dst_rel->S, (int)num_rels,
+                                                      by_dst_rel->hub_items, n_hub, by_dst->p1, part, sum, ret, (int)H, (int)D,
+                                                      h_inout, h_rows, q_rows, q_sum, q_ref));
+    HET_LAUNCH_CHECK("HET_rgat_finish_hubs");
+  }
+  return HET_OK;
+}
+
 extern "C" int64_t het_rgat_backward_compact_workspace(int64_t num_nodes, int64_t num_edges, int64_t H, int64_t D, int with_bias) {
   const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = (num_edges * H + 3) / 4 * 4;
   return (int64_t)sizeof(float) * (n_pack + n_tbuf + (with_bias ? (int64_t)2048 * (kBlock / 64) * H * D : 0));
 }
 
-extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
-                                         const float* el_c, const float* er_c, const float* sum, const float* ret,
-                                         const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
-                                         const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
-                                         float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
-                                         int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
-                                         int64_t workspace_bytes, het_stream stream) {
-  const char* op = "het_rgat_backward_compact";
+// runs (q_rows != NULL): grad_er from the run sums the forward left (no per-edge term, no by_drow); else from tbuf + by_drow
+struct RunSums {
+  const float *q_rows, *q_sum, *q_ref;
+  const int64_t* drow_nodes;
+};
+static int rgat_backward_compact_impl(const char* op, const het_grouping* by_srow, const het_grouping* by_drow, const RunSums* runs,
+                                      const float* feat_c, const float* el_c, const float* er_c, const float* sum, const float* ret,
+                                      const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
+                                      const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
+                                      float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
+                                      int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
+                                      int64_t workspace_bytes, het_stream stream) {
   hipStream_t s = (hipStream_t)stream;
-  HET_REQUIRE(by_srow && by_drow && sum && ret && gradout && grad_feat_c && grad_el_c && grad_er_c, "%s: null argument", op);
-  if (!compact_shape_ok(H, D) || !segment_rows_supported((int)H) || slope < 0) {
+  HET_REQUIRE(by_srow && (by_drow || runs) && sum && ret && gradout && grad_feat_c && grad_el_c && grad_er_c, "%s: null argument", op);
+  if (!compact_shape_ok(H, D) || !segment_rows_supported((int)H) || slope < 0 || (runs && !coop_shape_ok(H, D))) {
     het_set_error("%s: unsupported shape H=%lld D=%lld (or slope < 0)", op, (long long)H, (long long)D);
     return HET_ERR_UNSUPPORTED;
   }
   const int64_t E = by_srow->E, X = H * D;
-  HET_REQUIRE(by_srow->R == 0 && by_drow->R == 0 && by_drow->E == E && by_srow->key_bound <= num_src_rows &&
-                  by_drow->S == num_dst_rows && (E == 0 || (by_srow->p0 && by_srow->p1 && by_drow->p0)),
-              "%s: by_srow groups the positions by feat row (payload0 = destination, payload1 = er row); by_drow groups them by "
-              "er row with payload0 = their rank in by_srow and has one segment per er row", op);
+  HET_REQUIRE(by_srow->R == 0 && by_srow->key_bound <= num_src_rows && (E == 0 || (by_srow->p0 && by_srow->p1)),
+              "%s: by_srow groups the positions by feat row (payload0 = destination, payload1 = er row)", op);
+  HET_REQUIRE(runs || (by_drow->R == 0 && by_drow->E == E && by_drow->S == num_dst_rows && (E == 0 || by_drow->p0)),
+              "%s: by_drow groups the positions by er row with payload0 = their rank in by_srow and has one segment per er row", op);
   HET_REQUIRE(!fold_attn_l || (row_rel_ptrs && num_rels > 0), "%s: fold_attn_l needs the relation pointers of the feat rows", op);
   const bool coop = coop_shape_ok(H, D);
   constexpr int kBiasBlocks = 2048;
   const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
-  const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
+  const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = runs ? 0 : (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
   const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X);
   HET_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
               "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_backward_compact_workspace)", op, (long long)need);
   float* pack = (float*)workspace;  // [N, 2H]
-  float* tbuf = pack + n_pack;      // [E, H], rank order of by_srow
-  float* bias_part = grad_bias ? tbuf + n_tbuf : nullptr;
+  float* tbuf = runs ? nullptr : pack + n_pack;  // [E, H], rank order of by_srow
+  float* bias_part = grad_bias ? pack + n_pack + n_tbuf : nullptr;
   if (by_srow->S != num_src_rows) {  // feat rows without an edge (none when the lists come from the graph): zero gradient
     HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
     HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
@@ -972,6 +1343,45 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
     }
   }
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
+  if (runs) {
+    if (num_dst_rows > 0) {
+      HET_KTIME("HET_rgat_grad_er_runs", s);
+      HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_grad_er_runs<LPR>, dim3(grid_for(num_dst_rows * (X / 4))), dim3(kBlock),
+                                                        0, s, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
+                                                        grad_er_c, num_dst_rows, (int)H, (int)D));
+    }
+    HET_LAUNCH_CHECK("HET_rgat_grad_er_runs");
+    return HET_OK;
+  }
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[rank, :]   (segments of by_drow are the er rows in order)
   return launch_segment_sum(by_drow, tbuf, grad_er_c, (int)H, nullptr, s);
+}
+
+extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* by_drow, const float* feat_c,
+                                         const float* el_c, const float* er_c, const float* sum, const float* ret,
+                                         const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
+                                         const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
+                                         float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
+                                         int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
+                                         int64_t workspace_bytes, het_stream stream) {
+  HET_REQUIRE(by_drow, "het_rgat_backward_compact: null argument");
+  return rgat_backward_compact_impl("het_rgat_backward_compact", by_srow, by_drow, nullptr, feat_c, el_c, er_c, sum, ret, gradout,
+                                    grad_feat_c, grad_el_c, grad_er_c, fold_attn_l, row_rel_ptrs, num_rels, grad_bias, bias_rows,
+                                    num_nodes, num_src_rows, num_dst_rows, H, D, slope, workspace, workspace_bytes, stream);
+}
+
+// The backward after het_rgat_aggregate_compact_runs: q_rows / q_sum / q_ref as that call left them, drow_nodes [num_dst_rows] the
+// destination node of every er row.  Workspace: het_rgat_backward_compact_workspace with num_edges = 0.
+extern "C" int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_rows, const float* q_sum, const float* q_ref,
+                                              const int64_t* drow_nodes, const float* feat_c, const float* el_c, const float* er_c,
+                                              const float* sum, const float* ret, const float* gradout, float* grad_feat_c,
+                                              float* grad_el_c, float* grad_er_c, const float* fold_attn_l,
+                                              const int64_t* row_rel_ptrs, int64_t num_rels, float* grad_bias, int64_t bias_rows,
+                                              int64_t num_nodes, int64_t num_src_rows, int64_t num_dst_rows, int64_t H, int64_t D,
+                                              double slope, void* workspace, int64_t workspace_bytes, het_stream stream) {
+  HET_REQUIRE(q_rows && q_sum && q_ref && (drow_nodes || num_dst_rows == 0), "het_rgat_backward_compact_runs: null argument");
+  const RunSums runs{q_rows, q_sum, q_ref, drow_nodes};
+  return rgat_backward_compact_impl("het_rgat_backward_compact_runs", by_srow, nullptr, &runs, feat_c, el_c, er_c, sum, ret, gradout,
+                                    grad_feat_c, grad_el_c, grad_er_c, fold_attn_l, row_rel_ptrs, num_rels, grad_bias, bias_rows,
+                                    num_nodes, num_src_rows, num_dst_rows, H, D, slope, workspace, workspace_bytes, stream);
 }

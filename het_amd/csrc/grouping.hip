@@ -89,6 +89,31 @@ __global__ void HET_grouping_long_items(const int32_t* __restrict__ seg_ptr, con
   }
 }
 
+// is_hub[t] = the key of item t's segment (seg_key / R) owns more than hub_min positions in the twin grouping
+__global__ void HET_grouping_hub_flags(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_key,
+                                       const int32_t* __restrict__ item_seg, int64_t num_items, int R,
+                                       const int32_t* __restrict__ twin_key, const int32_t* __restrict__ twin_ptr, int64_t twin_S,
+                                       int hub_min, uint8_t* __restrict__ is_hub) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < num_items; t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = item_seg[t];
+    bool hub = seg_ptr[s + 1] - seg_ptr[s] > hub_min;
+    if (!hub) {
+      const int32_t v = seg_key[s] / R;
+      int64_t lo = 0, hi = twin_S;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (twin_key[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      hub = lo < twin_S && twin_key[lo] == v && twin_ptr[lo + 1] - twin_ptr[lo] > hub_min;
+    }
+    is_hub[t] = hub;
+  }
+}
+__global__ void HET_grouping_long_seg_flags(const int32_t* __restrict__ seg_ptr, int64_t S, int min_len, uint8_t* __restrict__ flag) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x)
+    flag[s] = seg_ptr[s + 1] - seg_ptr[s] > min_len;
+}
+
 __global__ void HET_grouping_pack_flags(const int32_t* __restrict__ seg_ptr, int64_t S, uint8_t* __restrict__ flag) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
     const int32_t b = seg_ptr[s], e = seg_ptr[s + 1];
@@ -146,7 +171,7 @@ struct Scratch {  // frees device temporaries on every exit path
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -168,6 +193,7 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
   if (g->p01) b += 8 * (E > 0 ? E : 1);
   if (g->kp01) b += 16 * (E + 1);
+  if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1);
   return b;
 }
 
@@ -367,6 +393,58 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   g->num_long_items = h_num[1];
   g->num_packs = h_num[0];
   g->pack_ptr = pack_ptr;
+  return HET_OK;
+}
+
+int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, int hub_min, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->num_hub_items >= 0) {
+    if (g->hub_twin != twin || g->hub_min != hub_min) {
+      het_set_error("grouping_hub_items: the grouping was paired with another grouping (or threshold) before");
+      return HET_ERR_INVALID_ARG;
+    }
+    return HET_OK;
+  }
+  const int64_t NI = g->num_items, TS = twin->S;
+  int32_t *items = nullptr, *segs = nullptr;
+  int32_t h_num[2] = {0, 0};
+  if (NI > 0 && TS > 0) {
+    Scratch tmp;
+    uint8_t *is_hub = nullptr, *is_long = nullptr;
+    int32_t *d_num = nullptr, *sel = nullptr, *sel2 = nullptr;
+    HET_HIP(tmp.alloc((void**)&is_hub, (size_t)NI));
+    HET_HIP(tmp.alloc((void**)&is_long, (size_t)TS));
+    HET_HIP(tmp.alloc((void**)&d_num, sizeof(int32_t) * 2));
+    HET_HIP(tmp.alloc((void**)&sel, sizeof(int32_t) * (size_t)NI));
+    HET_HIP(tmp.alloc((void**)&sel2, sizeof(int32_t) * (size_t)TS));
+    hipLaunchKernelGGL(HET_grouping_hub_flags, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->seg_key, g->item_seg, NI, R,
+                       twin->seg_key, twin->seg_ptr, TS, hub_min, is_hub);
+    HET_LAUNCH_CHECK("HET_grouping_hub_flags");
+    hipLaunchKernelGGL(HET_grouping_long_seg_flags, dim3(blocks_for(TS)), dim3(256), 0, s, twin->seg_ptr, TS, hub_min, is_long);
+    HET_LAUNCH_CHECK("HET_grouping_long_seg_flags");
+    hipcub::CountingInputIterator<int32_t> ranks(0);
+    size_t tb = 0, tb2 = 0;
+    HET_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, ranks, is_hub, sel, d_num, (int)NI, s));
+    HET_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb2, ranks, is_long, sel2, d_num + 1, (int)TS, s));
+    void* t0 = nullptr;
+    HET_HIP(tmp.alloc(&t0, tb > tb2 ? tb : tb2));
+    HET_HIP(hipcub::DeviceSelect::Flagged(t0, tb, ranks, is_hub, sel, d_num, (int)NI, s));
+    HET_HIP(hipcub::DeviceSelect::Flagged(t0, tb2, ranks, is_long, sel2, d_num + 1, (int)TS, s));
+    HET_HIP(hipMemcpyAsync(h_num, d_num, sizeof(h_num), hipMemcpyDeviceToHost, s));
+    HET_HIP(hipStreamSynchronize(s));
+    HET_HIP(hipMalloc((void**)&items, sizeof(int32_t) * ((size_t)h_num[0] + 1)));
+    hipError_t e = hipMalloc((void**)&segs, sizeof(int32_t) * ((size_t)h_num[1] + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(items, sel, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(segs, sel2, sizeof(int32_t) * (size_t)h_num[1], hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(items); (void)hipFree(segs); HET_HIP(e); }
+  }
+  g->hub_items = items;
+  g->hub_segs = segs;
+  g->num_hub_segs = h_num[1];
+  g->hub_twin = twin;
+  g->hub_min = hub_min;
+  g->num_hub_items = h_num[0];
   return HET_OK;
 }
 

@@ -41,6 +41,14 @@ struct het_grouping {
   // number of their vector-memory instructions.
   mutable int2* p01 = nullptr;    // [E]   {p0[j], p1[j]}
   mutable int4* kp01 = nullptr;   // [E+1] {key_of_rank[j], p0[j], p1[j], 0}; sentinel key -1 at E (needs the packs)
+  // Hub items (grouping_hub_items): for a grouping by key * R + relation, the work items (ascending) whose key belongs to a
+  // segment of more than hub_min positions in the twin grouping by key alone (het_rgat_aggregate_compact_runs).
+  mutable int32_t* hub_items = nullptr;
+  mutable int64_t num_hub_items = -1;         // -1: not built
+  mutable int32_t* hub_segs = nullptr;        // the twin's segments of more than hub_min positions (ascending)
+  mutable int64_t num_hub_segs = 0;
+  mutable int hub_min = 0;
+  mutable const het_grouping* hub_twin = nullptr;
 };
 
 constexpr int HET_PACK_T = 32;
@@ -48,3 +56,6 @@ constexpr int HET_PACK_T = 32;
 int grouping_packs(const het_grouping* g, hipStream_t s);
 // Builds g->p01 (with_keys == false) or g->kp01 (true; builds the packs first) once, thread-safe, published after a sync.
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s);
+// Builds g_rel->hub_items once (thread-safe, published after a sync): g_rel groups the same positions as `twin` by
+// key * R + relation.  An error if g_rel was built against another twin (or threshold) before.
+int grouping_hub_items(const het_grouping* g_rel, const het_grouping* twin, int R, int hub_min, hipStream_t s);

@@ -576,27 +576,71 @@ def grouping_rank_of_position(g):
     return r
 
 
-def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_rows):
-    """The three groupings of the compact RGAT passes (include/het_amd.h: het_rgat_aggregate_compact): by destination,
-    by feat row and by er row.  ``srow`` / ``drow`` [E] int64: feat row and er row of every edge position."""
+def rgat_runs_shape_ok(H: int, D: int) -> bool:
+    """Shapes of the run-sum form of the compact RGAT pair (include/het_amd.h: het_rgat_aggregate_compact_runs): rows of 32 / 64 /
+    128 floats, heads of at least 16."""
+    X = H * D
+    return X in (32, 64, 128) and D >= 16 and D & (D - 1) == 0 and X % D == 0
+
+
+def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_rows, rel_ptrs=None, drow_nodes=None,
+                           drow_rel_ptrs=None):
+    """The groupings of the compact RGAT passes (include/het_amd.h: het_rgat_aggregate_compact): (by destination, by feat row,
+    by er row, None).  ``srow`` / ``drow`` [E] int64: feat row and er row of every edge position.
+    With ``rel_ptrs`` (relation pointers of the positions; they are relation-major): the run-sum form
+    (het_rgat_aggregate_compact_runs) -- (by destination, by feat row, None, by (destination, relation)).  That form needs the er
+    rows to BE the distinct (relation, destination) pairs: ``drow_nodes`` [S_col] / ``drow_rel_ptrs`` [R+1] (the list the rows
+    index) are checked against the edges once per list."""
     by_dst = _plan.get_grouping(None, col, num_nodes, srow, drow)
     by_srow = _plan.get_grouping(None, srow, num_src_rows, col, drow)
     if by_dst is None or by_srow is None:
         return None
+    if rel_ptrs is not None:
+        R = rel_ptrs.numel() - 1
+
+        def build():
+            rel = torch.repeat_interleave(torch.arange(R, dtype=torch.int64, device=col.device), rel_ptrs[1:] - rel_ptrs[:-1])
+            if drow_nodes is not None:
+                ok = bool((drow_nodes[drow] == col).all()) and drow.numel() == rel.numel()
+                if ok and drow_rel_ptrs is not None:
+                    ok = bool(((drow >= drow_rel_ptrs[rel]) & (drow < drow_rel_ptrs[rel + 1])).all())
+                if not ok:
+                    raise _lib.HetError("rgat_compact_groupings: the run-sum form needs every er row to be the (relation, "
+                                        "destination) pair of its edges")
+            return (col * R + rel).contiguous()
+        key = _derived_get("dst_rel_key", (col, rel_ptrs, drow) + ((drow_nodes,) if drow_nodes is not None else ()), build)
+        return by_dst, by_srow, None, _plan.get_grouping(None, key, num_nodes * R, None, None)
     by_drow = _plan.get_grouping(None, drow, num_dst_rows, grouping_rank_of_position(by_srow), None)
-    return by_dst, by_srow, by_drow
+    return by_dst, by_srow, by_drow, None
 
 
-def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None):
+def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None, num_rels=None):
     """h_inout [rows, H*D] (optional): ret's rows are also added into it in place (include/het_amd.h).  ``sum`` receives the
-    log-sum-exp of every (destination, head) -- these two entry points subtract a running maximum (no overflow for any el + er)."""
+    log-sum-exp of every (destination, head) -- these two entry points subtract a running maximum (no overflow for any el + er).
+    Groupings in the run-sum form (rgat_compact_groupings with rel_ptrs; ``num_rels`` required): returns (q_rows, q_sum, q_ref)
+    for rgat_backward_compact."""
     _chk("rgat_aggregate_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, h_inout) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
+    if groupings[3] is not None:
+        S_col = er_c.shape[0]
+        q_rows = torch.empty((S_col, H, D), dtype=ret.dtype, device=ret.device)
+        q_sum, q_ref = torch.empty_like(er_c), torch.empty_like(er_c)
+        with torch.cuda.device(ret.device):
+            nbytes = int(_lib.lib().het_rgat_aggregate_compact_runs_workspace(groupings[0].handle, groupings[3].handle, int(num_rels), H, D,
+                                                                              _stream(ret)))
+        if nbytes < 0:
+            raise _lib.HetError("het_rgat_aggregate_compact_runs_workspace: " + _lib.lib().het_last_error().decode())
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device) if nbytes else None
+        _call(ret, "het_rgat_aggregate_compact_runs", groupings[0].handle, groupings[3].handle, int(num_rels), _p(feat_c), _p(el_c),
+              _p(er_c), _p(sum), _p(ret), N, H, D, float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0],
+              _p(q_rows), _p(q_sum), _p(q_ref), S_col, _p(ws), nbytes, _stream(ret))
+        return q_rows, q_sum, q_ref
     nbytes = int(_lib.lib().het_rgat_aggregate_compact_workspace(groupings[0].handle, H, D))  # (hub destinations only)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device) if nbytes else None
     _call(ret, "het_rgat_aggregate_compact", groupings[0].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), N, H, D,
           float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0], _p(ws), nbytes, _stream(ret))
+    return None
 
 
 def rows_matmul_backward_split_ok(H: int, K: int, D: int) -> bool:
@@ -660,19 +704,24 @@ def rows_linear_bias(offsets, x, w, bias):
 
 
 def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c, slope,
-                          fold_attn_l=None, row_rel_ptrs=None, grad_bias=None, bias_rows=0):
+                          fold_attn_l=None, row_rel_ptrs=None, grad_bias=None, bias_rows=0, runs=None, drow_nodes=None):
+    """runs = (q_rows, q_sum, q_ref) of rgat_aggregate_compact in the run-sum form, drow_nodes [S_col] int64 the destination of
+    every er row: grad_er_c from the run sums (het_rgat_backward_compact_runs)."""
     _chk("rgat_backward_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c,
-                                                    fold_attn_l, grad_bias) if t is not None),
-         () if row_rel_ptrs is None else (row_rel_ptrs,))
+                                                    fold_attn_l, grad_bias) + (tuple(runs) if runs else ()) if t is not None),
+         tuple(t for t in (row_rel_ptrs, drow_nodes) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
-    E = groupings[1]._keep[1].numel()
+    E = 0 if runs else groupings[1]._keep[1].numel()
     nbytes = int(_lib.lib().het_rgat_backward_compact_workspace(N, E, H, D, int(grad_bias is not None)))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device)
-    _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, _p(feat_c), _p(el_c), _p(er_c), _p(sum),
-          _p(ret), _p(gradout), _p(grad_feat_c), _p(grad_el_c), _p(grad_er_c), _p(fold_attn_l), _p(row_rel_ptrs),
-          0 if row_rel_ptrs is None else row_rel_ptrs.numel() - 1, _p(grad_bias), int(bias_rows), N, feat_c.shape[0],
-          er_c.shape[0], H, D, float(slope), _p(ws), ws.numel() * 4, _stream(ret))
+    tail = (_p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), _p(gradout), _p(grad_feat_c), _p(grad_el_c), _p(grad_er_c),
+            _p(fold_attn_l), _p(row_rel_ptrs), 0 if row_rel_ptrs is None else row_rel_ptrs.numel() - 1, _p(grad_bias),
+            int(bias_rows), N, feat_c.shape[0], er_c.shape[0], H, D, float(slope), _p(ws), ws.numel() * 4, _stream(ret))
+    if runs:
+        _call(ret, "het_rgat_backward_compact_runs", groupings[1].handle, _p(runs[0]), _p(runs[1]), _p(runs[2]), _p(drow_nodes), *tail)
+    else:
+        _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, *tail)
 
 
 def hgt_compact_shape_ok(H: int, D: int) -> bool:

@@ -483,6 +483,36 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
                               int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
                               int64_t workspace_bytes, het_stream stream);
 
+/* The same pair with grad_er taken from per-RUN sums instead of a per-edge term (a run = the edges of one (relation,
+ * destination) pair = one er row).  The reference's backward adds grad_er edge by edge with float atomics
+ * (RGATBackwardKernelsSeparateCOO.cu.h:60-117); het_rgat_backward_compact writes a per-edge term [E,H] in (relation, source)
+ * order and sums it in (relation, destination) order.  gradout[v] is common to a run, so the forward -- which visits the feat
+ * rows of the run anyway -- can leave
+ *   q_rows[w,h,:] = SUM_e w_e dl_e feat_c[srow_e,h,:],  q_sum[w,h] = SUM_e w_e dl_e,   w_e = exp(leaky(el + er) - q_ref[w,h]),
+ *   dl_e = 1 or slope (the leaky-ReLU branch of edge e)
+ * per er row w, and grad_er_c[w,h] = exp(q_ref[w,h] - lse[v,h]) (<gradout[v,h,:], q_rows[w,h,:]> - <gradout, ret>[v,h] q_sum[w,h]).
+ *   by_dst_rel: het_grouping_create(NULL, 0, col * num_rels + relation of the position, E, N * num_rels, NULL, NULL) -- the same
+ *     sorted order as by_dst when the positions are relation-major (a separate-COO list); its work items never cross a run.
+ *   q_rows [S_col,H,D], q_sum / q_ref [S_col,H]: written by the forward, read by the backward.  drow_nodes [S_col] int64:
+ *     destination node of every er row.  Shapes: rows of 32 / 64 / 128 floats with heads of >= 16 (else HET_ERR_UNSUPPORTED).
+ *   workspaces: het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream) -- one record per work item of
+ *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel, which is
+ *     thereby paired with this by_dst); -1 on error;  het_rgat_backward_compact_workspace(N, 0, H, D, .) */
+int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
+                                                  int64_t H, int64_t D, het_stream stream);
+int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
+                                    const float* feat_c, const float* el_c, const float* er_c, float* sum, float* ret,
+                                    int64_t num_nodes, int64_t H, int64_t D, double slope, float* h_inout, int64_t h_rows,
+                                    float* q_rows, float* q_sum, float* q_ref, int64_t num_dst_rows, void* workspace,
+                                    int64_t workspace_bytes, het_stream stream);
+int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_rows, const float* q_sum, const float* q_ref,
+                                   const int64_t* drow_nodes, const float* feat_c, const float* el_c, const float* er_c,
+                                   const float* sum, const float* ret, const float* gradout, float* grad_feat_c,
+                                   float* grad_el_c, float* grad_er_c, const float* fold_attn_l, const int64_t* row_rel_ptrs,
+                                   int64_t num_rels, float* grad_bias, int64_t bias_rows, int64_t num_nodes,
+                                   int64_t num_src_rows, int64_t num_dst_rows, int64_t H, int64_t D, double slope,
+                                   void* workspace, int64_t workspace_bytes, het_stream stream);
+
 /* The two halves of a2 (backward_rgnn_relational_matmul, one input head, matrix-core shapes) as separate calls, so that a
  * caller can order them around a collective (het_amd/dist.py).  Rows i in [0, num_rows) of relation-bucketed lists:
  *   dx: grad_x[gather_idx[i], :] (+)= gradout[g_rows[i], :] . Wt[r(i)]      atomic 0: "=";  1: "+=" with float atomics (rows

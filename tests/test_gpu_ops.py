@@ -271,6 +271,89 @@ def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
         assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
 
 
+@pytest.mark.parametrize("fold,bias", [(False, False), (True, True)])
+@pytest.mark.parametrize("H,D,n,e", [(4, 16, 300, 5000), (1, 64, 300, 5000), (4, 16, 12, 9000), (4, 32, 300, 700), (4, 16, 40, 9000),
+                                     (2, 32, 12, 9000), (1, 32, 40, 9000), (2, 16, 20, 9000), (2, 16, 300, 3000)])
+def test_rgat_compact_run_sums(K, H, D, n, e, fold, bias):
+    """het_rgat_aggregate_compact_runs / het_rgat_backward_compact_runs (grad_er from the sums the forward leaves per er row, no
+    per-edge term) against the oracle's CompactAsOfNodeKind-4 pair.  The er rows are the distinct (relation, destination) pairs
+    here -- the precondition of this form (include/het_amd.h).  n = 12 / 20: hubs (more than 256 in-edges: parked work items,
+    several runs per hub); n = 40: destinations of 33 .. 256 in-edges (a pack of their own); n = 300: several destinations per pack."""
+    import het_amd.kernels as k
+    g = random_graph(seed=31, n=n, r=4, e=e)
+    s = g.get_separate_coo_original()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    N, E, R, slope = g.get_num_nodes(), g.get_num_edges(), g.get_num_rels(), 0.2
+    rel = torch.repeat_interleave(torch.arange(R), s["rel_ptrs"][1:] - s["rel_ptrs"][:-1])
+
+    def rows_of(ptrs, nodes, ids):  # row of (relation, node) of every position in a unique (relation, node) list
+        key = torch.repeat_interleave(torch.arange(R), ptrs[1:] - ptrs[:-1]) * N + nodes
+        return torch.searchsorted(key, rel * N + ids).contiguous()
+    srow_p = rows_of(ss["rel_ptrs_row"], ss["node_indices_row"], s["row_indices"])
+    drow_p = rows_of(ss["rel_ptrs_col"], ss["node_indices_col"], s["col_indices"])
+    assert bool((ss["node_indices_col"][drow_p] == s["col_indices"]).all())
+    S_row, S_col = ss["node_indices_row"].numel(), ss["node_indices_col"].numel()
+    gen = torch.Generator().manual_seed(13)
+    feat, el, er = torch.randn(S_row, H, D, generator=gen), torch.randn(S_row, H, generator=gen), torch.randn(S_col, H, generator=gen)
+    go, attn = torch.randn(N, H, D, generator=gen), torch.randn(R, H, D, generator=gen)
+    # the oracle's maps are indexed by edge id
+    m_row, m_col = torch.empty(E, dtype=torch.int64), torch.empty(E, dtype=torch.int64)
+    m_row[s["eids"]], m_col[s["eids"]] = srow_p, drow_p
+    df = {"edata_idx_to_inverse_idx_row": m_row, "edata_idx_to_inverse_idx_col": m_col}
+    idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+    sm_r, ex_r, ret_r = (torch.empty(N, H, dtype=torch.float64), torch.empty(E, H, dtype=torch.float64),
+                         torch.empty(N, H, D, dtype=torch.float64))
+    O.relational_fused_gat_separate_coo(*idx, 4, df, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r, slope)
+    gf_r, gl_r, gr_r = torch.zeros_like(to64(feat)), torch.zeros_like(to64(el)), torch.zeros_like(to64(er))
+    O.backward_relational_fused_gat_separate_coo(*idx, 4, df, to64(feat), to64(el), to64(er), sm_r, ex_r, ret_r,
+                                                 to64(go), gf_r, gl_r, gr_r, slope)
+    if fold:
+        rel_of_row = torch.repeat_interleave(torch.arange(R), ss["rel_ptrs_row"][1:] - ss["rel_ptrs_row"][:-1])
+        gf_r = gf_r + gl_r.unsqueeze(-1) * attn.double()[rel_of_row]
+    grp = k.rgat_compact_groupings(s["col_indices"].to(DEV), srow_p.to(DEV), drow_p.to(DEV), N, S_row, S_col, rel_ptrs=s["rel_ptrs"].to(DEV),
+                                   drow_nodes=ss["node_indices_col"].to(DEV), drow_rel_ptrs=ss["rel_ptrs_col"].to(DEV))
+    assert grp[2] is None and grp[3] is not None
+    f, l, r_ = feat.to(DEV), el.to(DEV), er.to(DEV)
+    has_in = torch.zeros(N, dtype=torch.bool)
+    has_in[s["col_indices"]] = True
+    sm, ret = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
+    runs = k.rgat_aggregate_compact(grp, f, l, r_, sm, ret, slope, num_rels=R)
+    assert_close(sm[has_in.to(DEV)], torch.log(sm_r[has_in]), what="log-sum-exp")
+    assert float(sm[(~has_in).to(DEV)].abs().max() if (~has_in).any() else 0.0) == 0.0
+    assert_close(ret, ret_r, what="ret")
+    # the run sums themselves: q_rows * exp(q_ref) = SUM_e exp(s_e) dl_e feat[srow_e] over the run
+    z = to64(el)[srow_p] + to64(er)[drow_p]
+    wd = torch.exp(torch.nn.functional.leaky_relu(z, slope)) * torch.where(z > 0, 1.0, slope)
+    q_ref = torch.zeros(S_col, H, dtype=torch.float64).index_add_(0, drow_p, wd)
+    Q_ref = torch.zeros(S_col, H, D, dtype=torch.float64).index_add_(0, drow_p, wd.unsqueeze(-1) * to64(feat)[srow_p])
+    sc = torch.exp(runs[2].double().cpu())
+    assert_close(runs[1].double().cpu() * sc, q_ref, what="q_sum")
+    assert_close(runs[0].double().cpu() * sc.unsqueeze(-1), Q_ref, what="q_rows")
+    nh = N - 2
+    h0 = torch.randn(nh, H * D, generator=gen)
+    hio, ret2, sm2 = h0.to(DEV), torch.full((N, H, D), 7.0, device=DEV), torch.full((N, H), 7.0, device=DEV)
+    k.rgat_aggregate_compact(grp, f, l, r_, sm2, ret2, slope, h_inout=hio, num_rels=R)
+    assert_close(hio, h0.double() + ret_r.view(N, -1)[:nh], what="h_inout")
+    assert_close(ret2[has_in.to(DEV)], ret_r[has_in], what="ret (destinations with in-edges)")
+    gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
+    gb = torch.full((H * D,), float("nan"), device=DEV) if bias else None
+    nb = N - 3
+    k.rgat_backward_compact(grp, f, l, r_, sm, ret, go.to(DEV), gf, gl, gr, slope, fold_attn_l=attn.to(DEV) if fold else None,
+                            row_rel_ptrs=ss["rel_ptrs_row"].to(DEV) if fold else None, grad_bias=gb, bias_rows=nb, runs=runs,
+                            drow_nodes=ss["node_indices_col"].to(DEV))
+    assert_close(gf, gf_r, what="grad_feat")
+    assert_close(gl, gl_r, what="grad_el")
+    assert_close(gr, gr_r, what="grad_er")
+    if bias:
+        assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
+    # er rows that are not the (relation, destination) pairs of their edges are refused (checked once per list)
+    bad = drow_p.clone()
+    bad[0] = (bad[0] + 1) % S_col
+    with pytest.raises(Exception, match="er row"):
+        k.rgat_compact_groupings(s["col_indices"].to(DEV), srow_p.to(DEV), bad.to(DEV), N, S_row, S_col, rel_ptrs=s["rel_ptrs"].to(DEV),
+                                 drow_nodes=ss["node_indices_col"].to(DEV), drow_rel_ptrs=ss["rel_ptrs_col"].to(DEV))
+
+
 @pytest.mark.parametrize("H,D,n,e", [(8, 8, 300, 5000), (1, 64, 300, 5000), (4, 16, 40, 9000), (2, 8, 12, 9000), (4, 32, 300, 700),
                                      (1, 32, 30, 4000), (2, 32, 300, 3000), (1, 8, 300, 5000), (1, 8, 12, 9000)])
 def test_hgt_compact_passes(K, H, D, n, e):
