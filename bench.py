@@ -291,10 +291,12 @@ def _main():
     # live per-kernel durations of the timed region: {kernel: (avg ms per launch, launches per step, ms per step)}; the roofline
     # objects use ms per step = the summed duration of the launches that together implement the op in one step
     kt = {}
-    for name in ("HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_src", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
+    for name in ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs",
+                 "HET_rgat_backward_src", "HET_rgat_backward", "HET_rgat_aggregate_packs", "HET_rgat_aggregate_hubs",
+                 "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
                  "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
                  "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
-                 "HET_node_dx", "HET_node_dw_rows", "HET_node_dw_narrow", "HET_node_forward",
+                 "HET_node_dx",
                  "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"):
         ms, n = HL.kernel_timing_read(name)
         if n:
@@ -377,19 +379,35 @@ def _main():
                 req = nb_ + (E_local - S_row) * 4 * X  # one gradout row per edge instead of per source row
                 ex.update(bytes_with_per_edge_row_gather=int(req),
                           frac_with_per_edge_row_gather=round(req / (kt[bname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-            pm = ("HET_rgat_backward_src_coop", "HET_rgat_backward_src_long") if bname == "HET_rgat_backward_src" else bname
-            roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {'4: rows of the distinct (relation, node) projections; short + long segment launches' if S_row else 0})",
-                                kt[bname][2], nb_, ex, pmc_name=pm)
+            pm, b_ms, what = bname, kt[bname][2], "0"
+            if bname == "HET_rgat_backward_src":
+                # every launch of the op: per-destination pack, short + long (relation, source) segments, grad_er (from the run
+                # sums the forward left: HET_rgat_grad_er_runs; else the segmented sum of the per-edge term)
+                runs = "HET_rgat_backward_er_runs" in kt
+                pm = ("HET_rgat_dst_pack", "HET_rgat_backward_src_coop", "HET_rgat_backward_src_long",
+                      "HET_rgat_grad_er_runs" if runs else "HET_segment_sum_flat4")
+                b_ms = kt["HET_rgat_backward"][2] + (0.0 if runs else kt.get("HET_segment_sum", (0, 0, 0.0))[2])
+                bname = "HET_rgat_dst_pack + HET_rgat_backward_src_coop + _src_long + " + ("HET_rgat_grad_er_runs" if runs else "HET_segment_sum")
+                what = "4: rows of the distinct (relation, node) projections; all launches of the op"
+                ex["frac_with_per_edge_row_gather"] = round(req / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {what})", b_ms, nb_, ex, pmc_name=pm)
         fname = next((n for n in ("HET_rgat_aggregate", "HET_gat_aggregate_grouped") if n in kt), None)
         if fname:
             nf_ = gat_fwd_bytes(E_local, N_local, H, X, S_row, S_col)
+            f_ms = kt[fname][2]  # (the timers are read by prefix: every launch of the op)
             ex = dict(gather)
             if S_row is not None:
                 req = nf_ + (E_local - S_row) * 4 * X
                 ex.update(bytes_with_per_edge_row_gather=int(req),
                           frac_with_per_edge_row_gather=round(req / (kt[fname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-            roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0})",
-                                    kt[fname][2], nf_, ex, pmc_name="HET_rgat_aggregate_coop" if fname == "HET_rgat_aggregate" else fname)
+            pmf = fname
+            if fname == "HET_rgat_aggregate":  # (one launch, or packs + hub work items + hub finish when the run sums are on)
+                runs = "HET_rgat_aggregate_hubs" in kt or "HET_rgat_aggregate_packs" in kt
+                pmf = ("HET_rgat_aggregate_runs_packed", "HET_rgat_aggregate_hub_items", "HET_rgat_finish_hubs") if runs else "HET_rgat_aggregate_coop"
+                if runs:
+                    fname = "HET_rgat_aggregate_runs_packed + _hub_items + HET_rgat_finish_hubs"
+            roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0}{'; also leaves the per-run sums grad_er is formed from' if isinstance(pmf, tuple) else ''})",
+                                    f_ms, nf_, ex, pmc_name=pmf)
     if args.model == "rgcn" and "HET_segment_sum" in kt and not use_dist:
         # RGCN (BASELINE.json configs[1]): the step is two gather-sums (x[src] * norm per (relation, destination) forward,
         # gradout[dst] * norm per (relation, source) backward) + GEMMs on the distinct rows.  a7 / a8 bytes per SURVEY.md 8d

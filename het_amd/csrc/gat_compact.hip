@@ -1195,7 +1195,7 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
   if (int rc = grouping_packed_ids(by_dst, true, s)) return rc;  // (builds the packs too)
   float* part = static_cast<float*>(workspace);
   {
-    HET_KTIME("HET_rgat_aggregate", s);
+    HET_KTIME("HET_rgat_aggregate_packs", s);
     Packs pk{by_dst->pack_ptr, by_dst->key_of_rank, by_dst->num_packs};
     const unsigned nb = (unsigned)ceil_div64(by_dst->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
     HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
@@ -1210,7 +1210,7 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
              by_dst_rel->num_items};
     const int64_t n_hub = by_dst_rel->num_hub_items;
     {
-      HET_KTIME("HET_rgat_hub_items", s);
+      HET_KTIME("HET_rgat_aggregate_hubs", s);
       const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
                         hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s, it,
@@ -1218,6 +1218,7 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
     const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);
+    HET_KTIME("HET_rgat_aggregate_finish", s);
     HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s, by_dst_rel->hub_segs,
                                                       by_dst_rel->num_hub_segs, by_dst->seg_key, it, by_dst_rel->S, (int)num_rels,
                                                       by_dst_rel->hub_items, n_hub, by_dst->p1, part, sum, ret, (int)H, (int)D,
@@ -1272,8 +1273,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   }
   if (num_nodes > 0) {
     const unsigned nbp = grad_bias ? kBiasBlocks : grid_for(num_nodes * (X / 4));
-    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_dst_pack<LPR>, dim3(nbp), dim3(kBlock), 0, s, sum, ret, gradout,
-                                                      pack, num_nodes, (int)H, (int)D, bias_part, bias_rows, (int)coop));
+    {
+      HET_KTIME("HET_rgat_backward_dst_pack", s);
+      HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_dst_pack<LPR>, dim3(nbp), dim3(kBlock), 0, s, sum, ret, gradout,
+                                                        pack, num_nodes, (int)H, (int)D, bias_part, bias_rows, (int)coop));
+    }
     HET_LAUNCH_CHECK("HET_rgat_dst_pack");
     if (grad_bias) {
       hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s, bias_part, bias_part_rows, (int)X, grad_bias);
@@ -1345,7 +1349,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
   if (runs) {
     if (num_dst_rows > 0) {
-      HET_KTIME("HET_rgat_grad_er_runs", s);
+      HET_KTIME("HET_rgat_backward_er_runs", s);
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_grad_er_runs<LPR>, dim3(grid_for(num_dst_rows * (X / 4))), dim3(kBlock),
                                                         0, s, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
                                                         grad_er_c, num_dst_rows, (int)H, (int)D));
