@@ -38,6 +38,7 @@ _OFFS = {}
 PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on the per-edge (kind 0) dataflow
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
 RUN_SUMS = os.environ.get("HET_RGAT_RUN_SUMS", "1") != "0"  # A/B switch: grad_er from the forward's run sums
+OVERLAP = os.environ.get("HET_RGAT_OVERLAP", "1") != "0"  # independent launches on a second HIP stream (see _side_stream)
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
 
 
@@ -117,6 +118,21 @@ def rgat_layer_fused_ok(g, x, W, slope, compact, mulfirst=False):
     return _k.matmul_attn_dot_only_ok(by_dst, W, x)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """A second HIP stream per device for launches that do not depend on each other and are bound by different units: the
+    weight-gradient passes (HBM-bound: they stream x / feat_c / gradient rows once) beside the node-major input-gradient pass
+    (matrix-core-bound), the self-loop GEMM (HBM-bound) beside the projection GEMM.  The caller brackets the side work with
+    events: it starts after everything it reads and the main stream waits for it before anything reads its outputs (or frees
+    its inputs), so the allocator never sees a cross-stream use."""
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = th.cuda.Stream(device=dev)
+    return s
+
+
 @_consistent_plan
 class RgatLayerFunction(th.autograd.Function):
     @staticmethod
@@ -161,10 +177,19 @@ class RgatLayerFunction(th.autograd.Function):
                 featd = new(erc.shape[0], H, D)
                 _k.matmul_attn_dot(d_col, 1, W, x, featd, attn_r, erc)
                 saved = (featc, elc, erc, featd)
+            side = None
             if loop_w is not None and _k.rows_linear_bias_ok(Kd, X):
                 # self-loop + bias first (bias in the GEMM epilogue); the aggregation adds its rows into h in place: no
                 # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
-                h = _k.rows_linear_bias(offs, x[:nd], loop_w, None if bias is None else bias.contiguous())
+                bias_c = None if bias is None else bias.contiguous()
+                if OVERLAP and halo is None:  # (HBM-bound; beside the projection GEMM on the side stream: _side_stream)
+                    main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
+                    side.wait_stream(main)
+                    with th.cuda.stream(side):
+                        h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
+                    h.record_stream(main)  # (allocated under the side stream, used and freed under the main one)
+                else:
+                    h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
             if halo is not None:
                 halo.finish_push()
             if _k.matmul_attn_dot_ok(H, Kd, D):
@@ -172,6 +197,8 @@ class RgatLayerFunction(th.autograd.Function):
             else:  # other widths: any-shape projection, then el_c as a row-dot over the relation-bucketed rows
                 K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)
                 K.rgnn_relational_matmul_no_scatter_gather_list(ss["rel_ptrs_row"], attn_l.unsqueeze(-1), featc, elc.view(-1, H, 1))
+            if side is not None:
+                th.cuda.current_stream(x.device).wait_stream(side)
             # edge softmax + aggregation straight from the compact tables: no exp [E,H] tensor (csrc/gat_compact.hip)
             srow, drow = _edge_rows(g, ss, direct, rp, row, col, eids)
             # (run sums: grad_er from S_col rows the forward leaves instead of a per-edge term -- csrc/gat_compact.hip)
@@ -333,20 +360,35 @@ class RgatLayerFunction(th.autograd.Function):
         grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
         grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
         gh = grad_h if ctx.has_loop else None
-        _k.rgat_node_backward_dx(0, N, nd, gh, loop_w.t().contiguous() if ctx.has_loop else None, g_featc.view(-1, X), Wt, row_map,
-                                 g_erc, wa_t, dst_map, grad_x)
-        # the weight gradients per product (four launches; each reads its own rows of x / feat_c -- a node-major pass that reads x
-        # once was measured in five forms and lost: it multiplies zero rows wherever a node has no row in a relation,
-        # exp/node_dw.hip.txt)
         grad_attn_l = th.empty_like(attn_l)
-        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
-                                             accumulate=False)
-        if ctx.has_loop:
-            _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
-        _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
+        loop_wt = loop_w.t().contiguous() if ctx.has_loop else None
         d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
-        _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
-                           accumulate=False)
+
+        def weight_gradients():
+            # per product (four launches; each reads its own rows of x / feat_c -- a node-major pass that reads x once was
+            # measured in five forms and lost: it multiplies zero rows wherever a node has no row in a relation, exp/node_dw.hip.txt)
+            _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                                 accumulate=False)
+            if ctx.has_loop:
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+            _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
+            _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
+                               accumulate=False)
+
+        def input_gradient():
+            _k.rgat_node_backward_dx(0, N, nd, gh, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t, dst_map, grad_x)
+        if OVERLAP:
+            # the weight gradients (HBM-bound streams of rows) on the side stream while the node-major pass (matrix-core-bound)
+            # runs on this one; both read g_featc / g_erc / grad_h, neither writes what the other reads
+            main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
+            side.wait_stream(main)
+            with th.cuda.stream(side):
+                weight_gradients()
+            input_gradient()
+            main.wait_stream(side)
+        else:
+            input_gradient()
+            weight_gradients()
         grad_W.addcmul_(grad_wa.unsqueeze(-1), attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
         grad_attn_r = (W * grad_wa.unsqueeze(-1)).sum(2)
         return None, None, None, None, None, None, None, grad_x, grad_W, grad_attn_l, grad_attn_r, grad_loop, grad_bias
