@@ -68,6 +68,21 @@ extern "C" int het_kernel_timing_enable(int on) {
   return HET_OK;
 }
 
+hipStream_t het_side_stream() {
+  static const bool off = [] { const char* v = getenv("HET_SIDE_STREAM"); return v && v[0] == '0'; }();
+  if (off) return nullptr;
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    streams[dev] = nullptr;
+  }
+  return streams[dev];
+}
+
 extern "C" int het_kernel_timing_read(const char* name_prefix, double* total_ms, int64_t* launches) {
   HET_REQUIRE(name_prefix && total_ms && launches, "het_kernel_timing_read: null argument");
   std::lock_guard<std::mutex> lk(g_kmu);

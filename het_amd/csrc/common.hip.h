@@ -51,6 +51,36 @@ struct HetKTimer {  // scope guard: { HET_KTIME("HET_kernel", s); hipLaunchKerne
 };
 #define HET_KTIME(name, s) HetKTimer het_ktimer__(name, s)
 
+// ---- fork / join onto the library's side stream -------------------------------------------------------------------
+// Independent launches of ONE entry point that are bound by latency rather than by a saturated unit (the short- and the
+// long-segment gather passes, the pack-form and the hub passes of the RGAT forward) run side by side: the side stream (one per
+// device, made on first use) starts after everything enqueued on the caller's stream so far and the caller's stream waits for
+// it before the entry point returns -- to the caller the call is still ordered on `stream` alone.  HET_SIDE_STREAM=0 runs
+// everything on the caller's stream.  (Works inside a stream capture: event record / wait become graph dependencies.)
+hipStream_t het_side_stream();  // NULL when switched off or when it could not be made
+struct HetFork {
+  hipStream_t main, side;
+  hipEvent_t ev = nullptr;
+  explicit HetFork(hipStream_t m) : main(m), side(het_side_stream()) {
+    if (!side) { side = main; return; }
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, main) != hipSuccess ||
+        hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+      side = main;  // no fork: the side launches simply follow on the caller's stream
+    }
+  }
+  // the caller's stream waits for the side stream's work so far
+  hipError_t join() {
+    if (side == main || !ev) return hipSuccess;
+    hipError_t e = hipEventRecord(ev, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, ev, 0);
+    return e;
+  }
+  ~HetFork() { if (ev) (void)hipEventDestroy(ev); }  // (destruction is deferred by the runtime until the event has completed)
+};
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- device helpers -----------------------------------------------------------

@@ -1193,7 +1193,10 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
   if (!h_inout) HET_HIP(hipMemsetAsync(ret, 0, sizeof(float) * num_nodes * X, s));
   if (by_dst->E == 0) return HET_OK;
   if (int rc = grouping_packed_ids(by_dst, true, s)) return rc;  // (builds the packs too)
+  if (by_dst_rel->num_hub_items > 0)
+    if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
   float* part = static_cast<float*>(workspace);
+  HetFork fk(s);  // the hub launches beside the pack-form one: disjoint destinations, both bound by gather latency
   {
     HET_KTIME("HET_rgat_aggregate_packs", s);
     Packs pk{by_dst->pack_ptr, by_dst->key_of_rank, by_dst->num_packs};
@@ -1205,26 +1208,29 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
   }
   HET_LAUNCH_CHECK("HET_rgat_aggregate_runs_packed");
   if (by_dst_rel->num_hub_items > 0) {
-    if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
+    hipStream_t s2 = fk.side;
     Items it{by_dst_rel->item_seg, by_dst_rel->item_begin, by_dst_rel->item_end, by_dst_rel->seg_ptr, by_dst_rel->seg_key,
              by_dst_rel->num_items};
     const int64_t n_hub = by_dst_rel->num_hub_items;
     {
-      HET_KTIME("HET_rgat_aggregate_hubs", s);
+      HET_KTIME("HET_rgat_aggregate_hubs", s2);
       const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s, it,
+                        hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s2, it,
                                            by_dst_rel->hub_items, n_hub, by_dst->p01, feat_c, el_c, er_c, (int)H, (float)slope, part));
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
     const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);
-    HET_KTIME("HET_rgat_aggregate_finish", s);
-    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s, by_dst_rel->hub_segs,
+    {
+    HET_KTIME("HET_rgat_aggregate_finish", s2);
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s2, by_dst_rel->hub_segs,
                                                       by_dst_rel->num_hub_segs, by_dst->seg_key, it, by_dst_rel->S, (int)num_rels,
                                                       by_dst_rel->hub_items, n_hub, by_dst->p1, part, sum, ret, (int)H, (int)D,
                                                       h_inout, h_rows, q_rows, q_sum, q_ref));
+    }
     HET_LAUNCH_CHECK("HET_rgat_finish_hubs");
   }
+  HET_HIP(fk.join());
   return HET_OK;
 }
 
@@ -1303,6 +1309,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;
     if (by_srow->num_long_items > 0)
       if (int rc = grouping_packed_ids(by_srow, false, s)) return rc;
+  }
+  // the long-segment launch (and grad_er from the run sums) beside the short-segment one: disjoint rows, all bound by gather latency
+  HetFork fk(s);
+  hipStream_t s2 = fk.side;
+  if (coop) {
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
@@ -1314,9 +1325,9 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     if (by_srow->num_long_items > 0) {
       Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
       const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
-      HET_KTIME("HET_rgat_backward_src_long", s);
+      HET_KTIME("HET_rgat_backward_src_long", s2);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s, it,
+                        hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s2, it,
                                            by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
                                            er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
                                            row_rel_ptrs, (int)num_rels));
@@ -1338,9 +1349,9 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
       HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
       Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
       const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
-      HET_KTIME("HET_rgat_backward_src_long", s);
+      HET_KTIME("HET_rgat_backward_src_long", s2);
       HET_DISPATCH_LPR((int)(X / 4),
-                       hipLaunchKernelGGL(HET_rgat_backward_src_long_any<LPR>, dim3(nbl), dim3(kBlock), 0, s, it, by_srow->long_items,
+                       hipLaunchKernelGGL(HET_rgat_backward_src_long_any<LPR>, dim3(nbl), dim3(kBlock), 0, s2, it, by_srow->long_items,
                                           by_srow->num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c, er_c, pack, gradout,
                                           grad_feat_c, grad_el_c, tbuf, (int)H, (int)D, (float)slope, fold_attn_l, row_rel_ptrs,
                                           (int)num_rels));
@@ -1349,14 +1360,16 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
   if (runs) {
     if (num_dst_rows > 0) {
-      HET_KTIME("HET_rgat_backward_er_runs", s);
+      HET_KTIME("HET_rgat_backward_er_runs", s2);
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_grad_er_runs<LPR>, dim3(grid_for(num_dst_rows * (X / 4))), dim3(kBlock),
-                                                        0, s, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
+                                                        0, s2, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
                                                         grad_er_c, num_dst_rows, (int)H, (int)D));
     }
     HET_LAUNCH_CHECK("HET_rgat_grad_er_runs");
+    HET_HIP(fk.join());
     return HET_OK;
   }
+  HET_HIP(fk.join());
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[rank, :]   (segments of by_drow are the er rows in order)
   return launch_segment_sum(by_drow, tbuf, grad_er_c, (int)H, nullptr, s);
 }
