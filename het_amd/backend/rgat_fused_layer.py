@@ -352,13 +352,19 @@ class RgatLayerFunction(th.autograd.Function):
         go = grad_h.view(nd, H, D)  # every edge points at one of the first nd nodes (checked by the caller)
         g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
+        main, side = th.cuda.current_stream(x.device), _side_stream(x.device) if OVERLAP else None
+        if side is not None and ctx.has_loop:
+            # the self-loop weight gradient needs x and grad_h only: an HBM-bound stream of rows beside the gather passes below
+            side.wait_stream(main)
+            with th.cuda.stream(side):
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
                                  drow_nodes=ss["node_indices_col"])
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
         grad_x = th.empty_like(x)
         grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
-        grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
         gh = grad_h if ctx.has_loop else None
         grad_attn_l = th.empty_like(attn_l)
         loop_wt = loop_w.t().contiguous() if ctx.has_loop else None
@@ -369,7 +375,7 @@ class RgatLayerFunction(th.autograd.Function):
             # measured in five forms and lost: it multiplies zero rows wherever a node has no row in a relation, exp/node_dw.hip.txt)
             _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
                                                  accumulate=False)
-            if ctx.has_loop:
+            if ctx.has_loop and side is None:
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
             _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
             _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
@@ -377,10 +383,9 @@ class RgatLayerFunction(th.autograd.Function):
 
         def input_gradient():
             _k.rgat_node_backward_dx(0, N, nd, gh, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t, dst_map, grad_x)
-        if OVERLAP:
+        if side is not None:
             # the weight gradients (HBM-bound streams of rows) on the side stream while the node-major pass (matrix-core-bound)
             # runs on this one; both read g_featc / g_erc / grad_h, neither writes what the other reads
-            main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
             side.wait_stream(main)
             with th.cuda.stream(side):
                 weight_gradients()
