@@ -170,21 +170,25 @@ class RgatLayerFunction(th.autograd.Function):
             elc = new(featc.shape[0], H)
             erc = new(ss["node_indices_col"].numel(), H)
             # (the destination side and the self-loop read rows of destination nodes only -- owned rows on a partition)
+            side = None
+            fused_loop = loop_w is not None and _k.rows_linear_bias_ok(Kd, X)
+            if OVERLAP and halo is None and fused_loop and mulfirst:
+                # er_c (a row-dot) and the self-loop GEMM are HBM-bound streams of rows: on the side stream beside the projection
+                main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
+                side.wait_stream(main)
             if mulfirst:
-                K.rgnn_relational_matmul(d_col, 1, wa, x, erc.view(-1, H, 1), True)
+                with th.cuda.stream(side if side is not None else th.cuda.current_stream(x.device)):
+                    K.rgnn_relational_matmul(d_col, 1, wa, x, erc.view(-1, H, 1), True)
                 saved = (featc, elc, erc)
             else:
                 featd = new(erc.shape[0], H, D)
                 _k.matmul_attn_dot(d_col, 1, W, x, featd, attn_r, erc)
                 saved = (featc, elc, erc, featd)
-            side = None
-            if loop_w is not None and _k.rows_linear_bias_ok(Kd, X):
+            if fused_loop:
                 # self-loop + bias first (bias in the GEMM epilogue); the aggregation adds its rows into h in place: no
                 # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
                 bias_c = None if bias is None else bias.contiguous()
-                if OVERLAP and halo is None:  # (HBM-bound; beside the projection GEMM on the side stream: _side_stream)
-                    main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
-                    side.wait_stream(main)
+                if side is not None:
                     with th.cuda.stream(side):
                         h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
                     h.record_stream(main)  # (allocated under the side stream, used and freed under the main one)

@@ -1285,24 +1285,18 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
                                                         pack, num_nodes, (int)H, (int)D, bias_part, bias_rows, (int)coop));
     }
     HET_LAUNCH_CHECK("HET_rgat_dst_pack");
-    if (grad_bias) {
-      hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s, bias_part, bias_part_rows, (int)X, grad_bias);
-      HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
-    }
   } else if (grad_bias) {
     HET_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * X, s));
   }
   if (E == 0) {
+    if (grad_bias && num_nodes > 0) {
+      hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s, bias_part, bias_part_rows, (int)X, grad_bias);
+      HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
+    }
     HET_HIP(hipMemsetAsync(grad_er_c, 0, sizeof(float) * num_dst_rows * H, s));
     return HET_OK;
   }
   if (int rc = grouping_packs(by_srow, s)) return rc;
-  if (by_srow->num_split > 0) {  // segments of several work items (> HET_ITEM_MAX edges): their items add atomically
-    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_zero_long_rows<LPR>, dim3(grid_for(by_srow->num_split * (X / 4))),
-                                                      dim3(kBlock), 0, s, by_srow->split_seg, by_srow->seg_key, by_srow->num_split,
-                                                      grad_feat_c, grad_el_c, (int)H));
-    HET_LAUNCH_CHECK("HET_rgat_zero_long_rows");
-  }
   Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   if (coop) {
@@ -1310,9 +1304,22 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     if (by_srow->num_long_items > 0)
       if (int rc = grouping_packed_ids(by_srow, false, s)) return rc;
   }
-  // the long-segment launch (and grad_er from the run sums) beside the short-segment one: disjoint rows, all bound by gather latency
+  // Two chains after the per-destination pack, joined at the end (kernel trace on ogbn-mag: the short-segment launch 1.10 ms beside
+  // the long-segment one 1.09 ms; with the small launches in front of the short one the op was 0.1 ms longer):
+  //   caller's stream: short segments, grad_er from the run sums
+  //   side stream:     bias column sums (needed by nobody here), zeroed rows of the split segments, long segments
   HetFork fk(s);
   hipStream_t s2 = fk.side;
+  if (grad_bias && num_nodes > 0) {
+    hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s2, bias_part, bias_part_rows, (int)X, grad_bias);
+    HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
+  }
+  if (by_srow->num_split > 0) {  // segments of several work items (> HET_ITEM_MAX edges): their items add atomically
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_zero_long_rows<LPR>, dim3(grid_for(by_srow->num_split * (X / 4))),
+                                                      dim3(kBlock), 0, s2, by_srow->split_seg, by_srow->seg_key, by_srow->num_split,
+                                                      grad_feat_c, grad_el_c, (int)H));
+    HET_LAUNCH_CHECK("HET_rgat_zero_long_rows");
+  }
   if (coop) {
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
@@ -1360,9 +1367,9 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
   if (runs) {
     if (num_dst_rows > 0) {
-      HET_KTIME("HET_rgat_backward_er_runs", s2);
+      HET_KTIME("HET_rgat_backward_er_runs", s);
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_grad_er_runs<LPR>, dim3(grid_for(num_dst_rows * (X / 4))), dim3(kBlock),
-                                                        0, s2, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
+                                                        0, s, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,
                                                         grad_er_c, num_dst_rows, (int)H, (int)D));
     }
     HET_LAUNCH_CHECK("HET_rgat_grad_er_runs");
