@@ -667,16 +667,17 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a
 // that grouping with a test for "hub" spent 1.7 ms on 1.3 M early exits).  part[k] = {O[X], Q[X], max[H], sum[H], q[H]}.
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
-    Items it, const int32_t* __restrict__ hub_items, int64_t num_hub_items, const int2* __restrict__ p01,
-    const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er, int H, float slope,
-    float* __restrict__ part) {
+    Items it, const int32_t* __restrict__ hub_items, const int32_t* __restrict__ hub_order, int64_t num_hub_items,
+    const int2* __restrict__ p01, const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er, int H,
+    float slope, float* __restrict__ part) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
   const int dq = d < U ? d : U - 1;
-  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (k >= num_hub_items) return;
+  const int64_t kk = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (kk >= num_hub_items) return;
+  const int64_t k = hub_order ? hub_order[kk] : kk;  // launch order: by the first feat row of the item (grouping_hub_items)
   const int item = hub_items[k];
   const int b = it.begin[item], e = it.end[item];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accq = acc;
@@ -1160,6 +1161,11 @@ static int rgat_hub_min() {
   return v;
 }
 
+static bool hub_in_row_order() {
+  static const bool on = [] { const char* e = getenv("HET_RGAT_HUB_ORDER"); return !(e && e[0] == '0'); }();  // A/B switch
+  return on;
+}
+
 extern "C" int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel,
                                                              int64_t num_rels, int64_t H, int64_t D, het_stream stream) {
   if (!by_dst || !by_dst_rel || num_rels <= 0) return -1;
@@ -1217,7 +1223,8 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
       const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
                         hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s2, it,
-                                           by_dst_rel->hub_items, n_hub, by_dst->p01, feat_c, el_c, er_c, (int)H, (float)slope, part));
+                                           by_dst_rel->hub_items, hub_in_row_order() ? by_dst_rel->hub_order : nullptr, n_hub, by_dst->p01,
+                                           feat_c, el_c, er_c, (int)H, (float)slope, part));
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
     const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);

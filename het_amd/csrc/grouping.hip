@@ -109,6 +109,14 @@ __global__ void HET_grouping_hub_flags(const int32_t* __restrict__ seg_ptr, cons
     is_hub[t] = hub;
   }
 }
+// key[k] = payload0 of the twin at the first rank of hub item k (the twin shares the sorted order); val[k] = k
+__global__ void HET_grouping_hub_first_p0(const int32_t* __restrict__ hub_items, int64_t n, const int32_t* __restrict__ item_begin,
+                                          const int32_t* __restrict__ twin_p0, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    key[k] = (uint32_t)twin_p0[item_begin[hub_items[k]]];
+    val[k] = (int32_t)k;
+  }
+}
 __global__ void HET_grouping_long_seg_flags(const int32_t* __restrict__ seg_ptr, int64_t S, int min_len, uint8_t* __restrict__ flag) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x)
     flag[s] = seg_ptr[s + 1] - seg_ptr[s] > min_len;
@@ -156,10 +164,12 @@ unsigned blocks_for(int64_t n) {
 }
 
 struct Scratch {  // frees device temporaries on every exit path
-  void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kSlots = 16;
+  void* p[kSlots] = {};
   int n = 0;
   ~Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
   hipError_t alloc(void** out, size_t bytes) {
+    if (n >= kSlots) return hipErrorOutOfMemory;  // (more temporaries than slots: a bug in the caller, not a crash)
     hipError_t e = hipMalloc(out, bytes ? bytes : 4);
     if (e == hipSuccess) p[n++] = *out;
     return e;
@@ -171,7 +181,7 @@ struct Scratch {  // frees device temporaries on every exit path
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete g;
@@ -193,7 +203,7 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
   if (g->p01) b += 8 * (E > 0 ? E : 1);
   if (g->kp01) b += 16 * (E + 1);
-  if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1);
+  if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1) + (g->hub_order ? 4 * g->num_hub_items : 0);
   return b;
 }
 
@@ -406,7 +416,7 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
     return HET_OK;
   }
   const int64_t NI = g->num_items, TS = twin->S;
-  int32_t *items = nullptr, *segs = nullptr;
+  int32_t *items = nullptr, *segs = nullptr, *order = nullptr;
   int32_t h_num[2] = {0, 0};
   if (NI > 0 && TS > 0) {
     Scratch tmp;
@@ -436,9 +446,30 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
     hipError_t e = hipMalloc((void**)&segs, sizeof(int32_t) * ((size_t)h_num[1] + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(items, sel, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(segs, sel2, sizeof(int32_t) * (size_t)h_num[1], hipMemcpyDeviceToDevice, s);
+    // launch order of the hub items: by the first payload0 (feat row) of the item, so that items in flight together read the
+    // same window of the table (within a run the rows ascend when the positions are in (relation, source) order)
+    if (e == hipSuccess && h_num[0] > 0 && twin->p0) {
+      e = hipMalloc((void**)&order, sizeof(int32_t) * (size_t)h_num[0]);
+      uint32_t *k_in = nullptr, *k_out = nullptr;
+      int32_t* v_in = nullptr;
+      if (e == hipSuccess) e = tmp.alloc((void**)&k_in, sizeof(uint32_t) * (size_t)h_num[0]);
+      if (e == hipSuccess) e = tmp.alloc((void**)&k_out, sizeof(uint32_t) * (size_t)h_num[0]);
+      if (e == hipSuccess) e = tmp.alloc((void**)&v_in, sizeof(int32_t) * (size_t)h_num[0]);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(HET_grouping_hub_first_p0, dim3(blocks_for(h_num[0])), dim3(256), 0, s, items, (int64_t)h_num[0], g->item_begin,
+                           twin->p0, k_in, v_in);
+        e = hipGetLastError();
+      }
+      size_t sb = 0;
+      void* st = nullptr;
+      if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sb, k_in, k_out, v_in, order, h_num[0], 0, 32, s);
+      if (e == hipSuccess) e = tmp.alloc(&st, sb);
+      if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(st, sb, k_in, k_out, v_in, order, h_num[0], 0, 32, s);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(items); (void)hipFree(segs); HET_HIP(e); }
+    if (e != hipSuccess) { (void)hipFree(items); (void)hipFree(segs); (void)hipFree(order); HET_HIP(e); }
   }
+  g->hub_order = order;
   g->hub_items = items;
   g->hub_segs = segs;
   g->num_hub_segs = h_num[1];

@@ -45,6 +45,7 @@ struct het_grouping {
   // segment of more than hub_min positions in the twin grouping by key alone (het_rgat_aggregate_compact_runs).
   mutable int32_t* hub_items = nullptr;
   mutable int64_t num_hub_items = -1;         // -1: not built
+  mutable int32_t* hub_order = nullptr;       // [num_hub_items] indices into hub_items, by the first payload0 of the twin in the item
   mutable int32_t* hub_segs = nullptr;        // the twin's segments of more than hub_min positions (ascending)
   mutable int64_t num_hub_segs = 0;
   mutable int hub_min = 0;
