@@ -7,13 +7,18 @@
 // ogbn-mag: they live in L2 / Infinity Cache), so the [E,H] tensor, its pass (HET_gat_exp_edge) and its 16-byte-per-128-
 // byte-line gathers are gone.  Same values: exp is a pure function of el + er.
 //
-//   forward   wave per destination work item (het_grouping by destination, payload0 = feat row, payload1 = er row)
+//   forward   wave per destination work item (het_grouping by destination, payload0 = feat row, payload1 = er row); round 3's
+//             default form also leaves per-RUN sums for grad_er (one run = the edges of one er row): lane group per pack of
+//             whole destinations walking the edges in order, hubs through the work items of a (destination, relation)
+//             grouping + a finish pass -- "grad_er without a per-edge term" below
 //   backward  SHORT (relation, source) segments (<= HET_PACK_T edges; the median is 2): lane group per PACK of whole
 //             segments (grouping_packs) -- a work unit per segment would spend its time in dependent prologues (item
 //             record -> ids -> rows); a pack of ~32 consecutive ranks streams its ids a step ahead and keeps 4 gradient
 //             rows in flight per lane group whatever the segment lengths are; rows of a segment are summed in registers
 //             and stored once.  LONG segments (61 % of the edges of the skewed ogbn-mag-like graph): wave per work item
 //             of <= HET_ITEM_MAX edges, lane groups round-robin, one cross-group reduction and store per item.
+//             grad_er: from the forward's run sums (HET_rgat_grad_er_runs), or -- het_rgat_backward_compact -- a per-edge
+//             term summed per er row.
 #include <stdlib.h>
 
 #include "coop.hip.h"
@@ -467,7 +472,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long_any(
 //  * also accumulating P[(r,v),h,:] = SUM_e w_e dl_e feat_c[srow_e] per (relation, destination) here, so that the backward
 //    gets grad_er from S_col rows instead of a per-edge term [E,H] + a segmented sum of 16-byte gathers (0.59 ms, 3 GB):
 //    the per-relation accumulators take the kernel from 53 to 104 VGPRs = 8 -> 4 waves per SIMD and 0.93 -> 1.44-1.81 ms,
-//    more than the 0.7 ms it saves in the backward.
+//    more than the 0.7 ms it saves in the backward.  (Round 3 does it with ONE accumulator by walking the edges in run
+//    order: HET_rgat_aggregate_runs_packed / _hub_items below.)
 template <int LPR, int DL>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, const int2* __restrict__ p01,
                                                                    const float* __restrict__ feat,

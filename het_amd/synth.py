@@ -71,8 +71,10 @@ def make_hetero_graph(
     """relations: iterable of (src_type_idx, dst_type_idx, num_edges).
 
     ``scale`` shrinks node and edge counts together (tests use ~1e-3).
-    ``edge_order``: "src" sorts each relation's edges by source id (the raw
-    order of the OGB edge lists), "random" keeps generation order."""
+    ``edge_order``: "src_dst" lists each relation's edges in (source, destination) order -- the order of the OGB
+    edge lists (the reference's shipped slice hrt/data/ogbn_mag_0.1/*_coo_2.npy: every relation is sorted by one end and
+    ascending in the other within equal keys); "src" sorts by source id only (destinations of a source in generation
+    order: rounds 1-2), "random" keeps generation order."""
     rng = np.random.Generator(np.random.PCG64(seed))
     counts = [max(2, int(round(c * scale))) for c in node_counts]
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -83,6 +85,9 @@ def make_hetero_graph(
         dst = _skewed_ids(rng, counts[dt], ne, offset=16.0) + offs[dt]
         if edge_order == "src":
             o = np.argsort(src, kind="stable")
+            src, dst = src[o], dst[o]
+        elif edge_order == "src_dst":
+            o = np.lexsort((dst, src))
             src, dst = src[o], dst[o]
         elif edge_order != "random":
             raise ValueError(edge_order)
@@ -103,7 +108,7 @@ def make_hetero_graph(
     )
 
 
-def make_mag_like(scale: float = 1.0, seed: int = SEED, edge_order: str = "src") -> IntegratedCOO:
+def make_mag_like(scale: float = 1.0, seed: int = SEED, edge_order: str = "src_dst") -> IntegratedCOO:
     t = {n: i for i, n in enumerate(MAG_NODE_TYPES)}
     rels = [(t[s], t[d], e) for (_, s, d, e) in MAG_RELATIONS]
     return make_hetero_graph(MAG_NODE_COUNTS, rels, seed=seed, scale=scale, edge_order=edge_order)
