@@ -118,6 +118,40 @@ Tensor cached_rel_by_position(const Tensor& rel_ptrs, int64_t n) {
   return t;
 }
 
+// Derived index tensors of a graph (row of every edge position in a unique (relation, node) list, edge-id -> row maps ...):
+// built once with ATen ops, looked up by the identity of ALL the tensors they were derived from (as het_amd/kernels.py does).
+struct DerivedSet { std::string tag; std::vector<Ident> ids; std::vector<Tensor> out, keep; };
+std::list<DerivedSet> g_sets;
+template <class F>
+std::vector<Tensor> derived(const char* tag, std::vector<const Tensor*> src, F build) {
+  std::vector<Ident> ids;
+  for (const Tensor* t : src) ids.push_back(ident(t));
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_sets.begin(); it != g_sets.end(); ++it)
+      if (it->tag == tag && it->ids == ids) {
+        g_sets.splice(g_sets.begin(), g_sets, it);
+        return g_sets.front().out;
+      }
+  }
+  std::vector<Tensor> out = build();
+  DerivedSet e{tag, ids, out, {}};
+  for (const Tensor* t : src)
+    if (t && t->defined()) e.keep.push_back(*t);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_sets.push_front(std::move(e));
+  while (g_sets.size() > 24) g_sets.pop_back();
+  return out;
+}
+
+// row of (relation of the position, node) in a unique (relation, node) list: ua = its relation pointers, ub = its node ids
+Tensor rows_by_search(const Tensor& rel_of_pos, const Tensor& nodes, const Tensor& ua, const Tensor& ub) {
+  const int64_t Ru = ua.numel() - 1;
+  const int64_t bound = std::max<int64_t>(nodes.numel() ? nodes.max().item<int64_t>() : 0, ub.numel() ? ub.max().item<int64_t>() : 0) + 1;
+  Tensor rel_u = at::repeat_interleave(at::arange(Ru, ua.options()), ua.slice(0, 1) - ua.slice(0, 0, Ru));
+  return at::searchsorted(rel_u * bound + ub, rel_of_pos * bound + nodes).contiguous();
+}
+
 // ---- info + layout converters (DataConverters.inc.h) ------------------------------------------------------------------
 void build_debug_info() { printf("%s\n", het_build_info()); }
 
@@ -263,35 +297,99 @@ inline bool gat_grouped_shape_ok(int64_t H, int64_t D) {
   return D >= 4 && (D & (D - 1)) == 0 && (X & (X - 1)) == 0 && X / 4 <= 64;
 }
 
-void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m,
+// The compact kinds on the grouped kernels (as het_amd/kernels.py::_gat_direct / _by_dst): every kind becomes the direct-index
+// kind 4 once per graph -- {feat row, er row} of every edge POSITION and of every edge ID -- so the kernels read rows without
+// searching.  out: {srow_by_position, drow_by_position, row_of_eid, col_row_of_eid}
+std::vector<Tensor> direct_rows(int64_t kind, const Maps& m, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, const Tensor& eids) {
+  return derived(kind == 4 ? "gat4" : (kind == 2 ? "gat2" : (kind == 1 ? "gat1" : "gat3")),
+                 {m.m[0], m.m[1], m.m[2], m.m[3], &rel_ptrs, &row, &col, &eids}, [&]() -> std::vector<Tensor> {
+    Tensor srow, drow;
+    if (kind == 4 || kind == 2) {
+      srow = m.m[0]->index({eids}).contiguous();
+      drow = m.m[2]->index({eids}).contiguous();
+      return {srow, drow, *m.m[0], *m.m[2]};
+    }
+    Tensor relp = rel_by_position(rel_ptrs, eids.numel());
+    srow = rows_by_search(relp, row, *m.m[0], *m.m[1]);
+    drow = rows_by_search(relp, col, *m.m[2], *m.m[3]);
+    const int64_t n = eids.numel() ? eids.max().item<int64_t>() + 1 : 0;
+    Tensor mr = at::empty({n}, eids.options()), mc = at::empty({n}, eids.options());
+    mr.index_put_({eids}, srow);
+    mc.index_put_({eids}, drow);
+    return {srow, drow, mr, mc};
+  });
+}
+
+void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m_in,
                  const Tensor& feat, const Tensor& el, const Tensor& er, Tensor& sum, Tensor& exp, Tensor& ret, double slope) {
   const int64_t E = eids.numel(), N = ret.size(0), H = sum.size(1);
   const int64_t D = feat.numel() ? feat.numel() / (feat.size(0) * H) : ret.numel() / std::max<int64_t>(1, N * H);
   const het_grouping* g = nullptr;
+  Maps m = m_in;
+  std::vector<Tensor> dr;
   if (kind == 0 && E > 0) {  // positions by destination; payload0 = edge id, payload1 = relation of the position
     Tensor relp = cached_rel_by_position(rel_ptrs, E);
     g = grouping(nullptr, col, N, &eids, &relp);
+  } else if (kind != 0 && E > 0 && groupings_enabled() && gat_grouped_shape_ok(H, D)) {  // payload1 = feat row of the position
+    dr = direct_rows(kind, m_in, rel_ptrs, row, col, eids);
+    g = grouping(nullptr, col, N, &eids, &dr[0]);
+    m = Maps{{&dr[2], nullptr, &dr[3], nullptr}};
+    kind = 4;
   }
   check(het_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]), mp(m.m[1]),
                                               mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fpw(sum), fpw(exp), fpw(ret), nullptr, H, D,
                                               slope, g, nullptr, nullptr, stream_of(ret)),
         "relational_fused_gat_separate_coo");
 }
-void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m,
+void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m_in,
                   const Tensor& feat, const Tensor& el, const Tensor& er, const Tensor& sum, const Tensor& exp, const Tensor& ret,
                   const Tensor& gradout, Tensor& gfeat, Tensor& gel, Tensor& ger, double slope) {
   const int64_t E = eids.numel(), N = ret.size(0), H = sum.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
-  const het_grouping* g = nullptr;
+  const het_grouping *g = nullptr, *gs = nullptr, *gd = nullptr;
+  Maps m = m_in;
+  std::vector<Tensor> dr;
+  Tensor ws;
   if (kind == 0 && E > 0) {
     Tensor relp = cached_rel_by_position(rel_ptrs, E);
     g = grouping(nullptr, col, N, &eids, &relp);
+  } else if (kind != 0 && E > 0 && groupings_enabled() && gat_grouped_shape_ok(H, D) && slope >= 0) {
+    // by feat row (payloads: edge id, destination) and by er row (payload: edge id): the compact backward sums a row's gradient in
+    // registers and stores it once (csrc/fused_gat_grouped.hip) instead of E*H*D float atomics
+    dr = direct_rows(kind, m_in, rel_ptrs, row, col, eids);
+    gs = grouping(nullptr, dr[0], feat.size(0), &eids, &col);
+    gd = grouping(nullptr, dr[1], er.size(0), &eids, nullptr);
+    if (gs && gd) {
+      ws = workspace(N * 2 * H + E * H, ret);
+      m = Maps{{&dr[2], nullptr, &dr[3], nullptr}};
+      kind = 4;
+    } else {
+      gs = gd = nullptr;
+    }
   }
   check(het_backward_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]),
                                                        mp(m.m[1]), mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fp(sum), fp(exp), fp(ret),
-                                                       nullptr, fp(gradout), fpw(gfeat), fpw(gel), fpw(ger), H, D, slope, g, nullptr, nullptr,
-                                                       feat.size(0), er.size(0), nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                                                       stream_of(ret)),
+                                                       nullptr, fp(gradout), fpw(gfeat), fpw(gel), fpw(ger), H, D, slope, g, gs, gd,
+                                                       feat.size(0), er.size(0), ws.defined() ? ws.data_ptr() : nullptr,
+                                                       ws.defined() ? ws.numel() * 4 : 0, nullptr, nullptr, nullptr, nullptr, stream_of(ret)),
         "backward_relational_fused_gat_separate_coo");
+}
+
+// CompactAsOfNodeFlag of the CSR pair (RGATOps.inc.h:251-277, 430-460): feat / el / er live on the rows of ONE unique (relation, node)
+// list and every edge end is looked up by (relation of the edge, node).  Once per graph: the direct-index maps of kind 4.
+// out: {rows of the CSR expanded per position, feat row of every edge id, er row of every edge id}
+std::vector<Tensor> csr_compact_maps(const Tensor& row_ptr, const Tensor& col, const Tensor& eids, const Tensor& reltypes, const Tensor& urp,
+                                     const Tensor& unodes, bool rows_are_dst) {
+  return derived(rows_are_dst ? "csrc_in" : "csrc_out", {&row_ptr, &col, &eids, &reltypes, &urp, &unodes}, [&]() -> std::vector<Tensor> {
+    Tensor rows = csr_rows(row_ptr);
+    const Tensor& src = rows_are_dst ? col : rows;
+    const Tensor& dst = rows_are_dst ? rows : col;
+    Tensor srow = rows_by_search(reltypes, src, urp, unodes), drow = rows_by_search(reltypes, dst, urp, unodes);
+    const int64_t n = eids.numel() ? eids.max().item<int64_t>() + 1 : 0;
+    Tensor mr = at::empty({n}, eids.options()), mc = at::empty({n}, eids.options());
+    mr.index_put_({eids}, srow);
+    mc.index_put_({eids}, drow);
+    return {rows, mr, mc};
+  });
 }
 
 void relational_fused_gat_separate_coo(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, int64_t kind, Dict d, Tensor feat, Tensor el,
@@ -313,6 +411,13 @@ void relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor re
     gat_forward(eids, rp1, col, dst, 0, gat_maps(0, Dict()), feat, el, er, sum, exp, ret, slope);
     return;
   }
+  if (compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D)) {
+    // compact rows: the separate-COO pair with CompactAsOfNodeKind 4 once every edge id knows its feat row and er row
+    std::vector<Tensor> cm = csr_compact_maps(row_ptr, col, eids, reltypes, urp, unodes, true);
+    Tensor rp1 = at::tensor({(int64_t)0, E}, row_ptr.options());
+    gat_forward(eids, rp1, col, cm[0], 4, Maps{{&cm[1], nullptr, &cm[2], nullptr}}, feat, el, er, sum, exp, ret, slope);
+    return;
+  }
   check(het_relational_fused_gat_csr(ip(row_ptr), ip(col), ip(eids), ip(reltypes), N, E, ip(urp), ip(unodes), std::max<int64_t>(0, urp.numel() - 1),
                                      fp(feat), fp(el), fp(er), fpw(sum), fpw(exp), fpw(ret), H, D, slope, compact, stream_of(ret)),
         "relational_fused_gat_csr");
@@ -324,6 +429,17 @@ void backward_relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, 
   if (!compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D) && slope >= 0) {
     Tensor src = csr_rows(row_ptr), rp1 = at::tensor({(int64_t)0, E}, row_ptr.options());  // out-CSR rows are the sources
     gat_backward(eids, rp1, src, col, 0, gat_maps(0, Dict()), feat, el, er, sum, exp, ret, gradout, gfeat, gel, ger, slope);
+    return;
+  }
+  if (compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D) && slope >= 0) {
+    std::vector<Tensor> cm = csr_compact_maps(row_ptr, col, eids, reltypes, urp, unodes, false);  // out-CSR rows are the sources
+    Tensor rp1 = at::tensor({(int64_t)0, E}, row_ptr.options());
+    // "+=" contract of the reference-named op: the grouped kind-4 kernels overwrite, so they run into temporaries that are added
+    Tensor gf = at::zeros_like(gfeat), gl = at::zeros_like(gel), gr = at::zeros_like(ger);
+    gat_backward(eids, rp1, cm[0], col, 4, Maps{{&cm[1], nullptr, &cm[2], nullptr}}, feat, el, er, sum, exp, ret, gradout, gf, gl, gr, slope);
+    gfeat.add_(gf);
+    gel.add_(gl);
+    ger.add_(gr);
     return;
   }
   check(het_backward_relational_fused_gat_csr(ip(row_ptr), ip(col), ip(eids), ip(reltypes), N, E, ip(urp), ip(unodes),

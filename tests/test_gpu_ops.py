@@ -450,9 +450,9 @@ def test_fused_gat_csr(K, plan_mode, compact):
     HL.kernel_timing(False)
     import het_amd.kernels as k
     if k.COMPILED_LIB:
-        # the compiled registration object has its own switch (HET_GROUPINGS in its environment, not het_amd.plan) and routes the
-        # non-compact CSR pair to the grouped kernels; its compact pair runs on the edge-parallel kernels -- same results
-        assert compact or (fwd_grouped >= 1 and bwd_grouped >= 1), (fwd_grouped, bwd_grouped)
+        # the compiled registration object has its own switch (HET_SHIM_GROUPINGS in its environment, not het_amd.plan): both CSR
+        # pairs on the grouped kernels whatever plan_mode says
+        assert fwd_grouped >= 1 and bwd_grouped >= 1, (fwd_grouped, bwd_grouped)
     elif plan_mode:
         assert fwd_grouped >= 1 and bwd_grouped >= 1, (fwd_grouped, bwd_grouped)
     else:
