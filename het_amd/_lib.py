@@ -20,6 +20,7 @@ _SIGNATURES = {
     "het_rows_add_bias": [P, P, P, P, I64, I64, P],
     "het_rows_gather": [P, P, I64, I64, P, P],
     "het_rows_scatter_add": [P, P, I64, I64, P, P],
+    "het_rows_scatter_add_grouped": [P, P, I64, P, I64, P],
     "het_layout_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, P],
     "het_layout_coo_to_csr": [P, P, P, P, I64, I64, P, P, P, P, P],
     "het_layout_transpose_csr": [P, P, P, P, I64, I64, I64, P, P, P, P, P],

@@ -717,6 +717,19 @@ extern "C" int het_rows_gather(const float* x, const int64_t* idx, int64_t num_r
   return HET_OK;
 }
 
+// The same sum without float atomics: by_idx groups the positions of idx by their value (payload0 = the position), so a
+// destination row's contributions are summed in registers and added to it once (a row of a partition goes to up to 7 peers and
+// comes back as many times: 0.14 -> 0.05 ms for 670 K returned rows of 64 floats).  Deterministic.
+extern "C" int het_rows_scatter_add_grouped(const het_grouping* by_idx, const float* src, int64_t X, float* out, int64_t out_rows,
+                                            het_stream stream) {
+  HET_REQUIRE(by_idx && out_rows >= 0 && X > 0, "rows_scatter_add_grouped: bad arguments");
+  if (by_idx->E == 0) return HET_OK;
+  HET_REQUIRE(src && out && by_idx->R == 0 && by_idx->p0 && by_idx->key_bound <= out_rows,
+              "rows_scatter_add_grouped: by_idx = het_grouping_create(NULL, 0, idx, n, out_rows, positions 0 .. n-1, NULL)");
+  if (!segment_sum_supported((int)X)) { het_set_error("rows_scatter_add_grouped: rows of 4 .. 256 floats, a power of two"); return HET_ERR_UNSUPPORTED; }
+  return launch_segment_sum(by_idx, src, out, (int)X, nullptr, (hipStream_t)stream, 0, out_rows, /*accumulate=*/1);
+}
+
 extern "C" int het_rows_scatter_add(const float* src, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream) {
   HET_REQUIRE(num_rows >= 0 && X > 0 && (num_rows == 0 || (src && idx && out)), "rows_scatter_add: bad arguments");
   if (num_rows == 0) return HET_OK;

@@ -243,7 +243,14 @@ def rows_scatter_add_(out, idx, src):
     if not (out.is_cuda and out.dim() == 2 and out.dtype == torch.float32 and out.is_contiguous() and src.is_contiguous()):
         return out.index_add_(0, idx, src)
     _chk("rows_scatter_add", (out, src), (idx,))
-    _call(out, "het_rows_scatter_add", _p(src), _p(idx), idx.numel(), out.shape[1], _p(out), _stream(out))
+    X = out.shape[1]
+    if _plan.is_enabled() and idx.numel() > 0 and 4 <= X <= 256 and X & (X - 1) == 0:
+        # idx is a per-plan list (the halo send list): grouped by destination row once, then summed without atomics
+        pos = _derived_get("positions", (idx,), lambda: torch.arange(idx.numel(), dtype=torch.int64, device=idx.device))
+        g = _plan.get_grouping(None, idx, out.shape[0], pos, None)
+        _call(out, "het_rows_scatter_add_grouped", g.handle, _p(src), X, _p(out), out.shape[0], _stream(out))
+        return out
+    _call(out, "het_rows_scatter_add", _p(src), _p(idx), idx.numel(), X, _p(out), _stream(out))
     return out
 
 

@@ -565,6 +565,10 @@ int het_rows_add_bias(const float* a, const float* b, const float* bias, float* 
  *   het_rows_scatter_add:  out[idx[i], :] += src[i, :]     (atomic: idx may repeat) */
 int het_rows_gather(const float* x, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream);
 int het_rows_scatter_add(const float* src, const int64_t* idx, int64_t num_rows, int64_t X, float* out, het_stream stream);
+/*   het_rows_scatter_add_grouped: the same sum without float atomics (and deterministic) for an idx that is used every step:
+ *   by_idx = het_grouping_create(NULL, 0, idx, n, out_rows, payload0 = 0 .. n-1, NULL); X a power of two in 4 .. 256. */
+int het_rows_scatter_add_grouped(const het_grouping* by_idx, const float* src, int64_t X, float* out, int64_t out_rows,
+                                 het_stream stream);
 
 /* ------------------------------------------------------------------------
  * Layout builders (the step before the path).  Device-side replacements of the reference's CPU

@@ -901,8 +901,18 @@ def test_halo_pack_unpack_rows():
     src = torch.randn(3000, 64, generator=gen)
     acc = torch.randn(500, 64, generator=gen)
     ref = acc.double().index_add_(0, idx, src.double())
-    got = k.rows_scatter_add_(acc.to(DEV), idx.to(DEV), src.to(DEV))
+    got = k.rows_scatter_add_(acc.to(DEV), idx.to(DEV), src.to(DEV))  # (grouped by destination row: no atomics)
     assert_close(got, ref, what="scatter_add")
+    import het_amd.plan as plan
+    with plan.forced(False):  # the float-atomics kernel
+        got = k.rows_scatter_add_(acc.to(DEV), idx.to(DEV), src.to(DEV))
+    assert_close(got, ref, what="scatter_add (atomics)")
+    # a hub row (its contributions span several work items) and rows of other widths
+    idx2 = torch.cat([torch.full((2000,), 7), torch.randint(0, 500, (1000,), generator=gen)])
+    for X in (4, 32, 128):
+        s2, a2 = torch.randn(3000, X, generator=gen), torch.randn(500, X, generator=gen)
+        got = k.rows_scatter_add_(a2.to(DEV), idx2.to(DEV), s2.to(DEV))
+        assert_close(got, a2.double().index_add_(0, idx2, s2.double()), what=f"scatter_add X={X}")
     assert k.rows_gather(x.to(DEV), idx[:0].to(DEV)).shape == (0, 64)
 
 
