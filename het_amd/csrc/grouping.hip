@@ -411,11 +411,13 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
 int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, int hub_min, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_pack_mu);
   if (g->num_hub_items >= 0) {
-    if (g->hub_twin != twin || g->hub_min != hub_min) {
-      het_set_error("grouping_hub_items: the grouping was paired with another grouping (or threshold) before");
-      return HET_ERR_INVALID_ARG;
-    }
-    return HET_OK;
+    if (g->hub_twin == twin && g->hub_min == hub_min) return HET_OK;
+    // paired with another twin object before (a cache that evicted and rebuilt the grouping by key alone) or another threshold:
+    // the lists are rebuilt.  hipFree waits for the device, so a launch that still reads the old lists has finished.
+    (void)hipFree(g->hub_items); (void)hipFree(g->hub_segs); (void)hipFree(g->hub_order);
+    g->hub_items = g->hub_segs = g->hub_order = nullptr;
+    g->num_hub_items = -1;
+    g->num_hub_segs = 0;
   }
   const int64_t NI = g->num_items, TS = twin->S;
   int32_t *items = nullptr, *segs = nullptr, *order = nullptr;

@@ -58,5 +58,5 @@ int grouping_packs(const het_grouping* g, hipStream_t s);
 // Builds g->p01 (with_keys == false) or g->kp01 (true; builds the packs first) once, thread-safe, published after a sync.
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s);
 // Builds g_rel->hub_items once (thread-safe, published after a sync): g_rel groups the same positions as `twin` by
-// key * R + relation.  An error if g_rel was built against another twin (or threshold) before.
+// key * R + relation.  Rebuilt when g_rel was paired with another twin object (or threshold) before.
 int grouping_hub_items(const het_grouping* g_rel, const het_grouping* twin, int R, int hub_min, hipStream_t s);

@@ -496,8 +496,8 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
  *   q_rows [S_col,H,D], q_sum / q_ref [S_col,H]: written by the forward, read by the backward.  drow_nodes [S_col] int64:
  *     destination node of every er row.  Shapes: rows of 32 / 64 / 128 floats with heads of >= 16 (else HET_ERR_UNSUPPORTED).
  *   workspaces: het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream) -- one record per work item of
- *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel, which is
- *     thereby paired with this by_dst); -1 on error;  het_rgat_backward_compact_workspace(N, 0, H, D, .) */
+ *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel and
+ *     rebuilt if it is later used with another by_dst object); -1 on error;  het_rgat_backward_compact_workspace(N, 0, H, D, .) */
 int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
                                                   int64_t H, int64_t D, het_stream stream);
 int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,

@@ -346,6 +346,20 @@ def test_rgat_compact_run_sums(K, H, D, n, e, fold, bias):
     assert_close(gr, gr_r, what="grad_er")
     if bias:
         assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
+    # the cache evicts and rebuilds the grouping by destination while the (destination, relation) one stays: the hub lists that
+    # were built against the old object are rebuilt, same results
+    import het_amd.plan as plan
+    with plan._cache_lock:
+        for key in [kk for kk, v in plan._cache.items() if v is grp[0]]:
+            del plan._cache[key]
+    old_by_dst = grp[0]
+    grp = k.rgat_compact_groupings(s["col_indices"].to(DEV), srow_p.to(DEV), drow_p.to(DEV), N, S_row, S_col, rel_ptrs=s["rel_ptrs"].to(DEV),
+                                   drow_nodes=ss["node_indices_col"].to(DEV), drow_rel_ptrs=ss["rel_ptrs_col"].to(DEV))
+    assert grp[0] is not old_by_dst
+    sm3, ret5 = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
+    k.rgat_aggregate_compact(grp, f, l, r_, sm3, ret5, slope, num_rels=R)
+    assert torch.equal(ret5, ret) and torch.equal(sm3, sm)
+    del old_by_dst
     # er rows that are not the (relation, destination) pairs of their edges are refused (checked once per list)
     bad = drow_p.clone()
     bad[0] = (bad[0] + 1) % S_col
