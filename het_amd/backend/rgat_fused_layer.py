@@ -39,6 +39,7 @@ PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on th
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
 RUN_SUMS = os.environ.get("HET_RGAT_RUN_SUMS", "1") != "0"  # A/B switch: grad_er from the forward's run sums
 OVERLAP = os.environ.get("HET_RGAT_OVERLAP", "1") != "0"  # independent launches on a second HIP stream (see _side_stream)
+NODE_ORDER = os.environ.get("HET_RGAT_NODE_ORDER", "1") != "0"  # node-major pass over nodes sorted by relation presence
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
 
 
@@ -385,8 +386,11 @@ class RgatLayerFunction(th.autograd.Function):
             _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
                                accumulate=False)
 
+        order = _k.node_order_by_presence(row_map, dst_map) if NODE_ORDER else None
+
         def input_gradient():
-            _k.rgat_node_backward_dx(0, N, nd, gh, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t, dst_map, grad_x)
+            _k.rgat_node_backward_dx(0, N, nd, gh, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t, dst_map, grad_x,
+                                     node_order=order)
         if side is not None:
             # the weight gradients (HBM-bound streams of rows) on the side stream while the node-major pass (matrix-core-bound)
             # runs on this one; both read g_featc / g_erc / grad_h, neither writes what the other reads
@@ -439,7 +443,8 @@ class RgatLayerFunction(th.autograd.Function):
             row_map = _k.node_row_map(rp_row, rows_node, N)
             dst_map = _k.node_row_map(ss["rel_ptrs_col"], ss["node_indices_col"], N)
             loop_wt = loop_w.t().contiguous()
-            args = (grad_h, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t.view(R, H, Kd), dst_map, grad_x)
+            order = _k.node_order_by_presence(row_map, dst_map, split=nd) if NODE_ORDER else None
+            args = (grad_h, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t.view(R, H, Kd), dst_map, grad_x, order)
             _k.rgat_node_backward_dx(nd, N, nd, *args)
             halo.start_return(grad_x)
             _k.rgat_node_backward_dx(0, nd, nd, *args)

@@ -46,6 +46,8 @@ struct NodeArgs {
   const int32_t* row_map;  // [R, N]
   const float* g_er;       // [S_col, H]    gradient of er (NULL: none)
   const int32_t* dst_map;  // [R, N]
+  const int32_t* order;    // [N] or NULL: the node at position p of [n_begin, n_end) (NULL: node p).  A list sorted by which relations
+                           // a node has rows in makes the 32-node tiles homogeneous: no zero rows in the MFMA tiles
   // dx
   const float* loop_wt;    // [X, K]  W_loop^T
   const float* wt;         // [R, X, K]  (= weights_transposed [R,H,D,K])
@@ -71,8 +73,9 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
   const int R = a.R, nmat = 1 + R;
   float* Bs = smem;                                  // [1 + R][KS][XO]
   float* WAs = Bs + nmat * KS * XO;                  // [rhp][XO]
-  float* Ws = WAs + a.rhp * XO + wave * (32 * LD + nmat * 32);  // wave-private tile
+  float* Ws = WAs + a.rhp * XO + wave * (32 * LD + (nmat + 1) * 32);  // wave-private tile
   int* idsL = reinterpret_cast<int*>(Ws + 32 * LD);  // [1 + R][32] row ids of the tile's sources, -1 = none
+  int* idsN = idsL + nmat * 32;                      // [32] node of every row of the tile
   int* idsD = reinterpret_cast<int*>(Ws);            // [R][32] er rows: only live before the first source enters the tile
   for (int e = tid; e < KS * XO; e += WAVES * 64) Bs[e] = a.loop_wt ? a.loop_wt[e] : 0.f;
   for (int e = tid; e < R * KS * XO; e += WAVES * 64) Bs[KS * XO + e] = a.wt[e];
@@ -88,9 +91,12 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
   int64_t t = (int64_t)blockIdx.x * WAVES + wave;
   if (t >= tiles) return;
   int mcur[kMaxRels], dcur[kMaxRels];
+  int ncur = 0;
   auto load_maps = [&](int64_t tt) {
-    const int64_t node = a.n_begin + tt * 32 + row;
-    const int64_t nc = node < a.n_end ? node : a.n_end - 1;
+    const int64_t pos = a.n_begin + tt * 32 + row;
+    const int64_t pc = pos < a.n_end ? pos : a.n_end - 1;
+    const int64_t nc = a.order ? a.order[pc] : pc;
+    ncur = (int)nc;
 #pragma unroll
     for (int r = 0; r < kMaxRels; ++r) {
       mcur[r] = -1; dcur[r] = -1;
@@ -105,10 +111,11 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
     const int64_t nb = a.n_begin + t * 32;
     unsigned mask = 0, dmask = 0;
     {
-      const int64_t node = nb + row;
-      const bool nv = node < a.n_end;
+      const int64_t node = ncur;
+      const bool nv = nb + row < a.n_end;
       const int id0 = (a.gh && nv && node < a.n_loop) ? (int)node : -1;
       idsL[row] = id0;
+      idsN[row] = nv ? (int)node : -1;
       if (__ballot(id0 >= 0)) mask |= 1u;
 #pragma unroll
       for (int r = 0; r < kMaxRels; ++r) {
@@ -212,9 +219,9 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
         Ws[((reg & 3) + 8 * (reg >> 2) + 4 * half) * LD + (PAIRED ? 2 * row + nt : nt * 32 + row)] = acc[nt][reg];
 #pragma unroll
     for (int it = 0; it < NITC; ++it) {
-      const int64_t node = nb + it * RPIC + rc;
+      const int64_t node = idsN[it * RPIC + rc];
       const float4 v = ld4(&Ws[(it * RPIC + rc) * LD + cc]);
-      if (node < a.n_end) st4(a.grad_x + node * XO + cc, v);
+      if (node >= 0) st4(a.grad_x + node * XO + cc, v);
     }
   }
 }
@@ -226,7 +233,7 @@ int launch_dx(const NodeArgs& a, hipStream_t s) {
   constexpr int XO = NO * 32, LD = (KS > XO ? KS : XO) + 4;
   const int64_t tiles = (a.n_end - a.n_begin + 31) / 32;
   auto lds_for = [&](int waves) {
-    return sizeof(float) * ((size_t)(1 + a.R) * KS * XO + (size_t)a.rhp * XO + (size_t)waves * (32 * LD + (1 + a.R) * 32));
+    return sizeof(float) * ((size_t)(1 + a.R) * KS * XO + (size_t)a.rhp * XO + (size_t)waves * (32 * LD + (2 + a.R) * 32));
   };
   const size_t limit = 160 * 1024;
   HET_KTIME("HET_node_dx", s);
@@ -264,7 +271,7 @@ extern "C" int het_rgat_node_gemm_ok(int64_t R, int64_t H, int64_t K, int64_t D)
     return 0;
   // the input-gradient pass keeps all 1 + R transposed weights in LDS (4 waves at least)
   const int64_t KS = H * D, LD = (KS > K ? KS : K) + 4, rhp = (R * H + 7) / 8 * 8;
-  const int64_t lds = 4 * ((1 + R) * KS * K + rhp * K + 4 * (32 * LD + (1 + R) * 32));
+  const int64_t lds = 4 * ((1 + R) * KS * K + rhp * K + 4 * (32 * LD + (2 + R) * 32));
   return lds <= 160 * 1024 ? 1 : 0;
 }
 
@@ -289,7 +296,7 @@ extern "C" int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t
                                          const float* grad_h, const float* loop_wt, const float* g_rows,
                                          const float* weights_t, const int32_t* row_map, const float* g_er, const float* wa_t,
                                          const int32_t* dst_map, float* grad_x, int64_t H, int64_t K, int64_t D,
-                                         het_stream stream) {
+                                         const int32_t* node_order, het_stream stream) {
   const char* op = "het_rgat_node_backward_dx";
   if (int rc = check_node_args(op, n_begin, n_end, n_loop, num_nodes, num_rels, H, K, D)) return rc;
   if (n_begin == n_end) return HET_OK;
@@ -301,7 +308,7 @@ extern "C" int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t
   a.n_begin = n_begin; a.n_end = n_end; a.n_loop = grad_h ? n_loop : 0; a.N = num_nodes;
   a.R = (int)num_rels; a.H = (int)H; a.D = (int)D; a.rhp = g_er ? (int)((num_rels * H + 7) / 8 * 8) : 0;
   a.gh = grad_h; a.g_rows = g_rows; a.row_map = row_map; a.g_er = g_er; a.dst_map = dst_map;
-  a.loop_wt = loop_wt; a.wt = weights_t; a.wa_t = wa_t; a.grad_x = grad_x;
+  a.loop_wt = loop_wt; a.wt = weights_t; a.wa_t = wa_t; a.grad_x = grad_x; a.order = node_order;
   hipStream_t s = (hipStream_t)stream;
   const int KS = (int)(H * D);
   if (KS == 64) return K == 64 ? launch_dx<64, 2>(a, s) : launch_dx<64, 1>(a, s);

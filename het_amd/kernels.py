@@ -690,12 +690,31 @@ def node_row_map(rel_ptrs, nodes, num_nodes: int):
     return _derived_get(("nodemap", num_nodes), (rel_ptrs, nodes), build)
 
 
-def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weights_t, row_map, g_er, wa_t, dst_map, grad_x):
-    """grad_x rows [n_begin, n_end) of the one-node RGAT layer in one pass over the nodes (include/het_amd.h)."""
+def node_order_by_presence(row_map, dst_map=None, split=None):
+    """[N] int32: the nodes sorted (stably) by which relations they have a row in -- tiles of 32 consecutive entries are then
+    homogeneous and the node-major pass multiplies no zero rows (include/het_amd.h: node_order).  ``split``: nodes below it
+    stay in front of the others (the owned / halo ranges of a partition are passed as two calls).  Cached per map."""
+    def build():
+        R, N = row_map.shape
+        w = (1 << torch.arange(R, device=row_map.device, dtype=torch.int64)).view(R, 1)
+        mask = ((row_map >= 0).to(torch.int64) * w).sum(0)
+        if dst_map is not None:
+            mask = mask | (((dst_map >= 0).to(torch.int64) * w).sum(0) << R)
+        if split is not None:
+            mask = mask | ((torch.arange(N, device=row_map.device) >= int(split)).to(torch.int64) << (2 * R))
+        return torch.argsort(mask, stable=True).to(torch.int32).contiguous()
+    return _derived_get(("node_order", None if split is None else int(split)), (row_map,) + (() if dst_map is None else (dst_map,)), build)
+
+
+def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weights_t, row_map, g_er, wa_t, dst_map, grad_x,
+                          node_order=None):
+    """grad_x rows [n_begin, n_end) of the one-node RGAT layer in one pass over the nodes (include/het_amd.h).  node_order
+    (optional, [N] int32): the nodes of the call are the entries [n_begin, n_end) of this list."""
     _chk("rgat_node_backward_dx", tuple(t for t in (grad_h, loop_wt, g_rows, weights_t, g_er, wa_t, grad_x) if t is not None))
     R, H, D, K = weights_t.shape
     _call(grad_x, "het_rgat_node_backward_dx", int(n_begin), int(n_end), int(n_loop), grad_x.shape[0], R, _p(grad_h), _p(loop_wt),
-          _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _stream(grad_x))
+          _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _p(node_order),
+          _stream(grad_x))
 
 
 def rows_linear_bias_ok(K: int, X: int) -> bool:

@@ -538,6 +538,9 @@ int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const
  *   row_map / dst_map [R, num_nodes] int32: row of (relation, node) in the unique (relation, source) / (relation,
  *   destination) list, -1 if the node has none (het_node_row_map);  grad_h [n_loop, H*D];  g_rows [S_row, H*D];
  *   g_er [S_col, H] (NULL: no such term);  loop_wt [H*D, K] (= loop_weight^T);  weights_t [R,H,D,K];  wa_t [R,H,K].
+ *   node_order [num_nodes] int32 (optional): positions [n_begin, n_end) of this list are the nodes of the call (NULL: node p at
+ *   position p).  The kernel multiplies 32-node tiles per relation that has a row in the tile; a list sorted by WHICH relations a
+ *   node has rows in makes the tiles homogeneous (no zero rows: 26 % fewer matrix-core instructions on ogbn-mag).
  *   Shapes: K and H*D in {32, 64}, H in {1,2,4,8}, R*H <= 32, all 1 + R weights resident in LDS (het_rgat_node_gemm_ok);
  *   HET_ERR_INVALID_ARG otherwise -- callers fall back to the per-relation entry points. */
 int het_rgat_node_gemm_ok(int64_t num_rels, int64_t H, int64_t K, int64_t D);
@@ -546,7 +549,7 @@ int het_node_row_map(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* n
 int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t n_loop, int64_t num_nodes, int64_t num_rels,
                               const float* grad_h, const float* loop_wt, const float* g_rows, const float* weights_t,
                               const int32_t* row_map, const float* g_er, const float* wa_t, const int32_t* dst_map,
-                              float* grad_x, int64_t H, int64_t K, int64_t D, het_stream stream);
+                              float* grad_x, int64_t H, int64_t K, int64_t D, const int32_t* node_order, het_stream stream);
 
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.

@@ -993,4 +993,21 @@ def test_rgat_node_backward_dx(K, H, Kd, D, R, with_loop, with_er, typed):
         for b, e in ranges:
             k.rgat_node_backward_dx(b, e, n_loop, *args, out)
         assert_close(out, gx, what=f"grad_x {ranges}")
+    # node_order: the nodes of a call are entries [b, e) of a list -- sorted by relation presence (homogeneous tiles), whole
+    # range and the two ranges of a partition (split = 300), and an arbitrary permutation
+    order = k.node_order_by_presence(row_map, dst_map if with_er else None)
+    assert sorted(order.cpu().tolist()) == list(range(N))
+    out = torch.full((N, Kd), float("nan"), device=DEV)
+    k.rgat_node_backward_dx(0, N, n_loop, *args, out, node_order=order)
+    assert_close(out, gx, what="grad_x (nodes by relation presence)")
+    order2 = k.node_order_by_presence(row_map, dst_map if with_er else None, split=300)
+    assert int(order2[:300].max()) < 300 <= int(order2[300:].min())
+    out = torch.full((N, Kd), float("nan"), device=DEV)
+    for b, e in ((300, N), (0, 300)):
+        k.rgat_node_backward_dx(b, e, n_loop, *args, out, node_order=order2)
+    assert_close(out, gx, what="grad_x (nodes by relation presence, two ranges)")
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(torch.int32).to(DEV)
+    out = torch.full((N, Kd), float("nan"), device=DEV)
+    k.rgat_node_backward_dx(0, N, n_loop, *args, out, node_order=perm)
+    assert_close(out, gx, what="grad_x (random node order)")
 
