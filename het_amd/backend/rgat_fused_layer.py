@@ -190,9 +190,9 @@ class RgatLayerFunction(th.autograd.Function):
                 # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
                 bias_c = None if bias is None else bias.contiguous()
                 if side is not None:
+                    h = x.new_empty((nd, X))  # allocated (and later freed) under the main stream; the side stream only fills it
                     with th.cuda.stream(side):
-                        h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
-                    h.record_stream(main)  # (allocated under the side stream, used and freed under the main one)
+                        _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c, out=h)
                 else:
                     h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
             if halo is not None:

@@ -83,6 +83,17 @@ hipStream_t het_side_stream() {
   return streams[dev];
 }
 
+hipEvent_t het_fork_event() {
+  thread_local hipEvent_t events[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!events[dev] && hipEventCreateWithFlags(&events[dev], hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    events[dev] = nullptr;
+  }
+  return events[dev];
+}
+
 extern "C" int het_kernel_timing_read(const char* name_prefix, double* total_ms, int64_t* launches) {
   HET_REQUIRE(name_prefix && total_ms && launches, "het_kernel_timing_read: null argument");
   std::lock_guard<std::mutex> lk(g_kmu);

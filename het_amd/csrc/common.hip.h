@@ -58,15 +58,17 @@ struct HetKTimer {  // scope guard: { HET_KTIME("HET_kernel", s); hipLaunchKerne
 // it before the entry point returns -- to the caller the call is still ordered on `stream` alone.  HET_SIDE_STREAM=0 runs
 // everything on the caller's stream.  (Works inside a stream capture: event record / wait become graph dependencies.)
 hipStream_t het_side_stream();  // NULL when switched off or when it could not be made
+hipEvent_t het_fork_event();    // this thread's event for the current device (made on first use, never destroyed), or NULL
 struct HetFork {
   hipStream_t main, side;
   hipEvent_t ev = nullptr;
+  // The event is the calling thread's own and lives for the life of the process: destroying an event that a stream capture has
+  // seen leaves the runtime with a dangling pointer until the capture ends (hipStreamEndCapture crashed now and then).
   explicit HetFork(hipStream_t m) : main(m), side(het_side_stream()) {
     if (!side) { side = main; return; }
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, main) != hipSuccess ||
-        hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
+    ev = het_fork_event();
+    if (!ev || hipEventRecord(ev, main) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
       (void)hipGetLastError();
-      if (ev) (void)hipEventDestroy(ev);
       ev = nullptr;
       side = main;  // no fork: the side launches simply follow on the caller's stream
     }
@@ -78,7 +80,6 @@ struct HetFork {
     if (e == hipSuccess) e = hipStreamWaitEvent(main, ev, 0);
     return e;
   }
-  ~HetFork() { if (ev) (void)hipEventDestroy(ev); }  // (destruction is deferred by the runtime until the event has completed)
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -721,10 +721,12 @@ def rows_linear_bias_ok(K: int, X: int) -> bool:
     return K in (32, 64, 128) and X in (32, 64, 128)
 
 
-def rows_linear_bias(offsets, x, w, bias):
-    """x . w + bias for the rows [offsets[0], offsets[1]) of x (include/het_amd.h: het_rows_linear_bias)."""
-    _chk("rows_linear_bias", tuple(t for t in (x, w, bias) if t is not None), (offsets,))
-    out = torch.empty((x.shape[0], w.shape[1]), dtype=x.dtype, device=x.device)
+def rows_linear_bias(offsets, x, w, bias, out=None):
+    """x . w + bias for the rows [offsets[0], offsets[1]) of x (include/het_amd.h: het_rows_linear_bias).  ``out``: a tensor of the
+    caller (e.g. allocated under another stream than the one the product is launched on)."""
+    _chk("rows_linear_bias", tuple(t for t in (x, w, bias, out) if t is not None), (offsets,))
+    if out is None:
+        out = torch.empty((x.shape[0], w.shape[1]), dtype=x.dtype, device=x.device)
     _call(x, "het_rows_linear_bias", _p(offsets), _p(x), _p(w), _p(bias), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(x))
     return out
 
