@@ -26,7 +26,7 @@ from ..plan import consistent as _consistent_plan
 
 from .. import kernels as _k
 from ..kernels import K
-from .rgat_fused_layer import _edge_rows, _has_single_sided_lists
+from .rgat_fused_layer import OVERLAP, _edge_rows, _has_single_sided_lists, _side_stream
 from .rgnn_layers_and_funcs import rgnn_relational_matmul_no_scatter_gather_list as B_matmul_no_scatter_gather
 
 FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
@@ -99,20 +99,30 @@ class HgtAttentionFunction(th.autograd.Function):
         rp_row, rows_node = ss["rel_ptrs_row"], ss["node_indices_row"]
         S_row = rows_node.numel()
         new = lambda *shape: th.empty(shape, dtype=h.dtype, device=h.device)
+        # the destination-side projection beside the source-row one (rgat_fused_layer._side_stream: independent launches, the
+        # tensors are allocated and freed under the main stream)
+        main, side = th.cuda.current_stream(h.device), (_side_stream(h.device) if OVERLAP and h.is_cuda else None)
         if dst is None:
             ND, keys = N, s["col_indices"]
             q = new(ND, X)
-            K.rgnn_relational_matmul_no_scatter_gather_list(offs, q_w, h, q)
         else:
             dst_nodes, keys, run_ptrs = dst
             ND = dst_nodes.numel()
             q = new(ND, 1, X)
-            K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes},
-                                     1, q_w, h, q, True)
-            q = q.view(ND, X)
         kv_c = new(S_row, 1, 2 * X)
+        if side is not None:
+            side.wait_stream(main)
+        with th.cuda.stream(side if side is not None else main):
+            if dst is None:
+                K.rgnn_relational_matmul_no_scatter_gather_list(offs, q_w, h, q)
+            else:
+                K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes},
+                                         1, q_w, h, q, True)
+        q = q.view(ND, X)
         K.rgnn_relational_matmul({"unique_srcs_and_dests_rel_ptrs": rp_row, "unique_srcs_and_dests_node_indices": rows_node},
                                  1, w_kv, h, kv_c, True)
+        if side is not None:
+            main.wait_stream(side)
         srow, _ = _edge_rows(G, ss, True, s["rel_ptrs"], s["row_indices"], s["col_indices"], s["eids"])
         grp = _k.hgt_compact_groupings(keys, srow, ND, S_row)
         lsum, out = new(ND, H), new(ND, X)
@@ -134,6 +144,15 @@ class HgtAttentionFunction(th.autograd.Function):
         _k.hgt_backward_compact(ctx.grp, kv_c, q, lsum, out, grad_out, g_kv, g_q)
         # one input-gradient buffer for both consumers of h
         qwt = q_w.transpose(2, 3).contiguous()
+        wt = w_kv.transpose(2, 3).contiguous()
+        split_kv = _k.rows_matmul_backward_split_ok(1, K_in, 2 * X)
+        # the weight gradients (HBM-bound streams of rows) on the side stream beside the input-gradient chain
+        main, side = th.cuda.current_stream(h.device), (_side_stream(h.device) if OVERLAP and h.is_cuda else None)
+        grad_wkv = th.empty_like(w_kv) if split_kv else None
+        if side is not None and split_kv:
+            side.wait_stream(main)
+            with th.cuda.stream(side):
+                _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv.view(-1, 2 * X), grad_wkv, accumulate=False)
         if not ctx.compact_dst:  # the typed projection writes every row with plain stores, the source-row GEMM adds to it
             grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)
             _k.matmul_no_scatter_gather_backward(offs, qwt, h, g_q, grad_h, grad_qw, accumulate=False)
@@ -142,21 +161,28 @@ class HgtAttentionFunction(th.autograd.Function):
             grad_h = th.zeros_like(h)
             if _k.rows_matmul_backward_split_ok(1, K_in, X):
                 grad_qw = th.empty_like(q_w)
+                if side is not None:
+                    if not split_kv:
+                        side.wait_stream(main)
+                    with th.cuda.stream(side):
+                        _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
                 _k.rows_matmul_backward_dx(run_ptrs, dst_nodes, qwt, g_q, grad_h, atomic=False)  # distinct nodes, first writer: "="
-                _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
+                if side is None:
+                    _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
             else:
                 grad_qw = th.zeros_like(q_w)
                 _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": run_ptrs, "unique_srcs_and_dests_node_indices": dst_nodes}, 1,
                                    qwt, h, g_q.view(-1, 1, X), grad_h, grad_qw, True, accumulate=True, distinct_rows=True)
-        wt = w_kv.transpose(2, 3).contiguous()
-        if _k.rows_matmul_backward_split_ok(1, K_in, 2 * X):
-            grad_wkv = th.empty_like(w_kv)
+        if split_kv:
             _k.rows_matmul_backward_dx(rp_row, rows_node, wt, g_kv.view(-1, 2 * X), grad_h, atomic=2)  # rows of a relation: distinct nodes
-            _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv.view(-1, 2 * X), grad_wkv, accumulate=False)
+            if side is None:
+                _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv.view(-1, 2 * X), grad_wkv, accumulate=False)
         else:
             grad_wkv = th.zeros_like(w_kv)
             _k.matmul_backward({"unique_srcs_and_dests_rel_ptrs": rp_row, "unique_srcs_and_dests_node_indices": rows_node}, 1, wt, h,
                                g_kv, grad_h, grad_wkv, True, accumulate=True, distinct_rows=True)
+        if side is not None:
+            main.wait_stream(side)  # (a wait for a stream without new work is free)
         return None, None, None, grad_h, grad_wkv, grad_qw, None
 
 
