@@ -386,7 +386,8 @@ class RgatLayerFunction(th.autograd.Function):
             _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
                                accumulate=False)
 
-        order = _k.node_order_by_presence(row_map, dst_map) if NODE_ORDER else None
+        # (on a block only the first nd nodes carry the self-loop term: they stay in front, so that term's tiles are whole too)
+        order = _k.node_order_by_presence(row_map, dst_map, split=nd if nd < N else None) if NODE_ORDER else None
 
         def input_gradient():
             _k.rgat_node_backward_dx(0, N, nd, gh, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t, dst_map, grad_x,
