@@ -45,6 +45,13 @@ struct Items {
 // reference stores the sum, and the backward forms the attention weight as exp(s - lse[v,h]).  Same value as
 // exp(s) / SUM exp(s) wherever the reference's formula is finite; finite everywhere else too (|el + er| of 100 and more).
 __device__ __forceinline__ float lrelu(float z, float slope) { return z > 0.f ? z : slope * z; }
+// The stored log-sum-exp of a destination WITH in-edges is never exactly 0 (an exact 0 becomes the smallest normal float: a
+// relative change of 1e-38 in the weights), so that "lse == 0" means "no in-edges" -- the zero fill of the forward -- and the
+// backward's per-destination pass can leave the rows of those nodes (60 % of ogbn-mag's) unread.
+__device__ __forceinline__ float lse_of(float m, float ssum) {
+  const float L = m + __logf(ssum);
+  return L == 0.f ? 1.17549435e-38f : L;
+}
 
 // ret[v,h,:] = SUM_e w_e * feat[srow_e,h,:] / SUM_e w_e,  w_e = exp(leaky(el[srow_e,h] + er[drow_e,h])); sum[v,h] = SUM_e w_e
 // Same schedule as HET_gat_aggregate_grouped (fused_gat_grouped.hip): 64/LPR lane groups take the item's edges
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_compact(Items it, c
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     st4(ret + v * X + x, r4);
     if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (x % D == 0) lse[v * H + h] = m + __logf(ssum);
+    if (x % D == 0) lse[v * H + h] = lse_of(m, ssum);
   } else {  // a piece of a hub destination: parked for HET_rgat_finish_split
     float* pp = part + item * (X + 2 * H);
     st4(pp + x, acc);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_finish_split(const int32_t* _
     const float4 h0 = ld4(hio + v * X + x);
     st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
   }
-  if (x % D == 0) lse[v * H + h] = M + __logf(ssum);
+  if (x % D == 0) lse[v * H + h] = lse_of(M, ssum);
 }
 
 // pack[v] = { lse[v,h] (H floats), <gradout[v,h,:], ret[v,h,:]> (H floats) }, or interleaved per head ([N,H,2]); bias_part (optional, [gridDim.x * waves, X]):
@@ -218,14 +225,18 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_dst_pack(const float* __restr
   for (int64_t v0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * EPW; v0 < N; v0 += step) {
     const bool ok = v0 + slot < N;
     const int64_t v = ok ? v0 + slot : N - 1;  // past the end: the last node again (same bytes rewritten)
-    const float4 g = ld4(gradout + v * X + x), r = ld4(ret + v * X + x);
-    float dot = g.x * r.x + g.y * r.y + g.z * r.z + g.w * r.w;
+    // a node without in-edges (lse == 0: lse_of) has no row of ret worth reading and no edge reads its pack record: its load goes
+    // to row 0 (cached) and its dot is 0
+    const float ls = sum[v * H + h];
+    const bool has = ls != 0.f;
+    const float4 g = ld4(gradout + v * X + x), r = ld4(ret + (has ? v : 0) * X + x);
+    float dot = has ? g.x * r.x + g.y * r.y + g.z * r.z + g.w * r.w : 0.f;
     for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
     if ((sub & (DL - 1)) == 0) {
       if (interleaved) {
-        *reinterpret_cast<float2*>(pack + (v * H + h) * 2) = make_float2(sum[v * H + h], dot);
+        *reinterpret_cast<float2*>(pack + (v * H + h) * 2) = make_float2(ls, dot);
       } else {
-        pack[v * 2 * H + h] = sum[v * H + h];
+        pack[v * 2 * H + h] = ls;
         pack[v * 2 * H + H + h] = dot;
       }
     }
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     st4(ret + v * X + x, r4);
     if (add_h) st4(hio + v * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (d == 0) lse[v * H + h] = m + __logf(ssum);
+    if (d == 0) lse[v * H + h] = lse_of(m, ssum);
   } else {  // a piece of a hub destination: parked for HET_rgat_finish_split
     float* pp = part + item * (X + 2 * H);
     st4(pp + x, acc);
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
               const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
               st4(ret + (int64_t)cur_dst * X + x, r4);
               if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-              if (d == 0) lse[(int64_t)cur_dst * H + h] = m + __logf(ssum);
+              if (d == 0) lse[(int64_t)cur_dst * H + h] = lse_of(m, ssum);
             }
             cur_dst = dstq;
             if (hio && dstq < hio_rows) h0 = ld4(hio + (int64_t)dstq * X + x);  // needed when the destination ends
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     st4(ret + (int64_t)cur_dst * X + x, r4);
     if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (d == 0) lse[(int64_t)cur_dst * H + h] = m + __logf(ssum);
+    if (d == 0) lse[(int64_t)cur_dst * H + h] = lse_of(m, ssum);
   }
 }
 
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
     acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
     ssum += __shfl_xor(ssum, off);
   }
-  const float L = M + __logf(ssum);  // (every lane group holds the totals of its head)
+  const float L = lse_of(M, ssum);  // (every lane group holds the totals of its head)
   if (slot == 0) {
     const float inv = 1.f / ssum;
     const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);

@@ -459,7 +459,9 @@ int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_
  *   reference-named a4 / a5 keep that because exp and sum are API tensors there).  These two entry points subtract a running
  *   maximum per (destination, head): `sum` receives lse[v,h] = log(SUM_e exp(leaky_relu(el + er))) instead of the sum itself and
  *   the backward forms the attention weight as exp(leaky_relu(el + er) - lse[v,h]) -- the reference's value wherever its formula
- *   is finite, finite for any pre-activation.  workspace (forward): het_rgat_aggregate_compact_workspace(by_dst, H, D) bytes,
+ *   is finite, finite for any pre-activation.  The stored lse of a destination with in-edges is never exactly 0 (an exact 0 is
+ *   stored as FLT_MIN), so `sum[v,h] == 0` -- the forward's zero fill -- marks a node without in-edges: the backward skips the
+ *   `ret` rows of those nodes, so `sum` has to be the forward's output.  workspace (forward): het_rgat_aggregate_compact_workspace(by_dst, H, D) bytes,
  *   16-byte aligned (0 unless a destination has more than 256 in-edges: its work items park their partial sums there and a
  *   finishing pass brings them to one maximum -- no float atomics).
  * forward:  sum [N,H] (= lse), ret [N,H,D] are overwritten (a4's ret; exp is not produced).  h_inout [h_rows, H*D] (optional):
