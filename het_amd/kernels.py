@@ -602,6 +602,8 @@ def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_row
     by_srow = _plan.get_grouping(None, srow, num_src_rows, col, drow)
     if by_dst is None or by_srow is None:
         return None
+    if rel_ptrs is not None and num_nodes * (rel_ptrs.numel() - 1) >= 2 ** 31:
+        rel_ptrs = None  # (destination * R + relation does not fit the groupings' int32 keys: the per-edge form)
     if rel_ptrs is not None:
         R = rel_ptrs.numel() - 1
 
