@@ -43,7 +43,7 @@ _SIGNATURES = {
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
-    "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
+    "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],
     "het_hgt_aggregate_compact": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
     "het_hgt_backward_compact": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
     "het_rgcn_layer1_separate_coo": [P, P, P, P, I64, I64, I64, P, P, P, P, I64, I64, P, P, I64, P],
@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
         L.het_rgat_aggregate_compact_workspace.restype = I64
         L.het_rgat_aggregate_compact_runs_workspace.argtypes = [P, P, I64, I64, I64, P]
         L.het_rgat_aggregate_compact_runs_workspace.restype = I64
+        L.het_rgat_backward_compact_runs_workspace.argtypes = [P, I64, I64, I64, INT, INT, P]
+        L.het_rgat_backward_compact_runs_workspace.restype = I64
         L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
         L.het_rgat_backward_compact_workspace.restype = I64
         L.het_hgt_aggregate_compact_workspace.argtypes = [P, I64, I64]

@@ -39,6 +39,7 @@ PER_EDGE = os.environ.get("HET_RGAT_PER_EDGE") == "1"      # default flags on th
 LITERAL_ER = os.environ.get("HET_RGAT_LITERAL_ER") == "1"  # er = (x . W) . attn_r unless the layer flag asks otherwise
 RUN_SUMS = os.environ.get("HET_RGAT_RUN_SUMS", "1") != "0"  # A/B switch: grad_er from the forward's run sums
 OVERLAP = os.environ.get("HET_RGAT_OVERLAP", "1") != "0"  # independent launches on a second HIP stream (see _side_stream)
+ATTN_GRAD_IN_PASS = os.environ.get("HET_RGAT_ATTN_GRAD_IN_PASS", "1") != "0"  # grad_attn_l from the source-row kernels
 NODE_ORDER = os.environ.get("HET_RGAT_NODE_ORDER", "1") != "0"  # node-major pass over nodes sorted by relation presence
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
 
@@ -364,22 +365,25 @@ class RgatLayerFunction(th.autograd.Function):
             side.wait_stream(main)
             with th.cuda.stream(side):
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+        # (the weight gradient of attn_l from the same pass when the forward left run sums: csrc/gat_compact.hip ga_block_reduce)
+        grad_attn_l = th.empty_like(attn_l)
+        attn_in_pass = ATTN_GRAD_IN_PASS and ctx.runs is not None and R <= 8
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
-                                 drow_nodes=ss["node_indices_col"])
+                                 drow_nodes=ss["node_indices_col"], grad_attn_l=grad_attn_l if attn_in_pass else None)
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
         grad_x = th.empty_like(x)
         grad_W, grad_wa = th.empty_like(W), th.empty((R, H, Kd), dtype=x.dtype, device=x.device)
         gh = grad_h if ctx.has_loop else None
-        grad_attn_l = th.empty_like(attn_l)
         loop_wt = loop_w.t().contiguous() if ctx.has_loop else None
         d_col = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_col"], "unique_srcs_and_dests_node_indices": ss["node_indices_col"]}
 
         def weight_gradients():
             # per product (four launches; each reads its own rows of x / feat_c -- a node-major pass that reads x once was
             # measured in five forms and lost: it multiplies zero rows wherever a node has no row in a relation, exp/node_dw.hip.txt)
-            _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
-                                                 accumulate=False)
+            if not attn_in_pass:
+                _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                                     accumulate=False)
             if ctx.has_loop and side is None:
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
             _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)

@@ -859,30 +859,108 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_grad_er_runs(const float* __r
   }
 }
 
+// ---- weight gradient of the attention vector from the rows the source-row kernels hold ---------------------------------
+// grad_attn_l[r,h,:] = SUM_u grad_el[u,h] feat_c[u,h,:] over the rows u of relation r: a separate row-dot pass read feat_c again
+// (0.6 GB, 0.15 ms alone and 0.4 ms beside the matrix-core passes).  The source-row kernels have both factors in registers where
+// a segment (or a piece of one: the sum is linear) ends, so they keep ga += grad_el * feat per lane group; the workgroup's
+// partial row (rows are relation-major: a workgroup sees one relation, two at a boundary) goes to part[workgroup] with its
+// relation, and HET_rgat_attn_grad_finish adds the partial rows up.  Pieces that do not fit that pattern (a second relation inside
+// a lane group, a wave or a workgroup) are added with float atomics -- a handful per launch.
+template <int LPR>
+__device__ __forceinline__ void ga_flush_atomic(float* __restrict__ out, int rel, int x, const float4& v) {
+  float* p = out + (int64_t)rel * (LPR * 4) + x;
+  atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+// every thread of the workgroup calls this once; (ga, rel) per lane group, rel < 0: none
+template <int LPR>
+__device__ __forceinline__ void ga_block_reduce(float4 ga, int rel, float* __restrict__ part, int* __restrict__ part_rel,
+                                                float* __restrict__ out) {
+  constexpr int X = LPR * 4, NW = kBlock / 64;
+  __shared__ float sg[NW][X];
+  __shared__ int sr[NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane / LPR, x = (lane % LPR) * 4;
+  int r0 = rel;
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) r0 = max(r0, __shfl_xor(r0, off));
+  if (rel >= 0 && rel != r0) {  // this lane group belongs to another relation than the wave's: added directly
+    ga_flush_atomic<LPR>(out, rel, x, ga);
+    ga = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (rel < 0) ga = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    ga.x += __shfl_xor(ga.x, off); ga.y += __shfl_xor(ga.y, off);
+    ga.z += __shfl_xor(ga.z, off); ga.w += __shfl_xor(ga.w, off);
+  }
+  if (slot == 0) st4(&sg[wave][x], ga);
+  if (lane == 0) sr[wave] = r0;
+  __syncthreads();
+  if (wave == 0 && slot == 0) {
+    int R0 = -1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) R0 = max(R0, sr[w]);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float4 v = ld4(&sg[w][x]);
+      if (sr[w] == R0) { t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      else if (sr[w] >= 0) ga_flush_atomic<LPR>(out, sr[w], x, v);
+    }
+    st4(part + (int64_t)blockIdx.x * X + x, t);
+    if (lane == 0) part_rel[blockIdx.x] = R0;
+  }
+}
+constexpr int kAttnFinishRows = 128;  // partial rows per workgroup of the finishing pass (52 workgroups of 1024 rows took 0.2 ms)
+// out[r, :] += SUM of the partial rows tagged r (out zeroed before the producers ran: they add boundary pieces atomically)
+__global__ __launch_bounds__(kBlock) void HET_rgat_attn_grad_finish(const float* __restrict__ part, const int* __restrict__ part_rel,
+                                                                     int64_t P, int X, float* __restrict__ out) {
+  const int x = threadIdx.x % X, sub = threadIdx.x / X, nsub = kBlock / X;
+  constexpr int kRowsPerBlock = kAttnFinishRows;
+  const int64_t p0 = (int64_t)blockIdx.x * kRowsPerBlock, p1 = p0 + kRowsPerBlock < P ? p0 + kRowsPerBlock : P;
+  int cur = -1;
+  float a = 0.f;
+  for (int64_t p = p0 + sub; p < p1; p += nsub) {
+    const int r = part_rel[p];
+    if (r != cur) {
+      if (cur >= 0) atomicAdd(out + (int64_t)cur * X + x, a);
+      cur = r;
+      a = 0.f;
+    }
+    if (r >= 0) a += part[p * X + x];
+  }
+  if (cur >= 0) atomicAdd(out + (int64_t)cur * X + x, a);
+}
+
 // Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {lse, <gradout, ret>} interleaved.
-template <int LPR, int DL>
-__global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
+// GA: also the partial rows of grad_attn_l (ga_block_reduce above; needs fold_w for the relation of a row)
+template <int LPR, int DL, bool GA = false>
+__global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat,
     const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack2,
     const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
     float* __restrict__ tbuf, int H, float slope, const float* __restrict__ fold_w,
-    const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+    const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part = nullptr, int* __restrict__ ga_rel = nullptr,
+    float* __restrict__ ga_out = nullptr) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
   const int dq = d < U ? d : U - 1;
   const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
-  if (pid >= pk.n) return;
-  const uint32_t pb = (uint32_t)pk.ptr[pid];
-  const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
-  if (pb >> 31) return;  // a long segment: HET_rgat_backward_src_long takes its work items
+  if (!GA && pid >= pk.n) return;
+  const int64_t pidc = pid < pk.n ? pid : pk.n - 1;  // (GA: every lane group stays for the workgroup reduction, with an empty range)
+  const uint32_t pb = (uint32_t)pk.ptr[pidc];
+  int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pidc + 1] & 0x7fffffffu);
+  if (!GA && (pb >> 31)) return;  // a long segment: HET_rgat_backward_src_long takes its work items
+  if (GA && (pid >= pk.n || (pb >> 31))) e = b;
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr bool partial = false;
   // first feat row of relations 1 .. 7 in scalar registers: the relation of a row is a few compares (rows are relation-major)
   int rp[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) rp[i] = (fold_w && i + 1 < R) ? (int)fold_row_rel_ptrs[i + 1] : 0x7fffffff;
   int jn = b + dq < e ? b + dq : e - 1;
+  if (GA && jn < 0) jn = 0;
   int4 idn = kp01[jn];  // {feat row, destination, er row} of the edge: one load (grouping_packed_ids)
   int prev_key = -1, rel_cur = -1;
   float4 fcur = make_float4(0.f, 0.f, 0.f, 0.f), wcur = fcur, acc = fcur;
@@ -927,6 +1005,10 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
             rel = find_segment(fold_row_rel_ptrs, R, (idx_t)u);
           }
           if (rel != rel_cur) {  // rows are relation-major: a handful of times per launch
+            if (GA) {  // (the segments summed so far belong to the old relation)
+              if (rel_cur >= 0) ga_flush_atomic<LPR>(ga_out, rel_cur, x, ga);
+              ga = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             wcur = ld4(fold_w + (int64_t)rel * X + x);
             rel_cur = rel;
           }
@@ -957,6 +1039,10 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
           atomicAdd(gp + 0, o.x); atomicAdd(gp + 1, o.y); atomicAdd(gp + 2, o.z); atomicAdd(gp + 3, o.w);
           if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
         }
+        if (GA) {  // grad_attn_l[rel_cur] += grad_el[u] * feat[u]  (flushed where rel_cur changes, above)
+          ga.x = fmaf(acc_el, fcur.x, ga.x); ga.y = fmaf(acc_el, fcur.y, ga.y);
+          ga.z = fmaf(acc_el, fcur.z, ga.z); ga.w = fmaf(acc_el, fcur.w, ga.w);
+        }
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         acc_el = 0.f;
       }
@@ -970,6 +1056,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
     if (tbuf && d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;  // (NULL: grad_er comes from the run sums)
     prev_key = key[U - 1];
   }
+  if (GA) ga_block_reduce<LPR>(ga, rel_cur, ga_part, ga_rel, ga_out);
 }
 
 
@@ -977,20 +1064,24 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_coop(
 // graph): wave per work item (<= HET_ITEM_MAX edges of ONE feat row), the 64/LPR lane groups take its edges round-robin
 // as the forward does, scalars fetched cooperatively; feat row, el and the fold row are per item.  One store per item
 // (atomic adds only for the items of a segment longer than HET_ITEM_MAX, whose rows HET_rgat_zero_long_rows cleared).
-template <int LPR, int DL>
+template <int LPR, int DL, bool GA = false>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int2* __restrict__ p01,
     const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ pack2, const float* __restrict__ gradout,
     float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, float slope,
-    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R) {
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part = nullptr,
+    int* __restrict__ ga_rel = nullptr, float* __restrict__ ga_out = nullptr) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
   const int dq = d < U ? d : U - 1;
   const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (wid >= num_long_items) return;
+  if (wid >= num_long_items) {  // (GA: the wave stays for the workgroup reduction)
+    if (GA) ga_block_reduce<LPR>(make_float4(0.f, 0.f, 0.f, 0.f), -1, ga_part, ga_rel, ga_out);
+    return;
+  }
   const int item = long_items[wid];
   const int seg = it.seg[item], b = it.begin[item], e = it.end[item];
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
@@ -1035,6 +1126,11 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
     acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
     acc_el += __shfl_xor(acc_el, off);
+  }
+  if (GA) {  // this item's piece of grad_attn_l[rel] = grad_el piece * feat row (lane group 0 carries it)
+    const int rel = find_segment(fold_row_rel_ptrs, R, (idx_t)u);
+    const float s0 = slot == 0 ? acc_el : 0.f;
+    ga_block_reduce<LPR>(make_float4(s0 * f.x, s0 * f.y, s0 * f.z, s0 * f.w), rel, ga_part, ga_rel, ga_out);
   }
   if (slot != 0) return;
   if (fold_w) {
@@ -1268,8 +1364,15 @@ struct RunSums {
   const float *q_rows, *q_sum, *q_ref;
   const int64_t* drow_nodes;
 };
+// rows of partial grad_attn_l sums the two source-row launches write (one per workgroup): needs the packs of by_srow
+static int64_t attn_grad_partial_rows(const het_grouping* by_srow, int64_t X) {
+  const int64_t nb = ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  const int64_t nbl = ceil_div64(by_srow->num_long_items, kBlock / 64);
+  return nb + nbl;
+}
+
 static int rgat_backward_compact_impl(const char* op, const het_grouping* by_srow, const het_grouping* by_drow, const RunSums* runs,
-                                      const float* feat_c, const float* el_c, const float* er_c, const float* sum, const float* ret,
+                                      float* grad_attn_l, const float* feat_c, const float* el_c, const float* er_c, const float* sum, const float* ret,
                                       const float* gradout, float* grad_feat_c, float* grad_el_c, float* grad_er_c,
                                       const float* fold_attn_l, const int64_t* row_rel_ptrs, int64_t num_rels,
                                       float* grad_bias, int64_t bias_rows, int64_t num_nodes, int64_t num_src_rows,
@@ -1288,15 +1391,22 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
               "%s: by_drow groups the positions by er row with payload0 = their rank in by_srow and has one segment per er row", op);
   HET_REQUIRE(!fold_attn_l || (row_rel_ptrs && num_rels > 0), "%s: fold_attn_l needs the relation pointers of the feat rows", op);
   const bool coop = coop_shape_ok(H, D);
+  HET_REQUIRE(!grad_attn_l || (coop && fold_attn_l && num_rels <= 8), "%s: grad_attn_l needs the cooperative shapes, fold_attn_l and <= 8 relations", op);
+  if (grad_attn_l && E > 0)
+    if (int rc = grouping_packs(by_srow, s)) return rc;  // (the partial rows are counted in workgroups of the two launches)
   constexpr int kBiasBlocks = 2048;
   const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
+  const int64_t ga_rows = (grad_attn_l && E > 0) ? attn_grad_partial_rows(by_srow, X) : 0, n_ga = (ga_rows * (X + 1) + 3) / 4 * 4;
   const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = runs ? 0 : (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
-  const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X);
+  const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X + n_ga);
   HET_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
               "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_backward_compact_workspace)", op, (long long)need);
   float* pack = (float*)workspace;  // [N, 2H]
   float* tbuf = runs ? nullptr : pack + n_pack;  // [E, H], rank order of by_srow
   float* bias_part = grad_bias ? pack + n_pack + n_tbuf : nullptr;
+  float* ga_part = ga_rows ? pack + n_pack + n_tbuf + bias_part_rows * X : nullptr;  // [ga_rows, X] then [ga_rows] relation tags
+  int* ga_rel = ga_rows ? reinterpret_cast<int*>(ga_part + ga_rows * X) : nullptr;
+  if (grad_attn_l) HET_HIP(hipMemsetAsync(grad_attn_l, 0, sizeof(float) * num_rels * X, s));  // (boundary pieces add atomically)
   if (by_srow->S != num_src_rows) {  // feat rows without an edge (none when the lists come from the graph): zero gradient
     HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
     HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
@@ -1347,21 +1457,37 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (coop) {
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
-      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
-                                           feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
-                                           (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels));
+      if (ga_rows) {
+        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                          hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL, true>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
+                                             feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope,
+                                             fold_attn_l, row_rel_ptrs, (int)num_rels, ga_part, ga_rel, grad_attn_l));
+      } else {
+        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                          hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
+                                             feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
+                                             (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels, nullptr, nullptr, nullptr));
+      }
     }
     HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
     if (by_srow->num_long_items > 0) {
       Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
       const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
+      int* ga_rel_long = ga_rel ? ga_rel + nb : nullptr;  // (the long launch's workgroups follow the short launch's in the partial rows)
       HET_KTIME("HET_rgat_backward_src_long", s2);
-      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s2, it,
-                                           by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
-                                           er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
-                                           row_rel_ptrs, (int)num_rels));
+      if (ga_rows) {
+        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                          hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, true>), dim3(nbl), dim3(kBlock), 0, s2, it,
+                                             by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
+                                             er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
+                                             row_rel_ptrs, (int)num_rels, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l));
+      } else {
+        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                          hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s2, it,
+                                             by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
+                                             er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
+                                             row_rel_ptrs, (int)num_rels, nullptr, nullptr, nullptr));
+      }
     }
   } else {
     static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
@@ -1398,9 +1524,19 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     }
     HET_LAUNCH_CHECK("HET_rgat_grad_er_runs");
     HET_HIP(fk.join());
+    if (ga_rows) {
+      hipLaunchKernelGGL(HET_rgat_attn_grad_finish, dim3((unsigned)ceil_div64(ga_rows, kAttnFinishRows)), dim3(kBlock), 0, s, ga_part, ga_rel, ga_rows,
+                         (int)X, grad_attn_l);
+      HET_LAUNCH_CHECK("HET_rgat_attn_grad_finish");
+    }
     return HET_OK;
   }
   HET_HIP(fk.join());
+  if (ga_rows) {
+    hipLaunchKernelGGL(HET_rgat_attn_grad_finish, dim3((unsigned)ceil_div64(ga_rows, kAttnFinishRows)), dim3(kBlock), 0, s, ga_part, ga_rel, ga_rows,
+                       (int)X, grad_attn_l);
+    HET_LAUNCH_CHECK("HET_rgat_attn_grad_finish");
+  }
   // grad_er[w, :] = SUM over the edges of er row w of tbuf[rank, :]   (segments of by_drow are the er rows in order)
   return launch_segment_sum(by_drow, tbuf, grad_er_c, (int)H, nullptr, s);
 }
@@ -1413,23 +1549,37 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
                                          int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
                                          int64_t workspace_bytes, het_stream stream) {
   HET_REQUIRE(by_drow, "het_rgat_backward_compact: null argument");
-  return rgat_backward_compact_impl("het_rgat_backward_compact", by_srow, by_drow, nullptr, feat_c, el_c, er_c, sum, ret, gradout,
+  return rgat_backward_compact_impl("het_rgat_backward_compact", by_srow, by_drow, nullptr, nullptr, feat_c, el_c, er_c, sum, ret, gradout,
                                     grad_feat_c, grad_el_c, grad_er_c, fold_attn_l, row_rel_ptrs, num_rels, grad_bias, bias_rows,
                                     num_nodes, num_src_rows, num_dst_rows, H, D, slope, workspace, workspace_bytes, stream);
 }
 
 // The backward after het_rgat_aggregate_compact_runs: q_rows / q_sum / q_ref as that call left them, drow_nodes [num_dst_rows] the
 // destination node of every er row.  Workspace: het_rgat_backward_compact_workspace with num_edges = 0.
+// bytes of het_rgat_backward_compact_runs' workspace (builds the packs of by_srow on `stream` the first time when the attention
+// gradient is asked for: its partial rows are counted in workgroups); -1 on error
+extern "C" int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t H, int64_t D,
+                                                            int with_bias, int with_attn_grad, het_stream stream) {
+  if (!by_srow) return -1;
+  int64_t bytes = het_rgat_backward_compact_workspace(num_nodes, 0, H, D, with_bias);
+  if (with_attn_grad && by_srow->E > 0) {
+    if (grouping_packs(by_srow, (hipStream_t)stream) != HET_OK) return -1;
+    bytes += (int64_t)sizeof(float) * ((attn_grad_partial_rows(by_srow, H * D) * (H * D + 1) + 3) / 4 * 4);
+  }
+  return bytes;
+}
+
 extern "C" int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_rows, const float* q_sum, const float* q_ref,
                                               const int64_t* drow_nodes, const float* feat_c, const float* el_c, const float* er_c,
                                               const float* sum, const float* ret, const float* gradout, float* grad_feat_c,
                                               float* grad_el_c, float* grad_er_c, const float* fold_attn_l,
                                               const int64_t* row_rel_ptrs, int64_t num_rels, float* grad_bias, int64_t bias_rows,
                                               int64_t num_nodes, int64_t num_src_rows, int64_t num_dst_rows, int64_t H, int64_t D,
-                                              double slope, void* workspace, int64_t workspace_bytes, het_stream stream) {
+                                              double slope, float* grad_attn_l, void* workspace, int64_t workspace_bytes,
+                                              het_stream stream) {
   HET_REQUIRE(q_rows && q_sum && q_ref && (drow_nodes || num_dst_rows == 0), "het_rgat_backward_compact_runs: null argument");
   const RunSums runs{q_rows, q_sum, q_ref, drow_nodes};
-  return rgat_backward_compact_impl("het_rgat_backward_compact_runs", by_srow, nullptr, &runs, feat_c, el_c, er_c, sum, ret, gradout,
+  return rgat_backward_compact_impl("het_rgat_backward_compact_runs", by_srow, nullptr, &runs, grad_attn_l, feat_c, el_c, er_c, sum, ret, gradout,
                                     grad_feat_c, grad_el_c, grad_er_c, fold_attn_l, row_rel_ptrs, num_rels, grad_bias, bias_rows,
                                     num_nodes, num_src_rows, num_dst_rows, H, D, slope, workspace, workspace_bytes, stream);
 }

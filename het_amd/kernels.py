@@ -734,24 +734,35 @@ def rows_linear_bias(offsets, x, w, bias, out=None):
 
 
 def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c, slope,
-                          fold_attn_l=None, row_rel_ptrs=None, grad_bias=None, bias_rows=0, runs=None, drow_nodes=None):
+                          fold_attn_l=None, row_rel_ptrs=None, grad_bias=None, bias_rows=0, runs=None, drow_nodes=None,
+                          grad_attn_l=None):
     """runs = (q_rows, q_sum, q_ref) of rgat_aggregate_compact in the run-sum form, drow_nodes [S_col] int64 the destination of
-    every er row: grad_er_c from the run sums (het_rgat_backward_compact_runs)."""
+    every er row: grad_er_c from the run sums (het_rgat_backward_compact_runs).  grad_attn_l [R,H,D] (run-sum form, with
+    fold_attn_l): also the weight gradient of el_c = <feat_c, attn_l[r]>, from the same pass."""
     _chk("rgat_backward_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, gradout, grad_feat_c, grad_el_c, grad_er_c,
-                                                    fold_attn_l, grad_bias) + (tuple(runs) if runs else ()) if t is not None),
+                                                    fold_attn_l, grad_bias, grad_attn_l) + (tuple(runs) if runs else ()) if t is not None),
          tuple(t for t in (row_rel_ptrs, drow_nodes) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
-    E = 0 if runs else groupings[1]._keep[1].numel()
-    nbytes = int(_lib.lib().het_rgat_backward_compact_workspace(N, E, H, D, int(grad_bias is not None)))
-    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device)
-    tail = (_p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), _p(gradout), _p(grad_feat_c), _p(grad_el_c), _p(grad_er_c),
-            _p(fold_attn_l), _p(row_rel_ptrs), 0 if row_rel_ptrs is None else row_rel_ptrs.numel() - 1, _p(grad_bias),
-            int(bias_rows), N, feat_c.shape[0], er_c.shape[0], H, D, float(slope), _p(ws), ws.numel() * 4, _stream(ret))
     if runs:
-        _call(ret, "het_rgat_backward_compact_runs", groupings[1].handle, _p(runs[0]), _p(runs[1]), _p(runs[2]), _p(drow_nodes), *tail)
+        with torch.cuda.device(ret.device):
+            nbytes = int(_lib.lib().het_rgat_backward_compact_runs_workspace(groupings[1].handle, N, H, D, int(grad_bias is not None),
+                                                                             int(grad_attn_l is not None), _stream(ret)))
+        if nbytes < 0:
+            raise _lib.HetError("het_rgat_backward_compact_runs_workspace: " + _lib.lib().het_last_error().decode())
     else:
-        _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, *tail)
+        assert grad_attn_l is None, "grad_attn_l comes with the run-sum form"
+        nbytes = int(_lib.lib().het_rgat_backward_compact_workspace(N, groupings[1]._keep[1].numel(), H, D, int(grad_bias is not None)))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device)
+    head = (_p(feat_c), _p(el_c), _p(er_c), _p(sum), _p(ret), _p(gradout), _p(grad_feat_c), _p(grad_el_c), _p(grad_er_c),
+            _p(fold_attn_l), _p(row_rel_ptrs), 0 if row_rel_ptrs is None else row_rel_ptrs.numel() - 1, _p(grad_bias),
+            int(bias_rows), N, feat_c.shape[0], er_c.shape[0], H, D, float(slope))
+    tail = (_p(ws), ws.numel() * 4, _stream(ret))
+    if runs:
+        _call(ret, "het_rgat_backward_compact_runs", groupings[1].handle, _p(runs[0]), _p(runs[1]), _p(runs[2]), _p(drow_nodes), *head,
+              _p(grad_attn_l), *tail)
+    else:
+        _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, *head, *tail)
 
 
 def hgt_compact_shape_ok(H: int, D: int) -> bool:

@@ -499,7 +499,7 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
  *     destination node of every er row.  Shapes: rows of 32 / 64 / 128 floats with heads of >= 16 (else HET_ERR_UNSUPPORTED).
  *   workspaces: het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream) -- one record per work item of
  *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel and
- *     rebuilt if it is later used with another by_dst object); -1 on error;  het_rgat_backward_compact_workspace(N, 0, H, D, .) */
+ *     rebuilt if it is later used with another by_dst object); -1 on error;  het_rgat_backward_compact_runs_workspace (below) */
 int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
                                                   int64_t H, int64_t D, het_stream stream);
 int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
@@ -513,7 +513,14 @@ int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_r
                                    float* grad_el_c, float* grad_er_c, const float* fold_attn_l, const int64_t* row_rel_ptrs,
                                    int64_t num_rels, float* grad_bias, int64_t bias_rows, int64_t num_nodes,
                                    int64_t num_src_rows, int64_t num_dst_rows, int64_t H, int64_t D, double slope,
-                                   void* workspace, int64_t workspace_bytes, het_stream stream);
+                                   float* grad_attn_l, void* workspace, int64_t workspace_bytes, het_stream stream);
+/* grad_attn_l [R,H,D] (optional; needs fold_attn_l, <= 8 relations): the weight gradient of el_c = <feat_c, attn_l[r]>,
+ *   SUM_u grad_el_c[u,h] feat_c[u,h,:] per relation, overwritten -- formed from the rows the source-row kernels hold where a
+ *   segment ends (per-workgroup partial rows + a finishing pass) instead of a row-dot pass that reads feat_c again.
+ * workspace: het_rgat_backward_compact_runs_workspace(by_srow, N, H, D, grad_bias != NULL, grad_attn_l != NULL, stream) bytes (the
+ *   first call with the attention gradient builds by_srow's packs on `stream`); -1 on error. */
+int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t H, int64_t D,
+                                                 int with_bias, int with_attn_grad, het_stream stream);
 
 /* The two halves of a2 (backward_rgnn_relational_matmul, one input head, matrix-core shapes) as separate calls, so that a
  * caller can order them around a collective (het_amd/dist.py).  Rows i in [0, num_rows) of relation-bucketed lists:

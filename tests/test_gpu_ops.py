@@ -338,14 +338,18 @@ def test_rgat_compact_run_sums(K, H, D, n, e, fold, bias):
     gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
     gb = torch.full((H * D,), float("nan"), device=DEV) if bias else None
     nb = N - 3
+    ga = torch.full((R, H, D), float("nan"), device=DEV) if fold else None  # (the attention-vector gradient from the same pass)
     k.rgat_backward_compact(grp, f, l, r_, sm, ret, go.to(DEV), gf, gl, gr, slope, fold_attn_l=attn.to(DEV) if fold else None,
                             row_rel_ptrs=ss["rel_ptrs_row"].to(DEV) if fold else None, grad_bias=gb, bias_rows=nb, runs=runs,
-                            drow_nodes=ss["node_indices_col"].to(DEV))
+                            drow_nodes=ss["node_indices_col"].to(DEV), grad_attn_l=ga)
     assert_close(gf, gf_r, what="grad_feat")
     assert_close(gl, gl_r, what="grad_el")
     assert_close(gr, gr_r, what="grad_er")
     if bias:
         assert_close(gb, to64(go).view(N, -1)[:nb].sum(0), what="grad_bias")
+    if fold:  # grad_attn_l[r,h,:] = SUM over the rows u of relation r of grad_el[u,h] * feat[u,h,:]
+        ga_r = torch.zeros(R, H, D, dtype=torch.float64).index_add_(0, rel_of_row, gl_r.unsqueeze(-1) * to64(feat))
+        assert_close(ga, ga_r, what="grad_attn_l")
     # the cache evicts and rebuilds the grouping by destination while the (destination, relation) one stays: the hub lists that
     # were built against the old object are rebuilt, same results
     import het_amd.plan as plan
