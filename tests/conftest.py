@@ -23,7 +23,7 @@ def pytest_collection_modifyitems(config, items):
 def load_golden(name):
     path = os.path.join(ROOT, "tests", "golden", name)
     z = np.load(path)
-    return {k: torch.from_numpy(z[k]) for k in z.files}
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "iuf" else z[k]) for k in z.files}
 
 
 @pytest.fixture(scope="session")
@@ -34,3 +34,9 @@ def golden_toy():
 @pytest.fixture(scope="session")
 def golden_mag():
     return load_golden("mag01_slice.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_mag_full():
+    """The whole shipped ogbn_mag_0.1 topology + reference outputs (tests/golden/make_golden.py::main_full)."""
+    return load_golden("mag01_full.npz")

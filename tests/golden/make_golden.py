@@ -22,9 +22,14 @@ What is pinned:
     ``grad_er`` (:64-65) are NOT pinned: they add ``slope`` to the leaky-ReLU
     derivative and drop the dot product, unlike the CUDA kernel they mirror.
 
-Two graphs: the 4-node toy graph of SURVEY.md section 10 and a slice of the
+Three fixtures: the 4-node toy graph of SURVEY.md section 10; a slice of the
 only real topology shipped with the reference, hrt/data/ogbn_mag_0.1/*.npy
-(first 4096 edges of each of the six relation files).
+(first 4096 edges of each of the six relation files), with every input and
+output stored; and that topology WHOLE (345 172 edges, the arrays the
+reference's own round-trip test loads, hrt/src/test_hyb.cu.cc:26-36) as
+mag01_full.npz: the edges as one [3, E] int32 array, the reference builders'
+layouts as SHA-256 digests, the reference's float outputs in full; its float
+inputs are regenerated from seeds on the test side (tests/golden/recipe.py).
 
 Usage: python tests/golden/make_golden.py
 """
@@ -37,6 +42,8 @@ import torch
 
 REF = "/root/reference/hrt"
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import recipe  # noqa: E402
 
 
 def load(path, name):
@@ -127,6 +134,60 @@ def gat_compact_exp_sum(lay, num_nodes, H, seed):
     return {"gatc_el": el_c, "gatc_er": er_c, "gatc_exp": exp, "gatc_sum": s}
 
 
+def main_full():
+    """The whole shipped topology (fixture 2)."""
+    import json
+    parts = []
+    for r, n in enumerate(recipe.MAG01_RELATIONS):
+        a = np.load(os.path.join(REF, "data/ogbn_mag_0.1", f"{n}_coo_2.npy"))
+        assert a.dtype == np.int32 and a.shape[0] == 2
+        parts.append(np.concatenate([a, np.full((1, a.shape[1]), r, dtype=np.int32)], axis=0))
+    coo3 = np.ascontiguousarray(np.concatenate(parts, axis=1))  # [3, E]: row (source), col (destination), relation; file order
+    row, col, rel, eids, n, R = recipe.integrated_coo(coo3)
+    E = row.numel()
+    lay = layouts(row, col, rel, eids, R)
+    H, D = recipe.H, recipe.D
+    inp = recipe.gat_inputs(E, n, lay["ss_node_indices_row"].numel(), lay["ss_node_indices_col"].numel())
+    out = {"coo": coo3, "num_nodes": np.int64(n), "num_rels": np.int64(R)}
+    # -- layouts: digests of everything, the small arrays also in full
+    dig = {}
+    for k in ("sep_rel_ptrs", "sep_row", "sep_col", "sep_eids", "ss_node_indices_row", "ss_rel_ptrs_row", "ss_node_indices_col",
+              "ss_rel_ptrs_col", "ss_inverse_indices_row", "ss_inverse_indices_col", "ts_node_indices", "ts_rel_ptrs",
+              "ts_inverse_indices", "csr_row_ptrs", "tcsr_row_ptrs"):
+        dig[k] = recipe.digest(lay[k])
+    for pre in ("csr", "tcsr"):  # rows as multisets: entries sorted by (col, rel, eid) inside every row (recipe.canonical_csr)
+        c, r_, e = recipe.canonical_csr(lay[pre + "_row_ptrs"], lay[pre + "_col"], lay[pre + "_rel"], lay[pre + "_eids"])
+        dig[pre + "_col_canonical"], dig[pre + "_rel_canonical"], dig[pre + "_eids_canonical"] = (recipe.digest(c), recipe.digest(r_),
+                                                                                                  recipe.digest(e))
+    for k in ("sep_rel_ptrs", "ss_rel_ptrs_row", "ss_rel_ptrs_col", "ts_rel_ptrs"):
+        out[k] = lay[k]
+    out["csr_row_ptrs"] = lay["csr_row_ptrs"].to(torch.int32)
+    out["tcsr_row_ptrs"] = lay["tcsr_row_ptrs"].to(torch.int32)
+    # -- the reference's float outputs on the regenerated inputs
+    for k, v in inp.items():
+        dig["input_" + k] = recipe.digest(v)
+    s, exp, ret = torch.zeros(n, H), torch.zeros(E, H), torch.zeros(n, H, 2)
+    feat = torch.zeros(max(E, n), H, 2)  # feeds the (discarded) ret only
+    ar = torch.arange(E)
+    ref_rgat.relational_fused_gat_separate_coo(ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"], feat, inp["gat_el"],
+                                              inp["gat_er"], s, exp, ret, recipe.SLOPE)
+    out["gat_exp"], out["gat_sum"] = exp, s
+    gfs = torch.zeros(n, H, D)
+    ref_rgat.backward_relational_fused_gat_separate_coo(ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"], torch.zeros(n, H, D),
+                                                       inp["gat_el"].unsqueeze(-1), inp["gat_er"].unsqueeze(-1), s, exp,
+                                                       torch.zeros(n, H, D), inp["gatb_gradout"], gfs, torch.zeros(E, H, D),
+                                                       torch.zeros(E, H, D), recipe.SLOPE)
+    out["gatb_grad_feat_src"] = gfs
+    s2, exp2 = torch.zeros(n, H), torch.zeros(E, H)
+    ref_rgat.towrap_relational_fused_gat_kernel_compact_as_of_node_separate_coo_dual_unique_node_list(
+        lay["ss_inverse_indices_row"], lay["ss_inverse_indices_col"], ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"],
+        lay["ss_rel_ptrs_row"], lay["ss_rel_ptrs_col"], lay["ss_node_indices_row"], lay["ss_node_indices_col"],
+        torch.zeros(n, H, 2), inp["gatc_el"], inp["gatc_er"], s2, exp2, torch.zeros(n, H, 2), recipe.SLOPE)
+    out["gatc_exp"], out["gatc_sum"] = exp2, s2
+    out["digests_json"] = np.array(json.dumps(dig, sort_keys=True))
+    save("mag01_full.npz", out)
+
+
 def save(name, d):
     arrs = {}
     for k, v in d.items():
@@ -168,6 +229,7 @@ def main():
     lay.update(gat_compact_exp_sum(lay, n, 4, seed=22))
     lay["num_nodes"], lay["num_rels"] = torch.tensor(n), torch.tensor(6)
     save("mag01_slice.npz", lay)
+    main_full()
 
 
 if __name__ == "__main__":

@@ -255,7 +255,7 @@ def test_hgt_layer_large_scores_stay_finite(monkeypatch):
     _run_hgt_fused(True, False, 4, 64, 64, monkeypatch, pri=(150.0, 300.0))
 
 
-def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri=(0.5, 1.5)):
+def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri=(0.5, 1.5), g=None):
     """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
     (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
     (BASELINE.json configs[3]: feat 64, heads 8) -- against the fp64 oracle: output and the gradients of the input and of all
@@ -265,7 +265,7 @@ def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri
     from het_amd.backend import hgt_fused_layer
     from het_amd.layers import HET_HGTLayerHetero
     monkeypatch.setattr(hgt_fused_layer, "COMPACT_DST_BELOW", 2.0 if compact_dst else 0.0)
-    g = mag_graph(1.5e-3)
+    g = mag_graph(1.5e-3) if g is None else g
     torch.manual_seed(4)
     N, R, T = g.get_num_nodes(), g.get_num_rels(), g.get_num_ntypes()
     layer = HET_HGTLayerHetero(T, R, in_dim, out_dim, num_heads=H, dropout=0.0, hgt_fused_attn_score_flag=fused_attn)
