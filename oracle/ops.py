@@ -26,7 +26,11 @@ unpinned", except:
 Where the CUDA code deviates from the reference's own stated intent (its DSL
 specs hrt/pyctor/examples/inter-op-dsl/*.inter-op and in-code TODO/FIXMEs) the
 oracle implements the INTENDED semantics; each such position is listed in
-DESIGN.md ("Reference quirks") with its SURVEY.md section-9 id.
+DESIGN.md ("Reference quirks") with its SURVEY.md section-9 id.  The ops with a deterministic
+quirk (Q3, Q4, Q6, Q7) also take ``reference_literal=True``: what the CUDA code computes as written,
+index for index, so that the distance between the two readings can be measured
+(tests/test_oracle.py::test_reference_literal_distance_on_the_shipped_topology; DESIGN.md section 3).
+Nothing in het_amd implements the literal readings.
 """
 from __future__ import annotations
 
@@ -299,12 +303,17 @@ def rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, W, norm, ret) -> None:
         ret.index_add_(0, col[a:b], msg)
 
 
-def backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, Wt, norm, grad_norm, grad_x, gradout, grad_W) -> None:
+def backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, Wt, norm, grad_norm, grad_x, gradout, grad_W,
+                                      reference_literal: bool = False) -> None:
     """grad_x[row[i]] += (gradout[col[i]] * norm[eids[i]]) @ Wt[r]       (intended direction, SURVEY Q3:
                         the CUDA code gathers gradout by row and scatters to col)
     grad_W[r]       += (x[row[i]] * norm[eids[i]])^T (x) gradout[col[i]]
     grad_norm is left untouched (the reference disables that output,
-    my_shmem_sgemm_func_rgcn_hgt.cu.h:680-684).  RGCNOps.inc.h:368-467."""
+    my_shmem_sgemm_func_rgcn_hgt.cu.h:680-684).  RGCNOps.inc.h:368-467.
+    reference_literal: grad_x[col[i]] += (gradout[row[i]] * norm[eids[i]]) @ Wt[r] -- the kernel's A_gather_list is
+    separate_coo_row_idx and its C_scatter_list separate_coo_col_idx in the non-outer-product case
+    (my_shmem_sgemm_func_rgcn_hgt.cu.h:118-125, launched for this op at :680-698 with the forward's COO); grad_W as above
+    (outer-product case: A by row, B by col -- correct as coded)."""
     R = Wt.shape[0]
     nv = norm.reshape(-1)
     for r in range(R):
@@ -313,7 +322,10 @@ def backward_rgcn_layer1_separate_coo(rel_ptrs, eids, row, col, x, Wt, norm, gra
             continue
         sc = nv[eids[a:b]].unsqueeze(-1)
         g = gradout[col[a:b]] * sc
-        grad_x.index_add_(0, row[a:b], g @ Wt[r])
+        if reference_literal:
+            grad_x.index_add_(0, col[a:b], (gradout[row[a:b]] * sc) @ Wt[r])
+        else:
+            grad_x.index_add_(0, row[a:b], g @ Wt[r])
         grad_W[r] += (x[row[a:b]]).t() @ g
 
 
@@ -328,12 +340,19 @@ def _rgcn_compact_rows(d, direct: bool, rel_ptrs, row, eids):
 
 
 def rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(eids, rel_ptrs, row, col, d, feat, enorm, ret,
-                                                               direct: bool) -> None:
+                                                               direct: bool, reference_literal: bool = False) -> None:
     """ret[col[i], :] += enorm[eids[i]] * feat[compact_row(rel(i), row[i]), :]
     RGCNOps.inc.h:24-82; kernel RGCN/RGCNKernelsEdgeParallel.cu.h:20-92 (which indexes feat by
     the raw src id -- its own TODO; intended mapping used here).  ``ret`` zeroed
-    here (allocated with th.empty by the caller, rgcn_layers_and_funcs.py:763-768)."""
-    fr = _rgcn_compact_rows(d, direct, rel_ptrs, row, eids)
+    here (allocated with th.empty by the caller, rgcn_layers_and_funcs.py:763-768).
+    reference_literal: feat row = row[i], the raw source id (RGCNKernelsEdgeParallel.cu.h:53-56 ``feat_src_entry_id =
+    src_vid``) -- defined only while every source id is below the number of compact rows (it reads out of bounds otherwise;
+    refused here)."""
+    if reference_literal:
+        assert not row.numel() or int(row.max()) < feat.shape[0], "the literal reading indexes the compact tensor out of bounds here"
+        fr = row
+    else:
+        fr = _rgcn_compact_rows(d, direct, rel_ptrs, row, eids)
     ret.zero_()
     ret.view(ret.shape[0], -1).index_add_(0, col, enorm.reshape(-1)[eids].unsqueeze(-1) * feat.reshape(feat.shape[0], -1)[fr])
 
@@ -391,13 +410,27 @@ def backward_inner_product_right_node_separatecoo(d, kind: int, rel_ptrs, eids, 
 # --------------------------------------------------------------------------
 # a10  HGT edge softmax with per-relation temperature mu
 # --------------------------------------------------------------------------
-def hgt_full_graph_edge_softmax_ops_separate_coo(row, col, eids, rel_ptrs, score, mu, sum_, m, a) -> None:
+def hgt_full_graph_edge_softmax_ops_separate_coo(row, col, eids, rel_ptrs, score, mu, sum_, m, a,
+                                                 reference_literal: bool = False) -> None:
     """m[eid,h] = exp(score[eid,h] * mu[r,h]);  sum[dst,h] = SUM over in-edges of dst;  a = m / sum[dst].
     Denominator keyed by the DESTINATION (col) over all E edges -- the intended semantics (the CUDA code
     keys by row_indices and drops the last edge).  HGTOpsEdgeParallel.inc.h:18-31 ->
-    HGTOps.inc.h:23-106; kernels HGT/HGTForwardKernels.cu.h:594-761."""
+    HGTOps.inc.h:23-106; kernels HGT/HGTForwardKernels.cu.h:594-761.
+    reference_literal: the launcher passes ``numel() - 1`` of the row-index array as the edge count (HGTOps.inc.h:70-71: the
+    argument doubles as a CSR row-pointer array in the vertex-parallel twin), so the LAST position is never visited (its m and a
+    keep what the caller's buffers held), and both kernels key the denominator by ``row_indices`` (HGTForwardKernels.cu.h:619
+    accumulates into sum[row[i]], :722 divides by it): a softmax over the OUT-edges of the source.  ``sum`` is accumulated into
+    as given (no fill in the launcher)."""
     H = score.shape[1]
     rel = rel_of_position(rel_ptrs)
+    if reference_literal:
+        n = max(0, eids.numel() - 1)
+        e, r_, key = eids[:n], rel[:n], row[:n]
+        mm = torch.exp(score.reshape(-1, H)[e] * mu.reshape(-1, H)[r_])
+        m.view(-1, H)[e] = mm
+        sum_.view(-1, H).index_add_(0, key, mm)
+        a.view(-1, H)[e] = mm / sum_.view(-1, H)[key]
+        return
     mm = torch.exp(score.reshape(-1, H)[eids] * mu.reshape(-1, H)[rel])
     m.view(-1, H)[eids] = mm
     sum_.zero_()
@@ -406,13 +439,35 @@ def hgt_full_graph_edge_softmax_ops_separate_coo(row, col, eids, rel_ptrs, score
 
 
 def backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(row, col, eids, rel_ptrs, score, a, grad_a,
-                                                                          mu, grad_score, grad_mu, tmp) -> None:
+                                                                          mu, grad_score, grad_mu, tmp,
+                                                                          reference_literal: bool = False) -> None:
     """tmp[dst,h] = SUM_in-edges a*grad_a;  c = (grad_a - tmp[dst]) * a;
     grad_score[eid,h] = c * mu[r,h];  grad_mu[r,h] += SUM c * score[eid,h].
     Intended formulas from the kernel's own comments (HGT/HGTBackwardKernels.cu.h:161-168, 309-312;
-    the code omits '* score' and loops over a fraction of the edges).  HGTOps.inc.h:597-648."""
+    the code omits '* score' and loops over a fraction of the edges).  HGTOps.inc.h:597-648.
+    reference_literal: the kernel is launched on the type-1 schedule (ThreadingGridsBlocksSchedules.h:9-26: threads (1, 32),
+    blocks (H, G), G = min(ceil(E / 32), 65535)) but its loops start at ``threadIdx`` alone (HGTBackwardKernels.cu.h:270 ``e =
+    threadIdx.y; e += blockDim.y * gridDim.y``, :290 ``head_idx = threadIdx.x; += blockDim.x * gridDim.x``): every one of the
+    H * G blocks visits the SAME positions e = t + 32 G k (t < 32) and head 0 only.  Stage 0 therefore adds grad_a * a of those
+    (position, head 0) pairs H * G times into tmp[row[e], 0] (keyed by the source, :304); stage 1 stores grad_score[eid, 0] =
+    (grad_a - tmp[row[e], 0]) * a * mu (idempotent) and adds (grad_a - tmp) * a -- without ``* score``, :325-329 -- H * G times
+    into grad_mu[r, 0].  Every other (edge, head) of grad_score keeps what the caller's buffer held; tmp and grad_mu are
+    accumulated into as given."""
     H = score.shape[1]
     rel = rel_of_position(rel_ptrs)
+    if reference_literal:
+        E = eids.numel()
+        G = min((E + 31) // 32, 65535)
+        pos = torch.arange(E)
+        pos = pos[(pos % (32 * G)) < 32] if G else pos[:0]
+        e, r_, key = eids[pos], rel[pos], row[pos]
+        av, gv = a.reshape(-1, H)[e, 0], grad_a.reshape(-1, H)[e, 0]
+        times = float(H * G)
+        tmp.view(-1, H)[:, 0].index_add_(0, key, times * av * gv)
+        c = (gv - tmp.view(-1, H)[key, 0]) * av
+        grad_score.view(-1, H)[e, 0] = c * mu.reshape(-1, H)[r_, 0]
+        grad_mu.view(-1, H)[:, 0].index_add_(0, r_, times * c)
+        return
     av, gv = a.reshape(-1, H)[eids], grad_a.reshape(-1, H)[eids]
     tmp.zero_()
     tmp.view(-1, H).index_add_(0, col, av * gv)
@@ -440,11 +495,15 @@ def hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(rel_ptrs
 
 def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(rel_ptrs, eids, row, col, v, Wt, a,
                                                                                  new_h, grad_v, grad_W, grad_a,
-                                                                                 gradout) -> None:
+                                                                                 gradout, reference_literal: bool = False) -> None:
     """grad_v[row[i],h,:] += (gradout[col[i],h,:] * a) @ Wt[r,h]      (intended direction, same quirk as SURVEY Q3)
     grad_W[r,h]        += (v[row[i],h,:] * a)^T (x) gradout[col[i],h,:]
     grad_a[eids[i],h]   = < gradout[col[i],h,:] @ Wt[r,h], v[row[i],h,:] >
-    HGTOpsEdgeParallel.inc.h:295-369; kernels my_shmem_sgemm_func_rgcn_hgt.cu.h:747-816."""
+    HGTOpsEdgeParallel.inc.h:295-369; kernels my_shmem_sgemm_func_rgcn_hgt.cu.h:747-816.
+    reference_literal (Q3 on this op): the input-gradient kernel (:780-816) gathers A = gradout by ``row`` scaled by a
+    (:391-400), scatters C to ``col`` (:118-125) and takes its inner-product term from v at the C row (:230-237):
+    grad_v[col[i],h,:] += (gradout[row[i],h,:] * a) @ Wt[r,h];  grad_a[eids[i],h] += < (gradout[row[i],h,:] * a) @ Wt[r,h],
+    v[col[i],h,:] > (atomicAdd into the caller's buffer, :577).  grad_W as above."""
     R, H, do, dk = Wt.shape
     N = gradout.shape[0]
     for r in range(R):
@@ -454,6 +513,12 @@ def backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo
         av = a.reshape(-1, H)[eids[a0:b0]].unsqueeze(-1)
         go = gradout.reshape(N, H, do)[col[a0:b0]]
         vv = v.reshape(v.shape[0], H, dk)[row[a0:b0]]
+        if reference_literal:
+            back_l = torch.einsum("nhd,hdk->nhk", gradout.reshape(N, H, do)[row[a0:b0]] * av, Wt[r])
+            grad_v.view(v.shape[0], H, dk).index_add_(0, col[a0:b0], back_l)
+            grad_W[r] += torch.einsum("nhk,nhd->hkd", vv * av, go)
+            grad_a.view(-1, H).index_add_(0, eids[a0:b0], (back_l * v.reshape(v.shape[0], H, dk)[col[a0:b0]]).sum(-1))
+            continue
         back = torch.einsum("nhd,hdk->nhk", go, Wt[r])
         grad_v.view(v.shape[0], H, dk).index_add_(0, row[a0:b0], back * av)
         grad_W[r] += torch.einsum("nhk,nhd->hkd", vv * av, go)
