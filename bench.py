@@ -28,6 +28,305 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6
 HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs at 2.4 GHz)
 
+PROF_ROUND = "r04"
+
+
+def kernel_source_sha16():
+    """Digest of het_amd/csrc/* (as profiles/tools/summarize.py records it with the counters)."""
+    import hashlib
+    root = os.path.join(ROOT, "het_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_views(args, world, prof_tag, default_heads, heads=None):
+    """(pmc, hbm_view) for one workload: prof_tag names the committed counter file profiles/<round>/<prof_tag>_pmc.json
+    ({default, compact, ..., rgcn, hgt})."""
+    prof_dir = os.path.join(ROOT, "profiles", PROF_ROUND)
+    tree_sha = kernel_source_sha16()
+    heads = args.heads if heads is None else heads
+
+    def pmc(kernel, field):
+        """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/<round>/,
+        written by profiles/tools/collect.sh on an earlier box): rocprofv3 cannot run inside the timed process, so
+        this is not an observation of this run -- the JSON says so (`traffic_source`).  None when no committed
+        profile matches this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
+        path = os.path.join(prof_dir, f"{prof_tag}_pmc.json")
+        if (args.scale != 1.0 or world != 1 or args.feat != 64 or heads != default_heads or args.edge_order != "src_dst"
+                or not os.path.exists(path)):
+            return None
+        prof = json.load(open(path))
+        if prof.get("kernel_source_sha16") != tree_sha:
+            return None  # the kernels changed since those counters were collected: a stale figure is worse than none
+        kernels = prof["kernels"]
+        if isinstance(kernel, (tuple, list)):  # an op implemented by several launches per step: the sum over them
+            parts = [pmc(k_, field) for k_ in kernel]
+            return None if any(p_ is None for p_ in parts) else sum(parts)
+        recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in kernels.items() if k.startswith(kernel) and field in v]
+        return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel
+
+    def hbm_view(kernel, k_ms, nbytes, extra=None, pmc_name=None):
+        ach = nbytes / (k_ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
+             "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(nbytes),
+             "traffic": pmc(pmc_name or kernel.split(" ")[0], "hbm_bytes_per_launch")}
+        r["traffic_source"] = (f"profiles/{PROF_ROUND}/{prof_tag}_pmc.json (committed rocprofv3 --pmc passes of this command on "
+                               "another box; not measured in this run)") if r["traffic"] else None
+        if r["traffic"]:
+            r["traffic_rate_GBps"] = round(r["traffic"] / (k_ms * 1e-3) / 1e9, 1)
+        if extra:
+            r.update(extra)
+        return r
+
+    return pmc, hbm_view
+
+
+GATHER_ROW_RATE_GBS = 6100.0  # MI355X_MICROARCH.md "Indexed rows": whole rows of a table larger than the Infinity Cache, each
+                              # fetched once: 5.5-5.8 TB/s gathered into registers, 6.0-6.1 TB/s swept in order into LDS
+
+
+def gather_ceiling(nbytes, rows_gathered, row_bytes):
+    """What `frac` can reach while every edge's row crosses the memory fabric: the op needs at least rows_gathered * row_bytes
+    of row traffic at the chip's gather rate (the L2-window experiment of profiles/r04/locality_*.txt: an L2-RESIDENT table
+    buys the round-3 kernels 21 % forward / 7 % backward, so blocking for locality cannot lift this by much)."""
+    t_ms = rows_gathered * row_bytes / GATHER_ROW_RATE_GBS / 1e6
+    return {"ceiling_frac": round(nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ceiling_ms": round(t_ms, 4),
+            "ceiling_what": f"{rows_gathered} gathered rows x {row_bytes} B at {GATHER_ROW_RATE_GBS / 1e3:.1f} TB/s (guide's rate for "
+                            "rows that miss the Infinity Cache); frac / ceiling_frac = how close the op is to that"}
+
+
+KT_NAMES = ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs",
+            "HET_rgat_backward_src", "HET_rgat_backward", "HET_rgat_aggregate_packs", "HET_rgat_aggregate_hubs",
+            "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
+            "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
+            "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
+            "HET_node_dx", "HET_hgt_node_dx",
+            "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long")
+
+
+def read_kernel_timers(ksteps):
+    """{timer label: (avg ms per launch, launches per step, ms per step)} of the library's per-kernel HIP-event timers."""
+    from het_amd import _lib as HL
+    kt = {}
+    for name in KT_NAMES:
+        ms, n = HL.kernel_timing_read(name)
+        if n:
+            kt[name] = (ms / n, n / ksteps, ms / ksteps)
+    return kt
+
+
+def rgcn_rooflines(g, kt, E_local, N_local, K, X, hbm_view):
+    """RGCN (BASELINE.json configs[1]): the step is two gather-sums (x[src] * norm per (relation, destination) forward,
+    gradout[dst] * norm per (relation, source) backward) + GEMMs on the distinct rows.  a7 / a8 bytes per SURVEY.md 8d
+    (U_src = distinct source nodes); the gather passes move one 256-byte row per edge like RGAT's."""
+    sc = g.get_separate_coo_original()
+    U_src = int(torch.unique(sc["row_indices"]).numel())
+    R_ = g.get_num_rels()
+    a7 = E_local * (3 * 8 + 4) + U_src * 4 * K + N_local * 4 * X + 4 * R_ * K * X
+    a8 = E_local * 28 + (U_src + N_local) * 4 * (K + X) + 8 * R_ * K * X
+    ss_ms = kt["HET_segment_sum"][0]  # one launch per op
+    note = ("kernel_ms = the gather-sum launches of one op (average of the forward and the backward one); the op's GEMMs on "
+            "the distinct rows are separate launches (kernel_ms).  requested_bytes counts one row per edge: the rate at "
+            "the kernels' load instructions, part of it served by L2 / Infinity Cache (the [N,64] table is 0.5 GB and "
+            "the degrees are Zipf-skewed), so it may exceed what HBM delivers")
+    pm = ("HET_segment_sum_packed", "HET_segment_sum_long")
+    bwd = hbm_view("HET_segment_sum_packed + _long (backward_rgcn_layer1_separate_coo: gradout rows by (relation, source))",
+                   ss_ms, a8, {"requested_bytes_one_row_per_edge": int(E_local * (4 * X + 12) + a8),
+                               "requested_rate_GBps": round((E_local * (4 * X + 12) + a8) / (ss_ms * 1e-3) / 1e9, 1),
+                               "note": note, **gather_ceiling(a8, E_local, 4 * X)}, pmc_name=pm)
+    fwd = hbm_view("HET_segment_sum_packed + _long (rgcn_layer1_separate_coo: x rows by (relation, destination))", ss_ms, a7,
+                   {"requested_bytes_one_row_per_edge": int(E_local * (4 * K + 12) + a7),
+                    "requested_rate_GBps": round((E_local * (4 * K + 12) + a7) / (ss_ms * 1e-3) / 1e9, 1),
+                    **gather_ceiling(a7, E_local, 4 * K)}, pmc_name=pm)
+    return bwd, fwd
+
+
+def hgt_rooflines(g, kt, E_local, N_local, K, X, H, hbm_view):
+    """HGT (BASELINE.json configs[3]): attention + aggregation on the distinct (relation, source) rows (csrc/hgt_compact.hip).
+    Algorithmic bytes: every tensor of the pass once (kv_c [S_row,2X], q / out / gradout [N,X], per-(node, head) scalars,
+    two 8-byte indices per edge); the passes gather one 2X-float row (forward, destination side) or two X-float rows
+    (source side) PER EDGE from tables larger than the Infinity Cache -- bytes_with_per_edge_row_gather counts those."""
+    ss = g.get_separate_unique_node_indices_single_sided()
+    S_row = int(ss["node_indices_row"].numel())
+    kvb, nxb, nhb = S_row * 2 * X * 4, N_local * X * 4, N_local * H * 4
+    f_b = kvb + 2 * nxb + nhb + E_local * 16
+    d_b = kvb + 4 * nxb + 3 * nhb + E_local * 16            # reads kv_c, q, gradout, out, lsum; writes grad_q, pack2
+    s_b = 2 * kvb + 2 * nxb + 2 * nhb + E_local * 16        # reads kv_c, q, gradout, pack2; writes grad_kv_c
+    f_req = f_b + (E_local - S_row) * 2 * X * 4
+    d_req = d_b + (E_local - S_row) * 2 * X * 4
+    s_req = s_b + (E_local - N_local) * (2 * X * 4 + 8 * H)
+    b_ms = sum(kt[n][2] for n in ("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long") if n in kt)
+    note = ("requested_bytes counts one gathered row per edge: the rate at the kernels' load instructions, part of it served by "
+            "L2 / Infinity Cache (kv_c is 1.2 GB, q / gradout 0.5 GB each, degrees Zipf-skewed), so it may exceed what HBM "
+            "delivers; `traffic` is what crossed the memory fabric")
+    ex = lambda req, ms, rows: {"S_row": S_row, "requested_bytes_one_row_per_edge": int(req),  # noqa: E731
+                                "requested_rate_GBps": round(req / (ms * 1e-3) / 1e9, 1), "note": note, **rows}
+    bwd = hbm_view("HET_hgt_backward_dst_rows + _src_short + _src_long (het_hgt_backward_compact: softmax + aggregation backward "
+                   "of the HGT layer, three launches)", b_ms, d_b + s_b, ex(d_req + s_req, b_ms, gather_ceiling(d_b + s_b, 2 * E_local, 2 * X * 4)),
+                   pmc_name=("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"))
+    f_ms = kt["HET_hgt_aggregate_rows"][2]
+    fwd = hbm_view("HET_hgt_aggregate_rows (het_hgt_aggregate_compact: score, edge softmax, message aggregation)",
+                   f_ms, f_b, ex(f_req, f_ms, gather_ceiling(f_b, E_local, 2 * X * 4)))
+    return bwd, fwd
+
+
+def other_model(model, args, coo, dev, world):
+    """BASELINE.json configs[1] (RGCN) / configs[3] (HGT, 8 heads) on the same graph, timed like the headline (barrier, K steps,
+    barrier) with fewer steps, with their own rooflines: the driver's default run then carries a number for every single-GPU
+    config, not only the headline."""
+    from het_amd import _lib as HL
+    from het_amd.graph import HetGraph
+    E, N, K = coo.num_edges, coo.num_nodes, args.feat
+    X, H = K, 8 if model == "hgt" else 1
+    g = HetGraph.from_integrated_coo(coo, full=model == "hgt")
+    torch.manual_seed(0)
+    extra = ()
+    if model == "rgcn":
+        from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
+        layer = HET_EglRelGraphConv_EdgeParallel(K, X, g.get_num_rels()).to(dev)
+        extra = (torch.rand(E, 1, device=dev),)
+    else:
+        from het_amd.layers import HET_HGTLayerHetero
+        layer = HET_HGTLayerHetero(g.get_num_ntypes(), g.get_num_rels(), K, X, num_heads=H, dropout=0.0).to(dev)
+    embed = torch.nn.Parameter(torch.empty(N, K, device=dev))
+    torch.nn.init.xavier_uniform_(embed)
+    go = torch.randn(N, X, device=dev)
+
+    def step():
+        for q in layer.parameters():
+            q.grad = None
+        embed.grad = None
+        layer(g, embed, *extra).backward(go)
+
+    steps = max(3, min(args.steps, 10))
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    HL.kernel_timing(True)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    HL.kernel_timing(False)
+    kt = read_kernel_timers(3)
+    _, view = make_views(args, world, model, 8 if model == "hgt" else 4, heads=8 if model == "hgt" else 4)
+    rb = rf = None
+    if model == "rgcn" and "HET_segment_sum" in kt:
+        rb, rf = rgcn_rooflines(g, kt, E, N, K, X, view)
+    if model == "hgt" and "HET_hgt_aggregate_rows" in kt:
+        rb, rf = hgt_rooflines(g, kt, E, N, K, X, H, view)
+    res = {"config": f"{model.upper()} layer fwd+bwd, same graph, feat={K}" + (f", heads={H}" if model == "hgt" else "") +
+                     " (BASELINE.json configs[%d]); layer swap: het_amd.layers.%s" % (3 if model == "hgt" else 1, type(layer).__name__),
+           "ms_per_step": round(dt * 1e3, 4), "million_edges_per_s": round(E / dt / 1e6, 2), "steps": steps, "warmup": 3,
+           "roofline": rb, "roofline_forward": rf,
+           "kernel_ms": {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}}
+    del layer, embed, go, g
+    torch.cuda.empty_cache()
+    return res
+
+
+def edge_order_random(args, dev):
+    """The headline layer on the same synthetic graph with every relation's edges in GENERATION order (SURVEY.md 8d's wording;
+    --edge-order random) instead of the sorted lists OGB ships: same edges, same counts, other list order."""
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    coo = make_mag_like(scale=args.scale, edge_order="random")
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    g = HetGraph.from_integrated_coo(coo, full=args.variant.startswith("compact"))
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(args.feat, args.feat, g.get_num_rels(), args.heads, self_loop=True, dropout=0.0, **layer_flags(args.variant)).to(dev)
+    embed = torch.nn.Parameter(torch.empty(coo.num_nodes, args.feat, device=dev))
+    torch.nn.init.xavier_uniform_(embed)
+    go = torch.randn(coo.num_nodes, args.feat, device=dev)
+
+    def step():
+        for q in layer.parameters():
+            q.grad = None
+        embed.grad = None
+        layer(g, embed).backward(go)
+
+    steps = max(3, min(args.steps, 10))
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    E = coo.num_edges
+    del layer, embed, go, g
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 4), "million_edges_per_s": round(E / dt / 1e6, 2), "steps": steps,
+            "what": "same layer, same edges, each relation's list in generation order (make_mag_like(edge_order='random'))"}
+
+
+def dry_run_exchange(args):
+    """`bench.py --gpus N --dry-run-exchange` under torch.distributed.run: the launch line, the rendezvous, every rank's plan of
+    the N-way partition and one halo exchange each way, on HOST tensors over gloo (no GPU is touched, no layer runs): rank 0
+    prints the `dist` object the real run prints, with checksums that prove every halo row arrived from its owner and every
+    returned gradient row reached it.  For rehearsing rank counts a one-GPU box cannot hold (its GPU takes 6 processes)."""
+    import torch.distributed as dist
+    from het_amd.dist import HaloExchange, build_plan
+    from het_amd.synth import make_mag_like
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(1, world)))
+    if "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo")
+    try:
+        coo = make_mag_like(scale=args.scale, edge_order=args.edge_order)
+        plan = build_plan(coo, rank, world)
+        K = args.feat
+        own = plan.node_order[int(plan.bounds[rank]): int(plan.bounds[rank + 1])]
+        # feature row of global node v = v + column / 1024: a received halo row names the node it belongs to
+        x_own = (own.to(torch.float64).unsqueeze(1) + torch.arange(K, dtype=torch.float64) / 1024.0).requires_grad_(True)
+        x_local = HaloExchange.apply(x_own, plan, None)
+        # halo_global holds renumbered ids: node_order maps them back to original ids
+        want = plan.node_order[plan.halo_global].to(torch.float64)
+        push_ok = bool(torch.equal(x_local[plan.n_own:, 0].detach(), want)) and bool(torch.equal(x_local[: plan.n_own].detach(), x_own.detach()))
+        # backward: every rank returns gradient 1 for each of its halo rows; an owner's row gets 1 + the number of ranks that hold it
+        x_local.backward(torch.ones_like(x_local))
+        holders = torch.zeros(coo.num_nodes, dtype=torch.float64)
+        for r in range(world):  # (every rank can derive every other rank's plan: no communication)
+            pr = plan if r == rank else build_plan(coo, r, world)
+            holders[pr.node_order[pr.halo_global]] += 1.0
+        ret_ok = bool(torch.equal(x_own.grad[:, 0], 1.0 + holders[own]))
+        mine = {"rank": rank, "owned_nodes": int(plan.n_own), "halo_rows_received": int(plan.n_halo), "halo_rows_sent": int(plan.send_idx.numel()),
+                "halo_MB_sent_per_exchange": round(int(plan.send_idx.numel()) * K * 4 / 1e6, 2),
+                "halo_MB_received_per_exchange": round(int(plan.n_halo) * K * 4 / 1e6, 2), "local_edges": int(plan.num_local_edges),
+                "send_counts": plan.send_counts, "push_rows_verified": push_ok, "returned_rows_verified": ret_ok}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            print(json.dumps({"metric": "million edges/s (fwd+bwd) RGAT layer, ogbn-mag feat=64", "value": None, "unit": "million edges/s",
+                              "n_gpus": world, "dry_run_exchange": True, "data": "synthetic",
+                              "config": {"workload": f"partition plan + halo exchange rehearsal on host tensors (gloo), N={coo.num_nodes}, "
+                                                     f"E={coo.num_edges}, feat={K}: no layer, no GPU, no timing",
+                                         "scale": args.scale, "edge_order": args.edge_order,
+                                         "parallelism": f"dst-range partition x{world}"},
+                              "dist": {"ranks": world, "backend": "gloo (host tensors)", "edge_cut": int(plan.edge_cut),
+                                       "edges_total": int(sum(r_["local_edges"] for r_ in allr)), "per_rank": allr,
+                                       "all_rows_verified": all(r_["push_rows_verified"] and r_["returned_rows_verified"] for r_ in allr)}}))
+        if not (push_ok and ret_ok):
+            raise SystemExit(f"rank {rank}: halo rows did not arrive where they belong (push {push_ok}, return {ret_ok})")
+    finally:
+        dist.destroy_process_group()
+
+
 
 def parse():
     p = argparse.ArgumentParser()
@@ -40,11 +339,18 @@ def parse():
     p.add_argument("--variant", default="default", choices=["default", "compact", "compact_mulfirst", "mulfirst"],
                    help="reference layer flags: default = per-edge projections (the reference's default flags); "
                         "compact = --compact_as_of_node_flag --compact_direct_indexing_flag")
-    p.add_argument("--edge-order", default="src", choices=["src", "random"])
+    p.add_argument("--edge-order", default="src_dst", choices=["src_dst", "src", "random"],
+                   help="order of a relation's edges in the synthetic lists (het_amd/synth.py): src_dst = sorted by (source, "
+                        "destination) as the OGB lists and the reference's shipped slice are (headline); random = generation order "
+                        "(SURVEY.md 8d's wording; reported beside the headline as edge_order_random); src = by source only (rounds 1-3)")
+    p.add_argument("--dry-run-exchange", action="store_true",
+                   help="multi-rank rehearsal WITHOUT a GPU: rendezvous (gloo), every rank's partition plan and one halo exchange each "
+                        "way on host tensors with checksums, then the `dist` object -- no layer, no timing, value null")
     p.add_argument("--model", default="rgat", choices=["rgat", "rgcn", "hgt"],
                    help="rgat = the BASELINE.json metric; rgcn / hgt time BASELINE.json configs[1] / configs[3] (single GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
+    p.add_argument("--no-models", action="store_true", help="skip the RGCN / HGT legs (BASELINE.json configs[1], configs[3]) of the default run")
     p.add_argument("--cpu-scale", type=float, default=0.25, help="graph scale of the CPU-baseline sample (1.0 = the full workload: "
                    "one warm-up + one timed iteration, about 3 minutes of host time -- outside the default run)")
     a = p.parse_args()
@@ -97,7 +403,7 @@ def cpu_baseline(args):
     lw = (torch.randn(K, K) * 0.1).requires_grad_(True)
     go = torch.randn(N, K)
     times = []
-    for it in range(2 if args.cpu_scale >= 0.2 else 4):  # (a quarter of the workload: ~14 s per step on the 128 host threads)
+    for it in range(4):  # one warm-up + three timed (a quarter of the workload: ~14 s per step on the 128 host threads)
         t0 = time.perf_counter()
         out = OL.rgat_layer(x, W, al, ar, s["rel_ptrs"], s["row_indices"], s["col_indices"], N, 0.2, lw, None)
         torch.autograd.grad(out, [x, W, al, ar, lw], go)
@@ -108,6 +414,8 @@ def cpu_baseline(args):
     med = times[len(times) // 2]
     return {"value": round(g.get_num_edges() / med / 1e6, 3), "unit": "million edges/s", "cores": torch.get_num_threads(),
             "kind": "port", "scale": args.cpu_scale, "sample_edges": g.get_num_edges(), "sample_seconds_per_step": round(med, 3),
+            "sample_seconds_per_step_min": round(times[0], 3), "timed_iterations": len(times),
+            "value_best_iteration": round(g.get_num_edges() / times[0] / 1e6, 3),
             "sample": f"oracle/layers.py rgat_layer fwd+bwd (torch CPU fp32, HET cross-relation softmax) on a mag-like "
                       f"graph at scale {args.cpu_scale} ({g.get_num_edges()} edges, {N} nodes), median of {len(times)} after 1 warm-up; "
                       f"os.cpu_count()={os.cpu_count()}"}
@@ -183,6 +491,8 @@ def main():
 
 def _main():
     args = parse()
+    if args.dry_run_exchange:
+        return dry_run_exchange(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -290,17 +600,7 @@ def _main():
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     # live per-kernel durations of the timed region: {kernel: (avg ms per launch, launches per step, ms per step)}; the roofline
     # objects use ms per step = the summed duration of the launches that together implement the op in one step
-    kt = {}
-    for name in ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs",
-                 "HET_rgat_backward_src", "HET_rgat_backward", "HET_rgat_aggregate_packs", "HET_rgat_aggregate_hubs",
-                 "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
-                 "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
-                 "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
-                 "HET_node_dx",
-                 "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"):
-        ms, n = HL.kernel_timing_read(name)
-        if n:
-            kt[name] = (ms / n, n / ksteps, ms / ksteps)
+    kt = read_kernel_timers(ksteps)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -322,52 +622,8 @@ def _main():
         per_op = {k[4:]: round(v, 3) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}
         per_op["(sum of C-ABI calls; launches on the side stream overlap others)"] = round(sum(acc.values()), 3)
 
-    prof_dir = os.path.join(ROOT, "profiles", "r03")
-    prof_tag = args.variant if args.model == "rgat" else args.model  # profiles/r03/{default,rgcn,hgt}_pmc.json
-
-    def kernel_source_sha16():
-        """Digest of het_amd/csrc/* (as profiles/tools/summarize.py records it with the counters)."""
-        import hashlib
-        root = os.path.join(ROOT, "het_amd", "csrc")
-        h = hashlib.sha256()
-        for f in sorted(os.listdir(root)):
-            if f.endswith((".hip", ".h", ".cpp")):
-                h.update(f.encode())
-                h.update(open(os.path.join(root, f), "rb").read())
-        return h.hexdigest()[:16]
-    tree_sha = kernel_source_sha16()
-
-    def pmc(kernel, field):
-        """Per-launch PMC figure of `kernel` from the COMMITTED counter passes of this same command (profiles/r03/,
-        written by profiles/tools/collect.sh on an earlier box): rocprofv3 cannot run inside the timed process, so
-        this is not an observation of this run -- the JSON says so (`traffic_source`).  None when no committed
-        profile matches this workload.  `kernel` is a prefix of the profile's key (kernel name + grid size)."""
-        path = os.path.join(prof_dir, f"{prof_tag}_pmc.json")
-        if args.scale != 1.0 or world != 1 or args.feat != 64 or args.heads != (8 if args.model == "hgt" else 4) or not os.path.exists(path):
-            return None
-        prof = json.load(open(path))
-        if prof.get("kernel_source_sha16") != tree_sha:
-            return None  # the kernels changed since those counters were collected: a stale figure is worse than none
-        kernels = prof["kernels"]
-        if isinstance(kernel, (tuple, list)):  # an op implemented by several launches per step: the sum over them
-            parts = [pmc(k_, field) for k_ in kernel]
-            return None if any(p_ is None for p_ in parts) else sum(parts)
-        recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in kernels.items() if k.startswith(kernel) and field in v]
-        return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel
-
-    def hbm_view(kernel, k_ms, nbytes, extra=None, pmc_name=None):
-        ach = nbytes / (k_ms * 1e-3) / 1e9
-        r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(ach / HBM_COPY_GBS, 4),
-             "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(nbytes),
-             "traffic": pmc(pmc_name or kernel.split(" ")[0], "hbm_bytes_per_launch")}
-        r["traffic_source"] = (f"profiles/r03/{prof_tag}_pmc.json (committed rocprofv3 --pmc passes of this command on "
-                               "another box; not measured in this run)") if r["traffic"] else None
-        if r["traffic"]:
-            r["traffic_rate_GBps"] = round(r["traffic"] / (k_ms * 1e-3) / 1e9, 1)
-        if extra:
-            r.update(extra)
-        return r
+    pmc, hbm_view = make_views(args, world, args.variant if args.model == "rgat" else args.model,
+                               8 if args.model == "hgt" else 4)
 
     # roofline of the step's dominant kernels: algorithmic bytes of the op the kernel implements (SURVEY.md 8d: every
     # API-visible tensor once, indices at 8 B) / the kernel's own average duration in the timed region.  Only the
@@ -391,7 +647,8 @@ def _main():
             if S_row is not None:
                 req = nb_ + (E_local - S_row) * 4 * X  # one gradout row per edge instead of per source row
                 ex.update(bytes_with_per_edge_row_gather=int(req),
-                          frac_with_per_edge_row_gather=round(req / (kt[bname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                          frac_with_per_edge_row_gather=round(req / (kt[bname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          **gather_ceiling(nb_, E_local, 4 * X))
             pm, b_ms, what = bname, kt[bname][2], "0"
             if bname == "HET_rgat_backward_src":
                 # every launch of the op: per-destination pack, short + long (relation, source) segments, grad_er (from the run
@@ -419,7 +676,8 @@ def _main():
             if S_row is not None:
                 req = nf_ + (E_local - S_row) * 4 * X
                 ex.update(bytes_with_per_edge_row_gather=int(req),
-                          frac_with_per_edge_row_gather=round(req / (kt[fname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                          frac_with_per_edge_row_gather=round(req / (kt[fname][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          **gather_ceiling(nf_, E_local, 4 * X))
             pmf = fname
             if fname == "HET_rgat_aggregate":  # (one launch, or packs + hub work items + hub finish when the run sums are on)
                 runs = "HET_rgat_aggregate_hubs" in kt or "HET_rgat_aggregate_packs" in kt
@@ -435,52 +693,9 @@ def _main():
             roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0}{'; also leaves the per-run sums grad_er is formed from' if isinstance(pmf, tuple) else ''})",
                                     f_ms, nf_, ex, pmc_name=pmf)
     if args.model == "rgcn" and "HET_segment_sum" in kt and not use_dist:
-        # RGCN (BASELINE.json configs[1]): the step is two gather-sums (x[src] * norm per (relation, destination) forward,
-        # gradout[dst] * norm per (relation, source) backward) + GEMMs on the distinct rows.  a7 / a8 bytes per SURVEY.md 8d
-        # (U_src = distinct source nodes); the gather passes move one 256-byte row per edge like RGAT's
-        sc = g.get_separate_coo_original()
-        U_src = int(torch.unique(sc["row_indices"]).numel())
-        R_ = g.get_num_rels()
-        a7 = E_local * (3 * 8 + 4) + U_src * 4 * K + N_local * 4 * X + 4 * R_ * K * X
-        a8 = E_local * 28 + (U_src + N_local) * 4 * (K + X) + 8 * R_ * K * X
-        ss_ms = kt["HET_segment_sum"][0]  # one launch per op
-        note = ("kernel_ms = the gather-sum launches of one op (average of the forward and the backward one); the op's GEMMs on "
-                "the distinct rows are separate launches (kernel_ms).  requested_bytes counts one row per edge: the rate at "
-                "the kernels' load instructions, part of it served by L2 / Infinity Cache (the [N,64] table is 0.5 GB and "
-                "the degrees are Zipf-skewed), so it may exceed what HBM delivers")
-        pm = ("HET_segment_sum_packed", "HET_segment_sum_long")
-        roofline = hbm_view("HET_segment_sum_packed + _long (backward_rgcn_layer1_separate_coo: gradout rows by (relation, source))",
-                            ss_ms, a8, {"requested_bytes_one_row_per_edge": int(E_local * (4 * X + 12) + a8),
-                                        "requested_rate_GBps": round((E_local * (4 * X + 12) + a8) / (ss_ms * 1e-3) / 1e9, 1),
-                                        "note": note}, pmc_name=pm)
-        roofline_fwd = hbm_view("HET_segment_sum_packed + _long (rgcn_layer1_separate_coo: x rows by (relation, destination))", ss_ms, a7,
-                                {"requested_bytes_one_row_per_edge": int(E_local * (4 * K + 12) + a7),
-                                 "requested_rate_GBps": round((E_local * (4 * K + 12) + a7) / (ss_ms * 1e-3) / 1e9, 1)}, pmc_name=pm)
+        roofline, roofline_fwd = rgcn_rooflines(g, kt, E_local, N_local, K, X, hbm_view)
     if args.model == "hgt" and "HET_hgt_aggregate_rows" in kt and not use_dist:
-        # HGT (BASELINE.json configs[3]): attention + aggregation on the distinct (relation, source) rows (csrc/hgt_compact.hip).
-        # Algorithmic bytes: every tensor of the pass once (kv_c [S_row,2X], q / out / gradout [N,X], per-(node, head) scalars,
-        # two 8-byte indices per edge); the passes gather one 2X-float row (forward, destination side) or two X-float rows
-        # (source side) PER EDGE from tables larger than the Infinity Cache -- bytes_with_per_edge_row_gather counts those.
-        ss = g.get_separate_unique_node_indices_single_sided()
-        S_row = int(ss["node_indices_row"].numel())
-        kvb, nxb, nhb = S_row * 2 * X * 4, N_local * X * 4, N_local * H * 4
-        f_b = kvb + 2 * nxb + nhb + E_local * 16
-        d_b = kvb + 4 * nxb + 3 * nhb + E_local * 16            # reads kv_c, q, gradout, out, lsum; writes grad_q, pack2
-        s_b = 2 * kvb + 2 * nxb + 2 * nhb + E_local * 16        # reads kv_c, q, gradout, pack2; writes grad_kv_c
-        f_req = f_b + (E_local - S_row) * 2 * X * 4
-        d_req = d_b + (E_local - S_row) * 2 * X * 4
-        s_req = s_b + (E_local - N_local) * (2 * X * 4 + 8 * H)
-        b_ms = sum(kt[n][2] for n in ("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long") if n in kt)
-        note = ("requested_bytes counts one gathered row per edge: the rate at the kernels' load instructions, part of it served by "
-                "L2 / Infinity Cache (kv_c is 1.2 GB, q / gradout 0.5 GB each, degrees Zipf-skewed), so it may exceed what HBM "
-                "delivers; `traffic` is what crossed the memory fabric")
-        ex = lambda req, ms: {"S_row": S_row, "requested_bytes_one_row_per_edge": int(req),
-                              "requested_rate_GBps": round(req / (ms * 1e-3) / 1e9, 1), "note": note}
-        roofline = hbm_view("HET_hgt_backward_dst_rows + _src_short + _src_long (het_hgt_backward_compact: softmax + aggregation backward "
-                            "of the HGT layer, three launches)", b_ms, d_b + s_b, ex(d_req + s_req, b_ms),
-                            pmc_name=("HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long"))
-        roofline_fwd = hbm_view("HET_hgt_aggregate_rows (het_hgt_aggregate_compact: score, edge softmax, message aggregation)",
-                                kt["HET_hgt_aggregate_rows"][2], f_b, ex(f_req, kt["HET_hgt_aggregate_rows"][2]))
+        roofline, roofline_fwd = hgt_rooflines(g, kt, E_local, N_local, K, X, H, hbm_view)
     kernel_ms = {k: {"avg_ms": round(v[0], 4), "launches_per_step": round(v[1], 2), "ms_per_step": round(v[2], 4)} for k, v in kt.items()}
 
     # the reference-named ops exactly as the reference's model code calls them (kind 0, [E,H,D] feat), each launched a
@@ -511,7 +726,7 @@ def _main():
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "mfma_busy_frac_pmc": busy,
                          "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "hbm_bytes_per_launch"),
-                         "traffic_source": f"profiles/r03/{prof_tag}_pmc.json (committed; not measured in this run)" if busy else None}
+                         "traffic_source": f"profiles/{PROF_ROUND}/{args.variant}_pmc.json (committed; not measured in this run)" if busy else None}
         # a4 / a5 on the per-edge tensor retp just written (feat_src_per_edge), reference argument order
         el = torch.randn(E_local, H, device=dev)
         er = torch.randn(E_local, H, device=dev)
@@ -577,7 +792,11 @@ def _main():
             "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model.upper()} layer fwd+bwd, ogbn-mag-shaped synthetic graph (N={N_global}, E={E_global}, R=4), "
-                                   f"feat={K}, heads={H}, self_loop, no optimizer step, layer flags: {args.variant}",
+                                   f"feat={K}, heads={H}, self_loop, no optimizer step, layer flags: {args.variant}; LAYER SWAP: the model "
+                                   f"script builds het_amd.layers.{'HET_RGATLayer' if args.model == 'rgat' else 'HET_EglRelGraphConv_EdgeParallel' if args.model == 'rgcn' else 'HET_HGTLayerHetero'} "
+                                   "(the reference's layer class name and arguments); swapping only hrt/python/backend or only "
+                                   "kernels/__init__.py under the reference's own model code gives variants.op_by_op / "
+                                   "variants.reference_op_sequence",
                        "edge_order": args.edge_order, "scale": args.scale, "device": torch.cuda.get_device_name(dev),
                        "torch": torch.__version__, "hip": torch.version.hip,
                        "layout_build_ms": None if layout_ms is None else round(layout_ms, 1),
@@ -596,6 +815,11 @@ def _main():
         }
         if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
             out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)
+        if world == 1 and not use_dist and not args.no_models and args.model == "rgat" and args.feat % 8 == 0:
+            # BASELINE.json configs[1] and configs[3] in the same line (about 10 s each)
+            out["models"] = {m: other_model(m, args, coo, dev, world) for m in ("rgcn", "hgt")}
+        if world == 1 and not use_dist and not args.no_variants and args.model == "rgat" and args.edge_order != "random":
+            out["edge_order_random"] = edge_order_random(args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

@@ -236,10 +236,10 @@ class HaloContext:
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            try:
-                self._work.wait()
-            finally:
-                self._work = self._keep = None
+            # (a wait that raised leaves the collective possibly still writing its buffers: they stay referenced -- and the
+            #  context unusable -- until abort() gets a wait through or the process ends)
+            self._work.wait()
+            self._work = self._keep = None
             if ev is not None:
                 ev[1].record()
                 self.timing.append((what, ev[0], ev[1]))
@@ -249,6 +249,9 @@ class HaloContext:
         be freed and the context reused."""
         try:
             self._wait("abort")
+        except BaseException:
+            self._work = None  # the handle is dropped, the buffers (`_keep`) are deliberately leaked with the failed collective
+            raise
         finally:
             self._back = None
 
@@ -306,12 +309,16 @@ class DistLayer:
     all-reduced after backward."""
 
     def __init__(self, coo: IntegratedCOO, layer_fn: Callable, params, group=None, full_layouts: bool = False,
-                 halo_layer_fn: Callable = None):
+                 halo_layer_fn: Callable = None, plan: DistPlan = None):
         """``halo_layer_fn(graph, x_own, halo)`` (optional): a layer that runs the exchange itself through a HaloContext and
-        overlaps it with its own work; it returns None when it cannot (then ``layer_fn`` runs behind HaloExchange)."""
+        overlaps it with its own work; it returns None when it cannot (then ``layer_fn`` runs behind HaloExchange).
+        ``plan`` (optional): a plan built elsewhere (LocalRanks builds all ranks' plans from one pass)."""
         self.group = group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.plan = build_plan(coo, self.rank, self.world)
+        if plan is None:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            plan = build_plan(coo, self.rank, self.world)
+        self.rank, self.world = plan.rank, plan.world
+        self.plan = plan
         self.graph = HetGraph.from_integrated_coo(self.plan.local, full=full_layouts)
         self.layer_fn = layer_fn
         self.halo_layer_fn = halo_layer_fn
@@ -342,11 +349,149 @@ class DistLayer:
             off += g.numel()
 
 
+def rccl_preflight(group=None, device=None, timeout_s: float = None) -> None:
+    """First RCCL contact, made boring: one tiny all_to_all_single (every rank sends its rank number to every peer) and a
+    barrier, under a watchdog.  A rank whose exchange has not completed within ``timeout_s`` (HET_DIST_PREFLIGHT_TIMEOUT,
+    default 60 s) -- a peer that never joined, an xGMI / IPC set-up that hangs inside the library -- prints which rank it is and
+    what it was waiting for and leaves with exit code 3 (torch.distributed.run then stops the others); a wrong payload raises.
+    Exit, never re-exec: this process has a GPU context."""
+    import sys
+    import threading
+    timeout_s = float(os.environ.get("HET_DIST_PREFLIGHT_TIMEOUT", "60")) if timeout_s is None else float(timeout_s)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    stage = ["communicator set-up"]
+
+    def expired():
+        sys.stderr.write(f"[het_amd.dist] RCCL preflight: rank {rank}/{world} still in '{stage[0]}' after {timeout_s:.0f} s "
+                         f"(device {device}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, HSA_ENABLE_IPC_MODE_LEGACY="
+                         f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}): giving up\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    dog = threading.Timer(timeout_s, expired)
+    dog.daemon = True
+    dog.start()
+    try:
+        send = torch.full((world,), float(rank), dtype=torch.float32, device=device)
+        recv = torch.full((world,), -1.0, dtype=torch.float32, device=device)
+        stage[0] = "all_to_all_single of one float per peer"
+        dist.all_to_all_single(recv, send, group=group)
+        if send.is_cuda:
+            torch.cuda.synchronize(send.device)
+        if not torch.equal(recv.cpu(), torch.arange(world, dtype=torch.float32)):
+            raise RuntimeError(f"RCCL preflight: rank {rank} received {recv.tolist()} instead of the peers' rank numbers")
+        stage[0] = "barrier"
+        dist.barrier(group=group)
+    finally:
+        dog.cancel()
+
+
+class _Loopback:
+    """The wire of LocalRanks: what each logical rank put up for its peers, kept in this process."""
+
+    def __init__(self):
+        self.push = {}   # rank -> rows it sends in the forward exchange (grouped by receiving rank)
+        self.back = {}   # rank -> gradients of its halo rows (grouped by owning rank), sent home in the backward exchange
+
+
+class LoopbackHalo(HaloContext):
+    """HaloContext of one logical rank of LocalRanks: same pack / unpack code, the all-to-all replaced by slicing the peers'
+    buffers.  The forward rows of every rank are put up before any rank's layer runs; the returned gradient rows are added to
+    their owners' gradients after every rank's backward has run (LocalRanks.backward) -- sums commute."""
+
+    def __init__(self, plan: DistPlan, plans, wire: _Loopback):
+        super().__init__(plan, None)
+        self.plans, self.wire = plans, wire
+
+    def start_push(self, x_own):
+        p = self.plan
+        x_local = x_own.new_empty((p.n_own + p.n_halo, x_own.shape[1]))
+        x_local[: p.n_own].copy_(x_own)
+        off = p.n_own
+        for q in range(p.world):  # the received buffer is ordered by sending rank (all_to_all_single)
+            n = p.recv_counts[q]
+            if n:
+                sq = self.plans[q].send_counts
+                a = sum(sq[: p.rank])
+                assert sq[p.rank] == n, "send / receive counts of the plans disagree"
+                x_local[off: off + n].copy_(self.wire.push[q][a: a + n])
+            off += n
+        return x_local
+
+    def finish_push(self):
+        pass
+
+    def start_return(self, grad_local):
+        self.wire.back[self.plan.rank] = grad_local[self.plan.n_own:].clone()
+
+    def finish_return(self, grad_own):
+        return grad_own
+
+
+class LocalRanks:
+    """All ``world`` ranks of a partition as LOGICAL ranks of one process on one device: every rank's DistPlan, local graph
+    and halo pack / unpack exactly as in a multi-process run, one replicated layer (its parameter gradients accumulate over
+    the ranks' backward passes = the all-reduce), the exchange by slicing.  A rehearsal of an N-GPU step where N GPUs (or N
+    processes on one GPU: the test boxes allow 6) are not to be had -- tests/test_gpu_dist.py runs BASELINE.json configs[4]
+    (RGAT, feat 128, 8-way) through it against the single-process layer."""
+
+    def __init__(self, coo: IntegratedCOO, world: int, layer, full_layouts: bool = False, overlap: bool = True):
+        self.world, self.layer, self.overlap = world, layer, overlap
+        self.plans = [build_plan(coo, r, world) for r in range(world)]
+        self.graphs = [HetGraph.from_integrated_coo(p.local, full=full_layouts) for p in self.plans]
+        self.wire = _Loopback()
+        self.halos = [LoopbackHalo(p, self.plans, self.wire) for p in self.plans]
+        self.took_halo_path = [False] * world
+        self._x_local = [None] * world
+
+    def owned_nodes(self, r):
+        p = self.plans[r]
+        return p.node_order[int(p.bounds[r]): int(p.bounds[r + 1])]
+
+    def forward(self, x_own: List[torch.Tensor]) -> List[torch.Tensor]:
+        for r, p in enumerate(self.plans):
+            self.wire.push[r] = _gather_rows(x_own[r].detach(), p.send_idx)
+        outs = []
+        for r, p in enumerate(self.plans):
+            out = self.layer.forward_with_halo(self.graphs[r], x_own[r], self.halos[r]) if self.overlap else None
+            self.took_halo_path[r] = out is not None
+            if out is None:  # exchange first, then the layer on the local graph (DistLayer.forward's other branch)
+                xl = self.halos[r].start_push(x_own[r].detach()).requires_grad_(True)
+                self._x_local[r] = xl
+                out = self.layer(self.graphs[r], xl, num_dst=p.n_own)[: p.n_own]
+            outs.append(out)
+        return outs
+
+    def backward(self, outs: List[torch.Tensor], gradouts: List[torch.Tensor], x_own: List[torch.Tensor]):
+        """Runs every rank's backward; x_own[r].grad then holds the owned rows' gradient including the rows peers returned."""
+        for r, p in enumerate(self.plans):
+            outs[r].backward(gradouts[r])
+            if not self.took_halo_path[r]:
+                g = self._x_local[r].grad
+                self.halos[r].start_return(g)
+                x_own[r].grad = g[: p.n_own].clone()
+                self._x_local[r] = None
+        for r, p in enumerate(self.plans):  # the reverse all-to-all: rank r gets back the gradients of the rows it sent
+            parts = []
+            for q in range(self.world):
+                n = p.send_counts[q]
+                if n:
+                    rq = self.plans[q].recv_counts
+                    a = sum(rq[:r])
+                    parts.append(self.wire.back[q][a: a + n])
+            if parts:
+                _scatter_add_rows(x_own[r].grad, p.send_idx, torch.cat(parts))
+        self.wire.back.clear()
+        self.wire.push.clear()
+
+
 class DistRGAT:
     """bench.py's multi-GPU step: a replicated HET_RGATLayer over the local shard of the graph."""
 
     def __init__(self, coo: IntegratedCOO, in_feat, out_feat, heads, device, **layer_flags):
         from .layers import HET_RGATLayer
+        if dist.get_backend() == "nccl" and os.environ.get("HET_DIST_PREFLIGHT", "1") == "1":
+            rccl_preflight(None, device)  # fails fast, naming the rank, before minutes of plan building behind a dead link
         for f in ("row", "col", "rel", "eids", "node_type_offsets"):
             setattr(coo, f, getattr(coo, f).to(device))
         torch.manual_seed(0)  # same weights on every rank

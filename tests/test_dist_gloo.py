@@ -57,6 +57,8 @@ class _HaloOracleLayer(torch.autograd.Function):
 
 def _worker(rank, world, port, kind, outdir, use_halo=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 4:
+        torch.set_num_threads(1)  # (8 ranks on the 8 cores of the build container)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from het_amd.dist import DistLayer
@@ -91,10 +93,11 @@ def _worker(rank, world, port, kind, outdir, use_halo=False):
 
 
 @pytest.mark.parametrize("kind,world,use_halo", [("mag", 2, False), ("random", 3, False), ("mag128", 2, False), ("mag", 2, True),
-                                                 ("random", 3, True)])
+                                                 ("random", 3, True), ("mag128", 8, True), ("random", 8, False)])
 def test_partitioned_layer_matches_single_process(kind, world, use_halo):
-    """mag128: feat 128, 4 heads -- the shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition).  use_halo: the
-    layer drives the exchange through dist.HaloContext (the overlapped form of the HIP layer) instead of HaloExchange."""
+    """mag128: feat 128, 4 heads -- the shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition; world 8 = its rank
+    count, eight gloo processes).  use_halo: the layer drives the exchange through dist.HaloContext (the overlapped form of the
+    HIP layer) instead of HaloExchange."""
     from het_amd.graph import HetGraph
     from oracle import layers as OL
     with tempfile.TemporaryDirectory() as d:
@@ -112,6 +115,8 @@ def test_partitioned_layer_matches_single_process(kind, world, use_halo):
                         0.2, p["lw"], p["b"])
     ref.backward(go)
     assert sum(q["edges"] for q in parts) == coo.num_edges  # every edge lives on exactly one rank
+    if world == 8:
+        assert sum(q["sent"] for q in parts) == sum(q["n_halo"] for q in parts) > 0  # every halo row has one sender
     assert parts[0]["lo"] == 0 and parts[-1]["hi"] == coo.num_nodes
     for a, b in zip(parts[:-1], parts[1:]):
         assert a["hi"] == b["lo"]
@@ -153,3 +158,96 @@ def test_source_only_nodes_are_dealt_out_evenly():
     assert sum(p.num_local_edges for p in plans) == coo.num_edges
     order = plans[0].node_order
     assert torch.equal(torch.sort(order).values, torch.arange(coo.num_nodes))
+
+
+class _OracleRGAT:
+    """The oracle layer behind the two entry points LocalRanks calls on a layer (HET_RGATLayer's forward / forward_with_halo)."""
+
+    def __init__(self, p, with_halo):
+        self.p, self.with_halo = p, with_halo
+
+    def _fn(self, g, x):
+        p, s = self.p, g.get_separate_coo_original()
+        from oracle import layers as OL
+        return OL.rgat_layer(x, p["W"], p["al"], p["ar"], s["rel_ptrs"], s["row_indices"], s["col_indices"], g.get_num_nodes(), 0.2,
+                             p["lw"], p["b"])
+
+    def __call__(self, g, x, num_dst=None):
+        return self._fn(g, x)
+
+    def forward_with_halo(self, g, x_own, halo):
+        if not self.with_halo:
+            return None
+        return _HaloOracleLayer.apply(x_own, halo, lambda xl: self._fn(g, xl), x_own.shape[0], *self.p.values())
+
+
+@pytest.mark.parametrize("world,with_halo", [(8, True), (8, False), (5, True), (1, True)])
+def test_local_ranks_rehearsal_matches_single_process(world, with_halo):
+    """dist.LocalRanks (every rank of the partition as a logical rank of one process, the all-to-all by slicing) with the oracle
+    as the layer: outputs, input gradients and the accumulated weight gradients equal the single-process oracle -- the harness
+    tests/test_gpu_dist.py runs the HIP layer through at 8 ranks."""
+    from het_amd.dist import LocalRanks
+    from het_amd.graph import HetGraph
+    from oracle import layers as OL
+    coo = make_mag_like(scale=1e-3)
+    H, K, D = 2, 8, 4
+    p = _params(coo.num_rels, H, K, D)
+    lr = LocalRanks(coo, world, _OracleRGAT(p, with_halo))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(coo.num_nodes, K, generator=gen, dtype=torch.float64)
+    go = torch.randn(coo.num_nodes, H * D, generator=gen, dtype=torch.float64)
+    mine = [lr.owned_nodes(r) for r in range(world)]
+    assert torch.equal(torch.sort(torch.cat(mine)).values, torch.arange(coo.num_nodes))
+    x_own = [x[m].clone().requires_grad_(True) for m in mine]
+    outs = lr.forward(x_own)
+    assert lr.took_halo_path == [with_halo] * world
+    lr.backward(outs, [go[m] for m in mine], x_own)
+    got = {k: v.grad.clone() for k, v in p.items()}
+    for v in p.values():
+        v.grad = None
+    g = HetGraph.from_integrated_coo(coo, full=False)
+    s = g.get_separate_coo_original()
+    xr = x.clone().requires_grad_(True)
+    ref = OL.rgat_layer(xr, p["W"], p["al"], p["ar"], s["rel_ptrs"], s["row_indices"], s["col_indices"], coo.num_nodes, 0.2, p["lw"], p["b"])
+    ref.backward(go)
+    for r in range(world):
+        torch.testing.assert_close(outs[r].detach(), ref.detach()[mine[r]])
+        torch.testing.assert_close(x_own[r].grad, xr.grad[mine[r]])
+    for k, v in p.items():
+        torch.testing.assert_close(got[k], v.grad)
+
+
+def test_rccl_preflight_logic_on_gloo():
+    """rccl_preflight (one float per peer + barrier under a watchdog) on a one-rank gloo group: passes; the watchdog is what a
+    dead peer meets (exercised over RCCL by tests/test_gpu_dist.py where the box has the GPUs)."""
+    from het_amd.dist import rccl_preflight
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        rccl_preflight(None, torch.device("cpu"), timeout_s=30)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_dry_run_exchange_eight_ranks():
+    """The driver's launch line for N = 8 (python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8) in
+    bench.py's --dry-run-exchange mode: rendezvous, the 8-way plan of every rank and one halo exchange each way on host tensors
+    (no GPU: a one-GPU box may not hold eight processes on its card), every row verified against the node it belongs to."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HET_FORCE_DIST", "HET_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--scale", "0.01", "--feat", "128",
+                        "--dry-run-exchange"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = out["dist"]
+    assert out["n_gpus"] == 8 and out["value"] is None and d["ranks"] == 8 and len(d["per_rank"]) == 8
+    assert d["all_rows_verified"] and all(q["halo_rows_received"] > 0 and q["halo_rows_sent"] > 0 for q in d["per_rank"])
+    assert sum(q["halo_rows_sent"] for q in d["per_rank"]) == sum(q["halo_rows_received"] for q in d["per_rank"])
+    assert any(c == 0 for q in d["per_rank"] for i, c in enumerate(q["send_counts"]) if i != q["rank"])  # an empty send list occurs
+    assert d["edges_total"] == 211111

@@ -20,6 +20,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, compact, outdir, feat=64):
+    if world > 2:
+        torch.set_num_threads(2)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,14 +49,15 @@ def _worker(rank, world, port, compact, outdir, feat=64):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact,feat", [(False, 64), (True, 64), (False, 128)])
-def test_two_ranks_on_one_gpu_match_single_process(compact, feat):
-    """feat 128 with 4 heads: the layer shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition)."""
+@pytest.mark.parametrize("compact,feat,world", [(False, 64, 2), (True, 64, 2), (False, 128, 2), (True, 128, 4)])
+def test_ranks_on_one_gpu_match_single_process(compact, feat, world):
+    """feat 128 with 4 heads: the layer shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition).  world 4: as many
+    processes as may share the test box's GPU beside this one (the box allows 6); the 8-way partition of configs[4] runs as
+    logical ranks of one process in test_eight_way_partition_feat128_on_one_gpu."""
     import torch.multiprocessing as mp
     from het_amd.graph import HetGraph
     from het_amd.layers import HET_RGATLayer
     from het_amd.synth import make_mag_like
-    world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.start_processes(_worker, args=(world, _free_port(), compact, d, feat), nprocs=world, join=True, start_method="spawn")
         parts = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
@@ -77,6 +80,80 @@ def test_two_ranks_on_one_gpu_match_single_process(compact, feat):
         torch.testing.assert_close(q["gx"], x.grad.cpu()[q["mine"]], rtol=2e-4, atol=2e-5)
         for n, p in layer.named_parameters():
             torch.testing.assert_close(q["grads"][n], p.grad.cpu(), rtol=5e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_eight_way_partition_feat128_on_one_gpu(compact):
+    """BASELINE.json configs[4] as far as one GPU goes: RGAT, feat 128, 4 heads, the graph split 8 ways by destination range --
+    every rank's plan, local graph, halo pack / unpack and the HIP layer's overlapped (forward_with_halo) path run as logical
+    ranks of this process (dist.LocalRanks; eight processes may not share the box's GPU), against the single-process HIP layer
+    AND the fp64 oracle layer on the whole graph: outputs, input gradients, all weight gradients.  The partition shows the
+    cases a rank has to survive: uneven splits, an empty send list between two ranks, a rank that owns no hub destination."""
+    from het_amd.dist import LocalRanks
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    from oracle import layers as OL
+    from tests.util import assert_close, rgat_min_abs_preactivation
+    dev = torch.device("cuda", 0)
+    world, feat, H = 8, 128, 4
+    coo = make_mag_like(scale=4e-3)
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(feat, feat, coo.num_rels, H, self_loop=True, dropout=0.0, compact_as_of_node_flag=compact,
+                          compact_direct_indexing_flag=compact)
+    with torch.no_grad():
+        layer.h_bias.uniform_(-0.1, 0.1)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(coo.num_nodes, feat, generator=gen) * 0.5
+    go = torch.randn(coo.num_nodes, feat, generator=gen)
+    g_cpu = HetGraph.from_integrated_coo(coo, full=True)
+    s = g_cpu.get_separate_coo_original()
+    for _ in range(64):  # (no pre-activation on the leaky-ReLU kink: tests/util.py)
+        if rgat_min_abs_preactivation(x, layer.conv_weights, layer.attn_l, layer.attn_r, s) >= 2e-6:
+            break
+        x = x + 1e-3 * torch.randn(coo.num_nodes, feat, generator=gen)
+    names = ["conv_weights", "attn_l", "attn_r", "loop_weight", "h_bias"]
+    p64 = {n: t.detach().double().requires_grad_(True) for n, t in layer.named_parameters()}
+    x64 = x.double().requires_grad_(True)
+    ref = OL.rgat_layer(x64, p64["conv_weights"], p64["attn_l"], p64["attn_r"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
+                        coo.num_nodes, 0.2, p64["loop_weight"], p64["h_bias"])
+    grads_ref = torch.autograd.grad(ref, [x64] + [p64[n] for n in names], go.double())
+
+    layer = layer.to(dev)
+    dcoo = make_mag_like(scale=4e-3)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(dcoo, f, getattr(dcoo, f).to(dev))
+    lr = LocalRanks(dcoo, world, layer, full_layouts=compact)
+    plans = lr.plans
+    indeg = torch.bincount(coo.col, minlength=coo.num_nodes)
+    owned_hubs = [int((indeg[lr.owned_nodes(r).cpu()] > 256).sum()) for r in range(world)]
+    assert len({p.n_own for p in plans}) > 1 and len({p.num_local_edges for p in plans}) > 1, "uneven splits expected"
+    assert any(p.send_counts[q] == 0 for p in plans for q in range(world) if q != p.rank), "an empty send list expected"
+    assert min(owned_hubs) == 0 and max(owned_hubs) > 0, owned_hubs
+    assert sum(p.num_local_edges for p in plans) == coo.num_edges and plans[0].edge_cut > 0.8 * coo.num_edges
+    mine = [lr.owned_nodes(r).cpu() for r in range(world)]
+    x_own = [x[m].to(dev).requires_grad_(True) for m in mine]
+    outs = lr.forward(x_own)
+    assert all(lr.took_halo_path), lr.took_halo_path  # the layer ran the exchange itself (forward_with_halo) on every rank
+    lr.backward(outs, [go[m].to(dev) for m in mine], x_own)
+    part_grads = {n: q.grad.detach().cpu().clone() for n, q in layer.named_parameters()}
+    for r in range(world):
+        assert_close(outs[r], ref.detach()[mine[r]], what=f"rank {r} out vs oracle")
+        assert_close(x_own[r].grad, grads_ref[0][mine[r]], what=f"rank {r} grad_x vs oracle")
+    for n, gr in zip(names, grads_ref[1:]):
+        assert_close(part_grads[n], gr, what="grad_" + n + " (sum over the 8 ranks) vs oracle")
+    # the single-process HIP layer on the whole graph
+    for q in layer.parameters():
+        q.grad = None
+    g = HetGraph.from_integrated_coo(dcoo, full=True)
+    xd = x.to(dev).requires_grad_(True)
+    one = layer(g, xd)
+    one.backward(go.to(dev))
+    for r in range(world):
+        torch.testing.assert_close(outs[r].detach().cpu(), one.detach().cpu()[mine[r]], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(x_own[r].grad.cpu(), xd.grad.cpu()[mine[r]], rtol=2e-4, atol=2e-5)
+    for n, q in layer.named_parameters():
+        torch.testing.assert_close(part_grads[n], q.grad.cpu(), rtol=5e-4, atol=1e-4)
 
 
 def _bench_line(cmd, env):
