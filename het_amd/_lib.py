@@ -65,6 +65,12 @@ class HetError(RuntimeError):
     pass
 
 
+class HetUnsupported(HetError, NotImplementedError):
+    """A configuration of the reference's model code that this build names but does not implement (the message says which
+    reference op it would need and what to use instead) -- raised where the reference's name is reached, instead of an
+    AttributeError from a missing function."""
+
+
 _lib = None
 
 
@@ -101,6 +107,10 @@ def lib() -> C.CDLL:
         L.het_hgt_compact_shape_ok.restype = INT
         L.het_rgat_node_gemm_ok.argtypes = [I64, I64, I64, I64]
         L.het_rgat_node_gemm_ok.restype = INT
+        L.het_set_allocator.argtypes = [P, P, P]
+        L.het_set_allocator.restype = INT
+        L.het_allocator_is_external.argtypes = []
+        L.het_allocator_is_external.restype = INT
         L.het_kernel_timing_enable.argtypes = [INT]
         L.het_kernel_timing_enable.restype = INT
         L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]
@@ -111,6 +121,49 @@ def lib() -> C.CDLL:
             f.restype = INT
         _lib = L
     return _lib
+
+
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_alloc_cbs = None  # the installed callbacks (kept alive: the library holds raw function pointers)
+
+
+def use_torch_allocator(on: bool = True) -> bool:
+    """Device memory the library keeps (groupings and their construction scratch: include/het_amd.h het_set_allocator) from
+    torch's caching allocator instead of hipMalloc: it then shows up in torch.cuda.memory_allocated / max_memory_allocated, goes
+    back to torch's pool when the plan cache evicts a grouping, and no hipFree (a device-wide synchronisation) happens on an
+    op's path.  Blocks are bound to the stream the library first uses them on, like any tensor.  ``on=False``: back to
+    hipMalloc (what a caller of the bare C ABI gets).  Returns whether an allocator is installed afterwards."""
+    global _alloc_cbs
+    L = lib()
+    if not on:
+        L.het_set_allocator(None, None, None)
+        return False
+    import torch
+
+    def _alloc(nbytes, stream, _user):
+        try:
+            return int(torch.cuda.caching_allocator_alloc(int(nbytes), stream=int(stream or 0)))
+        except BaseException:  # noqa: BLE001 -- out of memory: the C side reports it (NULL); an exception cannot cross the C frames
+            return None
+
+    def _free(ptr, _user):
+        try:
+            torch.cuda.caching_allocator_delete(int(ptr))
+        except BaseException:  # noqa: BLE001
+            pass
+
+    cbs = (_ALLOC_FN(_alloc), _FREE_FN(_free))
+    rc = L.het_set_allocator(C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p), None)
+    if rc != 0:
+        raise HetError(f"het_set_allocator failed (code {rc}): {L.het_last_error().decode()}")
+    # (earlier callbacks stay referenced: pointers handed out before are still released through them)
+    _alloc_cbs = (_alloc_cbs or ()) + (cbs,)
+    return True
+
+
+def allocator_is_external() -> bool:
+    return bool(lib().het_allocator_is_external())
 
 
 def call(name: str, *args) -> None:

@@ -12,6 +12,7 @@ __all__ = [
     "HGTFullGraphHeteroAttentionOps", "HGTFullGraphMessageCalcEdgeSoftmaxAndMessageMeanAggregationCOO",
     "hgt_full_graph_hetero_attention_ops_coo",
     "hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo",
+    "hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr",
     "RgnnInnerProductEdgeAndNode", "RgnnInnerProductNodeCompactAndNode",
     "RgnnInnerProductNodeCompactAndNodeWithDirectIndexing", "rgnn_inner_product_right_node",
 ]
@@ -108,6 +109,19 @@ def hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(re
 
 
 @_consistent_plan
+def hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(graph, message_per_edge, unnormalized_attn_score, mu):
+    """The reference's UNFUSED aggregation of HGT (hgt_layers_and_funcs.py:506-570, reached from HGT/models.py:271 when
+    ``--fused_message_mean_aggregation_flag`` is off: per-edge messages [E,H,dk] from a kind-0 rgnn_relational_matmul, then
+    the CSR edge softmax + aggregation ops ``hgt_full_graph_edge_softmax_ops_csr`` / ``hgt_full_graph_message_mean_aggregation_csr``,
+    which are outside SURVEY.md 8b's must-export set and not built).  Named here so that the reference's model code fails
+    with an explanation, not an AttributeError."""
+    from .._lib import HetUnsupported
+    raise HetUnsupported("hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr: the CSR edge-softmax / aggregation ops of HGT's "
+                         "unfused path (fused_message_mean_aggregation_flag=False) are not built; use the reference's default, "
+                         "fused_message_mean_aggregation_flag=True (hgt_full_graph_message_calc_edge_softmax_and_message_mean_"
+                         "aggregation_coo) -- same layer output, no [E,H,dk] message tensor")
+
+
 class _InnerProduct(th.autograd.Function):
     @staticmethod
     def forward(ctx, kind, map_a, map_b, rel_ptrs, eids, row, col, left, right, ret):

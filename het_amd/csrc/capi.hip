@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hip.h"
@@ -26,6 +27,71 @@ extern "C" const char* het_last_error(void) { return g_err; }
 extern "C" const char* het_build_info(void) {
   return "het_amd (libhet_amd.so) git " HET_GIT_SHA " | target gfx950 (MI355X, CDNA4) | hipcc " __VERSION__
          " | built " __DATE__ " " __TIME__;
+}
+
+// ---- device memory ---------------------------------------------------------------------
+namespace {
+std::mutex g_amu;
+het_alloc_fn g_alloc = nullptr;
+het_free_fn g_free = nullptr;
+void* g_alloc_user = nullptr;
+struct Owner { het_free_fn free; void* user; };
+std::unordered_map<void*, Owner> g_external;  // pointers that came from a caller's allocator (a few dozen per grouping)
+}  // namespace
+
+extern "C" int het_set_allocator(het_alloc_fn alloc, het_free_fn free_, void* user) {
+  HET_REQUIRE((alloc == nullptr) == (free_ == nullptr), "het_set_allocator: pass both functions or neither");
+  std::lock_guard<std::mutex> lk(g_amu);
+  g_alloc = alloc;
+  g_free = free_;
+  g_alloc_user = user;
+  return HET_OK;
+}
+
+extern "C" int het_allocator_is_external(void) {
+  std::lock_guard<std::mutex> lk(g_amu);
+  return g_alloc != nullptr;
+}
+
+int het_dev_alloc(void** out, size_t bytes, hipStream_t s) {
+  if (!bytes) bytes = 8;
+  het_alloc_fn a;
+  het_free_fn f;
+  void* u;
+  {
+    std::lock_guard<std::mutex> lk(g_amu);
+    a = g_alloc; f = g_free; u = g_alloc_user;
+  }
+  if (a) {
+    void* p = a(bytes, (het_stream)s, u);
+    if (!p) {
+      het_set_error("het_dev_alloc: the caller's allocator (het_set_allocator) returned NULL for %zu bytes", bytes);
+      return HET_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(g_amu);
+    g_external[p] = Owner{f, u};
+    *out = p;
+    return HET_OK;
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    het_set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    *out = nullptr;
+    return HET_ERR_HIP;
+  }
+  return HET_OK;
+}
+
+void het_dev_free(void* p) {
+  if (!p) return;
+  Owner o{nullptr, nullptr};
+  {
+    std::lock_guard<std::mutex> lk(g_amu);
+    auto it = g_external.find(p);
+    if (it != g_external.end()) { o = it->second; g_external.erase(it); }
+  }
+  if (o.free) o.free(p, o.user); else (void)hipFree(p);
 }
 
 // ---- per-kernel timing ---------------------------------------------------------------

@@ -39,6 +39,21 @@ void het_set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
+// ---- device memory the library keeps (groupings, layout scratch): hipMalloc / hipFree, or the caller's allocator ---------
+// (het_set_allocator, include/het_amd.h; capi.hip).  A pointer is released through the allocator it came from.
+int het_dev_alloc(void** out, size_t bytes, hipStream_t s);  // HET_OK, or HET_ERR_HIP with het_last_error() set
+void het_dev_free(void* p);                                  // NULL is fine
+// hipMalloc / hipFree-shaped forms for code written against hipError_t (the failing call's message is in het_last_error())
+static inline hipError_t het_malloc_e(void** out, size_t bytes, hipStream_t s) {
+  return het_dev_alloc(out, bytes, s) == HET_OK ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t het_free_e(void* p) { het_dev_free(p); return hipSuccess; }
+#define HET_ALLOC(ptr, bytes, s)                                          \
+  do {                                                                    \
+    int rc__ = het_dev_alloc((void**)&(ptr), (size_t)(bytes), (s));       \
+    if (rc__ != HET_OK) return rc__;                                      \
+  } while (0)
+
 // ---- optional per-kernel timing (het_kernel_timing_*; capi.hip) ---------------------
 bool het_ktime_on();
 void het_ktime_begin(const char* name, hipStream_t s);
@@ -73,13 +88,20 @@ struct HetFork {
       side = main;  // no fork: the side launches simply follow on the caller's stream
     }
   }
-  // the caller's stream waits for the side stream's work so far
+  // the caller's stream waits for the side stream's work so far (idempotent: the destructor joins whatever an early
+  // return -- a failed launch check between fork and join -- left on the side stream, so the caller never frees a workspace
+  // the side stream still uses, and a stream capture never ends with an unjoined fork)
+  bool joined = false;
   hipError_t join() {
-    if (side == main || !ev) return hipSuccess;
+    if (joined || side == main || !ev) { joined = true; return hipSuccess; }
+    joined = true;
     hipError_t e = hipEventRecord(ev, side);
     if (e == hipSuccess) e = hipStreamWaitEvent(main, ev, 0);
     return e;
   }
+  ~HetFork() { if (!joined && join() != hipSuccess) (void)hipGetLastError(); }
+  HetFork(const HetFork&) = delete;
+  HetFork& operator=(const HetFork&) = delete;
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

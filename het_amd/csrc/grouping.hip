@@ -1,6 +1,7 @@
 // Device-side construction of het_grouping (radix sort + run-length encode via hipCUB).
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <mutex>
 
 #include "grouping.hip.h"
@@ -167,10 +168,12 @@ struct Scratch {  // frees device temporaries on every exit path
   static constexpr int kSlots = 16;
   void* p[kSlots] = {};
   int n = 0;
-  ~Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
+  hipStream_t s = nullptr;  // the stream the temporaries are used on (a caller's allocator orders their reuse on it)
+  explicit Scratch(hipStream_t st) : s(st) {}
+  ~Scratch() { for (int i = 0; i < n; ++i) (void)het_free_e(p[i]); }
   hipError_t alloc(void** out, size_t bytes) {
     if (n >= kSlots) return hipErrorOutOfMemory;  // (more temporaries than slots: a bug in the caller, not a crash)
-    hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+    hipError_t e = het_malloc_e(out, bytes ? bytes : 4, s);
     if (e == hipSuccess) p[n++] = *out;
     return e;
   }
@@ -183,13 +186,15 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
                   g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order};
   for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+    if (p) (void)het_free_e(p);
+  for (void* p : g->retired) (void)het_free_e(p);
   delete g;
 }
 
 extern "C" int64_t het_grouping_num_segments(const het_grouping* g) { return g ? g->S : -1; }
 
-// Device bytes the grouping holds right now (hipMalloc, outside any caller's allocator): what a memory report has to add.
+// Device bytes the grouping holds right now: what a memory report has to add when they came from hipMalloc (the default);
+// with a caller's allocator (het_set_allocator) they are inside that allocator's own statistics.
 extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (!g) return 0;
   const int64_t E = g->E, S = g->S, I = g->num_items, R = g->R;
@@ -231,14 +236,16 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
   const int kb = bits_for(key_bound), rb = R > 0 ? bits_for(R) : 0;
 
   het_grouping* g = new het_grouping;
+  static std::atomic<uint64_t> next_serial{1};
+  g->serial = next_serial.fetch_add(1);
   g->E = E; g->R = R; g->key_bound = key_bound;
   struct Guard { het_grouping* g; ~Guard() { if (g) het_grouping_destroy(g); } } guard{g};
-#define GALLOC(field, count) HET_HIP(hipMalloc((void**)&g->field, sizeof(int32_t) * ((count) > 0 ? (count) : 1)))
+#define GALLOC(field, count) HET_HIP(het_malloc_e((void**)&g->field, sizeof(int32_t) * ((count) > 0 ? (count) : 1), s))
   GALLOC(perm, E);
   if (R > 0) GALLOC(seg_rel_ptr, R + 1);
-  if (R > 0) HET_HIP(hipMalloc((void**)&g->seg_rel_ptr64, sizeof(idx_t) * (R + 1)));
+  if (R > 0) HET_HIP(het_malloc_e((void**)&g->seg_rel_ptr64, sizeof(idx_t) * (R + 1), s));
 
-  Scratch tmp;
+  Scratch tmp(s);
   uint64_t *keys_in = nullptr, *keys_out = nullptr, *uniq = nullptr;
   int32_t *vals_in = nullptr, *counts = nullptr, *d_scalars = nullptr, *nitems = nullptr, *item_off = nullptr;
   HET_HIP(tmp.alloc((void**)&keys_in, sizeof(uint64_t) * E));
@@ -254,7 +261,7 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     size_t tb = 0;
     HET_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, g->perm, (int)E, 0, kb + rb, s));
     void* t0 = nullptr;
-    HET_HIP(hipMalloc(&t0, tb ? tb : 4));
+    HET_HIP(het_malloc_e(&t0, tb ? tb : 4, s));
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(t0, tb, keys_in, keys_out, vals_in, g->perm, (int)E, 0, kb + rb, s);
     // keys_in is dead after the sort: reuse it for the unique keys, vals_in for the run lengths
     uniq = keys_in;
@@ -263,21 +270,21 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     if (e == hipSuccess) e = hipcub::DeviceRunLengthEncode::Encode(nullptr, tb2, keys_out, uniq, counts, d_scalars, (int)E, s);
     if (e == hipSuccess && tb2 > tb) {
       (void)hipStreamSynchronize(s);
-      (void)hipFree(t0);
+      (void)het_free_e(t0);
       t0 = nullptr;
-      e = hipMalloc(&t0, tb2);
+      e = het_malloc_e(&t0, tb2, s);
     }
     if (e == hipSuccess) e = hipcub::DeviceRunLengthEncode::Encode(t0, tb2, keys_out, uniq, counts, d_scalars, (int)E, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_runs, d_scalars, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(t0);
+    (void)het_free_e(t0);
     HET_HIP(e);
   }
   const int64_t S = h_runs;
   g->S = S;
   GALLOC(seg_ptr, S + 1);
   GALLOC(seg_key, S);
-  HET_HIP(hipMalloc((void**)&g->seg_key64, sizeof(idx_t) * (S > 0 ? S : 1)));
+  HET_HIP(het_malloc_e((void**)&g->seg_key64, sizeof(idx_t) * (S > 0 ? S : 1), s));
   HET_HIP(tmp.alloc((void**)&nitems, sizeof(int32_t) * S));
   HET_HIP(tmp.alloc((void**)&item_off, sizeof(int32_t) * S));
   if (S == 0) {
@@ -289,7 +296,7 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     size_t tb = 0;
     HET_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, counts, g->seg_ptr, (int)S, s));
     void* t0 = nullptr;
-    HET_HIP(hipMalloc(&t0, tb ? tb : 4));
+    HET_HIP(het_malloc_e(&t0, tb ? tb : 4, s));
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(t0, tb, counts, g->seg_ptr, (int)S, s);
     if (e == hipSuccess) {
       const int64_t n = S > R + 1 ? S : R + 1;
@@ -301,16 +308,16 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, nitems, item_off, (int)S, s);
     if (e == hipSuccess && tb2 > tb) {
       (void)hipStreamSynchronize(s);
-      (void)hipFree(t0);
+      (void)het_free_e(t0);
       t0 = nullptr;
-      e = hipMalloc(&t0, tb2);
+      e = het_malloc_e(&t0, tb2, s);
     }
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(t0, tb2, nitems, item_off, (int)S, s);
     int32_t last_off = 0, last_n = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&last_off, item_off + (S - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&last_n, nitems + (S - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(t0);
+    (void)het_free_e(t0);
     HET_HIP(e);
     g->num_items = (int64_t)last_off + last_n;
     GALLOC(item_seg, g->num_items);
@@ -355,7 +362,7 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   if (g->pack_ptr || g->E == 0 || g->S == 0) return HET_OK;
   const int64_t E = g->E, S = g->S;
   if (int rc = grouping_seg_of_rank(g, s)) return rc;
-  Scratch tmp;
+  Scratch tmp(s);
   const int64_t NI = g->num_items;
   uint8_t *flag = nullptr, *is_long = nullptr;
   int32_t* d_num = nullptr;
@@ -382,9 +389,9 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   HET_HIP(hipMemcpyAsync(h_num, d_num, sizeof(h_num), hipMemcpyDeviceToHost, s));
   HET_HIP(hipStreamSynchronize(s));
   int32_t *pack_ptr = nullptr, *key_of_rank = nullptr, *long_items = nullptr;
-  HET_HIP(hipMalloc((void**)&pack_ptr, sizeof(int32_t) * ((size_t)h_num[0] + 1)));
-  hipError_t e = hipMalloc((void**)&key_of_rank, sizeof(int32_t) * ((size_t)E + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&long_items, sizeof(int32_t) * ((size_t)h_num[1] + 1));
+  HET_HIP(het_malloc_e((void**)&pack_ptr, sizeof(int32_t) * ((size_t)h_num[0] + 1), s));
+  hipError_t e = het_malloc_e((void**)&key_of_rank, sizeof(int32_t) * ((size_t)E + 1), s);
+  if (e == hipSuccess) e = het_malloc_e((void**)&long_items, sizeof(int32_t) * ((size_t)h_num[1] + 1), s);
   if (e == hipSuccess) e = hipMemcpyAsync(pack_ptr, pack_tmp, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
   // (issuing the long work items in the order of their first gathered row -- as the hub items of the RGAT forward are -- was
   //  measured with (source, destination)-ordered edge lists and lost: RGAT 4.17 -> 4.28 ms, RGCN 3.02 -> 3.12; segment order stays)
@@ -397,7 +404,7 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete: later users may be on other streams
   if (e != hipSuccess) {
-    (void)hipFree(pack_ptr); (void)hipFree(key_of_rank); (void)hipFree(long_items);
+    (void)het_free_e(pack_ptr); (void)het_free_e(key_of_rank); (void)het_free_e(long_items);
     HET_HIP(e);
   }
   g->key_of_rank = key_of_rank;
@@ -411,10 +418,13 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
 int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, int hub_min, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_pack_mu);
   if (g->num_hub_items >= 0) {
-    if (g->hub_twin == twin && g->hub_min == hub_min) return HET_OK;
+    if (g->hub_twin_serial == twin->serial && g->hub_min == hub_min) return HET_OK;
     // paired with another twin object before (a cache that evicted and rebuilt the grouping by key alone) or another threshold:
-    // the lists are rebuilt.  hipFree waits for the device, so a launch that still reads the old lists has finished.
-    (void)hipFree(g->hub_items); (void)hipFree(g->hub_segs); (void)hipFree(g->hub_order);
+    // the lists are rebuilt.  The old ones are RETIRED, not freed: another thread may be between its workspace query and its
+    // launch with the pointers it read (and a caller's allocator would hand the memory out again without waiting for the
+    // device); they go with the grouping (het_grouping_destroy).
+    for (int32_t* old : {g->hub_items, g->hub_segs, g->hub_order})
+      if (old) g->retired.push_back(old);
     g->hub_items = g->hub_segs = g->hub_order = nullptr;
     g->num_hub_items = -1;
     g->num_hub_segs = 0;
@@ -423,7 +433,7 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
   int32_t *items = nullptr, *segs = nullptr, *order = nullptr;
   int32_t h_num[2] = {0, 0};
   if (NI > 0 && TS > 0) {
-    Scratch tmp;
+    Scratch tmp(s);
     uint8_t *is_hub = nullptr, *is_long = nullptr;
     int32_t *d_num = nullptr, *sel = nullptr, *sel2 = nullptr;
     HET_HIP(tmp.alloc((void**)&is_hub, (size_t)NI));
@@ -446,14 +456,14 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
     HET_HIP(hipcub::DeviceSelect::Flagged(t0, tb2, ranks, is_long, sel2, d_num + 1, (int)TS, s));
     HET_HIP(hipMemcpyAsync(h_num, d_num, sizeof(h_num), hipMemcpyDeviceToHost, s));
     HET_HIP(hipStreamSynchronize(s));
-    HET_HIP(hipMalloc((void**)&items, sizeof(int32_t) * ((size_t)h_num[0] + 1)));
-    hipError_t e = hipMalloc((void**)&segs, sizeof(int32_t) * ((size_t)h_num[1] + 1));
+    HET_HIP(het_malloc_e((void**)&items, sizeof(int32_t) * ((size_t)h_num[0] + 1), s));
+    hipError_t e = het_malloc_e((void**)&segs, sizeof(int32_t) * ((size_t)h_num[1] + 1), s);
     if (e == hipSuccess) e = hipMemcpyAsync(items, sel, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(segs, sel2, sizeof(int32_t) * (size_t)h_num[1], hipMemcpyDeviceToDevice, s);
     // launch order of the hub items: by the first payload0 (feat row) of the item, so that items in flight together read the
     // same window of the table (within a run the rows ascend when the positions are in (relation, source) order)
     if (e == hipSuccess && h_num[0] > 0 && twin->p0) {
-      e = hipMalloc((void**)&order, sizeof(int32_t) * (size_t)h_num[0]);
+      e = het_malloc_e((void**)&order, sizeof(int32_t) * (size_t)h_num[0], s);
       uint32_t *k_in = nullptr, *k_out = nullptr;
       int32_t* v_in = nullptr;
       if (e == hipSuccess) e = tmp.alloc((void**)&k_in, sizeof(uint32_t) * (size_t)h_num[0]);
@@ -471,13 +481,13 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
       if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(st, sb, k_in, k_out, v_in, order, h_num[0], 0, 32, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(items); (void)hipFree(segs); (void)hipFree(order); HET_HIP(e); }
+    if (e != hipSuccess) { (void)het_free_e(items); (void)het_free_e(segs); (void)het_free_e(order); HET_HIP(e); }
   }
   g->hub_order = order;
   g->hub_items = items;
   g->hub_segs = segs;
   g->num_hub_segs = h_num[1];
-  g->hub_twin = twin;
+  g->hub_twin_serial = twin->serial;
   g->hub_min = hub_min;
   g->num_hub_items = h_num[0];
   return HET_OK;
@@ -506,16 +516,16 @@ int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s) {
   int4* o4 = nullptr;
   if (with_keys) {
     HET_REQUIRE(g->key_of_rank, "grouping_packed_ids: the grouping has no packs (no segments?)");
-    HET_HIP(hipMalloc((void**)&o4, sizeof(int4) * (size_t)(E + 1)));
+    HET_HIP(het_malloc_e((void**)&o4, sizeof(int4) * (size_t)(E + 1), s));
   } else {
-    HET_HIP(hipMalloc((void**)&o2, sizeof(int2) * (size_t)E));
+    HET_HIP(het_malloc_e((void**)&o2, sizeof(int2) * (size_t)E, s));
   }
   hipLaunchKernelGGL(HET_grouping_pack_ids, dim3(blocks_for(E + 1)), dim3(256), 0, s, g->key_of_rank, g->p0, g->p1, E, o2, o4);
   hipError_t e = hipGetLastError();
 
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete
   if (e != hipSuccess) {
-    (void)hipFree(o2); (void)hipFree(o4);
+    (void)het_free_e(o2); (void)het_free_e(o4);
     HET_HIP(e);
   }
   if (with_keys) g->kp01 = o4; else g->p01 = o2;

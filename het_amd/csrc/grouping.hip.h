@@ -1,6 +1,8 @@
 // het_grouping: positions of an index list sorted by (relation, key), with the
 // segments (runs of equal (relation, key)) and a list of wave-sized work items.
 #pragma once
+#include <vector>
+
 #include "common.hip.h"
 
 // Segments longer than this are split into several work items so that no single
@@ -8,6 +10,7 @@
 constexpr int HET_ITEM_MAX = 256;
 
 struct het_grouping {
+  uint64_t serial = 0;     // unique per object for the life of the process (an address can come back after a destroy)
   int64_t E = 0;           // positions
   int64_t S = 0;           // segments
   int64_t num_items = 0;   // work items (>= S)
@@ -49,7 +52,8 @@ struct het_grouping {
   mutable int32_t* hub_segs = nullptr;        // the twin's segments of more than hub_min positions (ascending)
   mutable int64_t num_hub_segs = 0;
   mutable int hub_min = 0;
-  mutable const het_grouping* hub_twin = nullptr;
+  mutable uint64_t hub_twin_serial = 0;       // serial of the twin the lists were built against
+  mutable std::vector<int32_t*> retired;      // hub lists replaced by a rebuild (grouping_hub_items): freed with the grouping
 };
 
 constexpr int HET_PACK_T = 32;

@@ -26,9 +26,11 @@ inline int bits_for(int64_t n) {  // bits to represent values in [0, n)
 struct Scratch {  // frees device temporaries on every exit path
   void* p[12] = {};
   int n = 0;
-  ~Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
+  hipStream_t s = nullptr;  // the stream the temporaries are used on (a caller's allocator orders their reuse on it)
+  explicit Scratch(hipStream_t st) : s(st) {}
+  ~Scratch() { for (int i = 0; i < n; ++i) (void)het_free_e(p[i]); }
   hipError_t alloc(void** out, size_t bytes) {
-    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    hipError_t e = het_malloc_e(out, bytes ? bytes : 8, s);
     if (e == hipSuccess) p[n++] = *out;
     return e;
   }
@@ -173,7 +175,7 @@ extern "C" int het_layout_separate_coo(const int64_t* row, const int64_t* col, c
   HET_REQUIRE(num_rels > 0 && out_rel_ptrs && (num_edges == 0 || (row && col && rel && eids && out_row && out_col && out_eids)),
               "%s: null pointer", op);
   hipStream_t s = (hipStream_t)stream;
-  Scratch tmp;
+  Scratch tmp(s);
   uint64_t* sorted = nullptr;
   int32_t* perm = nullptr;
   int lo_bits = 0;
@@ -199,7 +201,7 @@ extern "C" int het_layout_coo_to_csr(const int64_t* row, const int64_t* col, con
   HET_REQUIRE(out_row_ptrs && (num_edges == 0 || (row && col && rel && eids && out_col && out_rel && out_eids)),
               "%s: null pointer", op);
   hipStream_t s = (hipStream_t)stream;
-  Scratch tmp;
+  Scratch tmp(s);
   uint64_t* sorted = nullptr;
   int32_t* perm = nullptr;
   int lo_bits = 0;
@@ -226,7 +228,7 @@ extern "C" int het_layout_transpose_csr(const int64_t* row_ptrs, const int64_t* 
   HET_REQUIRE(row_ptrs && out_row_ptrs && (num_edges == 0 || (col && eids && rel && out_col && out_eids && out_rel)),
               "%s: null pointer", op);
   hipStream_t s = (hipStream_t)stream;
-  Scratch tmp;
+  Scratch tmp(s);
   idx_t* rows = nullptr;
   HET_HIP(tmp.alloc((void**)&rows, sizeof(idx_t) * num_edges));
   if (num_edges > 0) {
@@ -250,7 +252,7 @@ extern "C" int het_layout_unique_rel_nodes(const int64_t* rel_ptrs, int64_t num_
               "%s: null pointer", op);
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = nodes_b ? 2 * num_edges : num_edges;
-  Scratch tmp;
+  Scratch tmp(s);
   uint64_t* sorted = nullptr;
   int32_t *perm = nullptr, *head = nullptr, *run = nullptr;
   int lo_bits = 0;

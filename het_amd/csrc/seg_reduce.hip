@@ -495,16 +495,16 @@ int grouping_seg_of_rank(const het_grouping* g, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_seg_of_rank_mu);
   if (g->seg_of_rank || g->E == 0) return HET_OK;
   int32_t* p = nullptr;
-  HET_HIP(hipMalloc((void**)&p, sizeof(int32_t) * g->E));
+  HET_HIP(het_malloc_e((void**)&p, sizeof(int32_t) * g->E, s));
   int64_t nb0 = ceil_div64(g->E, kBlock);
   hipLaunchKernelGGL(HET_grouping_seg_of_rank, dim3((unsigned)(nb0 > 65536 ? 65536 : nb0)), dim3(kBlock), 0, s, g->seg_ptr,
                      g->S, g->E, p);
   if (hipGetLastError() != hipSuccess) {
-    (void)hipFree(p);
+    (void)het_free_e(p);
     HET_REQUIRE(false, "HET_grouping_seg_of_rank: launch failed");
   }
   if (hipStreamSynchronize(s) != hipSuccess) {
-    (void)hipFree(p);
+    (void)het_free_e(p);
     HET_REQUIRE(false, "HET_grouping_seg_of_rank: kernel failed");
   }
   g->seg_of_rank = p;

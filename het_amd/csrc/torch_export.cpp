@@ -10,10 +10,14 @@
 // the identity of the index tensors they were built from -- what het_amd/plan.py does for the Python registration.
 // Build: make -C het_amd/csrc torch_hrt   (hipcc + the torch headers of the running interpreter; links libhet_amd.so).
 #include <ATen/ATen.h>
+#include <ATen/DeviceGuard.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
 #include <list>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -27,6 +31,28 @@ using at::Tensor;
 using Dict = c10::Dict<std::string, Tensor>;
 
 inline het_stream stream_of(const Tensor& t) { return (het_stream)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// Every compute op starts with HET_ON_DEVICE_OF(<one of its GPU tensors>): the launches, the library's side stream and its fork /
+// join events key on the CURRENT device, so tensors on another GPU of the process make that GPU current for the op (what the
+// Python registration does with torch.cuda.device(tensor.device)).
+#define HET_ON_DEVICE_OF(t) const c10::OptionalDeviceGuard het_device_guard__(at::device_of(t))
+
+// The library's own device memory (groupings, construction scratch) from torch's caching allocator (include/het_amd.h:
+// het_set_allocator): inside torch.cuda.memory_allocated, back in torch's pool when a grouping is dropped, no hipFree on an op's path.
+void* torch_alloc(size_t bytes, het_stream stream, void*) {
+  try {
+    return c10::hip::HIPCachingAllocator::raw_alloc_with_stream(bytes, (hipStream_t)stream);
+  } catch (...) {
+    return nullptr;  // (out of memory: the library reports it through its error code)
+  }
+}
+void torch_free(void* p, void*) {
+  try { c10::hip::HIPCachingAllocator::raw_delete(p); } catch (...) {}
+}
+const bool g_allocator_installed = [] {
+  const char* v = getenv("HET_TORCH_ALLOCATOR");
+  if (v && v[0] == '0') return false;
+  return het_set_allocator(torch_alloc, torch_free, nullptr) == HET_OK;
+}();
 inline void check(int rc, const char* op) { TORCH_CHECK(rc == HET_OK, op, ": ", het_last_error()); }
 
 inline const float* fp(const Tensor& t) {
@@ -53,22 +79,30 @@ inline Ident ident(const Tensor* t) {
   if (!t || !t->defined()) return {nullptr, 0, 0};
   return {t->data_ptr(), t->numel(), (uint32_t)t->_version()};
 }
+// A grouping is shared between the cache and every op call that is using it: eviction only drops the cache's reference, the
+// object goes when the last op that holds it has enqueued its launches (a concurrent call on another thread -- the model thread
+// and an autograd worker -- can no longer destroy a grouping under a launch that is about to read its index arrays).
+using GroupingRef = std::shared_ptr<het_grouping>;
 struct Entry {
   Ident a, b, c, d; int64_t bound; int dev;
-  het_grouping* g;
+  GroupingRef g;
   std::vector<Tensor> keep;  // the source tensors stay alive with the grouping (a data_ptr cannot be recycled meanwhile)
 };
 std::mutex g_mu;
-std::list<Entry> g_cache;
+// (never destructed: at process exit the groupings would be released into a caching allocator that may already be gone)
+std::list<Entry>& g_cache = *new std::list<Entry>();
 constexpr size_t kMaxEntries = 24;
 bool groupings_enabled() {
   static const bool on = [] { const char* v = getenv("HET_SHIM_GROUPINGS"); return !(v && v[0] == '0'); }();
   return on;
 }
 
-// Grouping of the positions of `keys` by (relation, key); by key alone without rel_ptrs.  NULL when disabled.
-const het_grouping* grouping(const Tensor* rel_ptrs, const Tensor& keys, int64_t key_bound, const Tensor* p0, const Tensor* p1) {
+// Grouping of the positions of `keys` by (relation, key); by key alone without rel_ptrs.  NULL when disabled.  Hold the
+// returned reference until the op's launches are enqueued.  HET_SHIM_GROUPING_CACHE=<n>: entries kept (24; one-shot graphs --
+// sampled blocks -- want few).
+GroupingRef grouping(const Tensor* rel_ptrs, const Tensor& keys, int64_t key_bound, const Tensor* p0, const Tensor* p1) {
   if (!groupings_enabled()) return nullptr;
+  static const size_t max_entries = [] { const char* v = getenv("HET_SHIM_GROUPING_CACHE"); const long n = v ? atol(v) : 0; return n > 0 ? (size_t)n : kMaxEntries; }();
   const Ident a = ident(rel_ptrs), b = ident(&keys), c = ident(p0), d = ident(p1);
   const int dev = keys.device().index();
   std::lock_guard<std::mutex> lk(g_mu);
@@ -77,20 +111,18 @@ const het_grouping* grouping(const Tensor* rel_ptrs, const Tensor& keys, int64_t
       g_cache.splice(g_cache.begin(), g_cache, it);
       return g_cache.front().g;
     }
-  het_grouping* g = nullptr;
+  het_grouping* raw = nullptr;
   check(het_grouping_create(rel_ptrs ? ip(*rel_ptrs) : nullptr, rel_ptrs ? rel_ptrs->numel() - 1 : 0, ip(keys), keys.numel(), key_bound,
-                            p0 ? ip(*p0) : nullptr, p1 ? ip(*p1) : nullptr, stream_of(keys), &g),
+                            p0 ? ip(*p0) : nullptr, p1 ? ip(*p1) : nullptr, stream_of(keys), &raw),
         "het_grouping_create");
+  GroupingRef g(raw, [](het_grouping* q) { het_grouping_destroy(q); });
   Entry e{a, b, c, d, key_bound, dev, g, {}};
   if (rel_ptrs) e.keep.push_back(*rel_ptrs);
   e.keep.push_back(keys);
   if (p0) e.keep.push_back(*p0);
   if (p1) e.keep.push_back(*p1);
   g_cache.push_front(std::move(e));
-  while (g_cache.size() > kMaxEntries) {
-    het_grouping_destroy(g_cache.back().g);
-    g_cache.pop_back();
-  }
+  while (g_cache.size() > max_entries) g_cache.pop_back();  // (drops the cache's reference only)
   return g;
 }
 Tensor workspace(int64_t floats, const Tensor& like) {
@@ -226,43 +258,47 @@ Lists matmul_lists(const Dict& d, int64_t kind) {
 }
 
 void rgnn_relational_matmul(Dict d, int64_t kind, Tensor W, Tensor x, Tensor ret, bool in1head) {
+  HET_ON_DEVICE_OF(ret);
   const Lists l = matmul_lists(d, kind);
   const int64_t R = W.size(0), H = W.size(1), K = W.size(2), D = W.size(3), X = H * D;
   const bool mfma = (K == 32 || K == 64 || K == 128) && (X == 32 || X == 64 || X == 128);
-  const het_grouping* g = nullptr;
+  GroupingRef g;
   Tensor ws;
   if (kind == 0 && in1head && ((D == 1 && (H & (H - 1)) == 0) || (D > 1 && !mfma && (X & (X - 1)) == 0 && X <= 256)) &&
       l.g->numel() > 0 && l.g->data_ptr() != l.s->data_ptr()) {
     g = grouping(l.rp, *l.g, x.size(0), l.s, nullptr);
-    if (g) ws = workspace(std::max<int64_t>(1, het_grouping_num_segments(g)) * X, ret);
+    if (g) ws = workspace(std::max<int64_t>(1, het_grouping_num_segments(g.get())) * X, ret);
   }
   check(het_rgnn_relational_matmul(kind, ip(*l.rp), R, ip(*l.g), l.s ? ip(*l.s) : nullptr, l.g->numel(), fp(W), fp(x), fpw(ret), H, K, D,
-                                   in1head, g, ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? ws.numel() * 4 : 0, stream_of(ret)),
+                                   in1head, g.get(), ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? ws.numel() * 4 : 0, stream_of(ret)),
         "rgnn_relational_matmul");
 }
 
 void backward_rgnn_relational_matmul(Dict d, int64_t kind, Tensor Wt, Tensor x, Tensor gradout, Tensor grad_x, Tensor grad_w, bool in1head) {
+  HET_ON_DEVICE_OF(gradout);
   const Lists l = matmul_lists(d, kind);
   const int64_t R = Wt.size(0), H = Wt.size(1), D = Wt.size(2), K = Wt.size(3);
-  const het_grouping* g = nullptr;
+  GroupingRef g;
   Tensor ws;
   if (kind == 0 && l.g->data_ptr() != l.s->data_ptr() && (in1head || D > 1)) {
     g = grouping(l.rp, *l.g, x.size(0), l.s, nullptr);
-    if (g) ws = workspace(std::max<int64_t>(1, het_grouping_num_segments(g)) * H * D, gradout);
+    if (g) ws = workspace(std::max<int64_t>(1, het_grouping_num_segments(g.get())) * H * D, gradout);
   }
   check(het_backward_rgnn_relational_matmul(kind, ip(*l.rp), R, ip(*l.g), l.s ? ip(*l.s) : nullptr, l.g->numel(), x.size(0), fp(Wt), fp(x),
-                                            fp(gradout), fpw(grad_x), fpw(grad_w), H, K, D, in1head, HET_ACC_ADD, g,
+                                            fp(gradout), fpw(grad_x), fpw(grad_w), H, K, D, in1head, HET_ACC_ADD, g.get(),
                                             ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? ws.numel() * 4 : 0, stream_of(gradout)),
         "backward_rgnn_relational_matmul");
 }
 
 void rgnn_relational_matmul_no_scatter_gather_list(Tensor offsets, Tensor W, Tensor x, Tensor ret) {
+  HET_ON_DEVICE_OF(ret);
   const int64_t T = W.size(0), H = W.size(1), K = W.size(2), D = W.size(3), n = x.size(0);
   const int per_head = H > 1 && x.numel() == n * H * K;
   check(het_rgnn_relational_matmul_no_scatter_gather_list(ip(offsets), T, n, fp(W), fp(x), fpw(ret), H, K, D, per_head, stream_of(ret)),
         "rgnn_relational_matmul_no_scatter_gather_list");
 }
 void backward_rgnn_relational_matmul_no_scatter_gather_list(Tensor offsets, Tensor Wt, Tensor x, Tensor gradout, Tensor grad_x, Tensor grad_w) {
+  HET_ON_DEVICE_OF(gradout);
   const int64_t T = Wt.size(0), H = Wt.size(1), D = Wt.size(2), K = Wt.size(3), n = x.size(0);
   const int per_head = H > 1 && x.numel() == n * H * K;
   check(het_backward_rgnn_relational_matmul_no_scatter_gather_list(ip(offsets), T, n, fp(Wt), fp(x), fp(gradout), fpw(grad_x), fpw(grad_w), H,
@@ -324,7 +360,7 @@ void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, 
                  const Tensor& feat, const Tensor& el, const Tensor& er, Tensor& sum, Tensor& exp, Tensor& ret, double slope) {
   const int64_t E = eids.numel(), N = ret.size(0), H = sum.size(1);
   const int64_t D = feat.numel() ? feat.numel() / (feat.size(0) * H) : ret.numel() / std::max<int64_t>(1, N * H);
-  const het_grouping* g = nullptr;
+  GroupingRef g;
   Maps m = m_in;
   std::vector<Tensor> dr;
   if (kind == 0 && E > 0) {  // positions by destination; payload0 = edge id, payload1 = relation of the position
@@ -338,14 +374,14 @@ void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, 
   }
   check(het_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]), mp(m.m[1]),
                                               mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fpw(sum), fpw(exp), fpw(ret), nullptr, H, D,
-                                              slope, g, nullptr, nullptr, stream_of(ret)),
+                                              slope, g.get(), nullptr, nullptr, stream_of(ret)),
         "relational_fused_gat_separate_coo");
 }
 void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m_in,
                   const Tensor& feat, const Tensor& el, const Tensor& er, const Tensor& sum, const Tensor& exp, const Tensor& ret,
                   const Tensor& gradout, Tensor& gfeat, Tensor& gel, Tensor& ger, double slope) {
   const int64_t E = eids.numel(), N = ret.size(0), H = sum.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
-  const het_grouping *g = nullptr, *gs = nullptr, *gd = nullptr;
+  GroupingRef g, gs, gd;
   Maps m = m_in;
   std::vector<Tensor> dr;
   Tensor ws;
@@ -363,12 +399,12 @@ void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row,
       m = Maps{{&dr[2], nullptr, &dr[3], nullptr}};
       kind = 4;
     } else {
-      gs = gd = nullptr;
+      gs.reset(); gd.reset();
     }
   }
   check(het_backward_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]),
                                                        mp(m.m[1]), mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fp(sum), fp(exp), fp(ret),
-                                                       nullptr, fp(gradout), fpw(gfeat), fpw(gel), fpw(ger), H, D, slope, g, gs, gd,
+                                                       nullptr, fp(gradout), fpw(gfeat), fpw(gel), fpw(ger), H, D, slope, g.get(), gs.get(), gd.get(),
                                                        feat.size(0), er.size(0), ws.defined() ? ws.data_ptr() : nullptr,
                                                        ws.defined() ? ws.numel() * 4 : 0, nullptr, nullptr, nullptr, nullptr, stream_of(ret)),
         "backward_relational_fused_gat_separate_coo");
@@ -394,16 +430,19 @@ std::vector<Tensor> csr_compact_maps(const Tensor& row_ptr, const Tensor& col, c
 
 void relational_fused_gat_separate_coo(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, int64_t kind, Dict d, Tensor feat, Tensor el,
                                        Tensor er, Tensor sum, Tensor exp, Tensor ret, double slope) {
+  HET_ON_DEVICE_OF(ret);
   gat_forward(eids, rel_ptrs, row, col, kind, gat_maps(kind, d), feat, el, er, sum, exp, ret, slope);
 }
 void backward_relational_fused_gat_separate_coo(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, int64_t kind, Dict d, Tensor feat, Tensor el,
                                                 Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor gfeat, Tensor gel,
                                                 Tensor ger, double slope) {
+  HET_ON_DEVICE_OF(ret);
   gat_backward(eids, rel_ptrs, row, col, kind, gat_maps(kind, d), feat, el, er, sum, exp, ret, gradout, gfeat, gel, ger, slope);
 }
 
 void relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor reltypes, Tensor urp, Tensor unodes, Tensor feat, Tensor el, Tensor er,
                               Tensor sum, Tensor exp, Tensor ret, double slope, bool compact) {
+  HET_ON_DEVICE_OF(ret);
   const int64_t N = row_ptr.numel() - 1, E = eids.numel(), H = el.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
   if (!compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D)) {
     // the in-CSR IS the edge list grouped by destination: (eids, src, dst) in CSR order through the destination-grouped kernels
@@ -425,6 +464,7 @@ void relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor re
 void backward_relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor reltypes, Tensor urp, Tensor unodes, Tensor feat, Tensor el,
                                        Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor gfeat, Tensor gel, Tensor ger,
                                        double slope, bool compact) {
+  HET_ON_DEVICE_OF(ret);
   const int64_t N = row_ptr.numel() - 1, E = eids.numel(), H = el.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
   if (!compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D) && slope >= 0) {
     Tensor src = csr_rows(row_ptr), rp1 = at::tensor({(int64_t)0, E}, row_ptr.options());  // out-CSR rows are the sources
@@ -450,24 +490,27 @@ void backward_relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, 
 
 // ---- a7 / a8 / a9: RGCN (RGCNOps.inc.h) ----------------------------------------------------------------------------------
 void rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor W, Tensor norm, Tensor out) {
+  HET_ON_DEVICE_OF(out);
   const int64_t R = W.size(0), K = W.size(1), D = W.size(2), N = out.size(0);
-  const het_grouping* g = grouping(&rel_ptrs, col, N, &row, &eids);
-  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g)) * K, W) : Tensor();
-  check(het_rgcn_layer1_separate_coo(ip(rel_ptrs), ip(eids), ip(row), ip(col), R, eids.numel(), N, fp(x), fp(W), fp(norm), fpw(out), K, D, g,
+  GroupingRef g = grouping(&rel_ptrs, col, N, &row, &eids);
+  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g.get())) * K, W) : Tensor();
+  check(het_rgcn_layer1_separate_coo(ip(rel_ptrs), ip(eids), ip(row), ip(col), R, eids.numel(), N, fp(x), fp(W), fp(norm), fpw(out), K, D, g.get(),
                                      g ? ws.data_ptr() : nullptr, g ? ws.numel() * 4 : 0, stream_of(out)),
         "rgcn_layer1_separate_coo");
 }
 void backward_rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor Wt, Tensor norm, Tensor grad_norm,
                                        Tensor grad_x, Tensor gradout, Tensor grad_w) {
+  HET_ON_DEVICE_OF(gradout);
   const int64_t R = Wt.size(0), D = Wt.size(1), K = Wt.size(2), N = gradout.size(0);
-  const het_grouping* g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
-  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g)) * D, grad_w) : Tensor();
+  GroupingRef g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
+  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g.get())) * D, grad_w) : Tensor();
   check(het_backward_rgcn_layer1_separate_coo(ip(rel_ptrs), ip(eids), ip(row), ip(col), R, eids.numel(), N, fp(x), fp(Wt), fp(norm), fpw(grad_norm),
-                                              fpw(grad_x), fp(gradout), fpw(grad_w), K, D, g, g ? ws.data_ptr() : nullptr,
+                                              fpw(grad_x), fp(gradout), fpw(grad_w), K, D, g.get(), g ? ws.data_ptr() : nullptr,
                                               g ? ws.numel() * 4 : 0, stream_of(grad_w)),
         "backward_rgcn_layer1_separate_coo");
 }
 void rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, Dict d, Tensor feat, Tensor enorm, Tensor ret, bool direct) {
+  HET_ON_DEVICE_OF(ret);
   const Tensor* a = direct ? &key(d, "inverse_indices_row") : &key(d, "rel_ptrs_row");
   const Tensor* b = direct ? nullptr : &key(d, "node_indices_row");
   const int64_t N = ret.size(0);
@@ -478,6 +521,7 @@ void rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor
 }
 void backward_rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, Dict d, Tensor feat, Tensor enorm, Tensor ret,
                                          Tensor gradout, Tensor gfeat, bool direct) {
+  HET_ON_DEVICE_OF(ret);
   const Tensor* a = direct ? &key(d, "inverse_indices_row") : &key(d, "rel_ptrs_row");
   const Tensor* b = direct ? nullptr : &key(d, "node_indices_row");
   const int64_t N = ret.size(0);
@@ -497,6 +541,7 @@ IpMaps ip_maps(const Dict& d, int64_t kind) {
 }
 void rgnn_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor left, Tensor right,
                                                Tensor out) {
+  HET_ON_DEVICE_OF(out);
   const IpMaps m = ip_maps(d, kind);
   const int64_t H = out.size(1), D = right.numel() / std::max<int64_t>(1, right.size(0) * H);
   check(het_rgnn_inner_product_right_node_separatecoo(m.kind, mp(m.a), mp(m.b), ip(rel_ptrs), ip(eids), ip(row), ip(col), rel_ptrs.numel() - 1,
@@ -505,56 +550,62 @@ void rgnn_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_
 }
 void backward_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor left,
                                                    Tensor right, Tensor gradout, Tensor gleft, Tensor gright) {
+  HET_ON_DEVICE_OF(gradout);
   const IpMaps m = ip_maps(d, kind);
   const int64_t H = gradout.size(1), D = right.numel() / std::max<int64_t>(1, right.size(0) * H);
-  const het_grouping* g = m.kind == 0 ? grouping(nullptr, row, right.size(0), &eids, &eids) : nullptr;
+  GroupingRef g = m.kind == 0 ? grouping(nullptr, row, right.size(0), &eids, &eids) : nullptr;
   check(het_backward_inner_product_right_node_separatecoo(m.kind, mp(m.a), mp(m.b), ip(rel_ptrs), ip(eids), ip(row), ip(col),
                                                           rel_ptrs.numel() - 1, eids.numel(), fp(left), fp(right), fp(gradout), fpw(gleft),
-                                                          fpw(gright), H, D, 1, g, nullptr, left.size(0), right.size(0), stream_of(gradout)),
+                                                          fpw(gright), H, D, 1, g.get(), nullptr, left.size(0), right.size(0), stream_of(gradout)),
         "backward_inner_product_right_node_separatecoo");
 }
-const het_grouping* by_dst_rel(const Tensor& rel_ptrs, const Tensor& col, const Tensor& eids, int64_t N) {
+GroupingRef by_dst_rel(const Tensor& rel_ptrs, const Tensor& col, const Tensor& eids, int64_t N) {
   if (eids.numel() == 0) return nullptr;
   Tensor relp = cached_rel_by_position(rel_ptrs, eids.numel());
   return grouping(nullptr, col, N, &eids, &relp);
 }
 void hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor score, Tensor mu, Tensor sum, Tensor m, Tensor a) {
+  HET_ON_DEVICE_OF(sum);
   const int64_t H = mu.size(1), N = sum.size(0);
-  const het_grouping* g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
+  GroupingRef g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
   check(het_hgt_full_graph_edge_softmax_ops_separate_coo(ip(row), ip(col), ip(eids), ip(rel_ptrs), rel_ptrs.numel() - 1, eids.numel(), N, fp(score),
-                                                         fp(mu), fpw(sum), fpw(m), fpw(a), H, g, stream_of(mu)),
+                                                         fp(mu), fpw(sum), fpw(m), fpw(a), H, g.get(), stream_of(mu)),
         "hgt_full_graph_edge_softmax_ops_separate_coo");
 }
 void backward_hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor score, Tensor a, Tensor grad_a, Tensor mu, Tensor gscore,
                                Tensor gmu, Tensor tmp) {
+  HET_ON_DEVICE_OF(tmp);
   const int64_t H = mu.size(1), N = tmp.size(0);
-  const het_grouping* g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
+  GroupingRef g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
   check(het_backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(ip(row), ip(col), ip(eids), ip(rel_ptrs), rel_ptrs.numel() - 1,
                                                                                   eids.numel(), N, fp(score), fp(a), fp(grad_a), fp(mu),
-                                                                                  fpw(gscore), fpw(gmu), fpw(tmp), H, g, stream_of(mu)),
+                                                                                  fpw(gscore), fpw(gmu), fpw(tmp), H, g.get(), stream_of(mu)),
         "backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo");
 }
 void hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor W, Tensor norm, Tensor new_h) {
+  HET_ON_DEVICE_OF(new_h);
   const int64_t R = W.size(0), H = W.size(1), dk = W.size(2), dout = W.size(3);
-  const het_grouping* g = grouping(&rel_ptrs, col, new_h.size(0), &row, &eids);
-  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g)) * H * dk, new_h) : Tensor();
+  GroupingRef g = grouping(&rel_ptrs, col, new_h.size(0), &row, &eids);
+  Tensor ws = g ? workspace(std::max<int64_t>(1, het_grouping_num_segments(g.get())) * H * dk, new_h) : Tensor();
   check(het_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(ip(rel_ptrs), ip(eids), ip(row), ip(col), R, eids.numel(),
                                                                                 new_h.size(0), fp(x), fp(W), fp(norm), fpw(new_h), H, dk, dout,
-                                                                                g, g ? ws.data_ptr() : nullptr, g ? ws.numel() * 4 : 0,
+                                                                                g.get(), g ? ws.data_ptr() : nullptr, g ? ws.numel() * 4 : 0,
                                                                                 stream_of(new_h)),
         "hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo");
 }
 void backward_hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor Wt, Tensor norm, Tensor new_h,
                                            Tensor gx, Tensor gw, Tensor gnorm, Tensor gradout) {
+  HET_ON_DEVICE_OF(gradout);
   const int64_t R = Wt.size(0), H = Wt.size(1), dout = Wt.size(2), dk = Wt.size(3);
-  const het_grouping* g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
-  Tensor ws = g ? workspace(2 * std::max<int64_t>(1, het_grouping_num_segments(g)) * H * dout + Wt.numel(), gradout) : Tensor();
+  GroupingRef g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
+  Tensor ws = g ? workspace(2 * std::max<int64_t>(1, het_grouping_num_segments(g.get())) * H * dout + Wt.numel(), gradout) : Tensor();
   check(het_backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(
             ip(rel_ptrs), ip(eids), ip(row), ip(col), R, eids.numel(), new_h.size(0), fp(x), fp(Wt), fp(norm), fp(new_h), fpw(gx), fpw(gw),
-            fpw(gnorm), fp(gradout), H, dk, dout, g, g ? ws.data_ptr() : nullptr, g ? ws.numel() * 4 : 0, stream_of(gradout)),
+            fpw(gnorm), fp(gradout), H, dk, dout, g.get(), g ? ws.data_ptr() : nullptr, g ? ws.numel() * 4 : 0, stream_of(gradout)),
         "backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo");
 }
 void hgt_hetero_attention(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor k, Tensor q, Tensor W, Tensor inner, Tensor score) {
+  HET_ON_DEVICE_OF(score);
   const int64_t R = W.size(0), H = W.size(1), dk = W.size(2), dout = W.size(3);
   check(het_hgt_full_graph_hetero_attention_ops_coo(ip(row), ip(col), ip(eids), ip(rel_ptrs), R, eids.numel(), fp(k), fp(q), fp(W), fpw(inner),
                                                     fpw(score), H, dk, dout, stream_of(score)),
@@ -563,12 +614,13 @@ void hgt_hetero_attention(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, 
 void backward_hgt_hetero_attention(Tensor /*incsr_row_ptrs*/, Tensor /*incsr_col*/, Tensor /*incsr_eids*/, Tensor /*incsr_rel*/, Tensor row,
                                    Tensor col, Tensor eids, Tensor rel_ptrs, Tensor gW, Tensor Wt, Tensor k, Tensor q, Tensor inner, Tensor gscore,
                                    Tensor gk, Tensor gq) {
+  HET_ON_DEVICE_OF(gk);
   const int64_t R = Wt.size(0), H = Wt.size(1), dout = Wt.size(2), dk = Wt.size(3), nq = q.size(0);
-  const het_grouping* gd = grouping(nullptr, col, nq, &eids, nullptr);
-  const het_grouping* gs = grouping(&rel_ptrs, row, k.size(0), &col, &eids);
-  Tensor ws = gs ? workspace(std::max<int64_t>(1, het_grouping_num_segments(gs)) * H * dout, gk) : Tensor();
+  GroupingRef gd = grouping(nullptr, col, nq, &eids, nullptr);
+  GroupingRef gs = grouping(&rel_ptrs, row, k.size(0), &col, &eids);
+  Tensor ws = gs ? workspace(std::max<int64_t>(1, het_grouping_num_segments(gs.get())) * H * dout, gk) : Tensor();
   check(het_backward_hgt_full_graph_hetero_attention_ops_coo(ip(row), ip(col), ip(eids), ip(rel_ptrs), R, eids.numel(), fpw(gW), fp(Wt), fp(k), fp(q),
-                                                             fp(inner), fp(gscore), fpw(gk), fpw(gq), H, dk, dout, gd, gs, nq,
+                                                             fp(inner), fp(gscore), fpw(gk), fpw(gq), H, dk, dout, gd.get(), gs.get(), nq,
                                                              gs ? ws.data_ptr() : nullptr, gs ? ws.numel() * 4 : 0, stream_of(gk)),
         "backward_hgt_full_graph_hetero_attention_ops_coo");
 }

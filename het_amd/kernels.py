@@ -35,6 +35,11 @@ if COMPILED_LIB:
 else:
     _libdef = torch.library.Library(NAMESPACE, "DEF")
 _registered: List[str] = []
+# The library's own device memory (groupings, their construction scratch) comes from torch's caching allocator: inside
+# torch.cuda.memory_allocated, returned to torch's pool on eviction, no hipFree on an op's path (include/het_amd.h:
+# het_set_allocator).  HET_TORCH_ALLOCATOR=0: hipMalloc, as a caller of the bare C ABI gets.
+if _os.environ.get("HET_TORCH_ALLOCATOR", "1") != "0" and torch.cuda.is_available():
+    _lib.use_torch_allocator()
 
 
 def _p(t: Optional[Tensor]):

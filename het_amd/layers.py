@@ -285,7 +285,8 @@ class HET_HGTLayerHetero(nn.Module):
                  hgt_fused_attn_score_flag=False, compact_as_of_node_flag=False, compact_direct_indexing_flag=False,
                  fused_message_mean_aggregation_flag=True, multiply_among_weights_first_flag=False):
         super().__init__()
-        assert fused_message_mean_aggregation_flag, "only the fused message + aggregation op is built (the reference default)"
+        if not fused_message_mean_aggregation_flag:  # (the reference's HGT/models.py:251-277 branch)
+            B.hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(None, None, None, None)  # raises HetUnsupported, named
         assert not use_norm, "use_norm is off in the reference scripts"
         self.num_ntypes, self.num_relations, self.in_dim, self.out_dim = num_ntypes, num_rels, in_dim, out_dim
         self.num_heads, self.d_k = num_heads, out_dim // num_heads

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import sys
 import threading
 from collections import OrderedDict
 from typing import Optional
@@ -79,14 +80,16 @@ class Grouping:
 
     @property
     def nbytes(self) -> int:
-        """Device bytes the grouping holds (hipMalloc'ed by the library, invisible to torch's allocator statistics)."""
+        """Device bytes the grouping holds (inside torch's allocator statistics when _lib.use_torch_allocator() is in effect --
+        the default of het_amd.kernels -- else hipMalloc'ed by the library and invisible to them)."""
         return int(_lib.lib().het_grouping_bytes(self.handle)) if self.handle else 0
 
     def __del__(self):
-        # (the library may already be unloaded at interpreter exit: nothing left to free then)
+        # (the library may already be unloaded at interpreter exit: nothing left to free then; and with torch's allocator
+        #  installed a destroy calls back into Python -- not from a finalizing interpreter)
         handle, self.handle = self.handle, None
         lib = getattr(_lib, "_lib", None) if _lib is not None else None  # (module globals are cleared at shutdown)
-        if handle and lib is not None:
+        if handle and lib is not None and sys is not None and not sys.is_finalizing():
             lib.het_grouping_destroy(handle)
 
 
@@ -118,9 +121,19 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
                 raise _lib.HetError("groupings need contiguous int64 tensors on the GPU")
         out = C.c_void_p()
         stream = C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream)
+        args = (_ptr(rel_ptrs), 0 if rel_ptrs is None else rel_ptrs.numel() - 1, _ptr(keys), keys.numel(), int(key_bound),
+                _ptr(payload0), _ptr(payload1), stream, C.byref(out))
         with torch.cuda.device(keys.device):
-            _lib.call("het_grouping_create", _ptr(rel_ptrs), 0 if rel_ptrs is None else rel_ptrs.numel() - 1,
-                      _ptr(keys), keys.numel(), int(key_bound), _ptr(payload0), _ptr(payload1), stream, C.byref(out))
+            try:
+                _lib.call("het_grouping_create", *args)
+            except _lib.HetError:
+                # out of device memory while building: the cached groupings of other graphs are the first thing to give back
+                # (they live in torch's allocator when it is installed: het_amd/_lib.py use_torch_allocator), then once more
+                if not _cache:
+                    raise
+                _cache.clear()
+                torch.cuda.empty_cache()
+                _lib.call("het_grouping_create", *args)
         g = Grouping(out, (rel_ptrs, keys, payload0, payload1))
         _cache[k] = g
         while len(_cache) > _MAX_ENTRIES:
@@ -129,7 +142,8 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
 
 
 def cached_bytes() -> int:
-    """Device bytes of all cached groupings (add to torch.cuda.max_memory_allocated for a true footprint)."""
+    """Device bytes of all cached groupings (part of torch.cuda.memory_allocated when torch's allocator is installed,
+    _lib.allocator_is_external(); otherwise add them to it for a true footprint)."""
     with _cache_lock:
         return sum(g.nbytes for g in _cache.values())
 

@@ -69,9 +69,22 @@ int het_kernel_timing_read(const char* name_prefix, double* total_ms, int64_t* l
  * or by key[i] alone when rel_ptrs is NULL -- and records the segments.  It has
  * no counterpart in the reference (which uses atomicAdd everywhere, e.g.
  * RGAT/RGATKernelsSeparateCOO.cu.h:77,195); every op accepts NULL instead and
- * then runs its atomics-based kernel.  Allocates device memory (hipMalloc) and
- * synchronises `stream` once; destroy with het_grouping_destroy.
+ * then runs its atomics-based kernel.  Allocates device memory (hipMalloc, or
+ * the caller's allocator: het_set_allocator) and synchronises `stream` once;
+ * destroy with het_grouping_destroy.
  * ------------------------------------------------------------------------ */
+/* Device memory the library keeps beyond a call (groupings, their lazily built lists) and its construction scratch comes
+ * from hipMalloc / hipFree unless the host side installs its own allocator -- a framework binding passes its caching
+ * allocator here (csrc/torch_export.cpp: c10::hip::HIPCachingAllocator; het_amd/_lib.py: torch.cuda.caching_allocator_alloc),
+ * so that the groupings show up in that allocator's statistics, are returned to its pool when a cache evicts them, and no
+ * hipFree (a device-wide synchronisation) happens on an op's path.  `stream`: the stream the memory is first used on.
+ * alloc returns NULL on failure.  A pointer is always released through the allocator it came from, also after the
+ * allocator was changed or reset (NULL, NULL: back to hipMalloc).  No counterpart in the reference (its launchers allocate
+ * thrust::device_vector scratch per call, RGNNOps.inc.h:163-169). */
+typedef void* (*het_alloc_fn)(size_t bytes, het_stream stream, void* user);
+typedef void (*het_free_fn)(void* ptr, void* user);
+int het_set_allocator(het_alloc_fn alloc, het_free_fn free_, void* user);
+int het_allocator_is_external(void); /* 1 while an allocator is installed */
 typedef struct het_grouping het_grouping;
 /* payload0/payload1 (optional, [E]): per-position int64 arrays that are carried along in sorted
  * order (stored as int32), so that a grouped kernel reads them coalesced instead of chasing
@@ -83,7 +96,7 @@ int het_grouping_create(const int64_t* rel_ptrs /* [R+1] or NULL */, int64_t num
 void het_grouping_destroy(het_grouping* g);
 /* number of segments (distinct (relation, key) pairs) */
 int64_t het_grouping_num_segments(const het_grouping* g);
-/* device bytes the grouping currently holds (allocated with hipMalloc, outside the caller's allocator) */
+/* device bytes the grouping currently holds (with the default hipMalloc they are outside the caller's allocator statistics) */
 int64_t het_grouping_bytes(const het_grouping* g);
 /* out[i] = sorted rank of position i (the inverse of the grouping's permutation), [E] */
 int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream);

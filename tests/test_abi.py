@@ -43,9 +43,21 @@ def test_library_exports_every_declared_symbol():
                ("het_build_info", "het_last_error", "het_grouping_destroy", "het_grouping_num_segments", "het_grouping_bytes",
                 "het_kernel_timing_enable", "het_kernel_timing_read", "het_rgat_backward_compact_workspace",
                 "het_hgt_backward_compact_workspace", "het_hgt_compact_shape_ok", "het_rgat_node_gemm_ok", "het_rgat_aggregate_compact_workspace", "het_hgt_aggregate_compact_workspace",
-                "het_rgat_aggregate_compact_runs_workspace", "het_rgat_backward_compact_runs_workspace")]
+                "het_rgat_aggregate_compact_runs_workspace", "het_rgat_backward_compact_runs_workspace",
+                "het_set_allocator", "het_allocator_is_external")]
     assert not untyped, untyped
     assert "gfx950" in _lib.build_info()
+
+
+def test_allocator_hook_without_gpu():
+    """het_set_allocator takes both functions or neither; the default is hipMalloc (nothing installed)."""
+    import ctypes as C
+    from het_amd import _lib
+    L = _lib.lib()
+    assert not _lib.allocator_is_external()
+    cb = _lib._ALLOC_FN(lambda n, s, u: None)
+    assert L.het_set_allocator(C.cast(cb, C.c_void_p), None, None) != 0 and b"both" in L.het_last_error()
+    assert not _lib.allocator_is_external()
 
 
 def test_kernel_timing_api_without_gpu():
@@ -111,3 +123,16 @@ def test_compiled_registration_object_lists_every_op():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip() == "", "ops missing from libtorch_hrt.so: " + r.stdout
+
+
+def test_hgt_unfused_csr_path_is_a_named_error():
+    """HGT/models.py:271 reaches B.hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr when
+    --fused_message_mean_aggregation_flag is off: het_amd.backend names it and says what to use (no AttributeError)."""
+    import pytest
+    import het_amd.backend as B
+    from het_amd._lib import HetUnsupported
+    from het_amd.layers import HET_HGTLayerHetero
+    with pytest.raises(HetUnsupported, match="fused_message_mean_aggregation_flag"):
+        B.hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(None, None, None, None)
+    with pytest.raises(NotImplementedError):
+        HET_HGTLayerHetero(2, 3, 16, 16, num_heads=2, fused_message_mean_aggregation_flag=False)
