@@ -108,7 +108,6 @@ def hgt_full_graph_message_calc_edge_softmax_and_message_mean_aggregation_coo(re
         s["eids"], relation_meg_weight.contiguous(), inputs.contiguous(), score, sum_per_node, mu.contiguous(), m, a, new_h)
 
 
-@_consistent_plan
 def hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(graph, message_per_edge, unnormalized_attn_score, mu):
     """The reference's UNFUSED aggregation of HGT (hgt_layers_and_funcs.py:506-570, reached from HGT/models.py:271 when
     ``--fused_message_mean_aggregation_flag`` is off: per-edge messages [E,H,dk] from a kind-0 rgnn_relational_matmul, then
@@ -122,6 +121,7 @@ def hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(graph, message_
                          "aggregation_coo) -- same layer output, no [E,H,dk] message tensor")
 
 
+@_consistent_plan
 class _InnerProduct(th.autograd.Function):
     @staticmethod
     def forward(ctx, kind, map_a, map_b, rel_ptrs, eids, row, col, left, right, ret):
