@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0, attn_scale=1.0, **layer_kw):
+def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0, attn_scale=1.0, oracle_dev="cpu", **layer_kw):
+    """oracle_dev: where the fp64 oracle layer is evaluated (it is plain torch: "cuda" for graphs of 1e5+ edges, where the CPU
+    takes most of a minute per case)."""
     from het_amd.layers import HET_RGATLayer
     torch.manual_seed(seed)
     R, N = g.get_num_rels(), g.get_num_nodes()
@@ -31,12 +33,13 @@ def _run_rgat(g, H, K, X, compact, direct, mulfirst, edge_parallel=True, seed=0,
         if rgat_min_abs_preactivation(x, layer.conv_weights, layer.attn_l, layer.attn_r, s) >= 2e-6:
             break
         x = x + 1e-3 * torch.randn(N, K)
-    p = {n: t.detach().double().requires_grad_(True) for n, t in layer.named_parameters()}
-    x64 = x.double().requires_grad_(True)
-    ref = OL.rgat_layer(x64, p["conv_weights"], p["attn_l"], p["attn_r"], s["rel_ptrs"], s["row_indices"], s["col_indices"],
-                        N, 0.2, p["loop_weight"], p["h_bias"])
+    p = {n: t.detach().double().to(oracle_dev).requires_grad_(True) for n, t in layer.named_parameters()}
+    x64 = x.double().to(oracle_dev).requires_grad_(True)
+    ref = OL.rgat_layer(x64, p["conv_weights"], p["attn_l"], p["attn_r"], s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
+                        s["col_indices"].to(oracle_dev), N, 0.2, p["loop_weight"], p["h_bias"])
     names = ["conv_weights", "attn_l", "attn_r", "loop_weight", "h_bias"]
-    grads_ref = torch.autograd.grad(ref, [x64] + [p[n] for n in names], go.double())
+    grads_ref = [t.cpu() for t in torch.autograd.grad(ref, [x64] + [p[n] for n in names], go.double().to(oracle_dev))]
+    ref = ref.detach().cpu()
     # device
     g.to_(DEV)
     layer = layer.to(DEV)
@@ -178,7 +181,7 @@ def test_rgcn_layer_on_the_aifb_shaped_graph(R, compact):
     _run_rgcn(g, compact, compact, 16, 16, R)
 
 
-def _run_rgcn(g, compact, direct, K, D, R):
+def _run_rgcn(g, compact, direct, K, D, R, oracle_dev="cpu"):
     from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
     torch.manual_seed(1)
     N, E = g.get_num_nodes(), g.get_num_edges()
@@ -186,11 +189,13 @@ def _run_rgcn(g, compact, direct, K, D, R):
                                              compact_direct_indexing_flag=direct)
     x, norm, go = torch.randn(N, K), torch.rand(E, 1), torch.randn(N, D)
     s = g.get_separate_coo_original()
-    w64 = layer.weight.detach().double().requires_grad_(True)
-    b64 = layer.h_bias.detach().double().requires_grad_(True)
-    x64 = x.double().requires_grad_(True)
-    ref = OL.rgcn_layer(x64, w64, norm.double(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N, b64)
-    gx_r, gw_r = torch.autograd.grad(ref, [x64, w64], go.double())
+    w64 = layer.weight.detach().double().to(oracle_dev).requires_grad_(True)
+    b64 = layer.h_bias.detach().double().to(oracle_dev).requires_grad_(True)
+    x64 = x.double().to(oracle_dev).requires_grad_(True)
+    ref = OL.rgcn_layer(x64, w64, norm.double().to(oracle_dev), s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
+                        s["col_indices"].to(oracle_dev), N, b64)
+    gx_r, gw_r = (t.cpu() for t in torch.autograd.grad(ref, [x64, w64], go.double().to(oracle_dev)))
+    ref = ref.detach().cpu()
     g.to_(DEV)
     layer = layer.to(DEV)
     xd = x.to(DEV).requires_grad_(True)
@@ -255,7 +260,7 @@ def test_hgt_layer_large_scores_stay_finite(monkeypatch):
     _run_hgt_fused(True, False, 4, 64, 64, monkeypatch, pri=(150.0, 300.0))
 
 
-def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri=(0.5, 1.5), g=None):
+def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri=(0.5, 1.5), g=None, oracle_dev="cpu"):
     """The HGT layer with attention + aggregation as one node on the distinct (relation, source) rows
     (het_amd/backend/hgt_fused_layer.py, csrc/hgt_compact.hip) -- what a full graph with canonical relations runs by default
     (BASELINE.json configs[3]: feat 64, heads 8) -- against the fp64 oracle: output and the gradients of the input and of all
@@ -275,12 +280,14 @@ def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri
     h, go = torch.randn(N, in_dim) * 0.5, torch.randn(N, out_dim)
     s = g.get_separate_coo_original()
     names = ["k_linears", "q_linears", "v_linears", "a_linears", "relation_att", "relation_msg", "relation_pri", "skip"]
-    p = {n: getattr(layer, n).detach().double().requires_grad_(True) for n in names}
-    h64 = h.double().requires_grad_(True)
-    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"], s["row_indices"], s["col_indices"], N,
+    p = {n: getattr(layer, n).detach().double().to(oracle_dev).requires_grad_(True) for n in names}
+    h64 = h.double().to(oracle_dev).requires_grad_(True)
+    ref = OL.hgt_layer(h64, g.get_original_node_type_offsets(), s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
+                       s["col_indices"].to(oracle_dev), N,
                        p["k_linears"], p["q_linears"], p["v_linears"], p["a_linears"], p["relation_att"], p["relation_msg"],
                        p["relation_pri"], p["skip"], H, fused_attn=fused_attn)
-    grads_ref = torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double())
+    grads_ref = [t.cpu() for t in torch.autograd.grad(ref, [h64] + [p[n] for n in names], go.double().to(oracle_dev))]
+    ref = ref.detach().cpu()
     assert bool(torch.isfinite(ref).all())
     calls = []
     real_f, real_b = k.hgt_aggregate_compact, k.hgt_backward_compact

@@ -111,14 +111,14 @@ def test_rgat_layer_on_the_shipped_topology(full, compact, mulfirst):
     """HET_RGATLayer (feat 64, 4 heads; the one-node dataflow with hubs, run sums and the node-major input gradient) against the
     fp64 oracle layer on the shipped graph, on its one-id-space form (as test_hyb.cu.cc builds it) and typed."""
     from tests.test_gpu_layers import _run_rgat
-    _run_rgat(_graph(full, "cpu"), H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=mulfirst)
-    _run_rgat(_typed_graph(full), H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=mulfirst, seed=3)
+    _run_rgat(_graph(full, "cpu"), H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=mulfirst, oracle_dev=DEV)
+    _run_rgat(_typed_graph(full), H=4, K=64, X=64, compact=compact, direct=compact, mulfirst=mulfirst, seed=3, oracle_dev=DEV)
 
 
 @pytest.mark.parametrize("compact", [False, True])
 def test_rgcn_layer_on_the_shipped_topology(full, compact):
     from tests.test_gpu_layers import _run_rgcn
-    _run_rgcn(_graph(full, "cpu"), compact, compact, 64, 64, 6)
+    _run_rgcn(_graph(full, "cpu"), compact, compact, 64, 64, 6, oracle_dev=DEV)
 
 
 @pytest.mark.parametrize("H,fused_attn", [(8, False), (1, True)])
@@ -126,4 +126,4 @@ def test_hgt_layer_on_the_shipped_topology(full, H, fused_attn, monkeypatch):
     """HET_HGTLayerHetero (feat 64; BASELINE.json configs[3]'s 8 heads and the reference sweep's 1) on the typed view -- canonical
     edge types, three node types -- through the distinct-row kernels, against the fp64 oracle."""
     from tests.test_gpu_layers import _run_hgt_fused
-    _run_hgt_fused(fused_attn, True, H, 64, 64, monkeypatch, g=_typed_graph(full))
+    _run_hgt_fused(fused_attn, True, H, 64, 64, monkeypatch, g=_typed_graph(full), oracle_dev=DEV)
