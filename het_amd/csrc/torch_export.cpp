@@ -356,6 +356,41 @@ std::vector<Tensor> direct_rows(int64_t kind, const Maps& m, const Tensor& rel_p
   });
 }
 
+// ---- the op-level a5 streams the sorted copy of exp its a4 left (as het_amd/kernels.py: _sorted_stream_*) -------------------
+// Between the two reference-named calls the destination-sorted copy of exp that the grouped forward can write is kept, keyed by
+// the identity of the tensors the backward would otherwise gather by edge id (exp, el, er) and of the edge lists; weak
+// references make a recycled address a miss, _version an in-place edit.  A miss = the gathers.  HET_A5_SORTED_STREAM=0: off.
+struct SortedStream {
+  Ident exp, el, er, eids, col; double slope; int dev;
+  Tensor exs;
+  c10::weak_intrusive_ptr<c10::TensorImpl> w_exp, w_el, w_er;
+};
+std::list<SortedStream>& g_streams = *new std::list<SortedStream>();
+bool sorted_stream_on() {
+  static const bool on = [] { const char* v = getenv("HET_A5_SORTED_STREAM"); return !(v && v[0] == '0'); }();
+  return on;
+}
+void sorted_stream_put(const Tensor& exp, const Tensor& el, const Tensor& er, const Tensor& eids, const Tensor& col, double slope, Tensor exs) {
+  const Ident a = ident(&exp), b = ident(&el), c = ident(&er), d = ident(&eids), e = ident(&col);
+  const int dev = exp.device().index();
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_streams.remove_if([&](const SortedStream& q) { return q.exp.p == a.p && q.exp.n == a.n && q.dev == dev; });
+  if (!exs.defined()) return;
+  g_streams.push_front(SortedStream{a, b, c, d, e, slope, dev, std::move(exs), c10::weak_intrusive_ptr<c10::TensorImpl>(exp.getIntrusivePtr()),
+                                    c10::weak_intrusive_ptr<c10::TensorImpl>(el.getIntrusivePtr()),
+                                    c10::weak_intrusive_ptr<c10::TensorImpl>(er.getIntrusivePtr())});
+  while (g_streams.size() > 2) g_streams.pop_back();
+}
+Tensor sorted_stream_get(const Tensor& exp, const Tensor& el, const Tensor& er, const Tensor& eids, const Tensor& col, double slope) {
+  if (!sorted_stream_on() || !groupings_enabled()) return Tensor();
+  const Ident a = ident(&exp), b = ident(&el), c = ident(&er), d = ident(&eids), e = ident(&col);
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& q : g_streams)
+    if (q.exp == a && q.el == b && q.er == c && q.eids == d && q.col == e && q.slope == slope && q.dev == exp.device().index())
+      return (q.w_exp.expired() || q.w_el.expired() || q.w_er.expired()) ? Tensor() : q.exs;
+  return Tensor();
+}
+
 void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m_in,
                  const Tensor& feat, const Tensor& el, const Tensor& er, Tensor& sum, Tensor& exp, Tensor& ret, double slope) {
   const int64_t E = eids.numel(), N = ret.size(0), H = sum.size(1);
@@ -363,9 +398,12 @@ void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, 
   GroupingRef g;
   Maps m = m_in;
   std::vector<Tensor> dr;
+  Tensor exs;
+  const bool kind0 = kind == 0;
   if (kind == 0 && E > 0) {  // positions by destination; payload0 = edge id, payload1 = relation of the position
     Tensor relp = cached_rel_by_position(rel_ptrs, E);
     g = grouping(nullptr, col, N, &eids, &relp);
+    if (g && sorted_stream_on() && slope >= 0 && gat_grouped_shape_ok(H, D)) exs = at::empty({E, H}, exp.options());
   } else if (kind != 0 && E > 0 && groupings_enabled() && gat_grouped_shape_ok(H, D)) {  // payload1 = feat row of the position
     dr = direct_rows(kind, m_in, rel_ptrs, row, col, eids);
     g = grouping(nullptr, col, N, &eids, &dr[0]);
@@ -373,9 +411,11 @@ void gat_forward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, 
     kind = 4;
   }
   check(het_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]), mp(m.m[1]),
-                                              mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fpw(sum), fpw(exp), fpw(ret), nullptr, H, D,
-                                              slope, g.get(), nullptr, nullptr, stream_of(ret)),
+                                              mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fpw(sum), fpw(exp), fpw(ret),
+                                              exs.defined() ? exs.data_ptr<float>() : nullptr, H, D, slope, g.get(), nullptr, nullptr,
+                                              stream_of(ret)),
         "relational_fused_gat_separate_coo");
+  if (kind0) sorted_stream_put(exp, el, er, eids, col, slope, exs);
 }
 void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row, const Tensor& col, int64_t kind, const Maps& m_in,
                   const Tensor& feat, const Tensor& el, const Tensor& er, const Tensor& sum, const Tensor& exp, const Tensor& ret,
@@ -385,9 +425,11 @@ void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row,
   Maps m = m_in;
   std::vector<Tensor> dr;
   Tensor ws;
+  Tensor exs;
   if (kind == 0 && E > 0) {
     Tensor relp = cached_rel_by_position(rel_ptrs, E);
     g = grouping(nullptr, col, N, &eids, &relp);
+    if (g) exs = sorted_stream_get(exp, el, er, eids, col, slope);
   } else if (kind != 0 && E > 0 && groupings_enabled() && gat_grouped_shape_ok(H, D) && slope >= 0) {
     // by feat row (payloads: edge id, destination) and by er row (payload: edge id): the compact backward sums a row's gradient in
     // registers and stores it once (csrc/fused_gat_grouped.hip) instead of E*H*D float atomics
@@ -404,7 +446,8 @@ void gat_backward(const Tensor& eids, const Tensor& rel_ptrs, const Tensor& row,
   }
   check(het_backward_relational_fused_gat_separate_coo(ip(eids), ip(rel_ptrs), ip(row), ip(col), rel_ptrs.numel() - 1, E, N, kind, mp(m.m[0]),
                                                        mp(m.m[1]), mp(m.m[2]), mp(m.m[3]), fp(feat), fp(el), fp(er), fp(sum), fp(exp), fp(ret),
-                                                       nullptr, fp(gradout), fpw(gfeat), fpw(gel), fpw(ger), H, D, slope, g.get(), gs.get(), gd.get(),
+                                                       exs.defined() ? exs.data_ptr<float>() : nullptr, fp(gradout), fpw(gfeat), fpw(gel),
+                                                       fpw(ger), H, D, slope, g.get(), gs.get(), gd.get(),
                                                        feat.size(0), er.size(0), ws.defined() ? ws.data_ptr() : nullptr,
                                                        ws.defined() ? ws.numel() * 4 : 0, nullptr, nullptr, nullptr, nullptr, stream_of(ret)),
         "backward_relational_fused_gat_separate_coo");

@@ -492,8 +492,16 @@ def _by_dst(kind, maps, rel_ptrs, row, col, eids, num_nodes):
 def relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
                                       separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er, sum, exp,
                                       ret, slope):
-    fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
-                      IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, None)
+    # kind 0 on the destination-grouped kernels: the pass also leaves a copy of exp in the grouping's order (sequential 16-byte
+    # stores: +338 MB written on ogbn-mag), remembered against the identity of (exp, el, er) -- the backward op streams it
+    # when the same tensors come back (_sorted_stream_*)
+    exs = None
+    if (A5_SORTED_STREAM and IntKind == 0 and slope >= 0 and _plan.is_enabled() and separate_coo_eids.numel() > 0 and exp.dim() >= 2
+            and gat_grouped_shape_ok(sum.shape[1], ret.numel() // max(1, ret.shape[0] * sum.shape[1]))):
+        exs = torch.empty((separate_coo_eids.numel(), sum.shape[1]), dtype=exp.dtype, device=exp.device)
+    wrote = fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
+                              IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, slope, exs)
+    _sorted_stream_put(exp, el, er, separate_coo_eids, separate_coo_col_indices, float(slope), exs if wrote else None)
 
 
 def gat_grouped_shape_ok(H: int, D: int) -> bool:
@@ -527,6 +535,51 @@ def fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row
     return g is not None and exp_sorted is not None
 
 
+
+# ---- the op-level a5 streams the sorted copy of exp its a4 left --------------------------------------------------------
+# Called on their own (the reference's model code: RelationalFusedGatSeparateCOO, rgat_layers_and_funcs.py:262-330), a5 gathers
+# exp / el / er by edge id in destination order: a 128-byte line per 16-byte record (0.41 of the HBM roofline, 21 GB of traffic
+# for 13.9 GB of tensors).  The layer-private path avoids that with a destination-sorted copy of exp written by the forward;
+# here the same copy is kept BETWEEN the two reference-named calls, keyed by the identity of the tensors the backward would
+# otherwise read: (data_ptr, _version) of exp, el, er + the edge lists.  A weak reference per tensor makes a recycled address a
+# miss (a dead tensor's storage may be handed out again); an in-place edit bumps _version: also a miss.  A miss = the gathers.
+import weakref as _weakref
+A5_SORTED_STREAM = _os.environ.get("HET_A5_SORTED_STREAM", "1") != "0"
+_sorted_streams: "OrderedDict[tuple, tuple]" = OrderedDict()
+_SORTED_STREAMS_MAX = 2  # (a [E,H] float tensor each: 338 MB on ogbn-mag)
+sorted_stream_hits = 0   # (tests / bench: how often the backward op found its stream)
+
+
+def _sorted_stream_key(exp, el, er, eids, col, slope):
+    return (_plan._ident(exp)[:2], _plan._ident(el), _plan._ident(er), _plan._ident(eids), _plan._ident(col), slope, exp.device.index)
+
+
+def _sorted_stream_put(exp, el, er, eids, col, slope, exs):
+    key = _sorted_stream_key(exp, el, er, eids, col, slope)
+    with _derived_lock:
+        _sorted_streams.pop(key, None)
+        if exs is not None:
+            # exp's version is taken AFTER the op wrote it (the C side writes through the raw pointer: no bump of its own)
+            _sorted_streams[key] = (exs, exp._version, tuple(_weakref.ref(t) for t in (exp, el, er)))
+            while len(_sorted_streams) > _SORTED_STREAMS_MAX:
+                _sorted_streams.popitem(last=False)
+
+
+def _sorted_stream_get(exp, el, er, eids, col, slope):
+    global sorted_stream_hits
+    if not (A5_SORTED_STREAM and _plan.is_enabled()) or exp is None or el is None or er is None:
+        return None
+    with _derived_lock:
+        hit = _sorted_streams.get(_sorted_stream_key(exp, el, er, eids, col, slope))
+        if hit is None:
+            return None
+        exs, version, refs = hit
+        if exp._version != version or any(r() is None for r in refs):
+            return None
+        sorted_stream_hits += 1
+        return exs
+
+
 @_op("backward_relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
      "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, int IntKind, "
      "Dict(str, Tensor) args_tensor_dict, Tensor feat_src, Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, "
@@ -534,9 +587,10 @@ def fused_gat_forward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row
 def backward_relational_fused_gat_separate_coo(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices,
                                                separate_coo_col_indices, IntKind, args_tensor_dict, feat_src, el, er,
                                                sum, exp, ret, gradout, grad_feat_src, grad_el, grad_er, slope):
+    exs = _sorted_stream_get(exp, el, er, separate_coo_eids, separate_coo_col_indices, float(slope)) if IntKind == 0 else None
     fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,
                        IntKind, args_tensor_dict, feat_src, el, er, sum, exp, ret, gradout, grad_feat_src, grad_el,
-                       grad_er, slope, None)
+                       grad_er, slope, exs)
 
 
 def fused_gat_backward(separate_coo_eids, separate_coo_rel_ptrs, separate_coo_row_indices, separate_coo_col_indices,

@@ -213,6 +213,56 @@ def test_fused_gat_separate_coo(K, plan_mode, kind, H, D, n):
     assert_close(gr, gr_r, what="grad_er")
 
 
+@pytest.mark.parametrize("H,D", [(4, 16), (2, 4)])
+def test_gat_backward_streams_the_sorted_exp_its_forward_left(K, H, D):
+    """The reference-named pair called on its own (kind 0, grouped kernels): the forward leaves a destination-sorted copy of exp,
+    the backward streams it when (exp, el, er) come back untouched -- and falls back to gathering by edge id after an in-place
+    edit of exp, with other el / er tensors, or with another exp: every case against the oracle (what the backward computes
+    from the tensors it is GIVEN), hit / miss asserted through the Python registration's counter."""
+    import het_amd.kernels as k
+    import het_amd.plan as plan
+    old = plan.enabled
+    plan.enabled = True
+    plan.clear()
+    try:
+        g = random_graph(seed=23, n=300, r=4, e=5000)
+        s, feat, el, er, go, df, db = _gat_case(g, 0, H, D, seed=13)
+        N, E, slope = g.get_num_nodes(), g.get_num_edges(), 0.2
+        idx = (s["eids"], s["rel_ptrs"], s["row_indices"], s["col_indices"])
+        didx = tuple(t.to(DEV) for t in idx)
+        f, l, r_, god = feat.to(DEV), el.to(DEV), er.to(DEV), go.to(DEV)
+        sm, ex, ret = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV), torch.empty(N, H, D, device=DEV)
+
+        def oracle_backward(ex_t, l_t, r_t):
+            gf_r, gl_r, gr_r = torch.zeros_like(to64(feat)), torch.zeros_like(to64(el)), torch.zeros_like(to64(er))
+            O.backward_relational_fused_gat_separate_coo(*idx, 0, db, to64(feat), to64(l_t), to64(r_t), to64(sm), to64(ex_t), to64(ret),
+                                                         to64(go), gf_r, gl_r, gr_r, slope)
+            return gf_r, gl_r, gr_r
+
+        def run_backward(ex_t, l_t, r_t, expect_hit):
+            before = k.sorted_stream_hits
+            gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
+            K.backward_relational_fused_gat_separate_coo(*didx, 0, {}, f, l_t, r_t, sm, ex_t, ret, god, gf, gl, gr, slope)
+            if not k.COMPILED_LIB:  # (the compiled registration keeps its own cache: values only)
+                assert (k.sorted_stream_hits - before == 1) == expect_hit, (k.sorted_stream_hits - before, expect_hit)
+            for got, want, what in zip((gf, gl, gr), oracle_backward(ex_t, l_t, r_t), ("grad_feat", "grad_el", "grad_er")):
+                assert_close(got, want, what=what)
+
+        K.relational_fused_gat_separate_coo(*didx, 0, {}, f, l, r_, sm, ex, ret, slope)
+        run_backward(ex, l, r_, True)            # the same tensors come back: streamed
+        run_backward(ex, l, r_, True)            # (a second backward of the same forward: still there)
+        run_backward(ex.clone(), l, r_, False)   # another exp tensor (same values): gathers
+        run_backward(ex, l.clone(), r_, False)   # other attention terms: gathers
+        ex.mul_(0.5)                             # in-place edit (the version counter moves): gathers, and the new values count
+        sm.mul_(0.5)
+        run_backward(ex, l, r_, False)
+        K.relational_fused_gat_separate_coo(*didx, 0, {}, f, l, r_, sm, ex, ret, slope)  # a new forward into the same buffers
+        run_backward(ex, l, r_, True)
+    finally:
+        plan.enabled = old
+        plan.clear()
+
+
 @pytest.mark.parametrize("fold,bias", [(False, False), (True, True)])
 @pytest.mark.parametrize("H,D,n,e", [(4, 16, 300, 5000), (1, 64, 300, 5000), (8, 8, 40, 9000), (2, 4, 300, 5000), (4, 16, 12, 9000), (4, 32, 300, 700)])
 def test_rgat_compact_passes(K, H, D, n, e, fold, bias):
