@@ -41,6 +41,7 @@ _SIGNATURES = {
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_node_row_map": [P, I64, P, I64, I64, P, P],
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
+    "het_node_rows_matmul_sum": [I64, I64, I64, I64, P, P, P, P, P, P, I64, I64, P, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
     "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],
@@ -105,6 +106,8 @@ def lib() -> C.CDLL:
         L.het_hgt_backward_compact_workspace.restype = I64
         L.het_hgt_compact_shape_ok.argtypes = [I64, I64]
         L.het_hgt_compact_shape_ok.restype = INT
+        L.het_node_rows_matmul_sum_ok.argtypes = [I64, I64, I64]
+        L.het_node_rows_matmul_sum_ok.restype = INT
         L.het_rgat_node_gemm_ok.argtypes = [I64, I64, I64, I64]
         L.het_rgat_node_gemm_ok.restype = INT
         L.het_set_allocator.argtypes = [P, P, P]

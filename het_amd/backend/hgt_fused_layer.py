@@ -30,6 +30,47 @@ from .rgat_fused_layer import OVERLAP, _edge_rows, _has_single_sided_lists, _sid
 from .rgnn_layers_and_funcs import rgnn_relational_matmul_no_scatter_gather_list as B_matmul_no_scatter_gather
 
 FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
+# the layer's input gradient in one node-major pass per node type (csrc/node_sum.hip) instead of one read-modify-write launch
+# per relation on the 2X-wide source rows + the destination-side projection's own pass (HET_HGT_NODE_DX=0: the round-3 form)
+NODE_DX = os.environ.get("HET_HGT_NODE_DX", "1") != "0"
+
+
+def _node_dx_plan(G, ss, offs, K_in, X, dst):
+    """Per graph, cached on it: what the node-major input gradient needs -- [R,N] int32 row maps of the (relation, source) list,
+    the rank of every node in the list of destinations with in-edges (compact form), the nodes sorted by (node type, which
+    sources they have rows in) so that 32-node tiles are homogeneous, and per node type its position range + relations.
+    None when the graph or the shapes are outside the pass (sampled blocks with type runs, too many relations per type)."""
+    key = ("hgt_node_dx", K_in, X, dst is not None)
+    hit = G._plans.get(key)
+    if hit is not None:
+        return hit or None
+    plan = False
+    orig = G.graph_data["original"]
+    if orig.get("node_segment_types") is None and X in (32, 64) and K_in in (32, 64):
+        st, _ = G.get_rel_node_types()
+        st_l, offs_l = st.tolist(), offs.tolist()
+        T, R, N = len(offs_l) - 1, len(st_l), offs_l[-1]
+        rels_of = [[r for r in range(R) if st_l[r] == t] for t in range(T)]
+        if all(_k.node_rows_matmul_sum_ok(1 + 2 * len(rs), X, K_in) for rs in rels_of):
+            row_map = _k.node_row_map(ss["rel_ptrs_row"], ss["node_indices_row"], N)
+            dev = row_map.device
+            dst_rank = None
+            has_dst = [True] * T
+            if dst is not None:
+                dst_nodes, _, run_ptrs = dst
+                dst_rank = th.full((N,), -1, dtype=th.int32, device=dev)
+                dst_rank[dst_nodes] = th.arange(dst_nodes.numel(), dtype=th.int32, device=dev)
+                rl = run_ptrs.tolist()
+                has_dst = [rl[t + 1] > rl[t] for t in range(T)]
+            w = (1 << th.arange(R, device=dev, dtype=th.int64)).view(R, 1)
+            mask = ((row_map >= 0).to(th.int64) * w).sum(0)
+            if dst_rank is not None:
+                mask = mask | ((dst_rank >= 0).to(th.int64) << R)
+            typ = th.searchsorted(offs[1:].contiguous().to(dev), th.arange(N, device=dev), right=True)
+            order = th.argsort(mask | (typ << (R + 1)), stable=True).to(th.int32).contiguous()
+            plan = dict(row_map=row_map, dst_rank=dst_rank, order=order, offs=offs_l, rels_of=rels_of, has_dst=has_dst)
+    G._plans[key] = plan
+    return plan or None
 
 
 def hgt_fused_ok(G, h, num_heads, d_k):
@@ -153,6 +194,36 @@ class HgtAttentionFunction(th.autograd.Function):
             side.wait_stream(main)
             with th.cuda.stream(side):
                 _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv.view(-1, 2 * X), grad_wkv, accumulate=False)
+        nplan = _node_dx_plan(G, ss, offs, K_in, X, (lists[0], None, lists[1]) if ctx.compact_dst else None) if (NODE_DX and split_kv) else None
+        if nplan is not None:
+            # every consumer of h adds its term in ONE pass over the nodes: the destination-side projection's gradient rows
+            # (g_q . Q_t^T) and, per relation the node is a source of, the two halves of its [k' | m] gradient row
+            grad_h = th.empty_like(h)
+            g_kv2, g_q2 = g_kv.view(-1, 2 * X), g_q.view(-1, X)
+            wt2 = wt.view(-1, 2 * X, K_in)
+            for t, rels in enumerate(nplan["rels_of"]):
+                a, b = nplan["offs"][t], nplan["offs"][t + 1]
+                srcs = []
+                if nplan["has_dst"][t]:
+                    srcs.append((g_q2, 0, nplan["dst_rank"], qwt[t, 0]))
+                for r in rels:
+                    srcs.append((g_kv2, 0, nplan["row_map"][r], wt2[r, :X]))
+                    srcs.append((g_kv2, X, nplan["row_map"][r], wt2[r, X:]))
+                if not srcs:
+                    grad_h[a:b].zero_()  # (a node type that neither sends nor receives: its rows of the gradient are zero)
+                elif b > a:
+                    _k.node_rows_matmul_sum(a, b, srcs, grad_h, nplan["order"])
+            grad_qw = th.empty_like(q_w)
+            if ctx.compact_dst:
+                dst_nodes, run_ptrs = lists
+                _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q2, grad_qw, accumulate=False)
+            else:
+                _k.matmul_no_scatter_gather_backward(offs, qwt, h, g_q, None, grad_qw, accumulate=False)
+            if side is None:
+                _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv2, grad_wkv, accumulate=False)
+            else:
+                main.wait_stream(side)
+            return None, None, None, grad_h, grad_wkv, grad_qw, None
         if not ctx.compact_dst:  # the typed projection writes every row with plain stores, the source-row GEMM adds to it
             grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)
             _k.matmul_no_scatter_gather_backward(offs, qwt, h, g_q, grad_h, grad_qw, accumulate=False)

@@ -123,6 +123,15 @@ class DistPlan:
     recv_counts: List[int]
     num_global_edges: int
     edge_cut: int                 # edges whose source lives on another rank (all ranks)
+    # The exchanges run in `chunks` pieces (HET_DIST_CHUNKS): piece c moves, from every peer, the c-th C-th of the rows that peer
+    # sends -- all links busy in every piece -- so that the consumer of the halo rows (the projection of the (relation, source)
+    # rows) starts on piece 0 while piece 1 is on the wire.  Halo nodes are numbered piece-major (piece, then owning rank, then
+    # node id) and send_idx is ordered the same way: a piece is one contiguous range of both buffers.
+    chunks: int = 1
+    send_splits: List[List[int]] = None   # [chunks][world] rows of piece c that go to rank p
+    recv_splits: List[List[int]] = None   # [chunks][world] rows of piece c that come from rank p
+    halo_chunk_ptr: List[int] = None      # [chunks+1] halo-row range of piece c (add n_own for local node ids)
+    send_chunk_ptr: List[int] = None      # [chunks+1] send_idx range of piece c
 
     @property
     def num_local_edges(self) -> int:
@@ -133,9 +142,33 @@ class DistPlan:
         return self.n_own + self.n_halo
 
 
-def build_plan(coo: IntegratedCOO, rank: int, world: int) -> DistPlan:
+CHUNKS = int(os.environ.get("HET_DIST_CHUNKS", "4"))  # pieces of each halo exchange (1: one monolithic all-to-all)
+
+
+def _piece_major(counts: List[int], chunks: int):
+    """For blocks of counts[p] consecutive rows (one block per peer p): the permutation that lists the rows piece-major -- piece c
+    of block p is its rows [c * n // chunks, (c + 1) * n // chunks) -- and the [chunks][len(counts)] piece sizes.  Sender and
+    receiver cut a block of n rows at the same places."""
+    starts = [0]
+    for n in counts:
+        starts.append(starts[-1] + n)
+    order, splits = [], []
+    for c in range(chunks):
+        row = []
+        for p, n in enumerate(counts):
+            a, b = c * n // chunks, (c + 1) * n // chunks
+            row.append(b - a)
+            if b > a:
+                order.append(torch.arange(starts[p] + a, starts[p] + b, dtype=torch.int64))
+        splits.append(row)
+    perm = torch.cat(order) if order else torch.zeros(0, dtype=torch.int64)
+    return perm, splits
+
+
+def build_plan(coo: IntegratedCOO, rank: int, world: int, chunks: int = None) -> DistPlan:
     """Every rank holds the (seeded, identical) global edge list and derives its own share:
     no communication is needed to build the plan."""
+    chunks = max(1, CHUNKS if chunks is None else int(chunks))
     N = coo.num_nodes
     node_order, new_id, bounds = node_ownership(coo.col, N, world, row=coo.row)
     row, col, rel = new_id[coo.row], new_id[coo.col], coo.rel
@@ -147,25 +180,38 @@ def build_plan(coo: IntegratedCOO, rank: int, world: int) -> DistPlan:
     need_rank, need_node = pairs // N, pairs % N
     node_owner = torch.searchsorted(bounds[1:].contiguous(), need_node, right=True)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    dev = row.device
 
     mine = need_rank == rank
-    halo_global = need_node[mine]                    # sorted by global id => grouped by owner
+    halo_sorted = need_node[mine]                    # sorted by global id => grouped by owner
     recv_counts = torch.bincount(node_owner[mine], minlength=world).tolist()
     send_sel = node_owner == rank                    # pairs sorted by (needing rank, node)
-    send_idx = (need_node[send_sel] - lo).contiguous()
+    send_sorted = (need_node[send_sel] - lo).contiguous()
     send_counts = torch.bincount(need_rank[send_sel], minlength=world).tolist()
+    # piece-major order of both buffers (see DistPlan.chunks)
+    rperm, recv_splits = _piece_major(recv_counts, chunks)
+    sperm, send_splits = _piece_major(send_counts, chunks)
+    rperm, sperm = rperm.to(dev), sperm.to(dev)
+    halo_global = halo_sorted[rperm]
+    send_idx = send_sorted[sperm].contiguous()
+    halo_pos = torch.empty_like(rperm)               # sorted position -> local halo index
+    halo_pos[rperm] = torch.arange(rperm.numel(), device=dev)
+    cum = lambda rows: [0] + torch.cumsum(torch.tensor([sum(r) for r in rows]), 0).tolist()
 
     e_sel = owner_dst == rank
     l_row, l_col, l_rel = row[e_sel], col[e_sel] - lo, rel[e_sel]
     remote = (l_row < lo) | (l_row >= hi)
-    l_row_local = torch.where(remote, (hi - lo) + torch.searchsorted(halo_global, l_row), l_row - lo)
     n_own, n_halo = hi - lo, int(halo_global.numel())
+    if n_halo:
+        l_row_local = torch.where(remote, n_own + halo_pos[torch.searchsorted(halo_sorted, l_row).clamp(max=n_halo - 1)], l_row - lo)
+    else:
+        l_row_local = l_row - lo
     local = IntegratedCOO(num_nodes=n_own + n_halo, num_rels=coo.num_rels,
                           node_type_offsets=torch.tensor([0, n_own + n_halo], device=row.device),
                           row=l_row_local.contiguous(), col=l_col.contiguous(), rel=l_rel.contiguous(),
                           eids=torch.arange(int(l_row.numel()), dtype=torch.int64, device=row.device))
     return DistPlan(rank, world, bounds, node_order, n_own, n_halo, local, halo_global, send_idx, send_counts, recv_counts,
-                    coo.num_edges, int(cut.sum()))
+                    coo.num_edges, int(cut.sum()), chunks, send_splits, recv_splits, cum(recv_splits), cum(send_splits))
 
 
 def _all_to_all(recv, send, recv_counts, send_counts, group):
@@ -186,6 +232,23 @@ def _all_reduce(t, group):
         t.copy_(c)
     else:
         dist.all_reduce(t, group=group)
+
+
+def _pieces(plan: DistPlan, reverse: bool):
+    """(send range, send splits, recv range, recv splits) of every piece of an exchange.  Forward: the packed rows (send_idx
+    order) travel to the peers' halo rows; reverse: halo-row gradients travel back into a buffer in send_idx order."""
+    out = []
+    for c in range(plan.chunks):
+        packed = (plan.send_chunk_ptr[c], plan.send_chunk_ptr[c + 1], plan.send_splits[c])
+        halo = (plan.halo_chunk_ptr[c], plan.halo_chunk_ptr[c + 1], plan.recv_splits[c])
+        out.append((halo, packed) if reverse else (packed, halo))
+    return out
+
+
+def _exchange(plan: DistPlan, recv, send, reverse: bool, group):
+    """The whole exchange, piece after piece, synchronously (HaloExchange; HaloContext under gloo)."""
+    for (sa, sb, ssp), (ra, rb, rsp) in _pieces(plan, reverse):
+        _all_to_all(recv[ra:rb], send[sa:sb], rsp, ssp, group)
 
 
 def _gather_rows(x, idx):
@@ -214,35 +277,51 @@ class HaloContext:
 
     def __init__(self, plan: DistPlan, group):
         self.plan, self.group = plan, group
-        self._work = self._keep = self._back = None
-        # exposed wait of the launch stream for the two exchanges of a step (bench.py: `timing = []` switches it on):
+        self._works = None  # the pieces of the exchange in flight: [(work or None, piece index)], in issue order
+        self._keep = self._back = None
+        # exposed wait of the launch stream for the exchanges of a step (bench.py: `timing = []` switches it on):
         # (what, event recorded when the launch stream reaches the wait, event recorded when it resumes)
         self.timing = None
 
-    def _a2a(self, recv, send, recv_counts, send_counts):
+    @property
+    def chunks(self) -> int:
+        return self.plan.chunks
+
+    def _a2a(self, recv, send, reverse):
         # one exchange in flight per context: an unpaired start_* (an exception between start and finish, a re-entered layer)
-        # would silently drop the handle of a collective that is still writing `recv`
-        if self._work is not None:
+        # would silently drop the handles of collectives that are still writing `recv`
+        if self._works is not None:
             raise RuntimeError("HaloContext: an exchange is still in flight (start_* without its finish_*)")
         if send.is_cuda and dist.get_backend(self.group) != "gloo":
-            self._work = dist.all_to_all_single(recv, send, recv_counts, send_counts, group=self.group, async_op=True)
-            self._keep = (recv, send)  # alive until the collective has finished
+            works = []
+            for c, ((sa, sb, ssp), (ra, rb, rsp)) in enumerate(_pieces(self.plan, reverse)):
+                works.append((dist.all_to_all_single(recv[ra:rb], send[sa:sb], rsp, ssp, group=self.group, async_op=True), c))
+            self._works = works
+            self._keep = (recv, send)  # alive until the collectives have finished
         else:
-            _all_to_all(recv, send, recv_counts, send_counts, self.group)
+            _exchange(self.plan, recv, send, reverse, self.group)
+            self._works = []
 
-    def _wait(self, what="exchange"):
-        if self._work is not None:
+    def _wait(self, what="exchange", upto=None):
+        """Make the launch stream wait for the pieces of the exchange in flight up to piece ``upto`` (None: all of them, and the
+        exchange is over)."""
+        if self._works is None:
+            return
+        while self._works and (upto is None or self._works[0][1] <= upto):
+            work, c = self._works[0]
             ev = None
             if self.timing is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             # (a wait that raised leaves the collective possibly still writing its buffers: they stay referenced -- and the
             #  context unusable -- until abort() gets a wait through or the process ends)
-            self._work.wait()
-            self._work = self._keep = None
+            work.wait()
+            self._works.pop(0)
             if ev is not None:
                 ev[1].record()
-                self.timing.append((what, ev[0], ev[1]))
+                self.timing.append((f"{what}[{c}]" if self.plan.chunks > 1 else what, ev[0], ev[1]))
+        if upto is None:
+            self._works = self._keep = None
 
     def abort(self):
         """Wait for an exchange a failed step left in flight (exception between start_* and finish_*), so that its buffers may
@@ -250,7 +329,7 @@ class HaloContext:
         try:
             self._wait("abort")
         except BaseException:
-            self._work = None  # the handle is dropped, the buffers (`_keep`) are deliberately leaked with the failed collective
+            self._works = None  # the handles are dropped, the buffers (`_keep`) are deliberately leaked with the failed collective
             raise
         finally:
             self._back = None
@@ -260,8 +339,12 @@ class HaloContext:
         send = _gather_rows(x_own, p.send_idx)
         x_local = x_own.new_empty((p.n_own + p.n_halo, x_own.shape[1]))
         x_local[: p.n_own].copy_(x_own)
-        self._a2a(x_local[p.n_own:], send, p.recv_counts, p.send_counts)  # straight into the halo rows
+        self._a2a(x_local[p.n_own:], send, False)  # straight into the halo rows
         return x_local
+
+    def wait_push_piece(self, c: int):
+        """The halo rows of pieces 0..c have arrived (local nodes n_own + halo_chunk_ptr[c] .. n_own + halo_chunk_ptr[c + 1])."""
+        self._wait("push", upto=c)
 
     def finish_push(self):
         self._wait("push")
@@ -269,7 +352,7 @@ class HaloContext:
     def start_return(self, grad_local):
         p = self.plan
         self._back = grad_local.new_empty((int(p.send_idx.numel()), grad_local.shape[1]))
-        self._a2a(self._back, grad_local[p.n_own:], p.send_counts, p.recv_counts)
+        self._a2a(self._back, grad_local[p.n_own:], True)
 
     def finish_return(self, grad_own):
         self._wait("return")
@@ -288,7 +371,7 @@ class HaloExchange(torch.autograd.Function):
         send = _gather_rows(x_own, plan.send_idx)
         x_local = x_own.new_empty((plan.n_own + plan.n_halo, x_own.shape[1]))
         x_local[: plan.n_own].copy_(x_own)
-        _all_to_all(x_local[plan.n_own:], send, plan.recv_counts, plan.send_counts, group)  # straight into the halo rows
+        _exchange(plan, x_local[plan.n_own:], send, False, group)  # straight into the halo rows
         return x_local
 
     @staticmethod
@@ -297,7 +380,7 @@ class HaloExchange(torch.autograd.Function):
         g_own = grad[: plan.n_own].clone()
         g_halo = grad[plan.n_own:].contiguous()
         back = grad.new_empty((int(plan.send_idx.numel()), grad.shape[1]))
-        _all_to_all(back, g_halo, plan.send_counts, plan.recv_counts, ctx.group)
+        _exchange(plan, back, g_halo, True, ctx.group)
         _scatter_add_rows(g_own, plan.send_idx, back)
         return g_own, None, None
 
@@ -408,15 +491,19 @@ class LoopbackHalo(HaloContext):
         x_local = x_own.new_empty((p.n_own + p.n_halo, x_own.shape[1]))
         x_local[: p.n_own].copy_(x_own)
         off = p.n_own
-        for q in range(p.world):  # the received buffer is ordered by sending rank (all_to_all_single)
-            n = p.recv_counts[q]
-            if n:
-                sq = self.plans[q].send_counts
-                a = sum(sq[: p.rank])
-                assert sq[p.rank] == n, "send / receive counts of the plans disagree"
-                x_local[off: off + n].copy_(self.wire.push[q][a: a + n])
-            off += n
+        for c in range(p.chunks):       # a piece's received rows are ordered by sending rank (all_to_all_single)
+            for q in range(p.world):
+                n = p.recv_splits[c][q]
+                if n:
+                    pq = self.plans[q]
+                    assert pq.send_splits[c][p.rank] == n, "send / receive splits of the plans disagree"
+                    a = pq.send_chunk_ptr[c] + sum(pq.send_splits[c][: p.rank])
+                    x_local[off: off + n].copy_(self.wire.push[q][a: a + n])
+                off += n
         return x_local
+
+    def wait_push_piece(self, c: int):
+        pass
 
     def finish_push(self):
         pass
@@ -473,12 +560,13 @@ class LocalRanks:
                 self._x_local[r] = None
         for r, p in enumerate(self.plans):  # the reverse all-to-all: rank r gets back the gradients of the rows it sent
             parts = []
-            for q in range(self.world):
-                n = p.send_counts[q]
-                if n:
-                    rq = self.plans[q].recv_counts
-                    a = sum(rq[:r])
-                    parts.append(self.wire.back[q][a: a + n])
+            for c in range(p.chunks):
+                for q in range(self.world):
+                    n = p.send_splits[c][q]
+                    if n:
+                        pq = self.plans[q]
+                        a = pq.halo_chunk_ptr[c] + sum(pq.recv_splits[c][:r])
+                        parts.append(self.wire.back[q][a: a + n])
             if parts:
                 _scatter_add_rows(x_own[r].grad, p.send_idx, torch.cat(parts))
         self.wire.back.clear()

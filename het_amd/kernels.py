@@ -778,6 +778,29 @@ def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weigh
           _stream(grad_x))
 
 
+def node_rows_matmul_sum_ok(num_sources: int, KS: int, XO: int) -> bool:
+    return bool(_lib.lib().het_node_rows_matmul_sum_ok(int(num_sources), int(KS), int(XO)))
+
+
+def node_rows_matmul_sum(n_begin, n_end, sources, out, node_order=None):
+    """out[n] = SUM_s rows_s[map_s[n]] . wt_s for the nodes at positions [n_begin, n_end) of node_order (include/het_amd.h:
+    het_node_rows_matmul_sum).  sources: (rows [n_rows, W] float tensor, first column, map [N] int32 or None (row = node id),
+    wt [KS, XO]) each; a source reads the KS columns of its rows that start at ``first column``."""
+    N, XO = out.shape
+    S = len(sources)
+    KS = sources[0][3].shape[0]
+    _chk("node_rows_matmul_sum", tuple(t for src in sources for t in (src[0], src[3])) + (out,))
+    ptrs = (C.c_void_p * S)(*[src[0].data_ptr() + 4 * int(src[1]) for src in sources])
+    strides = (C.c_int64 * S)(*[src[0].shape[1] if src[0].dim() == 2 else src[0].numel() // src[0].shape[0] for src in sources])
+    maps = (C.c_void_p * S)(*[None if src[2] is None else src[2].data_ptr() for src in sources])
+    ident = (C.c_int64 * S)(*[min(N, src[0].shape[0]) if src[2] is None else 0 for src in sources])
+    wts = (C.c_void_p * S)(*[src[3].data_ptr() for src in sources])
+    for src in sources:
+        assert src[3].shape == (KS, XO) and src[3].is_contiguous() and (src[2] is None or (src[2].dtype == torch.int32 and src[2].numel() == N))
+    _call(out, "het_node_rows_matmul_sum", int(n_begin), int(n_end), N, S, ptrs, strides, maps, ident, wts, _p(out), KS, XO,
+          _p(node_order), _stream(out))
+
+
 def rows_linear_bias_ok(K: int, X: int) -> bool:
     return K in (32, 64, 128) and X in (32, 64, 128)
 

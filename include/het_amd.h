@@ -573,6 +573,23 @@ int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t n_loop, in
                               const int32_t* row_map, const float* g_er, const float* wa_t, const int32_t* dst_map,
                               float* grad_x, int64_t H, int64_t K, int64_t D, const int32_t* node_order, het_stream stream);
 
+/* Layer-level extension (no reference op of its own): the node-major sum of row x weight products
+ *     out[n, :] = SUM_s rows_s[map_s[n], :] . weights_t[s]          n = node_order[p] (or p) for p in [n_begin, n_end)
+ * -- the input gradient of a layer input that feeds several projections, formed in ONE pass over the nodes instead of one
+ * read-modify-write (the reference: float-atomic) pass per projection: replaces the a2 / a3 input-gradient launches behind the
+ * HGT layer (backward_rgnn_relational_matmul / ..._no_scatter_gather_list, OpExport/RGNNOps.inc.h:946-1010, 660-753, as
+ * HGT/models.py:159-262 composes them).  Source s: rows[s] = its first row (a column offset into a wider row is part of the
+ * pointer: the k' and the m half of HGT's [S_row, 2X] gradient are two sources), row_strides[s] floats between rows,
+ * maps[s] [num_nodes] int32 = row of node n or -1 (het_node_row_map gives [R, N] of them), or NULL: row = n for
+ * n < ident_rows[s]; weights_t[s] [KS, XO] row-major (the projection's weight transposed).  Every node of the range is
+ * written (zeros where it has no row).  KS, XO in {32, 64}; all weights of a call stay in LDS: at most 9 sources and
+ * het_node_rows_matmul_sum_ok(num_sources, KS, XO).  node_order as in het_rgat_node_backward_dx. */
+int het_node_rows_matmul_sum_ok(int64_t num_sources, int64_t KS, int64_t XO);
+int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
+                             const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
+                             const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS, int64_t XO,
+                             const int32_t* node_order, het_stream stream);
+
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.
  * Matrix-core shapes only (HET_ERR_UNSUPPORTED otherwise). */
