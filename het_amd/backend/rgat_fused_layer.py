@@ -135,6 +135,31 @@ def _side_stream(dev):
     return s
 
 
+PIECEWISE_PUSH = os.environ.get("HET_DIST_PIECEWISE", "1") != "0"  # project the halo rows piece by piece as they arrive
+
+
+def _halo_pieces(g, ss, plan):
+    """The unique (relation, source) list of a partition's local graph cut by where the source node's row of x comes from: the
+    owned nodes, then every piece of the halo exchange (local ids n_own + halo_chunk_ptr[c] ..).  Per cut a relation-bucketed
+    list (rel_ptrs [R+1], node ids, row index in the full list), built once per graph."""
+    key = ("halo_pieces", plan.chunks, plan.n_own, plan.n_halo)
+    hit = g._plans.get(key)
+    if hit is None:
+        rp_row, nodes = ss["rel_ptrs_row"], ss["node_indices_row"]
+        R = rp_row.numel() - 1
+        rel = th.repeat_interleave(th.arange(R, device=nodes.device), rp_row[1:] - rp_row[:-1])
+        cuts = [(0, plan.n_own)] + [(plan.n_own + plan.halo_chunk_ptr[c], plan.n_own + plan.halo_chunk_ptr[c + 1]) for c in range(plan.chunks)]
+        hit = []
+        for a, b in cuts:
+            sel = th.nonzero((nodes >= a) & (nodes < b)).flatten()  # ascending: still relation-major
+            rp_c = th.zeros(R + 1, dtype=th.int64, device=nodes.device)
+            rp_c[1:] = th.cumsum(th.bincount(rel[sel], minlength=R), 0)
+            hit.append((rp_c, nodes[sel].contiguous(), sel.contiguous()))
+        assert sum(int(h[2].numel()) for h in hit) == nodes.numel()
+        g._plans[key] = hit
+    return hit
+
+
 @_consistent_plan
 class RgatLayerFunction(th.autograd.Function):
     @staticmethod
@@ -196,9 +221,20 @@ class RgatLayerFunction(th.autograd.Function):
                         _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c, out=h)
                 else:
                     h = _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c)
-            if halo is not None:
+            dot_ok = _k.matmul_attn_dot_ok(H, Kd, D)
+            if halo is not None and halo.chunks > 1 and PIECEWISE_PUSH and dot_ok:
+                # the exchange arrives in pieces (het_amd/dist.py: DistPlan.chunks): the rows whose source node is owned are
+                # projected at once, the rows of piece c as soon as piece c is there -- piece c + 1 is on the wire meanwhile
+                for c, (rp_c, nodes_c, rows_c) in enumerate(_halo_pieces(g, ss, halo.plan)):
+                    if c > 0:
+                        halo.wait_push_piece(c - 1)
+                    _k.matmul_attn_dot_rows(rp_c, nodes_c, rows_c, W, x, featc, attn_l, elc)
                 halo.finish_push()
-            if _k.matmul_attn_dot_ok(H, Kd, D):
+            elif halo is not None:
+                halo.finish_push()
+            if halo is not None and halo.chunks > 1 and PIECEWISE_PUSH and dot_ok:
+                pass  # (projected above)
+            elif dot_ok:
                 _k.matmul_attn_dot(d_row, 1, W, x, featc, attn_l, elc)  # el_c = <feat_c, attn_l[r]> from the GEMM epilogue
             else:  # other widths: any-shape projection, then el_c as a row-dot over the relation-bucketed rows
                 K.rgnn_relational_matmul(d_row, 1, W, x, featc, True)

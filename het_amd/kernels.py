@@ -225,6 +225,18 @@ def matmul_attn_dot(args_tensor_dict, IntKind, weights, node_feat, ret, dot_w, d
     return comp
 
 
+def matmul_attn_dot_rows(rel_ptrs, gather_idx, scatter_idx, weights, node_feat, ret, dot_w, dot_out):
+    """ret[scatter_idx[i]] = node_feat[gather_idx[i]] . W[r(i)] and dot_out[scatter_idx[i], h] = <that row's head h, dot_w[r, h]> for
+    a relation-bucketed list of DISTINCT rows -- no grouping is looked up or built (a piece of a unique (relation, node) list:
+    the projection of the halo rows that have arrived, het_amd/backend/rgat_fused_layer.py)."""
+    _chk("rgnn_relational_matmul_attn_dot", (weights, node_feat, ret, dot_w, dot_out), (rel_ptrs, gather_idx, scatter_idx))
+    R, H, K, D = weights.shape
+    if gather_idx.numel() == 0:
+        return
+    _call(dot_out, "het_rgnn_relational_matmul_attn_dot", 0, _p(rel_ptrs), R, _p(gather_idx), _p(scatter_idx), gather_idx.numel(),
+          _p(weights), _p(node_feat), _p(ret), _p(dot_w), _p(dot_out), H, K, D, None, None, 0, None, None, _stream(dot_out))
+
+
 def rows_add_bias(a, b=None, bias=None):
     """out = a (+ b) (+ bias broadcast over rows) in one pass (include/het_amd.h: het_rows_add_bias)."""
     _chk("rows_add_bias", tuple(t for t in (a, b, bias) if t is not None))

@@ -94,12 +94,14 @@ def _worker(rank, world, port, kind, outdir, use_halo=False):
 
 @pytest.mark.parametrize("kind,world,use_halo", [("mag", 2, False), ("random", 3, False), ("mag128", 2, False), ("mag", 2, True),
                                                  ("random", 3, True), ("mag128", 8, True), ("random", 8, False)])
-def test_partitioned_layer_matches_single_process(kind, world, use_halo):
+def test_partitioned_layer_matches_single_process(kind, world, use_halo, monkeypatch):
     """mag128: feat 128, 4 heads -- the shape of BASELINE.json configs[4] (RGAT feat = 128 on a partition; world 8 = its rank
     count, eight gloo processes).  use_halo: the layer drives the exchange through dist.HaloContext (the overlapped form of the
     HIP layer) instead of HaloExchange."""
     from het_amd.graph import HetGraph
     from oracle import layers as OL
+    # (the workers are fresh interpreters: the pieces of the exchange come from the environment -- 1 = monolithic, 4 = default)
+    monkeypatch.setenv("HET_DIST_CHUNKS", "1" if (kind, world) == ("mag", 2) else ("3" if world == 3 else "4"))
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), kind, d, use_halo), nprocs=world, join=True)
         parts = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(world)]
@@ -181,14 +183,42 @@ class _OracleRGAT:
         return _HaloOracleLayer.apply(x_own, halo, lambda xl: self._fn(g, xl), x_own.shape[0], *self.p.values())
 
 
-@pytest.mark.parametrize("world,with_halo", [(8, True), (8, False), (5, True), (1, True)])
-def test_local_ranks_rehearsal_matches_single_process(world, with_halo):
+@pytest.mark.parametrize("chunks", [1, 3, 50])
+def test_exchange_pieces_cover_every_row_once(chunks, monkeypatch):
+    """The halo exchange in pieces (DistPlan.chunks): sender and receiver cut every peer's block at the same places, pieces are
+    contiguous ranges of the halo rows / of send_idx, and together they move every row exactly once -- also with more pieces
+    than a peer has rows (empty pieces)."""
+    import het_amd.dist as D
+    coo = make_mag_like(scale=5e-4)
+    world = 4
+    plans = [D.build_plan(coo, r, world, chunks=chunks) for r in range(world)]
+    base = [D.build_plan(coo, r, world, chunks=1) for r in range(world)]
+    for p, b in zip(plans, base):
+        assert p.chunks == chunks and p.n_halo == b.n_halo and p.send_counts == b.send_counts and p.recv_counts == b.recv_counts
+        assert torch.equal(torch.sort(p.halo_global).values, b.halo_global) and torch.equal(torch.sort(p.send_idx).values, torch.sort(b.send_idx).values)
+        assert p.halo_chunk_ptr[0] == 0 and p.halo_chunk_ptr[-1] == p.n_halo and p.send_chunk_ptr[-1] == p.send_idx.numel()
+        assert [sum(p.recv_splits[c][q] for c in range(chunks)) for q in range(world)] == p.recv_counts
+        for c in range(chunks):
+            for q in range(world):
+                assert p.recv_splits[c][q] == plans[q].send_splits[c][p.rank]
+        # same local graph up to the numbering of the halo nodes
+        assert p.num_local_edges == b.num_local_edges and torch.equal(p.local.col, b.local.col)
+        glob = lambda pl: torch.where(pl.local.row < pl.n_own, pl.local.row + int(pl.bounds[pl.rank]),
+                                      pl.halo_global[(pl.local.row - pl.n_own).clamp(min=0)])
+        assert torch.equal(glob(p), glob(b))
+
+
+@pytest.mark.parametrize("world,with_halo,chunks", [(8, True, None), (8, False, None), (5, True, 1), (1, True, None), (3, True, 7)])
+def test_local_ranks_rehearsal_matches_single_process(world, with_halo, chunks, monkeypatch):
     """dist.LocalRanks (every rank of the partition as a logical rank of one process, the all-to-all by slicing) with the oracle
     as the layer: outputs, input gradients and the accumulated weight gradients equal the single-process oracle -- the harness
     tests/test_gpu_dist.py runs the HIP layer through at 8 ranks."""
+    import het_amd.dist as hd
     from het_amd.dist import LocalRanks
     from het_amd.graph import HetGraph
     from oracle import layers as OL
+    if chunks is not None:
+        monkeypatch.setattr(hd, "CHUNKS", chunks)
     coo = make_mag_like(scale=1e-3)
     H, K, D = 2, 8, 4
     p = _params(coo.num_rels, H, K, D)
