@@ -105,7 +105,7 @@ KT_NAMES = ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rg
             "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
             "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
             "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
-            "HET_node_dx", "HET_hgt_node_dx",
+            "HET_node_dx", "HET_node_rows_sum",
             "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long")
 
 

@@ -198,9 +198,16 @@ class HgtAttentionFunction(th.autograd.Function):
         if nplan is not None:
             # every consumer of h adds its term in ONE pass over the nodes: the destination-side projection's gradient rows
             # (g_q . Q_t^T) and, per relation the node is a source of, the two halves of its [k' | m] gradient row
-            grad_h = th.empty_like(h)
+            grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)  # (allocated under the main stream)
             g_kv2, g_q2 = g_kv.view(-1, 2 * X), g_q.view(-1, X)
             wt2 = wt.view(-1, 2 * X, K_in)
+            with th.cuda.stream(side if side is not None else main):  # the other two weight gradients beside the node pass
+                if side is None:
+                    _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv2, grad_wkv, accumulate=False)
+                if ctx.compact_dst:
+                    _k.rows_matmul_backward_dw(lists[1], lists[0], h, g_q2, grad_qw, accumulate=False)
+                else:
+                    _k.rows_matmul_backward_dw(offs, None, h, g_q2, grad_qw, accumulate=False)
             for t, rels in enumerate(nplan["rels_of"]):
                 a, b = nplan["offs"][t], nplan["offs"][t + 1]
                 srcs = []
@@ -213,15 +220,7 @@ class HgtAttentionFunction(th.autograd.Function):
                     grad_h[a:b].zero_()  # (a node type that neither sends nor receives: its rows of the gradient are zero)
                 elif b > a:
                     _k.node_rows_matmul_sum(a, b, srcs, grad_h, nplan["order"])
-            grad_qw = th.empty_like(q_w)
-            if ctx.compact_dst:
-                dst_nodes, run_ptrs = lists
-                _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q2, grad_qw, accumulate=False)
-            else:
-                _k.matmul_no_scatter_gather_backward(offs, qwt, h, g_q, None, grad_qw, accumulate=False)
-            if side is None:
-                _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv2, grad_wkv, accumulate=False)
-            else:
+            if side is not None:
                 main.wait_stream(side)
             return None, None, None, grad_h, grad_wkv, grad_qw, None
         if not ctx.compact_dst:  # the typed projection writes every row with plain stores, the source-row GEMM adds to it
