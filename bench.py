@@ -808,10 +808,12 @@ def _main():
             "kernel_ms": kernel_ms,
             "per_op_ms": per_op,
             "dist": dist_info,
-            # torch's allocator peak + the groupings (hipMalloc'ed by the library at plan time, outside torch's statistics)
-            "peak_memory_GB": round((torch.cuda.max_memory_allocated(dev) + plan_bytes) / 2**30, 2),
+            # torch's allocator peak; the groupings are part of it when the library allocates through torch (het_set_allocator:
+            # the default of het_amd.kernels), else hipMalloc'ed by the library and added here
+            "peak_memory_GB": round((torch.cuda.max_memory_allocated(dev) + (0 if HL.allocator_is_external() else plan_bytes)) / 2**30, 2),
             "peak_memory_detail_GB": {"torch_allocator_peak": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
-                                      "groupings": round(plan_bytes / 2**30, 2)},
+                                      "groupings": round(plan_bytes / 2**30, 2),
+                                      "groupings_inside_torch_allocator": bool(HL.allocator_is_external())},
         }
         if world == 1 and not args.no_variants and args.variant == "default" and args.model == "rgat":
             out["variants"] = other_variants(args, coo, dev, min(args.steps, 10), ms_per_step, value)
