@@ -777,8 +777,10 @@ def _main():
         dist.all_gather_object(allr, mine)
         dist_info = {"ranks": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""),
                      "overlap": os.environ.get("HET_DIST_OVERLAP", "1") == "1",
-                     "exchange": "x[halo] forward and grad_x[halo] backward, one all_to_all_single each per step; "
-                                 "exposed_wait_ms = time the launch stream waited for it (0 when hidden or synchronous)",
+                     "pieces": int(p_.chunks),
+                     "exchange": "x[halo] forward and grad_x[halo] backward per step, each as `pieces` all_to_all_single calls (piece c = "
+                                 "the c-th part of the rows of every peer; the layer projects a piece's rows when it has landed); "
+                                 "exposed_wait_ms = time the launch stream waited per piece (0 when hidden or synchronous)",
                      "per_rank": allr,
                      "max_exposed_wait_ms": round(max(sum(r_["exposed_wait_ms"].values()) for r_ in allr), 4)}
 

@@ -180,18 +180,24 @@ def test_bench_distributed_flow_one_rank(backend):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "strong"
 
 
-def test_bench_two_ranks_through_torchrun():
-    """The driver's launch line for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), both ranks on the one GPU
-    of the test box with the gloo backend standing in for RCCL (HET_DIST_BACKEND): rank 0 prints the one JSON line."""
+@pytest.mark.parametrize("world,feat", [(2, 64), (4, 128)])
+def test_bench_ranks_through_torchrun(world, feat):
+    """The driver's launch line for N = 2 / 4 (python -m torch.distributed.run ... bench.py --gpus N), the ranks sharing the one
+    GPU of the test box with the gloo backend standing in for RCCL (HET_DIST_BACKEND): rank 0 prints the one JSON line, whose
+    `dist` object carries every rank's halo volume and the wait per piece of the exchanges.  (N = 8: tests/test_dist_gloo.py::
+    test_bench_dry_run_exchange_eight_ranks -- eight processes may not share the box's GPU.)"""
     import sys
     env = dict(os.environ, HET_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HET_FORCE_DIST"):
         env.pop(k, None)
-    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                       "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--scale", "0.02", "--steps",
-                       "3", "--warmup", "1", "--no-cpu-baseline"], env)
-    assert out["n_gpus"] == 2 and out["value"] > 0
+    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                       "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(world), "--scale", "0.02", "--feat",
+                       str(feat), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env)
+    assert out["n_gpus"] == world and out["value"] > 0
     assert "RCCL all-to-all" in out["config"]["parallelism"]
+    d = out["dist"]
+    assert d["ranks"] == world and len(d["per_rank"]) == world and all(q["halo_rows_sent"] > 0 and q["halo_rows_received"] > 0 for q in d["per_rank"])
+    assert sum(q["local_edges"] for q in d["per_rank"]) == 422220  # every edge of the 2 % graph on exactly one rank
 
 
 def _nccl_worker_script():
