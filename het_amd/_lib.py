@@ -96,7 +96,7 @@ def lib() -> C.CDLL:
         L.het_rgat_aggregate_compact_workspace.restype = I64
         L.het_rgat_aggregate_compact_runs_workspace.argtypes = [P, P, I64, I64, I64, P]
         L.het_rgat_aggregate_compact_runs_workspace.restype = I64
-        L.het_rgat_backward_compact_runs_workspace.argtypes = [P, I64, I64, I64, INT, INT, P]
+        L.het_rgat_backward_compact_runs_workspace.argtypes = [P, I64, I64, I64, I64, INT, INT, P]
         L.het_rgat_backward_compact_runs_workspace.restype = I64
         L.het_rgat_backward_compact_workspace.argtypes = [I64, I64, I64, I64, INT]
         L.het_rgat_backward_compact_workspace.restype = I64

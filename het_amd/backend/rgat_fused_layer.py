@@ -139,16 +139,19 @@ PIECEWISE_PUSH = os.environ.get("HET_DIST_PIECEWISE", "1") != "0"  # project the
 
 
 def _halo_pieces(g, ss, plan):
-    """The unique (relation, source) list of a partition's local graph cut by where the source node's row of x comes from: the
-    owned nodes, then every piece of the halo exchange (local ids n_own + halo_chunk_ptr[c] ..).  Per cut a relation-bucketed
-    list (rel_ptrs [R+1], node ids, row index in the full list), built once per graph."""
+    """The unique (relation, source) list of a partition's local graph cut by when the source node's row of x is there: the
+    owned nodes together with piece 0 of the halo exchange, then every further piece (local ids n_own + halo_chunk_ptr[c] ..).
+    Per cut a relation-bucketed list (rel_ptrs [R+1], node ids, row index in the full list), built once per graph."""
     key = ("halo_pieces", plan.chunks, plan.n_own, plan.n_halo)
     hit = g._plans.get(key)
     if hit is None:
         rp_row, nodes = ss["rel_ptrs_row"], ss["node_indices_row"]
         R = rp_row.numel() - 1
         rel = th.repeat_interleave(th.arange(R, device=nodes.device), rp_row[1:] - rp_row[:-1])
-        cuts = [(0, plan.n_own)] + [(plan.n_own + plan.halo_chunk_ptr[c], plan.n_own + plan.halo_chunk_ptr[c + 1]) for c in range(plan.chunks)]
+        # (the owned sources -- 5 % of a rank's rows on ogbn-mag at 8 ranks -- go with the first piece: a launch less per step, and
+        #  a rank's step at 8 ranks is short enough for every launch to count, profiles/r04/dist_rank_share_halo.txt)
+        cuts = [(0, plan.n_own + plan.halo_chunk_ptr[1])] + [(plan.n_own + plan.halo_chunk_ptr[c], plan.n_own + plan.halo_chunk_ptr[c + 1])
+                                                             for c in range(1, plan.chunks)]
         hit = []
         for a, b in cuts:
             sel = th.nonzero((nodes >= a) & (nodes < b)).flatten()  # ascending: still relation-major
@@ -226,8 +229,7 @@ class RgatLayerFunction(th.autograd.Function):
                 # the exchange arrives in pieces (het_amd/dist.py: DistPlan.chunks): the rows whose source node is owned are
                 # projected at once, the rows of piece c as soon as piece c is there -- piece c + 1 is on the wire meanwhile
                 for c, (rp_c, nodes_c, rows_c) in enumerate(_halo_pieces(g, ss, halo.plan)):
-                    if c > 0:
-                        halo.wait_push_piece(c - 1)
+                    halo.wait_push_piece(c)
                     _k.matmul_attn_dot_rows(rp_c, nodes_c, rows_c, W, x, featc, attn_l, elc)
                 halo.finish_push()
             elif halo is not None:
@@ -468,15 +470,36 @@ class RgatLayerFunction(th.autograd.Function):
         g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, 1, Kd)
-        grad_wa = th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
         grad_x = th.empty_like(x)
+        grad_W, grad_loop = th.empty_like(W), th.empty_like(loop_w)
+        grad_attn_l = th.empty_like(attn_l)
         node_major = NODE_GEMM and _k.rgat_node_gemm_ok(R, H, Kd, D)
+        # as on one GPU (_backward_node_major): the weight gradients are HBM-bound streams of rows -- on the side stream beside the
+        # gather passes and the matrix-core-bound node pass; the self-loop's needs x and grad_h only and starts at once
+        main, side = th.cuda.current_stream(x.device), (_side_stream(x.device) if OVERLAP and x.is_cuda else None)
+        if side is not None:
+            side.wait_stream(main)
+            with th.cuda.stream(side):
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
         if not node_major:
             grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
             _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
+        attn_in_pass = ATTN_GRAD_IN_PASS and ctx.runs is not None and R <= 8 and x.is_cuda
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
-                                 drow_nodes=ss["node_indices_col"])
+                                 drow_nodes=ss["node_indices_col"], grad_attn_l=grad_attn_l if attn_in_pass else None)
+        grad_wa = th.empty((R, H, Kd, 1), dtype=x.dtype, device=x.device) if node_major else th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
+
+        def weight_gradients():
+            if side is None:
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+            _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)
+            if not attn_in_pass:
+                _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
+                                                     accumulate=False)
+            if node_major:  # the er side's weight gradient alone (its input gradient is a term of the node pass)
+                _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), None, grad_wa, True, accumulate=False)
+
         if node_major:
             # one pass per node range (csrc/node_gemm.hip): the halo rows first -- only the (relation, source) projections reach
             # them -- so that they leave with the all-to-all while the owned rows (self-loop + projections + folded attention
@@ -488,19 +511,21 @@ class RgatLayerFunction(th.autograd.Function):
             args = (grad_h, loop_wt, g_featc.view(-1, X), Wt, row_map, g_erc, wa_t.view(R, H, Kd), dst_map, grad_x, order)
             _k.rgat_node_backward_dx(nd, N, nd, *args)
             halo.start_return(grad_x)
+            if side is not None:
+                side.wait_stream(main)  # (g_featc / g_erc are complete)
+                with th.cuda.stream(side):
+                    weight_gradients()
             _k.rgat_node_backward_dx(0, nd, nd, *args)
+            if side is None:
+                weight_gradients()
         else:
             _k.rows_matmul_backward_dx(rp_row, rows_node, Wt, g_featc.view(-1, X), grad_x, atomic=2)  # rows of a relation: distinct nodes
             halo.start_return(grad_x)
-        grad_W, grad_loop = th.empty_like(W), th.empty_like(loop_w)
-        _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)
-        _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
-        grad_attn_l = th.empty_like(attn_l)
-        _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
-                                             accumulate=False)
-        # the er side's weight gradient (and, on the per-relation path, its input gradient: owned rows only)
-        _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), None if node_major else grad_x, grad_wa, True, accumulate=True,
-                           distinct_rows=True)
+            weight_gradients()
+            # the er side's weight gradient and, on the per-relation path, its input gradient (owned rows only)
+            _k.matmul_backward(d_col, 1, wa_t, x, g_erc.view(-1, H, 1), grad_x, grad_wa, True, accumulate=True, distinct_rows=True)
+        if side is not None:
+            main.wait_stream(side)
         grad_W.addcmul_(grad_wa, attn_r.view(R, H, 1, D))  # through wa[r,h,k] = SUM_d W[r,h,k,d] * attn_r[r,h,d]
         grad_attn_r = (W * grad_wa).sum(2)
         grad_own = halo.finish_return(grad_x[:nd])

@@ -933,7 +933,10 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_attn_grad_finish(const float*
 
 // Backward, cooperative form of HET_rgat_backward_src_packed.  pack2 [N,H,2] = {lse, <gradout, ret>} interleaved.
 // GA: also the partial rows of grad_attn_l (ga_block_reduce above; needs fold_w for the relation of a row)
-template <int LPR, int DL, bool GA = false>
+// REC: er / lse / <gradout, ret> of an edge come from ONE 16-byte record per (er row, head) -- rec4 [S_col, H] {er, lse, dot, 0},
+// HET_rgat_drow_rec -- instead of a 4-byte gather from er and an 8-byte one from pack2: a vector-memory instruction and a
+// 128-byte line less per edge (the gathers of these kernels miss L2 once per table and edge: profiles/r04/locality_counters.txt)
+template <int LPR, int DL, bool GA = false, bool REC = false>
 __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat,
     const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack2,
@@ -968,8 +971,15 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
   for (int j0 = b; j0 < e; j0 += U) {
     const int keyv = idn.x, dstv = idn.y, drowv = idn.z;
     // scalars of the step: lane (h, q) fetches those of edge q, head h
-    const float zrv = er[(int64_t)drowv * H + h];
-    const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    float zrv;
+    float2 pkv;
+    if (REC) {
+      const float4 rv = ld4(er + ((int64_t)drowv * H + h) * 4);  // (er: the record table)
+      zrv = rv.x; pkv = make_float2(rv.y, rv.z);
+    } else {
+      zrv = er[(int64_t)drowv * H + h];
+      pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    }
     const float zlv = el[(int64_t)keyv * H + h];
     int key[U];
     float4 g[U], fq[U];
@@ -1064,7 +1074,7 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
 // graph): wave per work item (<= HET_ITEM_MAX edges of ONE feat row), the 64/LPR lane groups take its edges round-robin
 // as the forward does, scalars fetched cooperatively; feat row, el and the fold row are per item.  One store per item
 // (atomic adds only for the items of a segment longer than HET_ITEM_MAX, whose rows HET_rgat_zero_long_rows cleared).
-template <int LPR, int DL, bool GA = false>
+template <int LPR, int DL, bool GA = false, bool REC = false>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int2* __restrict__ p01,
     const float* __restrict__ feat, const float* __restrict__ el,
@@ -1094,8 +1104,15 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
   float acc_el = 0.f;
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     const int dstv = idn.x, drowv = idn.y;
-    const float zrv = er[(int64_t)drowv * H + h];
-    const float2 pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    float zrv;
+    float2 pkv;
+    if (REC) {
+      const float4 rv = ld4(er + ((int64_t)drowv * H + h) * 4);  // (er: the record table, see HET_rgat_backward_src_coop)
+      zrv = rv.x; pkv = make_float2(rv.y, rv.z);
+    } else {
+      zrv = er[(int64_t)drowv * H + h];
+      pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+    }
     float4 g[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
@@ -1145,6 +1162,21 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
   } else {
     atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
     if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+  }
+}
+
+// rec4[w, h] = {er[w, h], lse[v, h], <gradout, ret>[v, h], 0}, v = drow_nodes[w]: everything the source-row kernels need per edge
+// from the destination side, one 16-byte record per (er row, head).  pack2 [N,H,2] interleaved (HET_rgat_dst_pack).
+__global__ __launch_bounds__(kBlock) void HET_rgat_drow_rec(const float* __restrict__ er, const float* __restrict__ pack2,
+                                                             const int64_t* __restrict__ drow_nodes, int64_t n_rows, int H,
+                                                             float* __restrict__ rec4) {
+  const int64_t total = n_rows * H;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t w = t / H;
+    const int h = (int)(t - w * H);
+    const int64_t v = drow_nodes[w];
+    const float2 p = *reinterpret_cast<const float2*>(pack2 + (v * H + h) * 2);
+    st4(rec4 + t * 4, make_float4(er[t], p.x, p.y, 0.f));
   }
 }
 
@@ -1398,7 +1430,10 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
   const int64_t ga_rows = (grad_attn_l && E > 0) ? attn_grad_partial_rows(by_srow, X) : 0, n_ga = (ga_rows * (X + 1) + 3) / 4 * 4;
   const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = runs ? 0 : (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
-  const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X + n_ga);
+  static const bool rec_on = [] { const char* v = getenv("HET_RGAT_DROW_REC"); return !(v && v[0] == '0'); }();  // A/B switch
+  const bool use_rec = runs && coop && rec_on && E > 0 && num_dst_rows > 0;
+  const int64_t n_rec = (runs && coop) ? num_dst_rows * H * 4 : 0;
+  const int64_t need = (int64_t)sizeof(float) * (n_pack + n_tbuf + bias_part_rows * X + n_ga + n_rec);
   HET_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
               "%s: a 16-byte aligned workspace of %lld bytes is needed (het_rgat_backward_compact_workspace)", op, (long long)need);
   float* pack = (float*)workspace;  // [N, 2H]
@@ -1406,6 +1441,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   float* bias_part = grad_bias ? pack + n_pack + n_tbuf : nullptr;
   float* ga_part = ga_rows ? pack + n_pack + n_tbuf + bias_part_rows * X : nullptr;  // [ga_rows, X] then [ga_rows] relation tags
   int* ga_rel = ga_rows ? reinterpret_cast<int*>(ga_part + ga_rows * X) : nullptr;
+  float* rec4 = use_rec ? pack + n_pack + n_tbuf + bias_part_rows * X + n_ga : nullptr;  // [S_col, H, 4]
   if (grad_attn_l) HET_HIP(hipMemsetAsync(grad_attn_l, 0, sizeof(float) * num_rels * X, s));  // (boundary pieces add atomically)
   if (by_srow->S != num_src_rows) {  // feat rows without an edge (none when the lists come from the graph): zero gradient
     HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
@@ -1433,6 +1469,12 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (int rc = grouping_packs(by_srow, s)) return rc;
   Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  if (use_rec) {  // before the fork: both source-row launches read the records
+    hipLaunchKernelGGL(HET_rgat_drow_rec, dim3(grid_for(num_dst_rows * H)), dim3(kBlock), 0, s, er_c, pack, runs->drow_nodes, num_dst_rows,
+                       (int)H, rec4);
+    HET_LAUNCH_CHECK("HET_rgat_drow_rec");
+  }
+  const float* er_arg = use_rec ? rec4 : er_c;
   if (coop) {
     if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;
     if (by_srow->num_long_items > 0)
@@ -1457,17 +1499,17 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (coop) {
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
+#define HET_SRC_COOP(GA_, REC_, gp_, gr_, go_)                                                                                    \
+  HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),                                                                                 \
+                    hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL, GA_, REC_>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01, \
+                                       feat_c, el_c, er_arg, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope,   \
+                                       fold_attn_l, row_rel_ptrs, (int)num_rels, gp_, gr_, go_))
       if (ga_rows) {
-        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                          hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL, true>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
-                                             feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope,
-                                             fold_attn_l, row_rel_ptrs, (int)num_rels, ga_part, ga_rel, grad_attn_l));
+        if (use_rec) { HET_SRC_COOP(true, true, ga_part, ga_rel, grad_attn_l); } else { HET_SRC_COOP(true, false, ga_part, ga_rel, grad_attn_l); }
       } else {
-        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                          hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01,
-                                             feat_c, el_c, er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H,
-                                             (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels, nullptr, nullptr, nullptr));
+        if (use_rec) { HET_SRC_COOP(false, true, nullptr, nullptr, nullptr); } else { HET_SRC_COOP(false, false, nullptr, nullptr, nullptr); }
       }
+#undef HET_SRC_COOP
     }
     HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
     if (by_srow->num_long_items > 0) {
@@ -1475,19 +1517,19 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
       const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
       int* ga_rel_long = ga_rel ? ga_rel + nb : nullptr;  // (the long launch's workgroups follow the short launch's in the partial rows)
       HET_KTIME("HET_rgat_backward_src_long", s2);
+#define HET_SRC_LONG(GA_, REC_, gp_, gr_, go_)                                                                                    \
+  HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),                                                                                 \
+                    hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, GA_, REC_>), dim3(nbl), dim3(kBlock), 0, s2, it,     \
+                                       by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c, er_arg, pack,   \
+                                       gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l, row_rel_ptrs,   \
+                                       (int)num_rels, gp_, gr_, go_))
       if (ga_rows) {
-        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                          hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, true>), dim3(nbl), dim3(kBlock), 0, s2, it,
-                                             by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
-                                             er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
-                                             row_rel_ptrs, (int)num_rels, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l));
+        if (use_rec) { HET_SRC_LONG(true, true, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l); }
+        else { HET_SRC_LONG(true, false, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l); }
       } else {
-        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                          hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL>), dim3(nbl), dim3(kBlock), 0, s2, it,
-                                             by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c,
-                                             er_c, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l,
-                                             row_rel_ptrs, (int)num_rels, nullptr, nullptr, nullptr));
+        if (use_rec) { HET_SRC_LONG(false, true, nullptr, nullptr, nullptr); } else { HET_SRC_LONG(false, false, nullptr, nullptr, nullptr); }
       }
+#undef HET_SRC_LONG
     }
   } else {
     static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
@@ -1558,10 +1600,12 @@ extern "C" int het_rgat_backward_compact(const het_grouping* by_srow, const het_
 // destination node of every er row.  Workspace: het_rgat_backward_compact_workspace with num_edges = 0.
 // bytes of het_rgat_backward_compact_runs' workspace (builds the packs of by_srow on `stream` the first time when the attention
 // gradient is asked for: its partial rows are counted in workgroups); -1 on error
-extern "C" int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t H, int64_t D,
-                                                            int with_bias, int with_attn_grad, het_stream stream) {
-  if (!by_srow) return -1;
+extern "C" int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t num_dst_rows,
+                                                            int64_t H, int64_t D, int with_bias, int with_attn_grad,
+                                                            het_stream stream) {
+  if (!by_srow || num_dst_rows < 0) return -1;
   int64_t bytes = het_rgat_backward_compact_workspace(num_nodes, 0, H, D, with_bias);
+  if (coop_shape_ok(H, D)) bytes += (int64_t)sizeof(float) * num_dst_rows * H * 4;  // the per-(er row, head) records
   if (with_attn_grad && by_srow->E > 0) {
     if (grouping_packs(by_srow, (hipStream_t)stream) != HET_OK) return -1;
     bytes += (int64_t)sizeof(float) * ((attn_grad_partial_rows(by_srow, H * D) * (H * D + 1) + 3) / 4 * 4);

@@ -840,7 +840,7 @@ def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad
     D = ret.numel() // max(1, N * H)
     if runs:
         with torch.cuda.device(ret.device):
-            nbytes = int(_lib.lib().het_rgat_backward_compact_runs_workspace(groupings[1].handle, N, H, D, int(grad_bias is not None),
+            nbytes = int(_lib.lib().het_rgat_backward_compact_runs_workspace(groupings[1].handle, N, er_c.shape[0], H, D, int(grad_bias is not None),
                                                                              int(grad_attn_l is not None), _stream(ret)))
         if nbytes < 0:
             raise _lib.HetError("het_rgat_backward_compact_runs_workspace: " + _lib.lib().het_last_error().decode())

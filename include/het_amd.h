@@ -530,10 +530,12 @@ int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_r
 /* grad_attn_l [R,H,D] (optional; needs fold_attn_l, <= 8 relations): the weight gradient of el_c = <feat_c, attn_l[r]>,
  *   SUM_u grad_el_c[u,h] feat_c[u,h,:] per relation, overwritten -- formed from the rows the source-row kernels hold where a
  *   segment ends (per-workgroup partial rows + a finishing pass) instead of a row-dot pass that reads feat_c again.
- * workspace: het_rgat_backward_compact_runs_workspace(by_srow, N, H, D, grad_bias != NULL, grad_attn_l != NULL, stream) bytes (the
- *   first call with the attention gradient builds by_srow's packs on `stream`); -1 on error. */
-int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t H, int64_t D,
-                                                 int with_bias, int with_attn_grad, het_stream stream);
+ * workspace: het_rgat_backward_compact_runs_workspace(by_srow, N, num_dst_rows, H, D, grad_bias != NULL, grad_attn_l != NULL, stream)
+ *   bytes (the first call with the attention gradient builds by_srow's packs on `stream`); -1 on error.  It holds, beside the
+ *   per-destination {lse, <gradout, ret>} pairs, one 16-byte record {er, lse, <gradout, ret>, 0} per (er row, head): the source-row
+ *   kernels fetch everything they need from the destination side of an edge with one load (round 4; HET_RGAT_DROW_REC=0: two). */
+int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* by_srow, int64_t num_nodes, int64_t num_dst_rows, int64_t H,
+                                                 int64_t D, int with_bias, int with_attn_grad, het_stream stream);
 
 /* The two halves of a2 (backward_rgnn_relational_matmul, one input head, matrix-core shapes) as separate calls, so that a
  * caller can order them around a collective (het_amd/dist.py).  Rows i in [0, num_rows) of relation-bucketed lists:
