@@ -46,7 +46,15 @@ def _p(t: Optional[Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: Tensor):
+    """The current stream of the tensor's device as the raw hipStream_t (an int: the C entry points take it as void*).  The raw
+    getter skips building a torch.cuda.Stream object per call -- host time per launch is what a rank's step at 8 ranks and a
+    sampled block's step are made of (exp/host_profile_rank.py)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -81,6 +89,9 @@ event_timers: Dict[str, list] = {}
 
 
 def _call(dev_tensor: Tensor, cname: str, *args):
+    if not event_timers and dev_tensor.device.index == torch.cuda.current_device():
+        _lib.call(cname, *args)  # the common case: the tensor's device is current and nobody times the entry points
+        return
     with torch.cuda.device(dev_tensor.device):
         rec = event_timers.get(cname)
         if rec is None:
