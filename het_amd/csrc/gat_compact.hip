@@ -701,10 +701,11 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
   float ssum = 0.f, sq = 0.f, m = -INFINITY;
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
   int2 idn = p01[jn];
+  // an item of this grouping lies inside ONE run (one relation, one destination = one er row): its er term is loaded once
+  const float zrv = er[(int64_t)p01[b].y * H + h];
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
-    const int srowv = idn.x, drowv = idn.y;
+    const int srowv = idn.x;
     const float zlv = el[(int64_t)srowv * H + h];
-    const float zrv = er[(int64_t)drowv * H + h];
     float4 f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
