@@ -528,6 +528,9 @@ int launch_seg_gemm_mfma(const MfmaGemmArgs& a, hipStream_t s) {
     }
     return HET_OK;
   }
+  // (Measured and dropped in round 4: K = 128 as two 64-deep passes, the second adding into the rows the first stored -- the
+  //  64-deep kernel runs two workgroups per CU against one for the 128-deep one, but reading and writing C once more costs more
+  //  than the occupancy gives: RGAT at feat 128 10.7 -> 11.5 ms per step.)
   // K <= 64 into X = 128 (HGT's k' | m rows): two launches of the X = 64 kernel beat the one with four column tiles per
   // wave (0.60 -> 0.55 ms for 2.4 M rows), although the A rows are read twice.  HET_GEMM_XSLAB64=0: A/B switch
   static const bool xslab64 = [] { const char* v = getenv("HET_GEMM_XSLAB64"); return !(v && v[0] == '0'); }();
