@@ -14,7 +14,9 @@ for f in ("row", "col", "rel", "eids", "node_type_offsets"):
     setattr(coo, f, getattr(coo, f).to(dev))
 g = HetGraph.from_integrated_coo(coo, full=True)
 torch.manual_seed(0)
-layer = HET_RGATLayer(64, 64, g.get_num_rels(), 4, self_loop=True, dropout=0.0, reference_op_sequence=True).to(dev)
+VARIANT = os.environ.get("VARIANT", "reference_op_sequence")  # or op_by_op: the reference's model code on het_amd.backend
+layer = HET_RGATLayer(64, 64, g.get_num_rels(), 4, self_loop=True, dropout=0.0, reference_op_sequence=VARIANT == "reference_op_sequence").to(dev)
+layer.op_by_op = VARIANT == "op_by_op"
 x = torch.nn.Parameter(torch.randn(coo.num_nodes, 64, device=dev) * 0.1)
 go = torch.randn(coo.num_nodes, 64, device=dev)
 
@@ -34,7 +36,7 @@ n = int(os.environ.get("STEPS", "5"))
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print(f"reference op sequence: {(time.perf_counter() - t0) / n * 1e3:.2f} ms / step", flush=True)
+print(f"{VARIANT}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms / step", flush=True)
 HK.event_timers["*"] = []
 for _ in range(3):
     step()
