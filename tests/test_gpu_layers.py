@@ -307,9 +307,47 @@ def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri
     g.cpu_()
     assert calls == ["fwd", "bwd"]
     assert_close(out, ref, what="out")
-    assert_close(hd.grad, grads_ref[0], what="grad_h")
+    try:
+        assert_close(hd.grad, grads_ref[0], what="grad_h")
+    except AssertionError as ex:  # which node types / parameters are off: says where in the backward chain the rows went wrong
+        offs = g.get_original_node_type_offsets().tolist()
+        bad = ~torch.isclose(hd.grad.detach().cpu().double(), grads_ref[0], rtol=1e-3, atol=1e-4 * float(grads_ref[0].abs().max())).all(1)
+        zero = (hd.grad.detach().cpu() == 0).all(1)
+        per_type = [(int(bad[a:b].sum()), int((bad & zero)[a:b].sum()), b - a) for a, b in zip(offs[:-1], offs[1:])]
+        params = []
+        for n, gr in zip(names, grads_ref[1:]):
+            try:
+                assert_close(getattr(layer, n).grad, gr, what="grad_" + n)
+            except AssertionError:
+                params.append(n)
+        raise AssertionError(f"{ex}\n(bad rows, of them all-zero, nodes) per node type: {per_type}; parameter gradients off: {params}") from None
     for n, gr in zip(names, grads_ref[1:]):
         assert_close(getattr(layer, n).grad, gr, what="grad_" + n)
+
+
+@pytest.mark.parametrize("rels_per_type", [1, 3, 4])
+def test_hgt_layer_fused_node_major_input_gradient_shapes(rels_per_type, monkeypatch):
+    """The node-major input gradient of the HGT layer (csrc/node_sum.hip) on typed graphs with 1, 3 and 4 relations leaving the
+    same node type: 3 relations = 7 sources in one launch (4 waves per workgroup), 4 = 9 sources, more than the weights the
+    pass keeps in LDS -- the layer falls back to the per-relation launches; a node type that is only a destination and one that is
+    only a source are in the graph too.  Output and all gradients against the fp64 oracle either way."""
+    import het_amd.kernels as k
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_hetero_graph
+    # types: 0 source-only, 1 both, 2 destination-only; every relation leaves type 0 or 1
+    rels = [(0, 2, 900)] + [(1, 1 + (i % 2), 700 + 50 * i) for i in range(rels_per_type)]
+    g = HetGraph.from_integrated_coo(make_hetero_graph([150, 200, 120], rels, seed=5))
+    calls = []
+    real = k.node_rows_matmul_sum
+    monkeypatch.setattr(k, "node_rows_matmul_sum", lambda *a, **kw: (calls.append(len(a[2])), real(*a, **kw))[1])
+    _run_hgt_fused(False, True, 4, 64, 64, monkeypatch, g=g)
+    from het_amd.backend import hgt_fused_layer
+    if not hgt_fused_layer.NODE_DX:  # (HET_HGT_NODE_DX=0: the per-relation launches everywhere; parity was checked above)
+        assert not calls
+    elif rels_per_type <= 3:
+        assert calls and max(calls) == 1 + 2 * rels_per_type, calls  # the destination term + two halves per relation (type 1)
+    else:
+        assert not calls  # 9 sources: outside the pass
 
 
 @pytest.mark.parametrize("fused_attn", [False, True])
