@@ -187,6 +187,17 @@ def test_rgcn_layer_on_the_aifb_shaped_graph(R, compact):
     _run_rgcn(g, compact, compact, 16, 16, R)
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_rgcn_layer_many_seeds(compact):
+    """Eight random graphs per flag set: sizes, relation counts (one relation empty, one tiny), hub patterns, shuffled eids
+    (the edge norm is indexed by eid), widths 16 / 32 / 64 / 128 in and out."""
+    for seed in range(8):
+        R = 3 + seed % 5
+        g = random_graph(seed=300 + seed, n=90 + 53 * seed, r=R, e=1200 + 900 * seed, shuffle=seed % 2 == 1)
+        K, D = ((16, 16), (64, 64), (32, 64), (128, 32))[seed % 4]
+        _run_rgcn(g, compact, compact and seed % 3 != 0, K, D, R)
+
+
 def _run_rgcn(g, compact, direct, K, D, R, oracle_dev="cpu"):
     from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
     torch.manual_seed(1)
@@ -198,7 +209,8 @@ def _run_rgcn(g, compact, direct, K, D, R, oracle_dev="cpu"):
     w64 = layer.weight.detach().double().to(oracle_dev).requires_grad_(True)
     b64 = layer.h_bias.detach().double().to(oracle_dev).requires_grad_(True)
     x64 = x.double().to(oracle_dev).requires_grad_(True)
-    ref = OL.rgcn_layer(x64, w64, norm.double().to(oracle_dev), s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
+    # (the layer reads the norm of an edge by its eid; the oracle takes it in separate-COO position order)
+    ref = OL.rgcn_layer(x64, w64, norm.double()[s["eids"]].to(oracle_dev), s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
                         s["col_indices"].to(oracle_dev), N, b64)
     gx_r, gw_r = (t.cpu() for t in torch.autograd.grad(ref, [x64, w64], go.double().to(oracle_dev)))
     ref = ref.detach().cpu()
@@ -348,6 +360,27 @@ def test_hgt_layer_fused_node_major_input_gradient_shapes(rels_per_type, monkeyp
         assert calls and max(calls) == 1 + 2 * rels_per_type, calls  # the destination term + two halves per relation (type 1)
     else:
         assert not calls  # 9 sources: outside the pass
+
+
+def test_hgt_layer_fused_many_typed_graphs(monkeypatch):
+    """Twelve random typed graphs through the fused HGT layer: 1-4 node types of uneven sizes (one of them may neither send nor
+    receive), 1-6 relations with repeated (source type, destination type) pairs and relations inside one type, hubs, heads
+    1 / 2 / 4 / 8, q on the destinations with in-edges or on all nodes -- the node-major input gradient's tiles, sources per
+    launch and zero rows differ in every case.  Output and all gradients against the fp64 oracle."""
+    import numpy as np
+    from het_amd.graph import HetGraph
+    from het_amd.synth import make_hetero_graph
+    rng = np.random.Generator(np.random.PCG64(77))
+    for case in range(12):
+        T = int(rng.integers(1, 5))
+        counts = [int(rng.integers(3, 260)) for _ in range(T)]
+        live = list(range(T)) if (T == 1 or case % 3) else list(range(T - 1))  # every third case: the last type has no edges
+        R = int(rng.integers(1, 7))
+        rels = [(int(rng.choice(live)), int(rng.choice(live)), int(rng.integers(1, 2500))) for _ in range(R)]
+        g = HetGraph.from_integrated_coo(make_hetero_graph(counts, rels, seed=200 + case))
+        H = (1, 2, 4, 8)[case % 4]
+        in_dim, out_dim = ((64, 64), (32, 64), (64, 32), (32, 32))[(case // 4) % 4]
+        _run_hgt_fused(bool(case % 2), case % 5 != 0, H, in_dim, out_dim, monkeypatch, g=g)
 
 
 @pytest.mark.parametrize("fused_attn", [False, True])

@@ -36,6 +36,12 @@ def permute_eids(g, seed):
                 walk(v)
             elif k == "eids":
                 d[k] = pi[v]
+            elif k in ("inverse_indices_row", "inverse_indices_col") and v.numel() == E:
+                # the single-sided inverse indices are read by EDGE ID (inverse_indices_row[eid] = compact row of that edge's
+                # source: SURVEY.md section 9, layouts table): the entry of position p moves to the position's new id
+                moved = torch.empty_like(v)
+                moved[pi] = v
+                d[k] = moved
 
     walk(g.graph_data)
     g._plans.clear()
