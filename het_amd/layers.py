@@ -21,6 +21,10 @@ from .backend import rgat_fused_layer as FL
 from .backend import hgt_fused_layer as _hgt_fused
 
 
+PAD_HEADS = os.environ.get("HET_RGAT_PAD_HEADS", "1") != "0"  # zero-pad narrow / odd RGAT heads to the row kernels' widths
+PAD_WIDTHS = os.environ.get("HET_PAD_WIDTHS", "1") != "0"     # zero-pad RGCN output widths to 32 / 64 / 128
+
+
 class HET_RelGraphEmbed(nn.Module):
     """Learnable node embeddings used as input features (RGNNUtils.py:78-119)."""
 
@@ -99,6 +103,41 @@ class HET_RGATLayer(nn.Module):
             h = self.activation(h)
         return self.dropout(h)
 
+    def _padded_head(self, g, inputs):
+        """Head width D' > D the one-node layer should run with, or None.  Narrow outputs -- the reference's own RGAT
+        experiment is 128 -> 8 classes over 8 heads, one float per head (hrt/experiments/run_het_rgat.sh) -- and heads whose
+        width is not a power of two are outside the row kernels (4+ floats per head, 32+ per row for the matrix-core
+        projection).  Zero-padding every head to D' changes no value: the padded columns of W, attn_l, attn_r, the self-loop
+        weight and the bias are zero, so el / er, the softmax and the first D components of every head are the same sums and
+        the padded output components are zero (dropped below); the gradients of the padding are dropped by autograd.
+        HET_RGAT_PAD_HEADS=0: off (op-by-op composition / any-shape kernels as before)."""
+        if not (PAD_HEADS and self.gat_edge_parallel_flag and not self.op_by_op and inputs.is_cuda):
+            return None
+        H, D = self.num_heads, self.out_feat // self.num_heads
+        if H & (H - 1) or H > 32:
+            return None
+        Dp = max(4, 32 // H, 1 << max(0, D - 1).bit_length())
+        if Dp == D or H * Dp > 256:
+            return None
+        shape = th.empty((self.num_rels, H, self.in_feat, Dp), device="meta")
+        ok = FL.rgat_layer_fused_ok(g, inputs, shape, self.leaky_relu_slope, self.compact_as_of_node_flag,
+                                    self.multiply_among_weights_first_flag)
+        return Dp if ok else None
+
+    def _forward_padded(self, g, inputs, num_dst, Dp, halo=None):
+        H, D = self.num_heads, self.out_feat // self.num_heads
+        pad = (0, Dp - D)
+        W = nn.functional.pad(self.conv_weights, pad)
+        al, ar = nn.functional.pad(self.attn_l, pad), nn.functional.pad(self.attn_r, pad)
+        loop = nn.functional.pad(self.loop_weight.view(self.in_feat, H, D), pad).view(self.in_feat, H * Dp) if self.self_loop else None
+        bias = nn.functional.pad(self.h_bias.view(H, D), pad).view(H * Dp) if self.bias else None
+        h = FL.rgat_layer_fused(g, inputs, W, al, ar, loop, bias, self.leaky_relu_slope, self.compact_as_of_node_flag,
+                                self.compact_direct_indexing_flag, num_dst, self.multiply_among_weights_first_flag, halo=halo)
+        h = h.view(h.shape[0], H, Dp)[:, :, :D].reshape(h.shape[0], self.out_feat)
+        if self.activation:
+            h = self.activation(h)
+        return self.dropout(h)
+
     def forward(self, g, inputs: th.Tensor, num_dst=None):
         """``num_dst``: the destination nodes of ``g`` are its first ``num_dst`` nodes (a sampled block, or the owned
         nodes of a partition followed by halo nodes): only their rows are returned and the self-loop runs on them only."""
@@ -106,6 +145,9 @@ class HET_RGATLayer(nn.Module):
             assert not self.compact_as_of_node_flag and num_dst is None and self.gat_edge_parallel_flag
             from .backend.reference_protocol import rgat_layer_reference_sequence
             return rgat_layer_reference_sequence(self, g, inputs)
+        Dp = self._padded_head(g, inputs)
+        if Dp is not None:
+            return self._forward_padded(g, inputs, num_dst, Dp)
         if (self.gat_edge_parallel_flag and not self.op_by_op and
                 FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                        self.multiply_among_weights_first_flag)):
@@ -237,6 +279,13 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
                 self.num_rels, self.in_feat, self.out_feat)
         else:
             weight = self.weight
+        Xp = next((w for w in (32, 64, 128) if w >= self.out_feat), self.out_feat)
+        if PAD_WIDTHS and x.is_cuda and Xp != self.out_feat:
+            # Output widths below / between the matrix-core kernels' (the reference's RGCN experiments are 128 | 32 -> 16 | 8
+            # classes, hrt/experiments/run_het_rgcn.sh): zero columns appended to the weights change no value -- the extra
+            # output columns are zero and dropped, their gradients too -- and the whole layer runs on the 32 / 64 / 128-wide
+            # kernels (ogbn-mag, 128 -> 8: 5.15 -> 3.9 ms per step).  HET_PAD_WIDTHS=0: the any-shape kernels as before.
+            weight = nn.functional.pad(weight, (0, Xp - self.out_feat))
         if self.compact_as_of_node_flag:  # RGCN.py:310-336
             ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"],
@@ -246,7 +295,7 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
                 g, feat_compact.view(feat_compact.shape[0], -1), norm, self.compact_direct_indexing_flag)
         else:
             # (the bias joins the op's output buffer when all rows are kept: backend RgcnLayer1SeparateCooBias)
-            bias_in_op = self.bias and (num_dst is None or num_dst >= g.get_num_nodes())
+            bias_in_op = self.bias and (num_dst is None or num_dst >= g.get_num_nodes()) and weight.shape[2] == self.out_feat
             node_repr = B.rgcn_layer1_separate_coo(g, x, weight, norm, self.h_bias if bias_in_op else None)
             if bias_in_op:
                 if self.activation:
@@ -254,6 +303,8 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
                 return self.dropout(node_repr)
         if num_dst is not None and num_dst < node_repr.shape[0]:
             node_repr = node_repr[:num_dst]
+        if node_repr.shape[1] != self.out_feat:  # (padded widths: see above)
+            node_repr = node_repr[:, :self.out_feat]
         if self.bias:
             node_repr = node_repr + self.h_bias
         if self.activation:

@@ -147,21 +147,29 @@ def test_rgat_layer_one_and_two_heads(H, compact, mulfirst):
               mulfirst=mulfirst)
 
 
-@pytest.mark.parametrize("H,K,X", [(1, 64, 8), (2, 64, 16), (1, 16, 16), (4, 64, 16), (1, 64, 4), (8, 64, 64), (4, 32, 32)])
-@pytest.mark.parametrize("compact,mulfirst", [(False, False), (True, True)])
-def test_rgat_layer_small_and_odd_widths(H, K, X, compact, mulfirst, monkeypatch):
+@pytest.mark.parametrize("H,K,X", [(1, 64, 8), (2, 64, 16), (1, 16, 16), (4, 64, 16), (1, 64, 4), (8, 64, 64), (4, 32, 32),
+                                   (8, 128, 8),   # the reference's experiments/run_het_rgat.sh: 128 -> 8 classes, 8 heads of ONE float
+                                   (4, 64, 8), (2, 64, 10), (2, 32, 6), (1, 64, 5)])  # heads of 2 / 5 / 3 / 5 floats
+@pytest.mark.parametrize("compact,mulfirst,pad", [(False, False, True), (True, True, True), (False, False, False)])
+def test_rgat_layer_small_and_odd_widths(H, K, X, compact, mulfirst, pad, monkeypatch):
     """Output widths outside the matrix-core shapes -- 64 -> 8 is the layer of the reference CLI's defaults (--n_infeat 64
-    --num_classes 8 --num_heads 1) -- and heads of 4 / 8 floats: the one-node layer runs them on the distinct-row dataflow
-    (any-shape projection + row-dot, the non-cooperative gather kernels incl. the wave-per-item kernel for long rows); a spy
-    checks that the row kernels ran, not the op-by-op composition.  n = 40: rows with hundreds of edges."""
+    --num_classes 8 --num_heads 1), 128 -> 8 over 8 heads the reference's RGAT experiment -- and heads of 1 - 8 floats or of a
+    width that is not a power of two.  pad: the layer zero-pads every head to the row kernels' widths (het_amd/layers.py
+    _padded_head) and runs the one-node layer on the distinct-row dataflow; a spy checks that the row kernels ran, not the
+    op-by-op composition.  Without the padding (HET_RGAT_PAD_HEADS=0): any-shape projection + row-dot and the non-cooperative
+    gather kernels where the shapes allow, the op-by-op composition elsewhere.  n = 40: rows with hundreds of edges."""
     import het_amd.kernels as k
+    import het_amd.layers as L
+    monkeypatch.setattr(L, "PAD_HEADS", pad)
+    D = X // H
+    fused_without_padding = D >= 4 and D & (D - 1) == 0
     calls = []
     real = k.rgat_aggregate_compact
     monkeypatch.setattr(k, "rgat_aggregate_compact", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
     for n in (320, 40):
         _run_rgat(random_graph(seed=45, n=n, r=4, e=5000, shuffle=False), H=H, K=K, X=X, compact=compact, direct=compact,
                   mulfirst=mulfirst)
-    assert len(calls) == 2
+    assert len(calls) == (2 if (pad or fused_without_padding) else 0)
 
 
 def test_rgat_layer_heads1_feat128():
@@ -169,8 +177,13 @@ def test_rgat_layer_heads1_feat128():
 
 
 @pytest.mark.parametrize("compact,direct", [(False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("K,D,R", [(16, 16, 4), (64, 64, 7)])
-def test_rgcn_layer(compact, direct, K, D, R):
+@pytest.mark.parametrize("K,D,R,pad", [(16, 16, 4, False), (16, 16, 4, True), (64, 64, 7, True),
+                                       (128, 8, 4, True), (32, 16, 4, True), (64, 40, 3, True)])  # (hrt/experiments/run_het_rgcn.sh: 128 | 32 -> 16 | 8)
+def test_rgcn_layer(compact, direct, K, D, R, pad, monkeypatch):
+    """pad: output widths outside 32 / 64 / 128 run zero-padded on the matrix-core kernels (het_amd/layers.py PAD_WIDTHS);
+    without it the any-shape kernels."""
+    import het_amd.layers as L
+    monkeypatch.setattr(L, "PAD_WIDTHS", pad)
     _run_rgcn(random_graph(seed=44, n=350, r=R, e=5000, shuffle=False), compact, direct, K, D, R)
 
 
