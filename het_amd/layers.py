@@ -25,6 +25,16 @@ PAD_HEADS = os.environ.get("HET_RGAT_PAD_HEADS", "1") != "0"  # zero-pad narrow 
 PAD_WIDTHS = os.environ.get("HET_PAD_WIDTHS", "1") != "0"     # zero-pad RGCN output widths to 32 / 64 / 128
 
 
+def _padded_in_width(K: int) -> int:
+    """Input width the matrix-core projections run with: 32 / 64 / 128.  Other widths up to 128 (16, 100 ...) run zero-padded --
+    zero columns appended to the input rows and zero rows to every weight that multiplies them add nothing to any product; the
+    padded columns of the input gradient are dropped by autograd.  One padded copy of the input per step (N x K' floats) against
+    the any-shape GEMMs: ogbn-mag, 100 -> 64: RGAT 27 -> 7 ms, RGCN 35 -> 5 ms."""
+    if not PAD_WIDTHS:
+        return K
+    return next((w for w in (32, 64, 128) if w >= K), K)
+
+
 class HET_RelGraphEmbed(nn.Module):
     """Learnable node embeddings used as input features (RGNNUtils.py:78-119)."""
 
@@ -104,7 +114,7 @@ class HET_RGATLayer(nn.Module):
         return self.dropout(h)
 
     def _padded_head(self, g, inputs):
-        """Head width D' > D the one-node layer should run with, or None.  Narrow outputs -- the reference's own RGAT
+        """(input width K', head width D') the one-node layer should run with, or None.  Narrow outputs -- the reference's own RGAT
         experiment is 128 -> 8 classes over 8 heads, one float per head (hrt/experiments/run_het_rgat.sh) -- and heads whose
         width is not a power of two are outside the row kernels (4+ floats per head, 32+ per row for the matrix-core
         projection).  Zero-padding every head to D' changes no value: the padded columns of W, attn_l, attn_r, the self-loop
@@ -113,25 +123,28 @@ class HET_RGATLayer(nn.Module):
         HET_RGAT_PAD_HEADS=0: off (op-by-op composition / any-shape kernels as before)."""
         if not (PAD_HEADS and self.gat_edge_parallel_flag and not self.op_by_op and inputs.is_cuda):
             return None
-        H, D = self.num_heads, self.out_feat // self.num_heads
+        H, D, K = self.num_heads, self.out_feat // self.num_heads, self.in_feat
         if H & (H - 1) or H > 32:
             return None
         Dp = max(4, 32 // H, 1 << max(0, D - 1).bit_length())
-        if Dp == D or H * Dp > 256:
+        Kp = _padded_in_width(K)  # (input widths outside 32 / 64 / 128: zero columns of x, zero rows of the weights)
+        if (Dp == D and Kp == K) or H * Dp > 256:
             return None
-        shape = th.empty((self.num_rels, H, self.in_feat, Dp), device="meta")
+        shape = th.empty((self.num_rels, H, Kp, Dp), device="meta")
         ok = FL.rgat_layer_fused_ok(g, inputs, shape, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                     self.multiply_among_weights_first_flag)
-        return Dp if ok else None
+        return (Kp, Dp) if ok else None
 
-    def _forward_padded(self, g, inputs, num_dst, Dp, halo=None):
-        H, D = self.num_heads, self.out_feat // self.num_heads
+    def _forward_padded(self, g, inputs, num_dst, KDp, halo=None):
+        H, D, K = self.num_heads, self.out_feat // self.num_heads, self.in_feat
+        Kp, Dp = KDp
         pad = (0, Dp - D)
-        W = nn.functional.pad(self.conv_weights, pad)
+        x = nn.functional.pad(inputs, (0, Kp - K)) if Kp != K else inputs
+        W = nn.functional.pad(self.conv_weights, pad + (0, Kp - K))
         al, ar = nn.functional.pad(self.attn_l, pad), nn.functional.pad(self.attn_r, pad)
-        loop = nn.functional.pad(self.loop_weight.view(self.in_feat, H, D), pad).view(self.in_feat, H * Dp) if self.self_loop else None
+        loop = nn.functional.pad(self.loop_weight.view(K, H, D), pad + (0, 0, 0, Kp - K)).view(Kp, H * Dp) if self.self_loop else None
         bias = nn.functional.pad(self.h_bias.view(H, D), pad).view(H * Dp) if self.bias else None
-        h = FL.rgat_layer_fused(g, inputs, W, al, ar, loop, bias, self.leaky_relu_slope, self.compact_as_of_node_flag,
+        h = FL.rgat_layer_fused(g, x, W, al, ar, loop, bias, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                 self.compact_direct_indexing_flag, num_dst, self.multiply_among_weights_first_flag, halo=halo)
         h = h.view(h.shape[0], H, Dp)[:, :, :D].reshape(h.shape[0], self.out_feat)
         if self.activation:
@@ -145,9 +158,9 @@ class HET_RGATLayer(nn.Module):
             assert not self.compact_as_of_node_flag and num_dst is None and self.gat_edge_parallel_flag
             from .backend.reference_protocol import rgat_layer_reference_sequence
             return rgat_layer_reference_sequence(self, g, inputs)
-        Dp = self._padded_head(g, inputs)
-        if Dp is not None:
-            return self._forward_padded(g, inputs, num_dst, Dp)
+        KDp = self._padded_head(g, inputs)
+        if KDp is not None:
+            return self._forward_padded(g, inputs, num_dst, KDp)
         if (self.gat_edge_parallel_flag and not self.op_by_op and
                 FL.rgat_layer_fused_ok(g, inputs, self.conv_weights, self.leaky_relu_slope, self.compact_as_of_node_flag,
                                        self.multiply_among_weights_first_flag)):
@@ -286,6 +299,9 @@ class HET_EglRelGraphConv_EdgeParallel(nn.Module):
             # output columns are zero and dropped, their gradients too -- and the whole layer runs on the 32 / 64 / 128-wide
             # kernels (ogbn-mag, 128 -> 8: 5.15 -> 3.9 ms per step).  HET_PAD_WIDTHS=0: the any-shape kernels as before.
             weight = nn.functional.pad(weight, (0, Xp - self.out_feat))
+        Kp = _padded_in_width(self.in_feat) if x.is_cuda else self.in_feat
+        if Kp != self.in_feat:  # (input widths outside 32 / 64 / 128: _padded_in_width)
+            x, weight = nn.functional.pad(x, (0, Kp - self.in_feat)), nn.functional.pad(weight, (0, 0, 0, Kp - self.in_feat))
         if self.compact_as_of_node_flag:  # RGCN.py:310-336
             ss = g.get_separate_unique_node_indices_single_sided()
             d_row = {"unique_srcs_and_dests_rel_ptrs": ss["rel_ptrs_row"],
@@ -370,8 +386,14 @@ class HET_HGTLayerHetero(nn.Module):
         if _hgt_fused.hgt_fused_ok(G, h, self.num_heads, self.d_k):
             # attention + aggregation as one node on the distinct (relation, source) rows (backend/hgt_fused_layer.py): the
             # same function of the parameters for every flag combination below, without the per-edge tensors
-            out = _hgt_fused.hgt_layer_fused(G, h, offs, per_run(self.q_linears), per_run(th.sigmoid(self.skip) * self.a_linears),
-                                             self.k_linears, self.v_linears, self.relation_att, self.relation_msg,
+            k_w, q_w, v_w = self.k_linears, self.q_linears, self.v_linears
+            Kp = _padded_in_width(self.in_dim)
+            if Kp != self.in_dim:  # (the layer input meets the three typed projections only: zero columns / zero weight rows)
+                rows = (0, 0, 0, Kp - self.in_dim)
+                h = nn.functional.pad(h, (0, Kp - self.in_dim))
+                k_w, q_w, v_w = nn.functional.pad(k_w, rows), nn.functional.pad(q_w, rows), nn.functional.pad(v_w, rows)
+            out = _hgt_fused.hgt_layer_fused(G, h, offs, per_run(q_w), per_run(th.sigmoid(self.skip) * self.a_linears),
+                                             k_w, v_w, self.relation_att, self.relation_msg,
                                              self.relation_pri, self.num_heads, self.hgt_fused_attn_score_flag)
             return out if num_dst is None else out[:num_dst]
         if self.multiply_among_weights_first_flag:

@@ -149,7 +149,8 @@ def test_rgat_layer_one_and_two_heads(H, compact, mulfirst):
 
 @pytest.mark.parametrize("H,K,X", [(1, 64, 8), (2, 64, 16), (1, 16, 16), (4, 64, 16), (1, 64, 4), (8, 64, 64), (4, 32, 32),
                                    (8, 128, 8),   # the reference's experiments/run_het_rgat.sh: 128 -> 8 classes, 8 heads of ONE float
-                                   (4, 64, 8), (2, 64, 10), (2, 32, 6), (1, 64, 5)])  # heads of 2 / 5 / 3 / 5 floats
+                                   (4, 64, 8), (2, 64, 10), (2, 32, 6), (1, 64, 5),  # heads of 2 / 5 / 3 / 5 floats
+                                   (4, 100, 64), (8, 16, 64), (2, 48, 24)])  # input widths outside 32 / 64 / 128: zero-padded columns
 @pytest.mark.parametrize("compact,mulfirst,pad", [(False, False, True), (True, True, True), (False, False, False)])
 def test_rgat_layer_small_and_odd_widths(H, K, X, compact, mulfirst, pad, monkeypatch):
     """Output widths outside the matrix-core shapes -- 64 -> 8 is the layer of the reference CLI's defaults (--n_infeat 64
@@ -162,7 +163,8 @@ def test_rgat_layer_small_and_odd_widths(H, K, X, compact, mulfirst, pad, monkey
     import het_amd.layers as L
     monkeypatch.setattr(L, "PAD_HEADS", pad)
     D = X // H
-    fused_without_padding = D >= 4 and D & (D - 1) == 0
+    # (without padding the one-node layer takes power-of-two heads of 4+ floats and, for er from the folded weight, a power-of-two K >= 4 H)
+    fused_without_padding = D >= 4 and D & (D - 1) == 0 and K & (K - 1) == 0 and K >= 4 * H
     calls = []
     real = k.rgat_aggregate_compact
     monkeypatch.setattr(k, "rgat_aggregate_compact", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
@@ -178,7 +180,8 @@ def test_rgat_layer_heads1_feat128():
 
 @pytest.mark.parametrize("compact,direct", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("K,D,R,pad", [(16, 16, 4, False), (16, 16, 4, True), (64, 64, 7, True),
-                                       (128, 8, 4, True), (32, 16, 4, True), (64, 40, 3, True)])  # (hrt/experiments/run_het_rgcn.sh: 128 | 32 -> 16 | 8)
+                                       (128, 8, 4, True), (32, 16, 4, True), (64, 40, 3, True),  # (hrt/experiments/run_het_rgcn.sh: 128 | 32 -> 16 | 8)
+                                       (100, 64, 4, True), (100, 64, 4, False), (48, 8, 3, True)])  # input widths outside 32 / 64 / 128
 def test_rgcn_layer(compact, direct, K, D, R, pad, monkeypatch):
     """pad: output widths outside 32 / 64 / 128 run zero-padded on the matrix-core kernels (het_amd/layers.py PAD_WIDTHS);
     without it the any-shape kernels."""
@@ -279,7 +282,8 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
 @pytest.mark.parametrize("fused_attn,compact_dst", [(False, True), (True, True), (False, False)])
 @pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (1, 64, 64), (4, 64, 64), (2, 32, 64), (1, 32, 32), (4, 128, 128), (2, 64, 16),
                                               (1, 64, 8),   # 64 -> 8, one head: the layer of the reference CLI's defaults
-                                              (4, 64, 8), (2, 64, 10), (1, 64, 4)])  # heads of 2 / 5 / 4 floats: zero-padded to 8
+                                              (4, 64, 8), (2, 64, 10), (1, 64, 4),  # heads of 2 / 5 / 4 floats: zero-padded to 8
+                                              (4, 100, 64), (2, 16, 32)])  # input widths outside 32 / 64 / 128: zero-padded columns
 def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch):
     _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch)
 
