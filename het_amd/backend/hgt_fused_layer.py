@@ -32,6 +32,7 @@ from .rgnn_layers_and_funcs import rgnn_relational_matmul_no_scatter_gather_list
 FUSED = os.environ.get("HET_HGT_FUSED", "1") != "0"
 # the layer's input gradient in one node-major pass per node type (csrc/node_sum.hip) instead of one read-modify-write launch
 # per relation on the 2X-wide source rows + the destination-side projection's own pass (HET_HGT_NODE_DX=0: the round-3 form)
+REFORK = os.environ.get("HET_HGT_REFORK", "1") != "0"  # diagnostic: 0 = the round-4 hazard of exp/hgt_cold_lag.py back in
 NODE_DX = os.environ.get("HET_HGT_NODE_DX", "1") != "0"
 
 
@@ -80,13 +81,24 @@ def hgt_fused_ok(G, h, num_heads, d_k):
         return False
     if not (_has_single_sided_lists(G) or hasattr(G, "generate_separate_unique_node_indices_single_sided_for_each_etype")):
         return False
-    if not _k.hgt_compact_shape_ok(num_heads, _padded_head(d_k)):
+    if _head_groups(num_heads, _padded_head(d_k)) is None:
         return False
     try:
         G.get_rel_node_types()
     except ValueError:  # a relation mixes node types: no single K / V projection per relation to fold
         return False
     return True
+
+
+def _head_groups(num_heads: int, d_pad: int):
+    """Number of head groups the attention runs in: 1 when the row kernels take all heads' rows at once (up to 128 floats per
+    row), else the smallest split into equal groups they do take -- heads are independent up to the output projection, so 8
+    heads of 32 floats (out = 256) run as two passes over 4 heads each (ogbn-mag: 53 -> 27 ms per step; the op-by-op composition
+    before).  None: no split fits (one head wider than 128 floats)."""
+    for groups in (1, 2, 4, 8):
+        if num_heads % groups == 0 and _k.hgt_compact_shape_ok(num_heads // groups, d_pad):
+            return groups
+    return None
 
 
 def _padded_head(d_k: int) -> int:
@@ -201,6 +213,12 @@ class HgtAttentionFunction(th.autograd.Function):
             grad_h, grad_qw = th.empty_like(h), th.empty_like(q_w)  # (allocated under the main stream)
             g_kv2, g_q2 = g_kv.view(-1, 2 * X), g_q.view(-1, X)
             wt2 = wt.view(-1, 2 * X, K_in)
+            if side is not None and REFORK:
+                # grad_qw (and, on a graph seen for the first time, the plan's temporaries) were allocated AFTER the fork above: the
+                # allocator may have handed out blocks whose previous main-stream use was enqueued after that fork (the kernels
+                # that build the plan), and the side stream would write grad_qw while they still run -- seen once in ~40 cold
+                # runs as rows of grad_h missing (the node order came out corrupted).  Fork again: free when nothing is pending.
+                side.wait_stream(main)
             with th.cuda.stream(side if side is not None else main):  # the other two weight gradients beside the node pass
                 if side is None:
                     _k.rows_matmul_backward_dw(rp_row, rows_node, h, g_kv2, grad_wkv, accumulate=False)
@@ -232,8 +250,7 @@ class HgtAttentionFunction(th.autograd.Function):
             if _k.rows_matmul_backward_split_ok(1, K_in, X):
                 grad_qw = th.empty_like(q_w)
                 if side is not None:
-                    if not split_kv:
-                        side.wait_stream(main)
+                    side.wait_stream(main)  # (grad_qw was allocated after the first fork: see the node-major branch)
                     with th.cuda.stream(side):
                         _k.rows_matmul_backward_dw(run_ptrs, dst_nodes, h, g_q, grad_qw, accumulate=False)
                 _k.rows_matmul_backward_dx(run_ptrs, dst_nodes, qwt, g_q, grad_h, atomic=False)  # distinct nodes, first writer: "="
@@ -299,10 +316,23 @@ def hgt_layer_fused(G, h, offs, q_w, a_w, k_lin, v_lin, rel_att, rel_msg, rel_pr
     unpad = (lambda t: t) if d_pad == d_k else (lambda t: t.view(t.shape[0], num_heads, d_pad)[..., :d_k].reshape(t.shape[0], -1))
     col = G.get_separate_coo_original()["col_indices"]
     dst = _k.destination_lists(col, offs)
+    groups = _head_groups(num_heads, d_pad)
+
+    def attention(dst_lists):
+        if groups == 1:
+            return HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, dst_lists)
+        # rows wider than the row kernels take: the heads in `groups` passes (columns of a head group in [k' | m] and in q)
+        X, Xg, Hg = num_heads * d_pad, num_heads * d_pad // groups, num_heads // groups
+        parts = []
+        for i in range(groups):
+            w_g = th.cat([w_kv[..., i * Xg:(i + 1) * Xg], w_kv[..., X + i * Xg:X + (i + 1) * Xg]], dim=-1).contiguous()
+            parts.append(HgtAttentionFunction.apply(G, Hg, offs, h, w_g, q_w[..., i * Xg:(i + 1) * Xg].contiguous(), dst_lists))
+        return th.cat(parts, dim=1)
+
     if dst[0].numel() >= COMPACT_DST_BELOW * N:
-        new_h = unpad(HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, None))
+        new_h = unpad(attention(None))
         return B_matmul_no_scatter_gather(offs, a_w, new_h)
-    new_h_c = unpad(HgtAttentionFunction.apply(G, num_heads, offs, h, w_kv, q_w, dst))
+    new_h_c = unpad(attention(dst))
     if _k.rows_matmul_backward_split_ok(1, a_w.shape[3], a_w.shape[2]):
         return RowsLinearScatter.apply(dst[2], dst[0], N, new_h_c, a_w)
     out_c = B_matmul_no_scatter_gather(dst[2], a_w, new_h_c)  # rows of a type are a contiguous piece of the sorted list

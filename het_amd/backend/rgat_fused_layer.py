@@ -205,6 +205,9 @@ class RgatLayerFunction(th.autograd.Function):
             if OVERLAP and halo is None and fused_loop and mulfirst:
                 # er_c (a row-dot) and the self-loop GEMM are HBM-bound streams of rows: on the side stream beside the projection
                 main, side = th.cuda.current_stream(x.device), _side_stream(x.device)
+                # everything the side stream WRITES is allocated before the fork: a block handed out later may have been freed by
+                # a tensor whose last main-stream kernel was enqueued after the fork -- the side stream would not wait for it
+                h = x.new_empty((nd, X))
                 side.wait_stream(main)
             if mulfirst:
                 with th.cuda.stream(side if side is not None else th.cuda.current_stream(x.device)):
@@ -218,8 +221,7 @@ class RgatLayerFunction(th.autograd.Function):
                 # self-loop + bias first (bias in the GEMM epilogue); the aggregation adds its rows into h in place: no
                 # separate h = ret + loop + bias pass and no zero fill of ret (read by the backward only where edges point)
                 bias_c = None if bias is None else bias.contiguous()
-                if side is not None:
-                    h = x.new_empty((nd, X))  # allocated (and later freed) under the main stream; the side stream only fills it
+                if side is not None:  # (h: allocated, and later freed, under the main stream; the side stream only fills it)
                     with th.cuda.stream(side):
                         _k.rows_linear_bias(offs, x[:nd], loop_w, bias_c, out=h)
                 else:

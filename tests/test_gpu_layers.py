@@ -283,7 +283,8 @@ def test_hgt_layer(fused_attn, compact, direct, H, in_dim, out_dim):
 @pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (1, 64, 64), (4, 64, 64), (2, 32, 64), (1, 32, 32), (4, 128, 128), (2, 64, 16),
                                               (1, 64, 8),   # 64 -> 8, one head: the layer of the reference CLI's defaults
                                               (4, 64, 8), (2, 64, 10), (1, 64, 4),  # heads of 2 / 5 / 4 floats: zero-padded to 8
-                                              (4, 100, 64), (2, 16, 32)])  # input widths outside 32 / 64 / 128: zero-padded columns
+                                              (4, 100, 64), (2, 16, 32),  # input widths outside 32 / 64 / 128: zero-padded columns
+                                              (8, 64, 256), (2, 32, 256)])  # rows wider than the row kernels take: the heads in two passes
 def test_hgt_layer_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch):
     _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch)
 
@@ -334,7 +335,8 @@ def _run_hgt_fused(fused_attn, compact_dst, H, in_dim, out_dim, monkeypatch, pri
     out = layer(g, hd)
     out.backward(go.to(DEV))
     g.cpu_()
-    assert calls == ["fwd", "bwd"]
+    passes = hgt_fused_layer._head_groups(H, hgt_fused_layer._padded_head(out_dim // H))  # (rows above 128 floats: the heads in groups)
+    assert calls == ["fwd"] * passes + ["bwd"] * passes
     assert_close(out, ref, what="out")
     try:
         assert_close(hd.grad, grads_ref[0], what="grad_h")
