@@ -17,6 +17,7 @@ P, I64, INT, DBL = C.c_void_p, C.c_int64, C.c_int, C.c_double
 _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
     "het_grouping_rank_of_position": [P, P, P],
+    "het_grouping_segment_map": [P, I64, P, P],
     "het_rows_add_bias": [P, P, P, P, I64, I64, P],
     "het_rows_gather": [P, P, I64, I64, P, P],
     "het_rows_scatter_add": [P, P, I64, I64, P, P],
@@ -42,6 +43,9 @@ _SIGNATURES = {
     "het_node_row_map": [P, I64, P, I64, I64, P, P],
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
     "het_node_rows_matmul_sum": [I64, I64, I64, I64, P, P, P, P, P, P, I64, I64, P, P],
+    "het_node_rows_matmul_sum_bias": [I64, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P],
+    "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, P, P, I64, I64, P],
+    "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, P, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
     "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],
@@ -108,6 +112,10 @@ def lib() -> C.CDLL:
         L.het_hgt_compact_shape_ok.restype = INT
         L.het_node_rows_matmul_sum_ok.argtypes = [I64, I64, I64]
         L.het_node_rows_matmul_sum_ok.restype = INT
+        L.het_rgcn_layer_ok.argtypes = [I64, I64, I64]
+        L.het_rgcn_layer_ok.restype = INT
+        L.het_rgcn_layer_backward_workspace.argtypes = [I64, I64]
+        L.het_rgcn_layer_backward_workspace.restype = I64
         L.het_rgat_node_gemm_ok.argtypes = [I64, I64, I64, I64]
         L.het_rgat_node_gemm_ok.restype = INT
         L.het_set_allocator.argtypes = [P, P, P]

@@ -220,6 +220,11 @@ extern "C" int het_grouping_rank_of_position(const het_grouping* g, int64_t* out
   return HET_OK;
 }
 
+extern "C" int het_grouping_segment_map(const het_grouping* g, int64_t num_keys, int32_t* map, het_stream stream) {
+  HET_REQUIRE(g && g->R > 0 && num_keys >= g->key_bound, "het_grouping_segment_map: needs a grouping by (relation, key) and num_keys >= its key bound");
+  return het_node_row_map(g->seg_rel_ptr64, g->R, g->seg_key64, g->S, num_keys, map, stream);
+}
+
 extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* keys,
                                    int64_t num_positions, int64_t key_bound, const int64_t* payload0,
                                    const int64_t* payload1, het_stream stream, het_grouping** out) {

@@ -34,6 +34,7 @@ struct SumArgs {
   const float* wt[kMaxSrc];      // [KS][XO] row-major
   const int32_t* order;          // [>= n_end] node at position p, or NULL (node p)
   float* out;                    // [N, XO]
+  const float* bias;             // [XO] added to every output row, or NULL
 };
 
 // Workgroup = WAVES independent waves sharing the S weights in LDS; a wave walks 32-node tiles (grid-stride), loads the rows of
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_rows_sum(SumArgs a) {
   const int64_t tiles = (a.n_end - a.n_begin + 31) / 32, stride = (int64_t)gridDim.x * WAVES;
   int64_t t = (int64_t)blockIdx.x * WAVES + wave;
   if (t >= tiles) return;
+  const float4 bias4 = a.bias ? ld4(a.bias + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
   int mcur[kMaxSrc];
   int ncur = 0;
   auto load_maps = [&](int64_t tt) {
@@ -151,10 +153,181 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_rows_sum(SumArgs a) {
 #pragma unroll
     for (int it = 0; it < NITC; ++it) {
       const int64_t node = idsN[it * RPIC + rc];
-      const float4 v = ld4(&Ws[(it * RPIC + rc) * LD + cc]);
+      float4 v = ld4(&Ws[(it * RPIC + rc) * LD + cc]);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (node >= 0) st4(a.out + node * XO + cc, v);
     }
   }
+}
+
+// compute units of the current device (cached per device; a benign race writes the same value twice)
+int64_t het_num_cus() {
+  static int cache[64];
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  if (dev >= 0 && dev < 64) cache[dev] = n;
+  return n;
+}
+
+// ---- round-4 form: twice the waves per CU -------------------------------------------------------------------------------
+// The kernel above keeps a [32][max(KS,XO)+4] tile + the row ids per wave in LDS (9.3 KB): beside 64-144 KB of weights that is 8
+// waves per CU, two per SIMD, and a wave's tile is a serial chain (row gather -> LDS -> 64 MFMAs -> transposed store), so the
+// matrix cores idle through every gather: 0.29 ms for a pass whose rows stream in 0.16 ms and whose MFMAs take 0.07 (RGCN, ogbn-mag).
+// Here a wave stages HALF a row width at a time (32 columns: [32][36] floats = 4.5 KB), keeps the row ids in registers (lane
+// l: the row of tile node l & 31; the loading lane fetches its row's id with a shuffle) and stores the accumulators straight
+// from registers (PAIRED layout: lane (i, kk) holds columns 2i, 2i+1 of a tile row per accumulator register -- the 32 lanes of
+// a half write one whole 256-byte output row), so 16 waves fit beside 64-88 KB of weights: four per SIMD hide each other's gathers.
+// k mapping of a 32-column phase p: MFMA step q of lane (i, kk) multiplies A[i][32p + 16kk + q] with B[32p + 16kk + q][col].
+template <int KS, int NO>
+__global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
+  constexpr int XO = NO * 32;
+  constexpr int LDA = 36;                                   // staged row: 32 floats + 4 (conflict-free 16-byte reads down a column of rows)
+  constexpr int LPRA = KS / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;
+  constexpr int PH = KS / 32;                               // phases per source
+  constexpr bool PAIRED = NO == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+  const int S = a.S;
+  float* Bs = smem;                                         // [S][KS][XO]
+  float* As = Bs + S * KS * XO + wave * (32 * LDA);         // wave-private [32][LDA]
+  for (int s = 0; s < S; ++s) {
+    const float4* src = reinterpret_cast<const float4*>(a.wt[s]);
+    float4* dst = reinterpret_cast<float4*>(Bs + s * KS * XO);
+    for (int e = tid; e < KS * XO / 4; e += blockDim.x) dst[e] = src[e];
+  }
+  __syncthreads();
+
+  const int i = lane & 31, kk = lane >> 5;
+  const int ra = lane / LPRA, ca = lane % LPRA;             // loading lane: row ra (+ RPIA per iteration), 16-byte chunk ca
+  const int64_t tiles = (a.n_end - a.n_begin + 31) / 32, stride = (int64_t)gridDim.x * waves;
+  int64_t t = (int64_t)blockIdx.x * waves + wave;
+  if (t >= tiles) return;
+  float2 bias2 = make_float2(0.f, 0.f);
+  if (a.bias) {
+    if (PAIRED) bias2 = *reinterpret_cast<const float2*>(a.bias + 2 * i);
+    else bias2.x = a.bias[i];
+  }
+  int mnext[kMaxSrc];
+  int nnext = -1;
+  auto load_maps = [&](int64_t tt) {
+    const int64_t pos = a.n_begin + tt * 32 + i;
+    const bool nv = pos < a.n_end;
+    const int64_t nc = a.order ? a.order[nv ? pos : a.n_end - 1] : (nv ? pos : a.n_end - 1);
+    nnext = nv ? (int)nc : -1;
+#pragma unroll
+    for (int s = 0; s < kMaxSrc; ++s) {
+      mnext[s] = -1;
+      if (s < S && nv) mnext[s] = a.map[s] ? a.map[s][nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
+    }
+  };
+  load_maps(t);
+  for (; t < tiles; t += stride) {
+    int ids[kMaxSrc];
+    const int node = nnext;
+    unsigned mask = 0;
+#pragma unroll
+    for (int s = 0; s < kMaxSrc; ++s) {
+      ids[s] = mnext[s];
+      if (s < S && __ballot(ids[s] >= 0)) mask |= 1u << s;
+    }
+    if (t + stride < tiles) load_maps(t + stride);  // consumed one tile later
+
+    f32x16 acc[NO];
+#pragma unroll
+    for (int nt = 0; nt < NO; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    float4 areg[NITA];
+    auto issue = [&](int s) {
+      // (ids[] is indexed with a wave-uniform s: a switch keeps it in registers)
+      int idl = -1;
+#pragma unroll
+      for (int q = 0; q < kMaxSrc; ++q)
+        if (q == s) idl = ids[q];
+      const float* base = a.rows[s];
+      const int64_t rs = a.stride[s];
+#pragma unroll
+      for (int it = 0; it < NITA; ++it) {
+        const int id = __shfl(idl, it * RPIA + ra);
+        const float4 v = ld4(base + (int64_t)(id < 0 ? 0 : id) * rs + ca * 4);
+        areg[it] = id >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    int s = mask ? __ffs(mask) - 1 : -1;
+    if (s >= 0) issue(s);
+    while (s >= 0) {
+      const unsigned rest = mask & ~((2u << s) - 1u);
+      const int sn = rest ? __ffs(rest) - 1 : -1;
+      const float* B = Bs + s * KS * XO;
+#pragma unroll
+      for (int p = 0; p < PH; ++p) {
+        // stage the 32 columns of phase p: the loading lanes whose chunk lies in them
+        if (PH == 1 || (ca >> 3) == p) {
+#pragma unroll
+          for (int it = 0; it < NITA; ++it) st4(&As[(it * RPIA + ra) * LDA + (ca & 7) * 4], areg[it]);
+        }
+        if (p == PH - 1 && sn >= 0) issue(sn);  // the row registers are free: the next source's rows fly during the MFMAs below
+        float af[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = ld4(&As[i * LDA + kk * 16 + q * 4]);
+          af[4 * q + 0] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int k = p * 32 + kk * 16 + q;
+          if (PAIRED) {
+            const float2 b2 = *reinterpret_cast<const float2*>(&B[k * XO + 2 * i]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], b2.x, acc[0], 0, 0, 0);
+            acc[NO - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], b2.y, acc[NO - 1], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NO; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], B[k * XO + nt * 32 + i], acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      s = sn;
+    }
+    // epilogue: accumulator register `reg` of lane (i, kk) is tile row (reg & 3) + 8 * (reg >> 2) + 4 * kk
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int64_t n = __shfl(node, (reg & 3) + 8 * (reg >> 2) + 4 * kk);
+      if (n >= 0) {
+        if (PAIRED) {
+          *reinterpret_cast<float2*>(a.out + n * XO + 2 * i) = make_float2(acc[0][reg] + bias2.x, acc[NO - 1][reg] + bias2.y);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NO; ++nt) a.out[n * XO + nt * 32 + i] = acc[nt][reg] + (a.bias ? a.bias[nt * 32 + i] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int NO>
+int launch_sum_w16(const SumArgs& a, hipStream_t s, bool* done) {
+  constexpr int XO = NO * 32;
+  const size_t limit = 160 * 1024, wbytes = sizeof(float) * (size_t)a.S * KS * XO, per_wave = sizeof(float) * 32 * 36;
+  *done = false;
+  if (wbytes + 8 * per_wave > limit) return HET_OK;  // fewer than 8 waves: the tile form above does as well
+  int waves = (int)((limit - wbytes) / per_wave);
+  if (waves > 16) waves = 16;
+  const int64_t tiles = (a.n_end - a.n_begin + 31) / 32;
+  int64_t gx = (tiles + waves - 1) / waves;
+  const int64_t cus = het_num_cus();
+  if (gx > cus) gx = cus;  // one workgroup per CU (the weights are staged once), its waves walk the tiles grid-stride
+  if (gx < 1) gx = 1;
+  const size_t lds = wbytes + (size_t)waves * per_wave;
+  HET_KTIME("HET_node_rows_sum", s);
+  HET_HIP(hipFuncSetAttribute((const void*)HET_node_rows_sum_w16<KS, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((HET_node_rows_sum_w16<KS, NO>), dim3((unsigned)gx), dim3(waves * 64), lds, s, a);
+  HET_LAUNCH_CHECK("HET_node_rows_sum_w16");
+  *done = true;
+  return HET_OK;
 }
 
 template <int KS, int NO>
@@ -165,6 +338,12 @@ size_t lds_for(int S, int waves) {
 
 template <int KS, int NO>
 int launch_sum(const SumArgs& a, hipStream_t s) {
+  static const bool tile_form = getenv("HET_NODE_SUM_LDS_TILE") && atoi(getenv("HET_NODE_SUM_LDS_TILE")) != 0;  // A/B: the round-4a kernel
+  if (!tile_form) {
+    bool done = false;
+    if (int rc = launch_sum_w16<KS, NO>(a, s, &done)) return rc;
+    if (done) return HET_OK;
+  }
   const int64_t tiles = (a.n_end - a.n_begin + 31) / 32;
   const size_t limit = 160 * 1024;
   HET_KTIME("HET_node_rows_sum", s);
@@ -198,18 +377,19 @@ extern "C" int het_node_rows_matmul_sum_ok(int64_t num_sources, int64_t KS, int6
   return lds_any((int)num_sources, KS, XO, 4) <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
-                                        const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
-                                        const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS,
-                                        int64_t XO, const int32_t* node_order, het_stream stream) {
+extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
+                                             const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
+                                             const int64_t* ident_rows, const float* const* weights_t, const float* bias,
+                                             float* out, int64_t KS, int64_t XO, const int32_t* node_order, het_stream stream) {
   const char* op = "het_node_rows_matmul_sum";
   HET_REQUIRE(0 <= n_begin && n_begin <= n_end && n_end <= num_nodes && num_nodes < (1ll << 31), "%s: bad node range", op);
   HET_REQUIRE(het_node_rows_matmul_sum_ok(num_sources, KS, XO), "%s: unsupported shape: %lld sources of %lld -> %lld floats", op,
               (long long)num_sources, (long long)KS, (long long)XO);
   if (n_begin == n_end) return HET_OK;
   HET_REQUIRE(rows && row_strides && maps && ident_rows && weights_t && out, "%s: null argument", op);
+  HET_REQUIRE(((uintptr_t)bias & 15) == 0 && ((uintptr_t)out & 15) == 0, "%s: bias / out not 16-byte aligned", op);
   SumArgs a{};
-  a.n_begin = n_begin; a.n_end = n_end; a.N = num_nodes; a.S = (int)num_sources; a.order = node_order; a.out = out;
+  a.n_begin = n_begin; a.n_end = n_end; a.N = num_nodes; a.S = (int)num_sources; a.order = node_order; a.out = out; a.bias = bias;
   for (int s = 0; s < a.S; ++s) {
     HET_REQUIRE(rows[s] && weights_t[s] && row_strides[s] >= KS && (row_strides[s] & 3) == 0 && ((uintptr_t)rows[s] & 15) == 0,
                 "%s: source %d: null pointer, row stride below the row width, or rows not 16-byte aligned", op, s);
@@ -219,4 +399,12 @@ extern "C" int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t 
   hipStream_t st = (hipStream_t)stream;
   if (KS == 64) return XO == 64 ? launch_sum<64, 2>(a, st) : launch_sum<64, 1>(a, st);
   return XO == 64 ? launch_sum<32, 2>(a, st) : launch_sum<32, 1>(a, st);
+}
+
+extern "C" int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
+                                        const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
+                                        const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS,
+                                        int64_t XO, const int32_t* node_order, het_stream stream) {
+  return het_node_rows_matmul_sum_bias(n_begin, n_end, num_nodes, num_sources, rows, row_strides, maps, ident_rows, weights_t, nullptr,
+                                       out, KS, XO, node_order, stream);
 }

@@ -649,6 +649,147 @@ extern "C" int het_backward_rgcn_layer1_separate_coo(const int64_t* rel_ptrs, co
   return launch_seg_dw(w, s);
 }
 
+// ---- the RGCN layer as two calls (layer-level fusion of a7 / a8 with the layer's bias; include/het_amd.h) -------------------
+namespace {
+// column sums of a [rows, 4 * LPR] matrix: per-workgroup partial rows (grid-stride, 16 bytes per lane), finished by HET_colsum_finish
+template <int LPR>
+__global__ __launch_bounds__(256) void HET_colsum_partial(const float* __restrict__ in, int64_t rows, float* __restrict__ part) {
+  constexpr int RPI = 256 / LPR;
+  __shared__ float4 red[256];
+  const int c = threadIdx.x % LPR, r = threadIdx.x / LPR;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * RPI + r; i < rows; i += (int64_t)gridDim.x * RPI) {
+    const float4 v = *reinterpret_cast<const float4*>(in + i * (4 * LPR) + 4 * c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < RPI; ++k) {
+      const float4 v = red[k * LPR + c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * (4 * LPR) + 4 * c) = acc;
+  }
+}
+__global__ __launch_bounds__(256) void HET_colsum_finish(const float* __restrict__ part, int P, int X, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int x = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int p = t; p < P; p += 256) a += part[(int64_t)p * X + x];
+  red[t] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[x] = red[0];
+}
+constexpr int kColsumBlocks = 1024;
+
+int launch_colsum(const float* in, int64_t rows, int X, float* part, float* out, hipStream_t s) {
+  HET_KTIME("HET_colsum", s);
+  const int lpr = X / 4;
+  const int64_t rpi = 256 / lpr;
+  int blocks = (int)(ceil_div64(rows, rpi) < kColsumBlocks ? ceil_div64(rows, rpi) : kColsumBlocks);
+  if (blocks < 1) blocks = 1;
+  switch (lpr) {
+    case 8: hipLaunchKernelGGL(HET_colsum_partial<8>, dim3(blocks), dim3(256), 0, s, in, rows, part); break;
+    case 16: hipLaunchKernelGGL(HET_colsum_partial<16>, dim3(blocks), dim3(256), 0, s, in, rows, part); break;
+    default: het_set_error("colsum: %d columns unsupported", X); return HET_ERR_UNSUPPORTED;
+  }
+  HET_LAUNCH_CHECK("HET_colsum_partial");
+  hipLaunchKernelGGL(HET_colsum_finish, dim3(X), dim3(256), 0, s, part, blocks, X, out);
+  HET_LAUNCH_CHECK("HET_colsum_finish");
+  return HET_OK;
+}
+
+bool rgcn_layer_shape_ok(int64_t R, int64_t K, int64_t D) {
+  return (K == 32 || K == 64) && (D == 32 || D == 64) && R >= 1 && het_node_rows_matmul_sum_ok(R, K, D) &&
+         het_node_rows_matmul_sum_ok(R, D, K) && segment_sum_supported((int)K) && segment_sum_supported((int)D) &&
+         mfma_dw_supported((int)K, (int)D);
+}
+}  // namespace
+
+extern "C" int het_rgcn_layer_ok(int64_t num_rels, int64_t K, int64_t D) { return rgcn_layer_shape_ok(num_rels, K, D) ? 1 : 0; }
+
+extern "C" int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t D) {
+  return (int64_t)sizeof(float) * ((n_src_rows > 0 ? n_src_rows : 1) * D + (int64_t)kColsumBlocks * D);
+}
+
+extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
+                                      const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
+                                      const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D,
+                                      het_stream stream) {
+  const char* op = "het_rgcn_layer_forward";
+  const het_grouping* g = by_rel_dst;
+  HET_REQUIRE(g && g->R == (int)num_rels && g->p0 && g->p1, "%s: needs the grouping by (relation, destination) with payloads (source row, edge id)", op);
+  HET_REQUIRE(rgcn_layer_shape_ok(num_rels, K, D), "%s: unsupported shape (het_rgcn_layer_ok)", op);
+  HET_REQUIRE(num_nodes >= 0 && num_nodes < (1ll << 31), "%s: bad node count", op);
+  if (num_nodes == 0) return HET_OK;
+  HET_REQUIRE(x && weights && norm && dst_map && ssum && ret, "%s: null pointer", op);
+  HET_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ssum) | reinterpret_cast<uintptr_t>(ret) |
+                reinterpret_cast<uintptr_t>(bias)) & 15) == 0, "%s: 16-byte aligned pointers expected", op);
+  hipStream_t s = (hipStream_t)stream;
+  // ssum[(r,v), :] = SUM over the in-edges of v in relation r of norm * x[src]   (one gather pass over x)
+  if (g->E > 0)
+    if (int rc = launch_segment_sum(g, x, ssum, (int)K, norm, s)) return rc;
+  // ret[v, :] = bias + SUM_r ssum[(r,v), :] . W[r]: one pass over the nodes, every output row stored once
+  const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
+  for (int r = 0; r < (int)num_rels; ++r) {
+    rows[r] = ssum; strides[r] = K; maps[r] = dst_map + (int64_t)r * num_nodes; ident[r] = 0; wts[r] = weights + (int64_t)r * K * D;
+  }
+  return het_node_rows_matmul_sum_bias(0, num_nodes, num_nodes, num_rels, rows, strides, maps, ident, wts, bias, ret, K, D, node_order, stream);
+}
+
+extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
+                                       int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
+                                       const float* norm,
+                                       const float* gradout, const int32_t* src_map, const int32_t* node_order, float* grad_x,
+                                       float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
+                                       int64_t workspace_bytes, het_stream stream) {
+  const char* op = "het_rgcn_layer_backward";
+  const het_grouping *gs = by_rel_src, *gd = by_rel_dst;
+  HET_REQUIRE(gs && gd && gs->R == (int)num_rels && gd->R == (int)num_rels && gs->E == gd->E && gs->p0 && gs->p1,
+              "%s: needs the groupings by (relation, source) [payloads: destination row, edge id] and by (relation, destination)", op);
+  HET_REQUIRE(rgcn_layer_shape_ok(num_rels, K, D), "%s: unsupported shape (het_rgcn_layer_ok)", op);
+  HET_REQUIRE(num_src_nodes >= 0 && num_src_nodes < (1ll << 31) && num_dst_nodes >= gd->key_bound, "%s: bad node count", op);
+  HET_REQUIRE(grad_w && (num_src_nodes == 0 || (ssum && weights_t && norm && gradout && src_map && grad_x)), "%s: null pointer", op);
+  HET_REQUIRE(workspace && workspace_bytes >= het_rgcn_layer_backward_workspace(gs->S, D) &&
+              ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gradout) | reinterpret_cast<uintptr_t>(grad_x) |
+                reinterpret_cast<uintptr_t>(ssum)) & 15) == 0, "%s: workspace too small (het_rgcn_layer_backward_workspace) or pointers not 16-byte aligned", op);
+  hipStream_t s = (hipStream_t)stream;
+  float* gsum = static_cast<float*>(workspace);
+  float* cpart = gsum + (gs->S > 0 ? gs->S : 1) * D;
+  {
+    // side stream: grad_w[r] = SUM over the (r, v) rows of ssum[(r,v)]^T (x) gradout[v] (half as many rows as the (relation, source)
+    // form, no second read of x) and the bias gradient -- streams of rows on the matrix cores beside the gather pass below
+    HetFork fk(s);
+    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * K * D, fk.side));
+    if (gd->S > 0) {
+      MfmaDwArgs w;
+      w.A = ssum; w.a_ld = K; w.G = gradout; w.g_ld = D; w.g_gather = gd->seg_key64; w.dW = grad_w; w.dw_rel_stride = K * D;
+      w.seg_ptrs = gd->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gd->S; w.K = (int)K; w.X = (int)D;
+      if (int rc = launch_seg_dw_mfma(w, fk.side)) return rc;
+    }
+    if (grad_bias)
+      if (int rc = launch_colsum(gradout, num_dst_nodes, (int)D, cpart, grad_bias, fk.side)) return rc;
+    // main: gsum[(r,u), :] = SUM over the out-edges of u in relation r of norm * gradout[dst]; grad_x[u] = SUM_r gsum[(r,u)] . Wt[r]
+    if (gs->E > 0)
+      if (int rc = launch_segment_sum(gs, gradout, gsum, (int)D, norm, s)) return rc;
+    if (num_src_nodes > 0) {
+      const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
+      for (int r = 0; r < (int)num_rels; ++r) {
+        rows[r] = gsum; strides[r] = D; maps[r] = src_map + (int64_t)r * num_src_nodes; ident[r] = 0; wts[r] = weights_t + (int64_t)r * D * K;
+      }
+      if (int rc = het_node_rows_matmul_sum_bias(0, num_src_nodes, num_src_nodes, num_rels, rows, strides, maps, ident, wts, nullptr, grad_x,
+                                                 D, K, node_order, stream)) return rc;
+    }
+    HET_HIP(fk.join());
+  }
+  return HET_OK;
+}
+
 // ---- layer epilogue: out[i, :] = a[i, :] (+ b[i, :]) (+ bias[:]) -- the "h + loop_message + h_bias" of the layers
 // (RGAT/models.py:377-383) as one pass instead of two elementwise adds
 namespace {

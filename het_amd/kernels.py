@@ -1037,6 +1037,66 @@ def backward_rgcn_layer1_separate_coo(separate_coo_relptrs, separate_coo_eids, s
           0 if ws is None else ws.numel() * 4, _stream(delta_weights))
 
 
+def rgcn_layer_ok(R: int, K: int, D: int) -> bool:
+    """Shapes of the two-call RGCN layer (include/het_amd.h: het_rgcn_layer_forward)."""
+    return bool(_lib.lib().het_rgcn_layer_ok(int(R), int(K), int(D)))
+
+
+def _grouping_segment_map(g, rel_ptrs, keys, num_keys: int):
+    """[R, num_keys] int32: segment of (relation, key) in the grouping ``g`` of ``keys`` by (relation, key), -1 = none (cached by
+    the identity of the lists the grouping was built from)."""
+    def build():
+        R = rel_ptrs.numel() - 1
+        m = torch.empty((R, num_keys), dtype=torch.int32, device=keys.device)
+        _call(keys, "het_grouping_segment_map", g.handle, num_keys, _p(m), _stream(keys))
+        return m
+    return _derived_get(("segmap", num_keys), (rel_ptrs, keys), build)
+
+
+def rgcn_layer_plan(rel_ptrs, eids, row, col, num_nodes: int):
+    """What the two-call RGCN layer needs per graph (groupings from het_amd.plan, the rest cached by tensor identity):
+    (by_rel_dst, by_rel_src, dst_map, dst_order, src_map, src_order), or None without groupings.  The maps come from the
+    groupings' own segment lists, so a graph needs no unique (relation, node) lists for this layer."""
+    gd = _plan.get_grouping(rel_ptrs, col, num_nodes, row, eids)
+    gs = _plan.get_grouping(rel_ptrs, row, num_nodes, col, eids)
+    if gd is None or gs is None:
+        return None
+    dst_map = _grouping_segment_map(gd, rel_ptrs, col, num_nodes)
+    src_map = _grouping_segment_map(gs, rel_ptrs, row, num_nodes)
+    return gd, gs, dst_map, node_order_by_presence(dst_map), src_map, node_order_by_presence(src_map)
+
+
+def rgcn_layer_forward(plan, x, weights, norm, bias):
+    """(ret [N,D], ssum [S_col,K]) of het_rgcn_layer_forward: ret = bias + SUM_r (SUM_e norm x[src]) . W[r]."""
+    gd, _, dst_map, dst_order, _, _ = plan
+    _chk("rgcn_layer_forward", tuple(t for t in (x, weights, norm, bias) if t is not None))
+    R, K, D = weights.shape
+    N = dst_map.shape[1]
+    ssum = torch.empty((max(1, gd.num_segments), K), dtype=torch.float32, device=x.device)
+    ret = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    _call(ret, "het_rgcn_layer_forward", gd.handle, R, N, _p(x), _p(weights), _p(norm), _p(bias), _p(dst_map), _p(dst_order),
+          _p(ssum), _p(ret), K, D, _stream(ret))
+    return ret, ssum
+
+
+def rgcn_layer_backward(plan, ssum, weights_t, norm, gradout, want_bias: bool):
+    """(grad_x [N,K], grad_w [R,K,D], grad_bias [D] or None) of het_rgcn_layer_backward."""
+    gd, gs, _, _, src_map, src_order = plan
+    _chk("rgcn_layer_backward", (ssum, weights_t, norm, gradout))
+    R, D, K = weights_t.shape
+    N = src_map.shape[1]
+    dev = gradout.device
+    grad_x = torch.empty((N, K), dtype=torch.float32, device=dev)
+    grad_w = torch.empty((R, K, D), dtype=torch.float32, device=dev)
+    grad_bias = torch.empty((D,), dtype=torch.float32, device=dev) if want_bias else None
+    nbytes = int(_lib.lib().het_rgcn_layer_backward_workspace(gs.num_segments, D))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    _call(gradout, "het_rgcn_layer_backward", gs.handle, gd.handle, R, N, gradout.shape[0], _p(ssum), _p(weights_t), _p(norm),
+          _p(gradout), _p(src_map), _p(src_order), _p(grad_x), _p(grad_w), _p(grad_bias), K, D, _p(ws), ws.numel() * 4,
+          _stream(gradout))
+    return grad_x, grad_w, grad_bias
+
+
 def _rgcn_maps(d: Dict[str, Tensor], direct: bool):
     if direct:
         return d["inverse_indices_row"], None

@@ -100,6 +100,10 @@ int64_t het_grouping_num_segments(const het_grouping* g);
 int64_t het_grouping_bytes(const het_grouping* g);
 /* out[i] = sorted rank of position i (the inverse of the grouping's permutation), [E] */
 int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_stream stream);
+/* map[r, k] = segment of (relation r, key k) of a grouping by (relation, key), -1 where that pair has no position; map
+ * [R, num_keys] int32, num_keys >= the grouping's key bound.  (Segments are in ascending (relation, key) order: segment s is
+ * row s of the sorted unique (relation, key) list of the positions -- het_node_row_map on that list gives the same map.) */
+int het_grouping_segment_map(const het_grouping* g, int64_t num_keys, int32_t* map, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * a1  rgnn_relational_matmul            OpExport/RGNNOps.inc.h:238-295
@@ -591,6 +595,40 @@ int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t num_nodes, 
                              const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
                              const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS, int64_t XO,
                              const int32_t* node_order, het_stream stream);
+
+/* the same with a bias row: out[n, :] = bias[:] + SUM_s ...   (bias [XO] or NULL; a node without any row gets the bias) */
+int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
+                                  const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
+                                  const int64_t* ident_rows, const float* const* weights_t, const float* bias, float* out,
+                                  int64_t KS, int64_t XO, const int32_t* node_order, het_stream stream);
+
+/* ------------------------------------------------------------------------
+ * The RGCN layer as two calls (layer-level fusion; no reference op of its own).  Inside het_amd/backend/rgcn_layers_and_funcs.py
+ * it replaces the pair a7 / a8 (rgcn_layer1_separate_coo / backward_rgcn_layer1_separate_coo, OpExport/RGCNOps.inc.h:84-138,
+ * 368-467) together with the layer's "node_repr + h_bias" (RGCN/RGCN.py:338-340) and the fills the
+ * reference wrappers make around the ops (rgcn_layers_and_funcs.py:481-601).  Same values:
+ *   forward   ssum[(r,v), :] = SUM over the in-edges e of v in relation r of norm[eid_e] * x[src_e, :]       (kept for the backward)
+ *             ret[v, :]      = bias[:] + SUM_r ssum[(r,v), :] . W[r]          one pass over the nodes, every row stored once
+ *   backward  gsum[(r,u), :] = SUM over the out-edges e of u in relation r of norm[eid_e] * gradout[dst_e, :]
+ *             grad_x[u, :]   = SUM_r gsum[(r,u), :] . Wt[r]                   one pass over the nodes, every row stored once
+ *             grad_w[r]      = SUM over the (r,v) rows of ssum[(r,v), :]^T (x) gradout[v, :];   grad_bias = column sums of gradout
+ *             (grad_w and grad_bias on the library's side stream beside the gather pass; joined before the call returns)
+ * by_rel_dst = het_grouping_create(rel_ptrs, R, col, E, N_dst, payload0 = row, payload1 = eids), by_rel_src = the same with row
+ * and col exchanged (the groupings of a7 / a8).  dst_map / src_map [R, N] int32: segment of (relation, node) in that grouping =
+ * its row in the sorted unique (relation, node) list, -1 = none (het_node_row_map on that list).  node_order: optional, as in
+ * het_rgat_node_backward_dx.  ssum [by_rel_dst segments, K];  weights [R,K,D];  weights_t [R,D,K];  bias / grad_bias [D] or NULL.
+ * Shapes: K, D in {32, 64}, all R weights resident in LDS (het_rgcn_layer_ok); HET_ERR_INVALID_ARG otherwise -- callers use a7 / a8.
+ * workspace: het_rgcn_layer_backward_workspace(segments of by_rel_src, D) bytes, 16-byte aligned. */
+int het_rgcn_layer_ok(int64_t num_rels, int64_t K, int64_t D);
+int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t D);
+int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
+                           const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
+                           const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D, het_stream stream);
+int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
+                            int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
+                            const float* norm, const float* gradout, const int32_t* src_map, const int32_t* node_order,
+                            float* grad_x, float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
+                            int64_t workspace_bytes, het_stream stream);
 
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.

@@ -228,7 +228,7 @@ def _run_rgcn(g, compact, direct, K, D, R, oracle_dev="cpu"):
     # (the layer reads the norm of an edge by its eid; the oracle takes it in separate-COO position order)
     ref = OL.rgcn_layer(x64, w64, norm.double()[s["eids"]].to(oracle_dev), s["rel_ptrs"].to(oracle_dev), s["row_indices"].to(oracle_dev),
                         s["col_indices"].to(oracle_dev), N, b64)
-    gx_r, gw_r = (t.cpu() for t in torch.autograd.grad(ref, [x64, w64], go.double().to(oracle_dev)))
+    gx_r, gw_r, gb_r = (t.cpu() for t in torch.autograd.grad(ref, [x64, w64, b64], go.double().to(oracle_dev)))
     ref = ref.detach().cpu()
     g.to_(DEV)
     layer = layer.to(DEV)
@@ -239,6 +239,26 @@ def _run_rgcn(g, compact, direct, K, D, R, oracle_dev="cpu"):
     assert_close(out, ref, what="out")
     assert_close(xd.grad, gx_r, what="grad_x")
     assert_close(layer.weight.grad, gw_r, what="grad_W")
+    assert_close(layer.h_bias.grad, gb_r, what="grad_bias")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("K,D,R", [(64, 64, 4), (64, 64, 7), (32, 64, 3), (64, 32, 5), (32, 32, 1), (64, 64, 8)])
+def test_rgcn_layer_two_call_form(K, D, R, fused, monkeypatch):
+    """The RGCN layer as two library calls (het_rgcn_layer_forward / _backward: node-major output and input gradient, weight
+    gradient from the kept (relation, destination) sums, bias gradient in the library) against the fp64 oracle, and the a7 / a8
+    pair on the same graphs (HET_RGCN_FUSED=0): graphs with an empty relation, nodes without edges, shuffled eids, a hub.
+    R = 8 at 64 x 64 exceeds the LDS the node pass keeps its weights in: the layer falls back to the pair."""
+    import het_amd.backend.rgcn_layers_and_funcs as B
+    import het_amd.kernels as k
+    monkeypatch.setattr(B, "FUSED", fused)
+    calls = []
+    real = k.rgcn_layer_forward
+    monkeypatch.setattr(k, "rgcn_layer_forward", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    for seed, n, e, shuffle in ((500, 97, 900, True), (501, 1500, 30000, False), (502, 4000, 2500, True)):
+        _run_rgcn(random_graph(seed=seed, n=n, r=R, e=e, shuffle=shuffle, empty_rel=R > 2), False, False, K, D, R)
+    assert len(calls) == (3 if fused and k.rgcn_layer_ok(R, K, D) else 0)
+    assert k.rgcn_layer_ok(R, K, D) == (R < 8)
 
 
 @pytest.mark.parametrize("fused_attn,compact,direct", [(False, False, False), (True, False, False), (False, True, False),
