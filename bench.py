@@ -105,7 +105,7 @@ KT_NAMES = ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rg
             "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
             "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
             "HET_seg_gemm_mfma<atomic>", "HET_seg_gemm_mfma<dot>", "HET_seg_gemm_mfma<rmw>", "HET_seg_dw_mfma", "HET_segment_sum",
-            "HET_node_dx", "HET_node_rows_sum",
+            "HET_node_dx", "HET_node_rows_sum", "HET_colsum",
             "HET_hgt_aggregate_rows", "HET_hgt_backward_dst_rows", "HET_hgt_backward_src_short", "HET_hgt_backward_src_long")
 
 
@@ -130,8 +130,9 @@ def rgcn_rooflines(g, kt, E_local, N_local, K, X, hbm_view):
     a7 = E_local * (3 * 8 + 4) + U_src * 4 * K + N_local * 4 * X + 4 * R_ * K * X
     a8 = E_local * 28 + (U_src + N_local) * 4 * (K + X) + 8 * R_ * K * X
     ss_ms = kt["HET_segment_sum"][0]  # one launch per op
-    note = ("kernel_ms = the gather-sum launches of one op (average of the forward and the backward one); the op's GEMMs on "
-            "the distinct rows are separate launches (kernel_ms).  requested_bytes counts one row per edge: the rate at "
+    note = ("kernel_ms = the gather-sum launches of one op (average of the forward and the backward one); the op's products on "
+            "the distinct rows are separate launches (kernel_ms: HET_node_rows_sum, the node-major pass of het_rgcn_layer_forward / "
+            "_backward; HET_seg_gemm_mfma<rmw> with HET_RGCN_FUSED=0).  requested_bytes counts one row per edge: the rate at "
             "the kernels' load instructions, part of it served by L2 / Infinity Cache (the [N,64] table is 0.5 GB and "
             "the degrees are Zipf-skewed), so it may exceed what HBM delivers")
     pm = ("HET_segment_sum_packed", "HET_segment_sum_long")

@@ -35,6 +35,11 @@ struct SumArgs {
   const int32_t* order;          // [>= n_end] node at position p, or NULL (node p)
   float* out;                    // [N, XO]
   const float* bias;             // [XO] added to every output row, or NULL
+  int by_pos;                    // maps indexed by position of `order` instead of by node (coalesced: node_gemm.hip NodeArgs::by_pos)
+  int64_t mix;                   // tile walked at step L of the grid-stride loop: (L * mix) % tiles (1: in list order).  A list sorted by
+                                 // presence puts the nodes without any row first: in list order every wave stores its empty tiles first
+                                 // (matrix cores idle) and multiplies afterwards (stores idle); a stride near 0.618 * tiles, coprime with
+                                 // tiles, hands every wave a uniform sample of the classes
 };
 
 // Workgroup = WAVES independent waves sharing the S weights in LDS; a wave walks 32-node tiles (grid-stride), loads the rows of
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_rows_sum(SumArgs a) {
 #pragma unroll
     for (int s = 0; s < kMaxSrc; ++s) {
       mcur[s] = -1;
-      if (s < S) mcur[s] = a.map[s] ? a.map[s][nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
+      if (s < S) mcur[s] = a.map[s] ? a.map[s][a.by_pos ? pc : nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
     }
   };
   load_maps(t);
@@ -214,15 +219,17 @@ __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
   auto load_maps = [&](int64_t tt) {
     const int64_t pos = a.n_begin + tt * 32 + i;
     const bool nv = pos < a.n_end;
-    const int64_t nc = a.order ? a.order[nv ? pos : a.n_end - 1] : (nv ? pos : a.n_end - 1);
+    const int64_t pc = nv ? pos : a.n_end - 1;
+    const int64_t nc = a.order ? a.order[pc] : pc;
     nnext = nv ? (int)nc : -1;
 #pragma unroll
     for (int s = 0; s < kMaxSrc; ++s) {
       mnext[s] = -1;
-      if (s < S && nv) mnext[s] = a.map[s] ? a.map[s][nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
+      if (s < S && nv) mnext[s] = a.map[s] ? a.map[s][a.by_pos ? pc : nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
     }
   };
-  load_maps(t);
+  const int64_t mix = a.mix;
+  load_maps(t * mix % tiles);
   for (; t < tiles; t += stride) {
     int ids[kMaxSrc];
     const int node = nnext;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
       ids[s] = mnext[s];
       if (s < S && __ballot(ids[s] >= 0)) mask |= 1u << s;
     }
-    if (t + stride < tiles) load_maps(t + stride);  // consumed one tile later
+    if (t + stride < tiles) load_maps((t + stride) * mix % tiles);  // consumed one tile later
 
     f32x16 acc[NO];
 #pragma unroll
@@ -322,9 +329,18 @@ int launch_sum_w16(const SumArgs& a, hipStream_t s, bool* done) {
   if (gx > cus) gx = cus;  // one workgroup per CU (the weights are staged once), its waves walk the tiles grid-stride
   if (gx < 1) gx = 1;
   const size_t lds = wbytes + (size_t)waves * per_wave;
+  SumArgs b = a;
+  static const bool no_mix = getenv("HET_NODE_SUM_MIX") && atoi(getenv("HET_NODE_SUM_MIX")) == 0;  // A/B: tiles in list order
+  b.mix = 1;
+  if (!no_mix && a.order && tiles > 4 * gx * waves) {
+    auto gcd = [](int64_t x, int64_t y) { while (y) { const int64_t r = x % y; x = y; y = r; } return x; };
+    int64_t m = (int64_t)(0.6180339887 * (double)tiles) | 1;
+    while (m > 1 && gcd(m, tiles) != 1) m -= 2;
+    b.mix = m < 1 ? 1 : m;
+  }
   HET_KTIME("HET_node_rows_sum", s);
   HET_HIP(hipFuncSetAttribute((const void*)HET_node_rows_sum_w16<KS, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((HET_node_rows_sum_w16<KS, NO>), dim3((unsigned)gx), dim3(waves * 64), lds, s, a);
+  hipLaunchKernelGGL((HET_node_rows_sum_w16<KS, NO>), dim3((unsigned)gx), dim3(waves * 64), lds, s, b);
   HET_LAUNCH_CHECK("HET_node_rows_sum_w16");
   *done = true;
   return HET_OK;
@@ -380,7 +396,8 @@ extern "C" int het_node_rows_matmul_sum_ok(int64_t num_sources, int64_t KS, int6
 extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
                                              const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
                                              const int64_t* ident_rows, const float* const* weights_t, const float* bias,
-                                             float* out, int64_t KS, int64_t XO, const int32_t* node_order, het_stream stream) {
+                                             float* out, int64_t KS, int64_t XO, const int32_t* node_order, int maps_by_position,
+                                             het_stream stream) {
   const char* op = "het_node_rows_matmul_sum";
   HET_REQUIRE(0 <= n_begin && n_begin <= n_end && n_end <= num_nodes && num_nodes < (1ll << 31), "%s: bad node range", op);
   HET_REQUIRE(het_node_rows_matmul_sum_ok(num_sources, KS, XO), "%s: unsupported shape: %lld sources of %lld -> %lld floats", op,
@@ -390,6 +407,7 @@ extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int
   HET_REQUIRE(((uintptr_t)bias & 15) == 0 && ((uintptr_t)out & 15) == 0, "%s: bias / out not 16-byte aligned", op);
   SumArgs a{};
   a.n_begin = n_begin; a.n_end = n_end; a.N = num_nodes; a.S = (int)num_sources; a.order = node_order; a.out = out; a.bias = bias;
+  a.by_pos = node_order && maps_by_position ? 1 : 0;
   for (int s = 0; s < a.S; ++s) {
     HET_REQUIRE(rows[s] && weights_t[s] && row_strides[s] >= KS && (row_strides[s] & 3) == 0 && ((uintptr_t)rows[s] & 15) == 0,
                 "%s: source %d: null pointer, row stride below the row width, or rows not 16-byte aligned", op, s);
@@ -406,5 +424,5 @@ extern "C" int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t 
                                         const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS,
                                         int64_t XO, const int32_t* node_order, het_stream stream) {
   return het_node_rows_matmul_sum_bias(n_begin, n_end, num_nodes, num_sources, rows, row_strides, maps, ident_rows, weights_t, nullptr,
-                                       out, KS, XO, node_order, stream);
+                                       out, KS, XO, node_order, 0, stream);
 }

@@ -719,8 +719,8 @@ extern "C" int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t
 
 extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
                                       const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
-                                      const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D,
-                                      het_stream stream) {
+                                      const int32_t* node_order, int maps_by_position, float* ssum, float* ret, int64_t K,
+                                      int64_t D, het_stream stream) {
   const char* op = "het_rgcn_layer_forward";
   const het_grouping* g = by_rel_dst;
   HET_REQUIRE(g && g->R == (int)num_rels && g->p0 && g->p1, "%s: needs the grouping by (relation, destination) with payloads (source row, edge id)", op);
@@ -739,15 +739,15 @@ extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t nu
   for (int r = 0; r < (int)num_rels; ++r) {
     rows[r] = ssum; strides[r] = K; maps[r] = dst_map + (int64_t)r * num_nodes; ident[r] = 0; wts[r] = weights + (int64_t)r * K * D;
   }
-  return het_node_rows_matmul_sum_bias(0, num_nodes, num_nodes, num_rels, rows, strides, maps, ident, wts, bias, ret, K, D, node_order, stream);
+  return het_node_rows_matmul_sum_bias(0, num_nodes, num_nodes, num_rels, rows, strides, maps, ident, wts, bias, ret, K, D, node_order, maps_by_position, stream);
 }
 
 extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
                                        int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
-                                       const float* norm,
-                                       const float* gradout, const int32_t* src_map, const int32_t* node_order, float* grad_x,
-                                       float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
-                                       int64_t workspace_bytes, het_stream stream) {
+                                       const float* norm, const float* gradout, const int32_t* src_map,
+                                       const int32_t* node_order, int maps_by_position, float* grad_x, float* grad_w,
+                                       float* grad_bias, int64_t K, int64_t D, void* workspace, int64_t workspace_bytes,
+                                       het_stream stream) {
   const char* op = "het_rgcn_layer_backward";
   const het_grouping *gs = by_rel_src, *gd = by_rel_dst;
   HET_REQUIRE(gs && gd && gs->R == (int)num_rels && gd->R == (int)num_rels && gs->E == gd->E && gs->p0 && gs->p1,
@@ -783,7 +783,7 @@ extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het
         rows[r] = gsum; strides[r] = D; maps[r] = src_map + (int64_t)r * num_src_nodes; ident[r] = 0; wts[r] = weights_t + (int64_t)r * D * K;
       }
       if (int rc = het_node_rows_matmul_sum_bias(0, num_src_nodes, num_src_nodes, num_rels, rows, strides, maps, ident, wts, nullptr, grad_x,
-                                                 D, K, node_order, stream)) return rc;
+                                                 D, K, node_order, maps_by_position, stream)) return rc;
     }
     HET_HIP(fk.join());
   }

@@ -44,7 +44,8 @@ def test_library_exports_every_declared_symbol():
                 "het_kernel_timing_enable", "het_kernel_timing_read", "het_rgat_backward_compact_workspace",
                 "het_hgt_backward_compact_workspace", "het_hgt_compact_shape_ok", "het_rgat_node_gemm_ok", "het_rgat_aggregate_compact_workspace", "het_hgt_aggregate_compact_workspace",
                 "het_rgat_aggregate_compact_runs_workspace", "het_rgat_backward_compact_runs_workspace",
-                "het_set_allocator", "het_allocator_is_external", "het_node_rows_matmul_sum_ok")]
+                "het_set_allocator", "het_allocator_is_external", "het_node_rows_matmul_sum_ok", "het_rgcn_layer_ok",
+                "het_rgcn_layer_backward_workspace")]
     assert not untyped, untyped
     assert "gfx950" in _lib.build_info()
 
