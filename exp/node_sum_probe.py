@@ -17,7 +17,7 @@ g = HetGraph.from_integrated_coo(coo, full=False)
 s = g.get_separate_coo_original()
 N, R, K = g.get_num_nodes(), g.get_num_rels(), 64
 plan = k.rgcn_layer_plan(s["rel_ptrs"], s["eids"], s["row_indices"], s["col_indices"], N)
-gd, gs, dst_map, dst_order, src_map, src_order, by_pos = plan
+gd, gs, dst_map, dst_order, src_map, src_order = plan
 torch.manual_seed(0)
 W = torch.randn(R, K, K, device=dev) * 0.1
 bias = torch.randn(K, device=dev)
@@ -53,7 +53,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     torch.cuda.synchronize()
     sys.exit(0)
 nz = int((dmap_node >= 0).any(0).sum())
-print(f"N={N} S_col={S_col} S_row={S_row} nodes with in-edges={nz} by_pos={by_pos}")
+print(f"N={N} S_col={S_col} S_row={S_row} nodes with in-edges={nz}")
 print("forward node pass, sorted order      %.4f ms" % timed(lambda: node_pass(ssum, dmap_node, dst_order, out)))
 print("forward node pass, node-id order     %.4f ms" % timed(lambda: node_pass(ssum, dmap_node, None, out)))
 print("backward node pass, sorted order     %.4f ms" % timed(lambda: node_pass(gsum, smap_node, src_order, out)))

@@ -41,11 +41,11 @@ _SIGNATURES = {
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_node_row_map": [P, I64, P, I64, I64, P, P],
-    "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, INT, P],
+    "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
     "het_node_rows_matmul_sum": [I64, I64, I64, I64, P, P, P, P, P, P, I64, I64, P, P],
-    "het_node_rows_matmul_sum_bias": [I64, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, INT, P],
-    "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, INT, P, P, I64, I64, P],
-    "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, INT, P, P, P, I64, I64, P, I64, P],
+    "het_node_rows_matmul_sum_bias": [I64, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P],
+    "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, P, P, I64, I64, P],
+    "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, P, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
     "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],

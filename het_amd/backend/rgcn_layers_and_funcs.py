@@ -86,7 +86,7 @@ class RgcnLayerFused(th.autograd.Function):
     def backward(ctx, gradout):
         weight, norm, ssum = ctx.saved_tensors
         grad_x, grad_w, grad_bias = _k.rgcn_layer_backward(ctx.plan, ssum, weight.transpose(1, 2).contiguous(), norm,
-                                                           gradout.contiguous(), ctx.has_bias)
+                                                           gradout.contiguous(), ctx.has_bias, want_x=ctx.needs_input_grad[1])
         # (the reference's a8 takes a grad_norm buffer and leaves it as it was given: zeros)
         grad_norm = th.zeros_like(norm) if ctx.needs_input_grad[3] else None
         return None, grad_x, grad_w, grad_norm, grad_bias

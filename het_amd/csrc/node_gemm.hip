@@ -48,9 +48,6 @@ struct NodeArgs {
   const int32_t* dst_map;  // [R, N]
   const int32_t* order;    // [N] or NULL: the node at position p of [n_begin, n_end) (NULL: node p).  A list sorted by which relations
                            // a node has rows in makes the 32-node tiles homogeneous: no zero rows in the MFMA tiles
-  int by_pos;              // the maps are indexed by POSITION of `order` (map[r, p] = row of node order[p]): with a sorted list the
-                           // per-node lookups map[r, order[p]] are 2 R random 4-byte gathers per node (the chip does ~36 G / s of those:
-                           // 0.4 ms on ogbn-mag); by position they are coalesced streams
   // dx
   const float* loop_wt;    // [X, K]  W_loop^T
   const float* wt;         // [R, X, K]  (= weights_transposed [R,H,D,K])
@@ -104,9 +101,8 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
     for (int r = 0; r < kMaxRels; ++r) {
       mcur[r] = -1; dcur[r] = -1;
       if (r < R) {
-        const int64_t mi = (int64_t)r * a.N + (a.by_pos ? pc : nc);
-        mcur[r] = a.row_map[mi];
-        if (a.g_er) dcur[r] = a.dst_map[mi];
+        mcur[r] = a.row_map[(int64_t)r * a.N + nc];
+        if (a.g_er) dcur[r] = a.dst_map[(int64_t)r * a.N + nc];
       }
     }
   };
@@ -300,7 +296,7 @@ extern "C" int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t
                                          const float* grad_h, const float* loop_wt, const float* g_rows,
                                          const float* weights_t, const int32_t* row_map, const float* g_er, const float* wa_t,
                                          const int32_t* dst_map, float* grad_x, int64_t H, int64_t K, int64_t D,
-                                         const int32_t* node_order, int maps_by_position, het_stream stream) {
+                                         const int32_t* node_order, het_stream stream) {
   const char* op = "het_rgat_node_backward_dx";
   if (int rc = check_node_args(op, n_begin, n_end, n_loop, num_nodes, num_rels, H, K, D)) return rc;
   if (n_begin == n_end) return HET_OK;
@@ -313,7 +309,6 @@ extern "C" int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t
   a.R = (int)num_rels; a.H = (int)H; a.D = (int)D; a.rhp = g_er ? (int)((num_rels * H + 7) / 8 * 8) : 0;
   a.gh = grad_h; a.g_rows = g_rows; a.row_map = row_map; a.g_er = g_er; a.dst_map = dst_map;
   a.loop_wt = loop_wt; a.wt = weights_t; a.wa_t = wa_t; a.grad_x = grad_x; a.order = node_order;
-  a.by_pos = node_order && maps_by_position ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int KS = (int)(H * D);
   if (KS == 64) return K == 64 ? launch_dx<64, 2>(a, s) : launch_dx<64, 1>(a, s);

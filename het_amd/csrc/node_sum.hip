@@ -35,11 +35,11 @@ struct SumArgs {
   const int32_t* order;          // [>= n_end] node at position p, or NULL (node p)
   float* out;                    // [N, XO]
   const float* bias;             // [XO] added to every output row, or NULL
-  int by_pos;                    // maps indexed by position of `order` instead of by node (coalesced: node_gemm.hip NodeArgs::by_pos)
   int64_t mix;                   // tile walked at step L of the grid-stride loop: (L * mix) % tiles (1: in list order).  A list sorted by
                                  // presence puts the nodes without any row first: in list order every wave stores its empty tiles first
                                  // (matrix cores idle) and multiplies afterwards (stores idle); a stride near 0.618 * tiles, coprime with
-                                 // tiles, hands every wave a uniform sample of the classes
+                                 // tiles, hands every wave a uniform sample of the classes (RGCN forward pass 0.239 -> 0.225 ms,
+                                 // the backward one unchanged; HET_NODE_SUM_MIX=0: A/B)
 };
 
 // Workgroup = WAVES independent waves sharing the S weights in LDS; a wave walks 32-node tiles (grid-stride), loads the rows of
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_rows_sum(SumArgs a) {
 #pragma unroll
     for (int s = 0; s < kMaxSrc; ++s) {
       mcur[s] = -1;
-      if (s < S) mcur[s] = a.map[s] ? a.map[s][a.by_pos ? pc : nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
+      if (s < S) mcur[s] = a.map[s] ? a.map[s][nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
     }
   };
   load_maps(t);
@@ -184,6 +184,12 @@ int64_t het_num_cus() {
 // l: the row of tile node l & 31; the loading lane fetches its row's id with a shuffle) and stores the accumulators straight
 // from registers (PAIRED layout: lane (i, kk) holds columns 2i, 2i+1 of a tile row per accumulator register -- the 32 lanes of
 // a half write one whole 256-byte output row), so 16 waves fit beside 64-88 KB of weights: four per SIMD hide each other's gathers.
+// Measured (exp/node_sum_probe.py, ogbn-mag, 4 relations of 64 x 64): forward pass 0.259 -> 0.227 ms, backward 0.355 -> 0.326; the
+// counters of the 16-wave form: MFMA busy 29 % of the launch, waves waiting on memory 35 % of their cycles.  What is left is the rate
+// of scattered 256-byte rows: the nodes WITHOUT rows alone (bias stores to 1.17 M scattered rows) take 0.076 ms = 3.9 TB/s where a
+// dense fill of as many bytes runs at 6.9 TB/s; the pass as a whole moves its 0.81 GB at 3.6 TB/s.  Looking the maps up by position
+// of the sorted list instead of by node id (coalesced instead of one random 4-byte gather per node and map) changed nothing
+// measurable -- the [R, N] int32 maps sit in the L2 / Infinity Cache -- and was removed again.
 // k mapping of a 32-column phase p: MFMA step q of lane (i, kk) multiplies A[i][32p + 16kk + q] with B[32p + 16kk + q][col].
 template <int KS, int NO>
 __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
 #pragma unroll
     for (int s = 0; s < kMaxSrc; ++s) {
       mnext[s] = -1;
-      if (s < S && nv) mnext[s] = a.map[s] ? a.map[s][a.by_pos ? pc : nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
+      if (s < S && nv) mnext[s] = a.map[s] ? a.map[s][nc] : (nc < a.ident_rows[s] ? (int)nc : -1);
     }
   };
   const int64_t mix = a.mix;
@@ -396,8 +402,7 @@ extern "C" int het_node_rows_matmul_sum_ok(int64_t num_sources, int64_t KS, int6
 extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
                                              const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
                                              const int64_t* ident_rows, const float* const* weights_t, const float* bias,
-                                             float* out, int64_t KS, int64_t XO, const int32_t* node_order, int maps_by_position,
-                                             het_stream stream) {
+                                             float* out, int64_t KS, int64_t XO, const int32_t* node_order, het_stream stream) {
   const char* op = "het_node_rows_matmul_sum";
   HET_REQUIRE(0 <= n_begin && n_begin <= n_end && n_end <= num_nodes && num_nodes < (1ll << 31), "%s: bad node range", op);
   HET_REQUIRE(het_node_rows_matmul_sum_ok(num_sources, KS, XO), "%s: unsupported shape: %lld sources of %lld -> %lld floats", op,
@@ -407,10 +412,10 @@ extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int
   HET_REQUIRE(((uintptr_t)bias & 15) == 0 && ((uintptr_t)out & 15) == 0, "%s: bias / out not 16-byte aligned", op);
   SumArgs a{};
   a.n_begin = n_begin; a.n_end = n_end; a.N = num_nodes; a.S = (int)num_sources; a.order = node_order; a.out = out; a.bias = bias;
-  a.by_pos = node_order && maps_by_position ? 1 : 0;
   for (int s = 0; s < a.S; ++s) {
-    HET_REQUIRE(rows[s] && weights_t[s] && row_strides[s] >= KS && (row_strides[s] & 3) == 0 && ((uintptr_t)rows[s] & 15) == 0,
-                "%s: source %d: null pointer, row stride below the row width, or rows not 16-byte aligned", op, s);
+    HET_REQUIRE(rows[s] && weights_t[s] && row_strides[s] >= KS && (row_strides[s] & 3) == 0 &&
+                    (((uintptr_t)rows[s] | (uintptr_t)weights_t[s]) & 15) == 0,
+                "%s: source %d: null pointer, row stride below the row width, or rows / weight not 16-byte aligned", op, s);
     HET_REQUIRE(maps[s] || (ident_rows[s] >= 0 && ident_rows[s] <= num_nodes), "%s: source %d: neither a map nor a valid identity range", op, s);
     a.rows[s] = rows[s]; a.stride[s] = row_strides[s]; a.map[s] = maps[s]; a.ident_rows[s] = ident_rows[s]; a.wt[s] = weights_t[s];
   }
@@ -424,5 +429,5 @@ extern "C" int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t 
                                         const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS,
                                         int64_t XO, const int32_t* node_order, het_stream stream) {
   return het_node_rows_matmul_sum_bias(n_begin, n_end, num_nodes, num_sources, rows, row_strides, maps, ident_rows, weights_t, nullptr,
-                                       out, KS, XO, node_order, 0, stream);
+                                       out, KS, XO, node_order, stream);
 }

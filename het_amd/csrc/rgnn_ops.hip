@@ -719,8 +719,8 @@ extern "C" int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t
 
 extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
                                       const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
-                                      const int32_t* node_order, int maps_by_position, float* ssum, float* ret, int64_t K,
-                                      int64_t D, het_stream stream) {
+                                      const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D,
+                                      het_stream stream) {
   const char* op = "het_rgcn_layer_forward";
   const het_grouping* g = by_rel_dst;
   HET_REQUIRE(g && g->R == (int)num_rels && g->p0 && g->p1, "%s: needs the grouping by (relation, destination) with payloads (source row, edge id)", op);
@@ -739,13 +739,13 @@ extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t nu
   for (int r = 0; r < (int)num_rels; ++r) {
     rows[r] = ssum; strides[r] = K; maps[r] = dst_map + (int64_t)r * num_nodes; ident[r] = 0; wts[r] = weights + (int64_t)r * K * D;
   }
-  return het_node_rows_matmul_sum_bias(0, num_nodes, num_nodes, num_rels, rows, strides, maps, ident, wts, bias, ret, K, D, node_order, maps_by_position, stream);
+  return het_node_rows_matmul_sum_bias(0, num_nodes, num_nodes, num_rels, rows, strides, maps, ident, wts, bias, ret, K, D, node_order, stream);
 }
 
 extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
                                        int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
                                        const float* norm, const float* gradout, const int32_t* src_map,
-                                       const int32_t* node_order, int maps_by_position, float* grad_x, float* grad_w,
+                                       const int32_t* node_order, float* grad_x, float* grad_w,
                                        float* grad_bias, int64_t K, int64_t D, void* workspace, int64_t workspace_bytes,
                                        het_stream stream) {
   const char* op = "het_rgcn_layer_backward";
@@ -754,7 +754,7 @@ extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het
               "%s: needs the groupings by (relation, source) [payloads: destination row, edge id] and by (relation, destination)", op);
   HET_REQUIRE(rgcn_layer_shape_ok(num_rels, K, D), "%s: unsupported shape (het_rgcn_layer_ok)", op);
   HET_REQUIRE(num_src_nodes >= 0 && num_src_nodes < (1ll << 31) && num_dst_nodes >= gd->key_bound, "%s: bad node count", op);
-  HET_REQUIRE(grad_w && (num_src_nodes == 0 || (ssum && weights_t && norm && gradout && src_map && grad_x)), "%s: null pointer", op);
+  HET_REQUIRE(grad_w && (num_src_nodes == 0 || (ssum && gradout && (!grad_x || (weights_t && norm && src_map)))), "%s: null pointer", op);
   HET_REQUIRE(workspace && workspace_bytes >= het_rgcn_layer_backward_workspace(gs->S, D) &&
               ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gradout) | reinterpret_cast<uintptr_t>(grad_x) |
                 reinterpret_cast<uintptr_t>(ssum)) & 15) == 0, "%s: workspace too small (het_rgcn_layer_backward_workspace) or pointers not 16-byte aligned", op);
@@ -775,15 +775,16 @@ extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het
     if (grad_bias)
       if (int rc = launch_colsum(gradout, num_dst_nodes, (int)D, cpart, grad_bias, fk.side)) return rc;
     // main: gsum[(r,u), :] = SUM over the out-edges of u in relation r of norm * gradout[dst]; grad_x[u] = SUM_r gsum[(r,u)] . Wt[r]
-    if (gs->E > 0)
+    // (grad_x NULL: the layer input needs no gradient -- fixed features -- and the gather pass + node pass are skipped)
+    if (gs->E > 0 && grad_x)
       if (int rc = launch_segment_sum(gs, gradout, gsum, (int)D, norm, s)) return rc;
-    if (num_src_nodes > 0) {
+    if (num_src_nodes > 0 && grad_x) {
       const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
       for (int r = 0; r < (int)num_rels; ++r) {
         rows[r] = gsum; strides[r] = D; maps[r] = src_map + (int64_t)r * num_src_nodes; ident[r] = 0; wts[r] = weights_t + (int64_t)r * D * K;
       }
       if (int rc = het_node_rows_matmul_sum_bias(0, num_src_nodes, num_src_nodes, num_rels, rows, strides, maps, ident, wts, nullptr, grad_x,
-                                                 D, K, node_order, maps_by_position, stream)) return rc;
+                                                 D, K, node_order, stream)) return rc;
     }
     HET_HIP(fk.join());
   }

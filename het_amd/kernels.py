@@ -790,29 +790,14 @@ def node_order_by_presence(row_map, dst_map=None, split=None):
     return _derived_get(("node_order", None if split is None else int(split)), (row_map,) + (() if dst_map is None else (dst_map,)), build)
 
 
-MAPS_BY_POSITION = _os.environ.get("HET_NODE_MAPS_BY_POSITION", "1") != "0"  # A/B: 0 = look the maps up by node id
-
-
-def maps_by_position(node_map, node_order):
-    """node_map[..., node_order] (int32, contiguous; cached by the identity of both): the node -> row map of a node-major pass
-    re-indexed by POSITION of its node list, so that the pass reads it as a coalesced stream -- by node id a sorted list costs
-    one random 4-byte gather per (node, map), which the chip serves at ~36 G / s (1.9 M nodes x 8 maps: 0.4 ms on ogbn-mag)."""
-    return _derived_get("maps_by_pos", (node_map, node_order),
-                        lambda: node_map.index_select(node_map.dim() - 1, node_order.long()).contiguous())
-
-
 def rgat_node_backward_dx(n_begin, n_end, n_loop, grad_h, loop_wt, g_rows, weights_t, row_map, g_er, wa_t, dst_map, grad_x,
                           node_order=None):
     """grad_x rows [n_begin, n_end) of the one-node RGAT layer in one pass over the nodes (include/het_amd.h).  node_order
     (optional, [N] int32): the nodes of the call are the entries [n_begin, n_end) of this list."""
     _chk("rgat_node_backward_dx", tuple(t for t in (grad_h, loop_wt, g_rows, weights_t, g_er, wa_t, grad_x) if t is not None))
     R, H, D, K = weights_t.shape
-    by_pos = int(MAPS_BY_POSITION and node_order is not None)
-    if by_pos:
-        row_map = None if row_map is None else maps_by_position(row_map, node_order)
-        dst_map = None if dst_map is None else maps_by_position(dst_map, node_order)
     _call(grad_x, "het_rgat_node_backward_dx", int(n_begin), int(n_end), int(n_loop), grad_x.shape[0], R, _p(grad_h), _p(loop_wt),
-          _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _p(node_order), by_pos,
+          _p(g_rows), _p(weights_t), _p(row_map), _p(g_er), _p(wa_t), _p(dst_map), _p(grad_x), H, K, D, _p(node_order),
           _stream(grad_x))
 
 
@@ -830,15 +815,13 @@ def node_rows_matmul_sum(n_begin, n_end, sources, out, node_order=None):
     _chk("node_rows_matmul_sum", tuple(t for src in sources for t in (src[0], src[3])) + (out,))
     ptrs = (C.c_void_p * S)(*[src[0].data_ptr() + 4 * int(src[1]) for src in sources])
     strides = (C.c_int64 * S)(*[src[0].shape[1] if src[0].dim() == 2 else src[0].numel() // src[0].shape[0] for src in sources])
-    by_pos = int(MAPS_BY_POSITION and node_order is not None)
-    pmaps = [src[2] if src[2] is None or not by_pos else maps_by_position(src[2], node_order) for src in sources]  # (kept alive below)
-    maps = (C.c_void_p * S)(*[None if m is None else m.data_ptr() for m in pmaps])
+    maps = (C.c_void_p * S)(*[None if src[2] is None else src[2].data_ptr() for src in sources])
     ident = (C.c_int64 * S)(*[min(N, src[0].shape[0]) if src[2] is None else 0 for src in sources])
     wts = (C.c_void_p * S)(*[src[3].data_ptr() for src in sources])
     for src in sources:
         assert src[3].shape == (KS, XO) and src[3].is_contiguous() and (src[2] is None or (src[2].dtype == torch.int32 and src[2].numel() == N))
     _call(out, "het_node_rows_matmul_sum_bias", int(n_begin), int(n_end), N, S, ptrs, strides, maps, ident, wts, None, _p(out), KS, XO,
-          _p(node_order), by_pos, _stream(out))
+          _p(node_order), _stream(out))
 
 
 def rows_linear_bias_ok(K: int, X: int) -> bool:
@@ -1072,7 +1055,7 @@ def _grouping_segment_map(g, rel_ptrs, keys, num_keys: int):
 
 def rgcn_layer_plan(rel_ptrs, eids, row, col, num_nodes: int):
     """What the two-call RGCN layer needs per graph (groupings from het_amd.plan, the rest cached by tensor identity):
-    (by_rel_dst, by_rel_src, dst_map, dst_order, src_map, src_order, maps_by_position), or None without groupings.  The maps come from the
+    (by_rel_dst, by_rel_src, dst_map, dst_order, src_map, src_order), or None without groupings.  The maps come from the
     groupings' own segment lists, so a graph needs no unique (relation, node) lists for this layer."""
     gd = _plan.get_grouping(rel_ptrs, col, num_nodes, row, eids)
     gs = _plan.get_grouping(rel_ptrs, row, num_nodes, col, eids)
@@ -1080,40 +1063,36 @@ def rgcn_layer_plan(rel_ptrs, eids, row, col, num_nodes: int):
         return None
     dst_map = _grouping_segment_map(gd, rel_ptrs, col, num_nodes)
     src_map = _grouping_segment_map(gs, rel_ptrs, row, num_nodes)
-    dst_order, src_order = node_order_by_presence(dst_map), node_order_by_presence(src_map)
-    by_pos = int(MAPS_BY_POSITION)
-    if by_pos:  # (the pass reads the maps by position of its node list: maps_by_position)
-        dst_map, src_map = maps_by_position(dst_map, dst_order), maps_by_position(src_map, src_order)
-    return gd, gs, dst_map, dst_order, src_map, src_order, by_pos
+    return gd, gs, dst_map, node_order_by_presence(dst_map), src_map, node_order_by_presence(src_map)
 
 
 def rgcn_layer_forward(plan, x, weights, norm, bias):
     """(ret [N,D], ssum [S_col,K]) of het_rgcn_layer_forward: ret = bias + SUM_r (SUM_e norm x[src]) . W[r]."""
-    gd, _, dst_map, dst_order, _, _, by_pos = plan
+    gd, _, dst_map, dst_order, _, _ = plan
     _chk("rgcn_layer_forward", tuple(t for t in (x, weights, norm, bias) if t is not None))
     R, K, D = weights.shape
     N = dst_map.shape[1]
     ssum = torch.empty((max(1, gd.num_segments), K), dtype=torch.float32, device=x.device)
     ret = torch.empty((N, D), dtype=torch.float32, device=x.device)
     _call(ret, "het_rgcn_layer_forward", gd.handle, R, N, _p(x), _p(weights), _p(norm), _p(bias), _p(dst_map), _p(dst_order),
-          by_pos, _p(ssum), _p(ret), K, D, _stream(ret))
+          _p(ssum), _p(ret), K, D, _stream(ret))
     return ret, ssum
 
 
-def rgcn_layer_backward(plan, ssum, weights_t, norm, gradout, want_bias: bool):
-    """(grad_x [N,K], grad_w [R,K,D], grad_bias [D] or None) of het_rgcn_layer_backward."""
-    gd, gs, _, _, src_map, src_order, by_pos = plan
+def rgcn_layer_backward(plan, ssum, weights_t, norm, gradout, want_bias: bool, want_x: bool = True):
+    """(grad_x [N,K] or None, grad_w [R,K,D], grad_bias [D] or None) of het_rgcn_layer_backward."""
+    gd, gs, _, _, src_map, src_order = plan
     _chk("rgcn_layer_backward", (ssum, weights_t, norm, gradout))
     R, D, K = weights_t.shape
     N = src_map.shape[1]
     dev = gradout.device
-    grad_x = torch.empty((N, K), dtype=torch.float32, device=dev)
+    grad_x = torch.empty((N, K), dtype=torch.float32, device=dev) if want_x else None
     grad_w = torch.empty((R, K, D), dtype=torch.float32, device=dev)
     grad_bias = torch.empty((D,), dtype=torch.float32, device=dev) if want_bias else None
     nbytes = int(_lib.lib().het_rgcn_layer_backward_workspace(gs.num_segments, D))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     _call(gradout, "het_rgcn_layer_backward", gs.handle, gd.handle, R, N, gradout.shape[0], _p(ssum), _p(weights_t), _p(norm),
-          _p(gradout), _p(src_map), _p(src_order), by_pos, _p(grad_x), _p(grad_w), _p(grad_bias), K, D, _p(ws),
+          _p(gradout), _p(src_map), _p(src_order), _p(grad_x), _p(grad_w), _p(grad_bias), K, D, _p(ws),
           ws.numel() * 4, _stream(gradout))
     return grad_x, grad_w, grad_bias
 

@@ -569,9 +569,6 @@ int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const
  *   node_order [num_nodes] int32 (optional): positions [n_begin, n_end) of this list are the nodes of the call (NULL: node p at
  *   position p).  The kernel multiplies 32-node tiles per relation that has a row in the tile; a list sorted by WHICH relations a
  *   node has rows in makes the tiles homogeneous (no zero rows: 26 % fewer matrix-core instructions on ogbn-mag).
- *   maps_by_position (with a node_order): row_map / dst_map are indexed by POSITION of node_order -- map[r, p] = row of node
- *   node_order[p] -- instead of by node: the lookups of a sorted list are then coalesced streams instead of 2 R random 4-byte
- *   gathers per node (ogbn-mag: the pass alone 0.50 -> see DESIGN.md 4.0).
  *   Shapes: K and H*D in {32, 64}, H in {1,2,4,8}, R*H <= 32, all 1 + R weights resident in LDS (het_rgat_node_gemm_ok);
  *   HET_ERR_INVALID_ARG otherwise -- callers fall back to the per-relation entry points. */
 int het_rgat_node_gemm_ok(int64_t num_rels, int64_t H, int64_t K, int64_t D);
@@ -580,8 +577,7 @@ int het_node_row_map(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* n
 int het_rgat_node_backward_dx(int64_t n_begin, int64_t n_end, int64_t n_loop, int64_t num_nodes, int64_t num_rels,
                               const float* grad_h, const float* loop_wt, const float* g_rows, const float* weights_t,
                               const int32_t* row_map, const float* g_er, const float* wa_t, const int32_t* dst_map,
-                              float* grad_x, int64_t H, int64_t K, int64_t D, const int32_t* node_order, int maps_by_position,
-                              het_stream stream);
+                              float* grad_x, int64_t H, int64_t K, int64_t D, const int32_t* node_order, het_stream stream);
 
 /* Layer-level extension (no reference op of its own): the node-major sum of row x weight products
  *     out[n, :] = SUM_s rows_s[map_s[n], :] . weights_t[s]          n = node_order[p] (or p) for p in [n_begin, n_end)
@@ -600,13 +596,11 @@ int het_node_rows_matmul_sum(int64_t n_begin, int64_t n_end, int64_t num_nodes, 
                              const int64_t* ident_rows, const float* const* weights_t, float* out, int64_t KS, int64_t XO,
                              const int32_t* node_order, het_stream stream);
 
-/* the same with a bias row: out[n, :] = bias[:] + SUM_s ...   (bias [XO] or NULL; a node without any row gets the bias), and
- * with maps_by_position != 0 (needs a node_order) maps indexed by position of node_order: maps[s][p] = row of node node_order[p]
- * (het_rgat_node_backward_dx) */
+/* the same with a bias row: out[n, :] = bias[:] + SUM_s ...   (bias [XO] or NULL; a node without any row gets the bias) */
 int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
                                   const float* const* rows, const int64_t* row_strides, const int32_t* const* maps,
                                   const int64_t* ident_rows, const float* const* weights_t, const float* bias, float* out,
-                                  int64_t KS, int64_t XO, const int32_t* node_order, int maps_by_position, het_stream stream);
+                                  int64_t KS, int64_t XO, const int32_t* node_order, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * The RGCN layer as two calls (layer-level fusion; no reference op of its own).  Inside het_amd/backend/rgcn_layers_and_funcs.py
@@ -621,21 +615,21 @@ int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_no
  *             (grad_w and grad_bias on the library's side stream beside the gather pass; joined before the call returns)
  * by_rel_dst = het_grouping_create(rel_ptrs, R, col, E, N_dst, payload0 = row, payload1 = eids), by_rel_src = the same with row
  * and col exchanged (the groupings of a7 / a8).  dst_map / src_map [R, N] int32: segment of (relation, node) in that grouping =
- * its row in the sorted unique (relation, node) list, -1 = none (het_grouping_segment_map).  node_order / maps_by_position:
- * optional, as in het_rgat_node_backward_dx.  ssum [by_rel_dst segments, K];  weights [R,K,D];  weights_t [R,D,K];  bias / grad_bias [D] or NULL.
+ * its row in the sorted unique (relation, node) list, -1 = none (het_grouping_segment_map).  node_order: optional, as in
+ * het_rgat_node_backward_dx.  ssum [by_rel_dst segments, K];  weights [R,K,D];  weights_t [R,D,K];  bias / grad_bias [D] or NULL.
  * Shapes: K, D in {32, 64}, all R weights resident in LDS (het_rgcn_layer_ok); HET_ERR_INVALID_ARG otherwise -- callers use a7 / a8.
- * workspace: het_rgcn_layer_backward_workspace(segments of by_rel_src, D) bytes, 16-byte aligned. */
+ * workspace: het_rgcn_layer_backward_workspace(segments of by_rel_src, D) bytes, 16-byte aligned.  grad_x NULL: the layer input
+ * needs no gradient (fixed features): only grad_w / grad_bias are formed -- no gather pass. */
 int het_rgcn_layer_ok(int64_t num_rels, int64_t K, int64_t D);
 int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t D);
 int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
                            const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
-                           const int32_t* node_order, int maps_by_position, float* ssum, float* ret, int64_t K, int64_t D,
-                           het_stream stream);
+                           const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D, het_stream stream);
 int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
                             int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
                             const float* norm, const float* gradout, const int32_t* src_map, const int32_t* node_order,
-                            int maps_by_position, float* grad_x, float* grad_w, float* grad_bias, int64_t K, int64_t D,
-                            void* workspace, int64_t workspace_bytes, het_stream stream);
+                            float* grad_x, float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
+                            int64_t workspace_bytes, het_stream stream);
 
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):
  * out[i,:] = x[i,:] . w + bias for rows [offsets[0], offsets[1]) (offsets: device array), w [K,X], bias [X] or NULL.

@@ -261,6 +261,28 @@ def test_rgcn_layer_two_call_form(K, D, R, fused, monkeypatch):
     assert k.rgcn_layer_ok(R, K, D) == (R < 8)
 
 
+def test_rgcn_layer_fixed_input_features():
+    """A layer input that needs no gradient (fixed features): the two-call form skips its gather pass and node pass in the backward
+    (grad_x NULL) -- weight and bias gradients as with the gradient."""
+    from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
+    g = random_graph(seed=510, n=700, r=4, e=9000, shuffle=True)
+    torch.manual_seed(3)
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    layer = HET_EglRelGraphConv_EdgeParallel(64, 64, 4, bias=True).to(DEV)
+    x, norm, go = torch.randn(N, 64, device=DEV), torch.rand(E, 1, device=DEV), torch.randn(N, 64, device=DEV)
+    g.to_(DEV)
+    grads = []
+    for needs in (True, False):
+        layer.zero_grad()
+        xd = x.clone().requires_grad_(needs)
+        layer(g, xd, norm).backward(go)
+        assert (xd.grad is not None) == needs
+        grads.append((layer.weight.grad.clone(), layer.h_bias.grad.clone()))
+    g.cpu_()
+    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-5, atol=1e-5)  # (dW runs beside another launch or alone: same sums)
+    torch.testing.assert_close(grads[0][1], grads[1][1], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("fused_attn,compact,direct", [(False, False, False), (True, False, False), (False, True, False),
                                                        (False, True, True)])
 @pytest.mark.parametrize("H,in_dim,out_dim", [(8, 64, 64), (2, 12, 8), (1, 64, 64), (2, 64, 64), (4, 256, 256), (1, 64, 8), (4, 256, 64)])
