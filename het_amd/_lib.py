@@ -18,6 +18,7 @@ _SIGNATURES = {
     "het_grouping_create": [P, I64, P, I64, I64, P, P, P, C.POINTER(P)],
     "het_grouping_rank_of_position": [P, P, P],
     "het_grouping_segment_map": [P, I64, P, P],
+    "het_grouping_gather_payload1": [P, P, I64, P, P],
     "het_rows_add_bias": [P, P, P, P, I64, I64, P],
     "het_rows_gather": [P, P, I64, I64, P, P],
     "het_rows_scatter_add": [P, P, I64, I64, P, P],
@@ -44,8 +45,8 @@ _SIGNATURES = {
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
     "het_node_rows_matmul_sum": [I64, I64, I64, I64, P, P, P, P, P, P, I64, I64, P, P],
     "het_node_rows_matmul_sum_bias": [I64, I64, I64, I64, P, P, P, P, P, P, P, I64, I64, P, P],
-    "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, P, P, I64, I64, P],
-    "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, P, I64, P],
+    "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, P],
+    "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, P, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
     "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
     "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],

@@ -711,6 +711,11 @@ bool rgcn_layer_shape_ok(int64_t R, int64_t K, int64_t D) {
 }
 }  // namespace
 
+extern "C" int het_grouping_gather_payload1(const het_grouping* g, const float* values, int64_t H, float* out, het_stream stream) {
+  HET_REQUIRE(g && (g->E == 0 || (values && out)) && H >= 1 && H <= 1024, "het_grouping_gather_payload1: bad arguments");
+  return launch_gather_by_p1(g, values, (int)H, out, (hipStream_t)stream);
+}
+
 extern "C" int het_rgcn_layer_ok(int64_t num_rels, int64_t K, int64_t D) { return rgcn_layer_shape_ok(num_rels, K, D) ? 1 : 0; }
 
 extern "C" int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t D) {
@@ -718,22 +723,24 @@ extern "C" int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t
 }
 
 extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
-                                      const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
-                                      const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D,
-                                      het_stream stream) {
+                                      const float* weights, const float* norm, const float* norm_sorted, const float* bias,
+                                      const int32_t* dst_map, const int32_t* node_order, float* ssum, float* ret, int64_t K,
+                                      int64_t D, het_stream stream) {
   const char* op = "het_rgcn_layer_forward";
   const het_grouping* g = by_rel_dst;
   HET_REQUIRE(g && g->R == (int)num_rels && g->p0 && g->p1, "%s: needs the grouping by (relation, destination) with payloads (source row, edge id)", op);
   HET_REQUIRE(rgcn_layer_shape_ok(num_rels, K, D), "%s: unsupported shape (het_rgcn_layer_ok)", op);
   HET_REQUIRE(num_nodes >= 0 && num_nodes < (1ll << 31), "%s: bad node count", op);
   if (num_nodes == 0) return HET_OK;
-  HET_REQUIRE(x && weights && norm && dst_map && ssum && ret, "%s: null pointer", op);
+  HET_REQUIRE(x && weights && (norm || norm_sorted) && dst_map && ssum && ret, "%s: null pointer", op);
   HET_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ssum) | reinterpret_cast<uintptr_t>(ret) |
                 reinterpret_cast<uintptr_t>(bias)) & 15) == 0, "%s: 16-byte aligned pointers expected", op);
   hipStream_t s = (hipStream_t)stream;
   // ssum[(r,v), :] = SUM over the in-edges of v in relation r of norm * x[src]   (one gather pass over x)
+  // (norm_sorted: the norm in the grouping's order, het_grouping_gather_payload1 -- a coalesced stream instead of a random 4-byte
+  //  gather per edge: the forward visits the edges by destination, their ids are scattered)
   if (g->E > 0)
-    if (int rc = launch_segment_sum(g, x, ssum, (int)K, norm, s)) return rc;
+    if (int rc = launch_segment_sum(g, x, ssum, (int)K, norm_sorted ? norm_sorted : norm, s, 0, -1, 0, 0, 0, norm_sorted ? 1 : 0)) return rc;
   // ret[v, :] = bias + SUM_r ssum[(r,v), :] . W[r]: one pass over the nodes, every output row stored once
   const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
   for (int r = 0; r < (int)num_rels; ++r) {
@@ -744,8 +751,8 @@ extern "C" int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t nu
 
 extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
                                        int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
-                                       const float* norm, const float* gradout, const int32_t* src_map,
-                                       const int32_t* node_order, float* grad_x, float* grad_w,
+                                       const float* norm, const float* norm_sorted, const float* gradout,
+                                       const int32_t* src_map, const int32_t* node_order, float* grad_x, float* grad_w,
                                        float* grad_bias, int64_t K, int64_t D, void* workspace, int64_t workspace_bytes,
                                        het_stream stream) {
   const char* op = "het_rgcn_layer_backward";
@@ -754,40 +761,64 @@ extern "C" int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het
               "%s: needs the groupings by (relation, source) [payloads: destination row, edge id] and by (relation, destination)", op);
   HET_REQUIRE(rgcn_layer_shape_ok(num_rels, K, D), "%s: unsupported shape (het_rgcn_layer_ok)", op);
   HET_REQUIRE(num_src_nodes >= 0 && num_src_nodes < (1ll << 31) && num_dst_nodes >= gd->key_bound, "%s: bad node count", op);
-  HET_REQUIRE(grad_w && (num_src_nodes == 0 || (ssum && gradout && (!grad_x || (weights_t && norm && src_map)))), "%s: null pointer", op);
+  HET_REQUIRE(grad_w && (num_src_nodes == 0 || (ssum && gradout && (!grad_x || (weights_t && (norm || norm_sorted) && src_map)))), "%s: null pointer", op);
   HET_REQUIRE(workspace && workspace_bytes >= het_rgcn_layer_backward_workspace(gs->S, D) &&
               ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(gradout) | reinterpret_cast<uintptr_t>(grad_x) |
                 reinterpret_cast<uintptr_t>(ssum)) & 15) == 0, "%s: workspace too small (het_rgcn_layer_backward_workspace) or pointers not 16-byte aligned", op);
   hipStream_t s = (hipStream_t)stream;
   float* gsum = static_cast<float*>(workspace);
   float* cpart = gsum + (gs->S > 0 ? gs->S : 1) * D;
-  {
-    // side stream: grad_w[r] = SUM over the (r, v) rows of ssum[(r,v)]^T (x) gradout[v] (half as many rows as the (relation, source)
-    // form, no second read of x) and the bias gradient -- streams of rows on the matrix cores beside the gather pass below
-    HetFork fk(s);
-    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * K * D, fk.side));
+  // grad_w[r] = SUM over the (r, v) rows of ssum[(r,v)]^T (x) gradout[v] (half as many rows as the (relation, source) form, no second
+  // read of x) and the bias gradient: streams of rows, on the library's side stream beside the node pass (HET_RGCN_BWD_FORK: 0 = on
+  // the caller's stream, 1 = beside the gather pass, 2 = beside the node pass)
+  static const int fork_mode = [] { const char* v = getenv("HET_RGCN_BWD_FORK"); return v ? atoi(v) : 2; }();
+  auto weight_gradients = [&](hipStream_t st) -> int {
+    HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * K * D, st));
     if (gd->S > 0) {
       MfmaDwArgs w;
       w.A = ssum; w.a_ld = K; w.G = gradout; w.g_ld = D; w.g_gather = gd->seg_key64; w.dW = grad_w; w.dw_rel_stride = K * D;
       w.seg_ptrs = gd->seg_rel_ptr64; w.num_segs = (int)num_rels; w.num_rows = gd->S; w.K = (int)K; w.X = (int)D;
-      if (int rc = launch_seg_dw_mfma(w, fk.side)) return rc;
+      if (int rc = launch_seg_dw_mfma(w, st)) return rc;
     }
     if (grad_bias)
-      if (int rc = launch_colsum(gradout, num_dst_nodes, (int)D, cpart, grad_bias, fk.side)) return rc;
-    // main: gsum[(r,u), :] = SUM over the out-edges of u in relation r of norm * gradout[dst]; grad_x[u] = SUM_r gsum[(r,u)] . Wt[r]
-    // (grad_x NULL: the layer input needs no gradient -- fixed features -- and the gather pass + node pass are skipped)
+      if (int rc = launch_colsum(gradout, num_dst_nodes, (int)D, cpart, grad_bias, st)) return rc;
+    return HET_OK;
+  };
+  // gsum[(r,u), :] = SUM over the out-edges of u in relation r of norm * gradout[dst]
+  // (grad_x NULL: the layer input needs no gradient -- fixed features -- and the gather pass + node pass are skipped)
+  auto gather_pass = [&]() -> int {
     if (gs->E > 0 && grad_x)
-      if (int rc = launch_segment_sum(gs, gradout, gsum, (int)D, norm, s)) return rc;
-    if (num_src_nodes > 0 && grad_x) {
-      const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
-      for (int r = 0; r < (int)num_rels; ++r) {
-        rows[r] = gsum; strides[r] = D; maps[r] = src_map + (int64_t)r * num_src_nodes; ident[r] = 0; wts[r] = weights_t + (int64_t)r * D * K;
-      }
-      if (int rc = het_node_rows_matmul_sum_bias(0, num_src_nodes, num_src_nodes, num_rels, rows, strides, maps, ident, wts, nullptr, grad_x,
-                                                 D, K, node_order, stream)) return rc;
+      return launch_segment_sum(gs, gradout, gsum, (int)D, norm_sorted ? norm_sorted : norm, s, 0, -1, 0, 0, 0, norm_sorted ? 1 : 0);
+    return HET_OK;
+  };
+  // grad_x[u] = SUM_r gsum[(r,u)] . Wt[r]
+  auto node_pass = [&]() -> int {
+    if (!(num_src_nodes > 0 && grad_x)) return HET_OK;
+    const float* rows[16]; int64_t strides[16]; const int32_t* maps[16]; int64_t ident[16]; const float* wts[16];
+    for (int r = 0; r < (int)num_rels; ++r) {
+      rows[r] = gsum; strides[r] = D; maps[r] = src_map + (int64_t)r * num_src_nodes; ident[r] = 0; wts[r] = weights_t + (int64_t)r * D * K;
     }
-    HET_HIP(fk.join());
+    return het_node_rows_matmul_sum_bias(0, num_src_nodes, num_src_nodes, num_rels, rows, strides, maps, ident, wts, nullptr, grad_x, D, K,
+                                         node_order, stream);
+  };
+  if (fork_mode == 0 || !grad_x) {
+    if (int rc = weight_gradients(s)) return rc;
+    if (int rc = gather_pass()) return rc;
+    return node_pass();
   }
+  if (fork_mode == 1) {
+    HetFork fk(s);
+    if (int rc = weight_gradients(fk.side)) return rc;
+    if (int rc = gather_pass()) return rc;
+    if (int rc = node_pass()) return rc;
+    HET_HIP(fk.join());
+    return HET_OK;
+  }
+  if (int rc = gather_pass()) return rc;
+  HetFork fk(s);
+  if (int rc = weight_gradients(fk.side)) return rc;
+  if (int rc = node_pass()) return rc;
+  HET_HIP(fk.join());
   return HET_OK;
 }
 

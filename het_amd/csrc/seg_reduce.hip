@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
   for (int u = 0; u < U; ++u) rown[u] = contig ? jn[u] : p_row[jn[u]];
   if (scale) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
+    for (int u = 0; u < U; ++u) sin[u] = p_scale ? p_scale[jn[u]] : jn[u];
   }
   for (int j0 = b; j0 < e; j0 += U) {
     float4 w[U];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum(const int32_t* __restr
     for (int u = 0; u < U; ++u) rown[u] = contig ? jn[u] : p_row[jn[u]];
     if (scale) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) sin[u] = p_scale[jn[u]];
+      for (int u = 0; u < U; ++u) sin[u] = p_scale ? p_scale[jn[u]] : jn[u];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_packed(const int32_t* 
   const int b = (int)pb, e = (int)((uint32_t)pack_ptr[pid + 1] & 0x7fffffffu);
   const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
   int jn = b + q4 < e ? b + q4 : e - 1;
-  int rown = contig ? jn : p_row[jn], segn = seg_of_rank[jn], sin = scale ? p_scale[jn] : 0;
+  int rown = contig ? jn : p_row[jn], segn = seg_of_rank[jn], sin = scale ? (p_scale ? p_scale[jn] : jn) : 0;
   int cur = -1;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   auto flush = [&](int seg) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_packed(const int32_t* 
     jn = j0 + U + q4 < e ? j0 + U + q4 : e - 1;
     rown = contig ? jn : p_row[jn];
     segn = seg_of_rank[jn];
-    if (scale) sin = p_scale[jn];
+    if (scale) sin = p_scale ? p_scale[jn] : jn;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (j0 + u < e) {  // uniform within the lane group
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_long(const int32_t* __
   const int seg = item_seg[item], b = item_begin[item], e = item_end[item];
   const int sld = scale_heads ? scale_heads : 1, sh = scale_heads ? x / (X / scale_heads) : 0;
   int jn = b + slot + q4 * EPW < e ? b + slot + q4 * EPW : e - 1;
-  int rown = contig ? jn : p_row[jn], sin = scale ? p_scale[jn] : 0;
+  int rown = contig ? jn : p_row[jn], sin = scale ? (p_scale ? p_scale[jn] : jn) : 0;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     const int rowv = rown;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_long(const int32_t* __
     for (int u = 0; u < U; ++u) f[u] = ld4(in + (int64_t)ss_bcast_i(rowv, u) * X + x);
     jn = j0 + (U + q4) * EPW < e ? j0 + (U + q4) * EPW : e - 1;
     rown = contig ? jn : p_row[jn];
-    if (scale) sin = p_scale[jn];
+    if (scale) sin = p_scale ? p_scale[jn] : jn;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // (padding edges of the last step: wv is 0 there; the per-lane scales are masked the same way)
@@ -323,8 +323,37 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_flat4(const int32_t* _
 bool segment_sum_supported(int X) { return X >= 4 && X <= 256 && (X & (X - 1)) == 0; }
 bool segment_rows_supported(int X) { return X == 1 || X == 2 || segment_sum_supported(X); }
 
+namespace {
+// out[split_seg[k], :] = 0 (X4 float4 pieces per row)
+__global__ __launch_bounds__(kBlock) void HET_segsum_zero_split(const int32_t* __restrict__ split_seg, int64_t n4, int X4,
+                                                                float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n4) return;
+  const int64_t k = t / X4;
+  reinterpret_cast<float4*>(out)[(int64_t)split_seg[k] * X4 + (t - k * X4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void HET_gather_by_index(const int32_t* __restrict__ idx, const float* __restrict__ in, int64_t n,
+                                                           int H, float* __restrict__ out) {
+  const int64_t total = n * H;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t j = t / H;
+    out[t] = in[(int64_t)idx[j] * H + (t - j * H)];
+  }
+}
+}  // namespace
+
+int launch_gather_by_p1(const het_grouping* g, const float* values, int H, float* out, hipStream_t s) {
+  HET_REQUIRE(g && g->p1 && H >= 1, "gather by payload1: the grouping carries no second payload");
+  if (g->E == 0) return HET_OK;
+  int64_t nb = ceil_div64(g->E * H, 256);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(HET_gather_by_index, dim3((unsigned)nb), dim3(256), 0, s, g->p1, values, g->E, H, out);
+  HET_LAUNCH_CHECK("HET_gather_by_index");
+  return HET_OK;
+}
+
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
-                       int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0, int nt_in) {
+                       int scale_heads, int64_t scatter_rows, int accumulate, int scale_by_p0, int nt_in, int scale_sorted) {
   HET_REQUIRE(segment_rows_supported(X) && g->p0, "segment sum: unsupported shape or grouping");
   if (X < 4) {
     HET_REQUIRE(!scale, "segment sum: rows of fewer than 4 floats take no scale");
@@ -344,16 +373,31 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
   // scatter_rows >= 0: out has that many rows and segment s lands in row seg_key[s] (rows without a
   // segment read zero unless accumulating); otherwise out is dense [S, X]
   const int32_t* out_row = scatter_rows >= 0 ? g->seg_key : nullptr;
+  bool split_rows_zeroed = true;
   if (!accumulate) {
     if (scatter_rows >= 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * scatter_rows * X, s));
-    else if (g->num_split > 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+    else if (g->num_split > 0) split_rows_zeroed = false;  // (below: only the rows the atomics add to)
   }
   if (g->S == 0) return HET_OK;
+  // Dense [S, X] output: every segment that is one work item is STORED; only the segments split over several items are summed
+  // with atomics and need zeros first -- a few thousand rows, not the whole output (ogbn-mag, [2.4 M, 64]: a 0.6 GB fill, 0.1 ms)
+  auto zero_split_rows = [&]() -> int {
+    if (split_rows_zeroed) return HET_OK;
+    split_rows_zeroed = true;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) {
+      HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));
+      return HET_OK;
+    }
+    const int64_t n4 = g->num_split * (X / 4);
+    hipLaunchKernelGGL(HET_segsum_zero_split, dim3((unsigned)ceil_div64(n4, kBlock)), dim3(kBlock), 0, s, g->split_seg, n4, X / 4, out);
+    HET_LAUNCH_CHECK("HET_segsum_zero_split");
+    return HET_OK;
+  };
   static const bool flat_off = [] { const char* v = getenv("HET_SEGSUM_FLAT"); return v && v[0] == '0'; }();  // A/B switch
   if (X == 4 && !scale && scatter_rows < 0 && !accumulate && !nt_in && !flat_off && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     if (int rc = grouping_seg_of_rank(g, s)) return rc;
-    if (g->num_split == 0) HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));  // (done above when segments are split)
+    HET_HIP(hipMemsetAsync(out, 0, sizeof(float) * g->S * X, s));  // (pieces of straddling segments are added atomically)
     constexpr int U = 4;
     HET_KTIME("HET_segment_sum", s);
     hipLaunchKernelGGL(HET_segment_sum_flat4<U>, dim3((unsigned)ceil_div64(g->E, (int64_t)(kBlock / 64) * 64 * U)), dim3(kBlock), 0, s,
@@ -361,7 +405,10 @@ int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X
     HET_LAUNCH_CHECK("HET_segment_sum_flat4");
     return HET_OK;
   }
-  const int32_t* p_scale = (g->p1 && !scale_by_p0) ? g->p1 : g->p0;
+  // scale_sorted: `scale` is already in the grouping's order (scale[j] belongs to sorted rank j: launch_gather_by_p1) -- a
+  // coalesced stream instead of an index load + a random 4-byte gather per edge (NULL index list = the rank itself)
+  if (int rc = zero_split_rows()) return rc;
+  const int32_t* p_scale = scale_sorted ? nullptr : ((g->p1 && !scale_by_p0) ? g->p1 : g->p0);
   const unsigned nb = (unsigned)ceil_div64(g->num_items, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   const int contig = g->p0_contiguous;  // same box: 2.35 -> 2.25 ms for the a2 backward of C3
   HET_KTIME("HET_segment_sum", s);

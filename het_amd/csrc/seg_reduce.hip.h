@@ -14,7 +14,11 @@ bool segment_rows_supported(int X);
 // i.e. out[s, :] = SUM scale[idx(j), :] * in[row(j), :].
 int launch_segment_sum(const het_grouping* g, const float* in, float* out, int X, const float* scale, hipStream_t s,
                        int scale_heads = 0, int64_t scatter_rows = -1, int accumulate = 0, int scale_by_p0 = 0,
-                       int nt_in = 0);  // nt_in: `in` is read once (an [E, X] stream): non-temporal loads
+                       int nt_in = 0,          // nt_in: `in` is read once (an [E, X] stream): non-temporal loads
+                       int scale_sorted = 0);  // `scale` is in the grouping's order: scale[j (* H + h)] belongs to sorted rank j
+// out[j, :] = values[payload1 of rank j, :] (H floats per entry): a per-edge-id scale brought into the grouping's order once, for
+// callers that pass the same scale every step (an edge norm)
+int launch_gather_by_p1(const het_grouping* g, const float* values, int H, float* out, hipStream_t s);
 
 // out[p0[j], :] = in[s, :] for every sorted rank j of segment s; optionally a second, narrower pair (X2 <= X/4 floats)
 int launch_segment_broadcast(const het_grouping* g, const float* in, float* out, int X, const float* in2, float* out2,

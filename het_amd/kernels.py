@@ -1066,6 +1066,31 @@ def rgcn_layer_plan(rel_ptrs, eids, row, col, num_nodes: int):
     return gd, gs, dst_map, node_order_by_presence(dst_map), src_map, node_order_by_presence(src_map)
 
 
+SCALE_SORTED = _os.environ.get("HET_RGCN_NORM_SORTED", "1") != "0"  # A/B: 0 = the norm is gathered by edge id in every pass
+
+
+def scale_in_rank_order(g, values):
+    """``values`` ([E] or [E, H] by edge id) in the order of the grouping ``g`` (whose second payload is the edge id), or None.
+    For a scale that is the same tensor step after step (an edge norm): built at its SECOND sighting -- a scale that changes every
+    step never pays for it -- and kept with the grouping, one per grouping (a new tensor replaces it); the entry holds the source
+    tensor, so its address cannot come back with other contents, and (data_ptr, numel, _version) catches in-place edits."""
+    if not SCALE_SORTED or g is None or values is None:
+        return None
+    ident = _plan._ident(values)
+    with _derived_lock:
+        hit = getattr(g, "_scale_sorted", None)
+        if hit is not None and hit[0] == ident:
+            return hit[2]
+        if getattr(g, "_scale_seen", None) != ident:
+            g._scale_seen, g._scale_sorted = ident, None
+            return None
+        out = torch.empty_like(values, memory_format=torch.contiguous_format)
+        H = values.numel() // max(1, values.shape[0])
+        _call(values, "het_grouping_gather_payload1", g.handle, _p(values), H, _p(out), _stream(values))
+        g._scale_sorted = (ident, values, out)
+        return out
+
+
 def rgcn_layer_forward(plan, x, weights, norm, bias):
     """(ret [N,D], ssum [S_col,K]) of het_rgcn_layer_forward: ret = bias + SUM_r (SUM_e norm x[src]) . W[r]."""
     gd, _, dst_map, dst_order, _, _ = plan
@@ -1074,7 +1099,8 @@ def rgcn_layer_forward(plan, x, weights, norm, bias):
     N = dst_map.shape[1]
     ssum = torch.empty((max(1, gd.num_segments), K), dtype=torch.float32, device=x.device)
     ret = torch.empty((N, D), dtype=torch.float32, device=x.device)
-    _call(ret, "het_rgcn_layer_forward", gd.handle, R, N, _p(x), _p(weights), _p(norm), _p(bias), _p(dst_map), _p(dst_order),
+    _call(ret, "het_rgcn_layer_forward", gd.handle, R, N, _p(x), _p(weights), _p(norm), _p(scale_in_rank_order(gd, norm)), _p(bias),
+          _p(dst_map), _p(dst_order),
           _p(ssum), _p(ret), K, D, _stream(ret))
     return ret, ssum
 
@@ -1092,6 +1118,7 @@ def rgcn_layer_backward(plan, ssum, weights_t, norm, gradout, want_bias: bool, w
     nbytes = int(_lib.lib().het_rgcn_layer_backward_workspace(gs.num_segments, D))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     _call(gradout, "het_rgcn_layer_backward", gs.handle, gd.handle, R, N, gradout.shape[0], _p(ssum), _p(weights_t), _p(norm),
+          _p(scale_in_rank_order(gs, norm) if want_x else None),
           _p(gradout), _p(src_map), _p(src_order), _p(grad_x), _p(grad_w), _p(grad_bias), K, D, _p(ws),
           ws.numel() * 4, _stream(gradout))
     return grad_x, grad_w, grad_bias

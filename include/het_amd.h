@@ -104,6 +104,9 @@ int het_grouping_rank_of_position(const het_grouping* g, int64_t* out, het_strea
  * [R, num_keys] int32, num_keys >= the grouping's key bound.  (Segments are in ascending (relation, key) order: segment s is
  * row s of the sorted unique (relation, key) list of the positions -- het_node_row_map on that list gives the same map.) */
 int het_grouping_segment_map(const het_grouping* g, int64_t num_keys, int32_t* map, het_stream stream);
+/* out[j, :] = values[payload1 of sorted rank j, :] (H floats per entry, [E, H]): per-edge-id values (an edge norm) brought into the
+ * grouping's order once, for callers that pass the same values every step -- the passes then read them as a stream */
+int het_grouping_gather_payload1(const het_grouping* g, const float* values, int64_t H, float* out, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * a1  rgnn_relational_matmul            OpExport/RGNNOps.inc.h:238-295
@@ -616,19 +619,22 @@ int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_no
  * by_rel_dst = het_grouping_create(rel_ptrs, R, col, E, N_dst, payload0 = row, payload1 = eids), by_rel_src = the same with row
  * and col exchanged (the groupings of a7 / a8).  dst_map / src_map [R, N] int32: segment of (relation, node) in that grouping =
  * its row in the sorted unique (relation, node) list, -1 = none (het_grouping_segment_map).  node_order: optional, as in
- * het_rgat_node_backward_dx.  ssum [by_rel_dst segments, K];  weights [R,K,D];  weights_t [R,D,K];  bias / grad_bias [D] or NULL.
+ * het_rgat_node_backward_dx.  norm [E] by edge id, or norm_sorted [E] in the order of the call's gather grouping (by_rel_dst forward,
+ * by_rel_src backward: het_grouping_gather_payload1; ogbn-mag: the forward's gather pass 0.85 -> see DESIGN.md 4.5) -- one of the two
+ * may be NULL.  ssum [by_rel_dst segments, K];  weights [R,K,D];  weights_t [R,D,K];  bias / grad_bias [D] or NULL.
  * Shapes: K, D in {32, 64}, all R weights resident in LDS (het_rgcn_layer_ok); HET_ERR_INVALID_ARG otherwise -- callers use a7 / a8.
  * workspace: het_rgcn_layer_backward_workspace(segments of by_rel_src, D) bytes, 16-byte aligned.  grad_x NULL: the layer input
  * needs no gradient (fixed features): only grad_w / grad_bias are formed -- no gather pass. */
 int het_rgcn_layer_ok(int64_t num_rels, int64_t K, int64_t D);
 int64_t het_rgcn_layer_backward_workspace(int64_t n_src_rows, int64_t D);
 int het_rgcn_layer_forward(const het_grouping* by_rel_dst, int64_t num_rels, int64_t num_nodes, const float* x,
-                           const float* weights, const float* norm, const float* bias, const int32_t* dst_map,
-                           const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D, het_stream stream);
+                           const float* weights, const float* norm, const float* norm_sorted, const float* bias,
+                           const int32_t* dst_map, const int32_t* node_order, float* ssum, float* ret, int64_t K, int64_t D,
+                           het_stream stream);
 int het_rgcn_layer_backward(const het_grouping* by_rel_src, const het_grouping* by_rel_dst, int64_t num_rels,
                             int64_t num_src_nodes, int64_t num_dst_nodes, const float* ssum, const float* weights_t,
-                            const float* norm, const float* gradout, const int32_t* src_map, const int32_t* node_order,
-                            float* grad_x, float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
+                            const float* norm, const float* norm_sorted, const float* gradout, const int32_t* src_map,
+                            const int32_t* node_order, float* grad_x, float* grad_w, float* grad_bias, int64_t K, int64_t D, void* workspace,
                             int64_t workspace_bytes, het_stream stream);
 
 /* self-loop + bias of a layer as one pass (RGAT/models.py:378-381: h + th.matmul(inputs_dst, loop_weight) + h_bias):

@@ -261,6 +261,51 @@ def test_rgcn_layer_two_call_form(K, D, R, fused, monkeypatch):
     assert k.rgcn_layer_ok(R, K, D) == (R < 8)
 
 
+def test_rgcn_layer_norm_in_rank_order():
+    """An edge norm that is the same tensor step after step is brought into the order of each gather grouping at its second
+    sighting (kernels.scale_in_rank_order: the passes read it as a stream): same results as the by-edge-id gather (shuffled
+    eids), an in-place edit of the norm is seen, a new tensor starts over."""
+    import het_amd.kernels as k
+    from het_amd.layers import HET_EglRelGraphConv_EdgeParallel
+    g = random_graph(seed=520, n=900, r=4, e=20000, shuffle=True)
+    torch.manual_seed(4)
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    layer = HET_EglRelGraphConv_EdgeParallel(64, 64, 4, bias=True).to(DEV)
+    x, go = torch.randn(N, 64, device=DEV), torch.randn(N, 64, device=DEV)
+    norm = torch.rand(E, 1, device=DEV)
+    g.to_(DEV)
+    s = g.get_separate_coo_original()
+
+    def step(nrm):
+        layer.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        out = layer(g, xd, nrm)
+        out.backward(go)
+        return out.detach().clone(), xd.grad.clone(), layer.weight.grad.clone()
+
+    def sorted_now():
+        gd = k._plan.get_grouping(s["rel_ptrs"], s["col_indices"], N, s["row_indices"], s["eids"])
+        gs = k._plan.get_grouping(s["rel_ptrs"], s["row_indices"], N, s["col_indices"], s["eids"])
+        return [getattr(q, "_scale_sorted", None) is not None for q in (gd, gs)]
+
+    first = step(norm)
+    assert sorted_now() == [False, False]
+    second = step(norm)
+    assert sorted_now() == [True, True]
+    third = step(norm)
+    for a, b, c in zip(first, second, third):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)  # (the same sums of the same products in the same order)
+        torch.testing.assert_close(a, c, rtol=0, atol=0)
+    norm.mul_(2.0)  # in place: the version counter moves, the sorted copy is stale
+    edited = step(norm)
+    assert sorted_now() == [False, False]
+    fresh = step(norm.clone())
+    for a, b in zip(edited, fresh):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+    torch.testing.assert_close(edited[1], 2.0 * first[1], rtol=1e-5, atol=1e-5)
+    g.cpu_()
+
+
 def test_rgcn_layer_fixed_input_features():
     """A layer input that needs no gradient (fixed features): the two-call form skips its gather pass and node pass in the backward
     (grad_x NULL) -- weight and bias gradients as with the gradient."""
