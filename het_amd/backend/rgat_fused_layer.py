@@ -42,6 +42,9 @@ OVERLAP = os.environ.get("HET_RGAT_OVERLAP", "1") != "0"  # independent launches
 ATTN_GRAD_IN_PASS = os.environ.get("HET_RGAT_ATTN_GRAD_IN_PASS", "1") != "0"  # grad_attn_l from the source-row kernels
 NODE_ORDER = os.environ.get("HET_RGAT_NODE_ORDER", "1") != "0"  # node-major pass over nodes sorted by relation presence
 NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs per node (csrc/node_gemm.hip); 0: per relation
+# A/B: the self-loop weight gradient with the other weight gradients beside the node-major pass instead of at the start of the
+# backward, where it stretches the two short per-destination passes (profiles/r04/default_timeline.txt): 3.97 -> 4.02 ms, kept off
+LOOP_DW_LATE = os.environ.get("HET_RGAT_LOOP_DW_LATE", "0") == "1"
 
 
 def _mulfirst_shape_ok(H, Kd):
@@ -400,7 +403,7 @@ class RgatLayerFunction(th.autograd.Function):
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
         main, side = th.cuda.current_stream(x.device), _side_stream(x.device) if OVERLAP else None
-        if side is not None and ctx.has_loop:
+        if side is not None and ctx.has_loop and not LOOP_DW_LATE:
             # the self-loop weight gradient needs x and grad_h only: an HBM-bound stream of rows beside the gather passes below
             side.wait_stream(main)
             with th.cuda.stream(side):
@@ -424,7 +427,7 @@ class RgatLayerFunction(th.autograd.Function):
             if not attn_in_pass:
                 _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
                                                      accumulate=False)
-            if ctx.has_loop and side is None:
+            if ctx.has_loop and (side is None or LOOP_DW_LATE):
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
             _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
             _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
