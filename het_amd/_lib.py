@@ -48,7 +48,7 @@ _SIGNATURES = {
     "het_rgcn_layer_forward": [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, P],
     "het_rgcn_layer_backward": [P, P, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, P, I64, P],
     "het_rgat_backward_compact": [P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, I64, P],
-    "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, I64, P],
+    "het_rgat_aggregate_compact_runs": [P, P, I64, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, P, P, I64, P, P, P, I64, P],
     "het_rgat_backward_compact_runs": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, DBL, P, P, I64, P],
     "het_hgt_aggregate_compact": [P, P, P, P, P, I64, I64, I64, I64, P, I64, P],
     "het_hgt_backward_compact": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, P, I64, P],

@@ -254,7 +254,9 @@ class RgatLayerFunction(th.autograd.Function):
             run_sums = RUN_SUMS and _k.rgat_runs_shape_ok(H, D)
             grp = _k.rgat_compact_groupings(col, srow, drow, N, featc.shape[0], erc.shape[0], rel_ptrs=rp if run_sums else None,
                                             drow_nodes=ss["node_indices_col"], drow_rel_ptrs=ss["rel_ptrs_col"])
-            ctx.runs = _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h, num_rels=R)
+            # (elc IS <featc, attn_l[relation of the row]>: the pass may form it from the rows it gathers -- kernels.py)
+            ctx.runs = _k.rgat_aggregate_compact(grp, featc, elc, erc, sm, ret, slope, h_inout=h, num_rels=R,
+                                                 attn_l=attn_l.contiguous() if run_sums else None, feat_rel_ptrs=ss["rel_ptrs_row"] if run_sums else None)
             ctx.grp = grp
             ex = x.new_empty(0)
         else:

@@ -585,6 +585,31 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
 //     order, items never cross a run -- partial {O[X], Q[X], max[H], sum[H], q[H]} parked; one wave per hub then finishes
 //     ret / lse and every run of the hub (ref = lse).
 
+// el recomputed from the gathered row instead of gathered itself: el[(r,u),h] = <feat_c[(r,u),h,:], attn_l[r,h,:]> is a function of the
+// row the edge loads anyway, so the forward passes can form it in registers (4 FMAs + two quad shuffles per edge and lane) and drop the
+// per-edge 16-byte gather of el_c -- a 128-byte line of a 38 MB table per edge, a quarter of the lines these passes request (the L2
+// window experiment of DESIGN.md 4.0 left exactly those misses: one per edge).  Needs heads of 16 floats (4 lanes per head: quad DPP)
+// and the relation of the row: rows are relation-major, so r = number of relation boundaries at or below the row id.
+constexpr int kElMaxRels = 8;
+struct ElFold {
+  const float* attn;  // [R, X] attn_l, or NULL: el is gathered
+  int R;
+  int thr[kElMaxRels - 1];  // first feat row of relations 1 .. R-1 (INT_MAX beyond)
+};
+__device__ __forceinline__ int el_relation(const ElFold& f, int srow) {
+  int r = 0;
+#pragma unroll
+  for (int k = 0; k < kElMaxRels - 1; ++k) r += srow >= f.thr[k] ? 1 : 0;
+  return r;
+}
+// sum over the 4 lanes of a quad (every lane gets it)
+__device__ __forceinline__ float quad_sum(float p) {
+  p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
+  p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x4E, 0xf, 0xf, false));  // quad_perm:[2,3,0,1]
+  return p;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
 // one edge joins the running sums of its destination (acc, ssum) and of its run (accq, sq); all relative to the running maximum m
 __device__ __forceinline__ void online_edge(float s, float dl, const float4& f, float& m, float4& acc, float& ssum, float4& accq,
                                             float& sq) {
@@ -598,13 +623,19 @@ __device__ __forceinline__ void online_edge(float s, float dl, const float4& f, 
   sq = fmaf(sq, c, wd);
 }
 
-template <int LPR, int DL>
+template <int LPR, int DL, bool ELR>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, float* __restrict__ lse, float* __restrict__ ret, int H, float slope, float* __restrict__ hio,
-    int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum, float* __restrict__ qref, int hub_min) {
+    int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum, float* __restrict__ qref, int hub_min, ElFold ef) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
+  static_assert(!ELR || DL == 4, "el from the row: heads of 4 lanes");
+  __shared__ float4 al_s[ELR ? kElMaxRels * LPR : 1];  // attn_l[r] as the lanes of a row hold it
+  if (ELR) {
+    for (int i = threadIdx.x; i < ef.R * LPR; i += kBlock) al_s[i] = ld4(ef.attn + (int64_t)i * 4);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
   const int dq = d < U ? d : U - 1;
@@ -620,11 +651,15 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
   float ssum = 0.f, sq = 0.f, m = -INFINITY;
   for (int j0 = b; j0 < e; j0 += U) {
     const int dstv = idn.x, srowv = idn.y, drowv = idn.z;
-    const float zlv = el[(int64_t)srowv * H + h];
+    const float zlv = ELR ? 0.f : el[(int64_t)srowv * H + h];
     const float zrv = er[(int64_t)drowv * H + h];
     float4 f[U];
+    int srq[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) f[q] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, q, lane) * X + x);
+    for (int q = 0; q < U; ++q) {
+      srq[q] = head_bcast_i<DL>(srowv, q, lane);
+      f[q] = ld4(feat + (int64_t)srq[q] * X + x);
+    }
     jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
     idn = kp01[jn];
     const float zv = zlv + zrv, sv = lrelu(zv, slope), dlv = zv > 0.f ? 1.f : slope;
@@ -655,7 +690,12 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
           accq = make_float4(0.f, 0.f, 0.f, 0.f);
           sq = 0.f;
         }
-        online_edge(head_bcast<DL>(sv, q, lane), head_bcast<DL>(dlv, q, lane), f[q], m, acc, ssum, accq, sq);
+        if (ELR) {  // s of the edge from its row: every lane of the head forms it (no broadcast of a gathered term)
+          const float zq = quad_sum(dot4(f[q], al_s[el_relation(ef, srq[q]) * LPR + sub])) + head_bcast<DL>(zrv, q, lane);
+          online_edge(lrelu(zq, slope), zq > 0.f ? 1.f : slope, f[q], m, acc, ssum, accq, sq);
+        } else {
+          online_edge(head_bcast<DL>(sv, q, lane), head_bcast<DL>(dlv, q, lane), f[q], m, acc, ssum, accq, sq);
+        }
       }
     }
   }
@@ -682,13 +722,14 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a
 // Hubs: wave per hub work item of the grouping by (destination, relation) `it` (keys destination * R + relation; same sorted
 // order as the grouping by destination whose packed ids p01 it reads; hub_items: grouping_hub_items -- a wave per item of
 // that grouping with a test for "hub" spent 1.7 ms on 1.3 M early exits).  part[k] = {O[X], Q[X], max[H], sum[H], q[H]}.
-template <int LPR, int DL>
+template <int LPR, int DL, bool ELR>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
     Items it, const int32_t* __restrict__ hub_items, const int32_t* __restrict__ hub_order, int64_t num_hub_items,
     const int2* __restrict__ p01, const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er, int H,
-    float slope, float* __restrict__ part) {
+    float slope, float* __restrict__ part, ElFold ef) {
   constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
   static_assert(DL >= U, "a head needs at least U lanes");
+  static_assert(!ELR || DL == 4, "el from the row: heads of 4 lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
   const int dq = d < U ? d : U - 1;
@@ -702,15 +743,24 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
   int jn = b + slot + dq * EPW < e ? b + slot + dq * EPW : e - 1;
   int2 idn = p01[jn];
   // an item of this grouping lies inside ONE run (one relation, one destination = one er row): its er term is loaded once
-  const float zrv = er[(int64_t)p01[b].y * H + h];
+  const int2 first = p01[b];
+  const float zrv = er[(int64_t)first.y * H + h];
+  // (the item lies in one relation: its attention vector is loaded once)
+  const float4 a4 = ELR ? ld4(ef.attn + (int64_t)el_relation(ef, first.x) * X + x) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     const int srowv = idn.x;
-    const float zlv = el[(int64_t)srowv * H + h];
+    float zlv = ELR ? 0.f : el[(int64_t)srowv * H + h];
     float4 f[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
     idn = p01[jn];
+    if (ELR) {  // el of the lane's own edge (edge dq of the step) from the rows: every lane forms all four, keeps its own
+      float zl[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) zl[u] = quad_sum(dot4(f[u], a4));
+      zlv = dq == 0 ? zl[0] : dq == 1 ? zl[1] : dq == 2 ? zl[2] : zl[3];
+    }
     const float zv = zlv + zrv;
     const float sv = j0 + dq * EPW < e ? lrelu(zv, slope) : -INFINITY;
     {
@@ -1323,7 +1373,8 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
                                                const float* feat_c, const float* el_c, const float* er_c, float* sum, float* ret,
                                                int64_t num_nodes, int64_t H, int64_t D, double slope, float* h_inout,
                                                int64_t h_rows, float* q_rows, float* q_sum, float* q_ref, int64_t num_dst_rows,
-                                               void* workspace, int64_t workspace_bytes, het_stream stream) {
+                                               const float* attn_l, const int64_t* feat_rel_ptrs_host, void* workspace,
+                                               int64_t workspace_bytes, het_stream stream) {
   const char* op = "het_rgat_aggregate_compact_runs";
   hipStream_t s = (hipStream_t)stream;
   HET_REQUIRE(by_dst && by_dst_rel && sum && ret && q_rows && q_sum && q_ref && num_nodes >= 0 && num_rels > 0, "%s: null argument", op);
@@ -1348,15 +1399,35 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
   if (by_dst_rel->num_hub_items > 0)
     if (int rc = grouping_packed_ids(by_dst, false, s)) return rc;
   float* part = static_cast<float*>(workspace);
+  // el from the gathered row (ElFold above): heads of 16 floats, up to 8 relations, the caller names the relation boundaries of the
+  // feat rows (host array [R+1]) and attn_l [R, H*D]; otherwise (or HET_RGAT_EL_FROM_ROW=0) el_c is gathered per edge
+  static const bool el_from_row = [] { const char* v = getenv("HET_RGAT_EL_FROM_ROW"); return !(v && v[0] == '0'); }();
+  ElFold ef{};
+  const bool elr = el_from_row && attn_l && feat_rel_ptrs_host && D == 16 && num_rels <= kElMaxRels &&
+                   (reinterpret_cast<uintptr_t>(attn_l) & 15) == 0;
+  if (elr) {
+    ef.attn = attn_l; ef.R = (int)num_rels;
+    for (int k = 0; k < kElMaxRels - 1; ++k)
+      ef.thr[k] = k + 1 < num_rels && feat_rel_ptrs_host[k + 1] < 0x7fffffffll ? (int)feat_rel_ptrs_host[k + 1] : 0x7fffffff;
+  }
   HetFork fk(s);  // the hub launches beside the pack-form one: disjoint destinations, both bound by gather latency
   {
     HET_KTIME("HET_rgat_aggregate_packs", s);
     Packs pk{by_dst->pack_ptr, by_dst->key_of_rank, by_dst->num_packs};
     const unsigned nb = (unsigned)ceil_div64(by_dst->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
-    HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                      hipLaunchKernelGGL((HET_rgat_aggregate_runs_packed<LPR, DL>), dim3(nb), dim3(kBlock), 0, s, pk, by_dst->kp01,
-                                         feat_c, el_c, er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows, q_rows, q_sum, q_ref,
-                                         rgat_hub_min()));
+#define HET_PACKS_LAUNCH(ELRV)                                                                                                     \
+  hipLaunchKernelGGL((HET_rgat_aggregate_runs_packed<LPR, DL, ELRV>), dim3(nb), dim3(kBlock), 0, s, pk, by_dst->kp01, feat_c, el_c, \
+                     er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows, q_rows, q_sum, q_ref, rgat_hub_min(), ef)
+    if (elr) {
+      switch (X / 4) {
+        case 8: { constexpr int LPR = 8, DL = 4; HET_PACKS_LAUNCH(true); break; }
+        case 16: { constexpr int LPR = 16, DL = 4; HET_PACKS_LAUNCH(true); break; }
+        default: { constexpr int LPR = 32, DL = 4; HET_PACKS_LAUNCH(true); break; }
+      }
+    } else {
+      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4), HET_PACKS_LAUNCH(false));
+    }
+#undef HET_PACKS_LAUNCH
   }
   HET_LAUNCH_CHECK("HET_rgat_aggregate_runs_packed");
   if (by_dst_rel->num_hub_items > 0) {
@@ -1367,10 +1438,20 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
     {
       HET_KTIME("HET_rgat_aggregate_hubs", s2);
       const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
-      HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
-                        hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL>), dim3(nbh), dim3(kBlock), 0, s2, it,
-                                           by_dst_rel->hub_items, hub_in_row_order() ? by_dst_rel->hub_order : nullptr, n_hub, by_dst->p01,
-                                           feat_c, el_c, er_c, (int)H, (float)slope, part));
+#define HET_HUBS_LAUNCH(ELRV)                                                                                                  \
+  hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL, ELRV>), dim3(nbh), dim3(kBlock), 0, s2, it, by_dst_rel->hub_items,     \
+                     hub_in_row_order() ? by_dst_rel->hub_order : nullptr, n_hub, by_dst->p01, feat_c, el_c, er_c, (int)H,         \
+                     (float)slope, part, ef)
+      if (elr) {
+        switch (X / 4) {
+          case 8: { constexpr int LPR = 8, DL = 4; HET_HUBS_LAUNCH(true); break; }
+          case 16: { constexpr int LPR = 16, DL = 4; HET_HUBS_LAUNCH(true); break; }
+          default: { constexpr int LPR = 32, DL = 4; HET_HUBS_LAUNCH(true); break; }
+        }
+      } else {
+        HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4), HET_HUBS_LAUNCH(false));
+      }
+#undef HET_HUBS_LAUNCH
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
     const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);

@@ -327,8 +327,10 @@ int launch_sum_w16(const SumArgs& a, hipStream_t s, bool* done) {
   const size_t limit = 160 * 1024, wbytes = sizeof(float) * (size_t)a.S * KS * XO, per_wave = sizeof(float) * 32 * 36;
   *done = false;
   if (wbytes + 8 * per_wave > limit) return HET_OK;  // fewer than 8 waves: the tile form above does as well
+  // (HET_NODE_SUM_WAVES: A/B -- 16 waves of 128 VGPRs are a CU's whole register file, nothing runs beside such a workgroup)
+  static const int max_waves = [] { const char* v = getenv("HET_NODE_SUM_WAVES"); const int w = v ? atoi(v) : 16; return w < 4 ? 4 : (w > 16 ? 16 : w); }();
   int waves = (int)((limit - wbytes) / per_wave);
-  if (waves > 16) waves = 16;
+  if (waves > max_waves) waves = max_waves;
   const int64_t tiles = (a.n_end - a.n_begin + 31) / 32;
   int64_t gx = (tiles + waves - 1) / waves;
   const int64_t cus = het_num_cus();

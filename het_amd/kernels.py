@@ -705,11 +705,13 @@ def rgat_compact_groupings(col, srow, drow, num_nodes, num_src_rows, num_dst_row
     return by_dst, by_srow, by_drow, None
 
 
-def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None, num_rels=None):
+def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_inout=None, num_rels=None, attn_l=None,
+                           feat_rel_ptrs=None):
     """h_inout [rows, H*D] (optional): ret's rows are also added into it in place (include/het_amd.h).  ``sum`` receives the
     log-sum-exp of every (destination, head) -- these two entry points subtract a running maximum (no overflow for any el + er).
     Groupings in the run-sum form (rgat_compact_groupings with rel_ptrs; ``num_rels`` required): returns (q_rows, q_sum, q_ref)
-    for rgat_backward_compact."""
+    for rgat_backward_compact.  attn_l [R,H,D] + feat_rel_ptrs [R+1] (relation pointers of the feat rows), run-sum form: el_c is
+    <feat_c, attn_l[relation of the row]> and the pass may form it from the rows it gathers (include/het_amd.h)."""
     _chk("rgat_aggregate_compact", tuple(t for t in (feat_c, el_c, er_c, sum, ret, h_inout) if t is not None))
     N, H = sum.shape[0], sum.shape[1]
     D = ret.numel() // max(1, N * H)
@@ -723,9 +725,16 @@ def rgat_aggregate_compact(groupings, feat_c, el_c, er_c, sum, ret, slope, h_ino
         if nbytes < 0:
             raise _lib.HetError("het_rgat_aggregate_compact_runs_workspace: " + _lib.lib().het_last_error().decode())
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device) if nbytes else None
+        host_ptrs = None
+        if attn_l is not None and feat_rel_ptrs is not None:
+            _chk("rgat_aggregate_compact", (attn_l,), (feat_rel_ptrs,))
+            # (the relation boundaries as host integers: one device read per list, cached by its identity)
+            lst = _derived_get("rel_ptrs_host", (feat_rel_ptrs,), lambda: feat_rel_ptrs.tolist())
+            host_ptrs = (C.c_int64 * len(lst))(*lst)
         _call(ret, "het_rgat_aggregate_compact_runs", groupings[0].handle, groupings[3].handle, int(num_rels), _p(feat_c), _p(el_c),
               _p(er_c), _p(sum), _p(ret), N, H, D, float(slope), _p(h_inout), 0 if h_inout is None else h_inout.shape[0],
-              _p(q_rows), _p(q_sum), _p(q_ref), S_col, _p(ws), nbytes, _stream(ret))
+              _p(q_rows), _p(q_sum), _p(q_ref), S_col, _p(attn_l) if host_ptrs is not None else None, host_ptrs, _p(ws), nbytes,
+              _stream(ret))
         return q_rows, q_sum, q_ref
     nbytes = int(_lib.lib().het_rgat_aggregate_compact_workspace(groupings[0].handle, H, D))  # (hub destinations only)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=ret.device) if nbytes else None

@@ -517,6 +517,10 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
  *     sorted order as by_dst when the positions are relation-major (a separate-COO list); its work items never cross a run.
  *   q_rows [S_col,H,D], q_sum / q_ref [S_col,H]: written by the forward, read by the backward.  drow_nodes [S_col] int64:
  *     destination node of every er row.  Shapes: rows of 32 / 64 / 128 floats with heads of >= 16 (else HET_ERR_UNSUPPORTED).
+ *   attn_l [R,H,D] + feat_rel_ptrs_host (HOST array [R+1]: first feat row of every relation; feat rows are relation-major) --
+ *     optional, both or neither: when el_c IS <feat_c[row,h,:], attn_l[relation of the row,h,:]> (the layer's case) the pass forms it
+ *     from the row it gathers anyway instead of gathering el_c per edge (heads of 16 floats, up to 8 relations; el_c is still read
+ *     by the other shapes and by the backward).
  *   workspaces: het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream) -- one record per work item of
  *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel and
  *     rebuilt if it is later used with another by_dst object); -1 on error;  het_rgat_backward_compact_runs_workspace (below) */
@@ -525,8 +529,8 @@ int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, co
 int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
                                     const float* feat_c, const float* el_c, const float* er_c, float* sum, float* ret,
                                     int64_t num_nodes, int64_t H, int64_t D, double slope, float* h_inout, int64_t h_rows,
-                                    float* q_rows, float* q_sum, float* q_ref, int64_t num_dst_rows, void* workspace,
-                                    int64_t workspace_bytes, het_stream stream);
+                                    float* q_rows, float* q_sum, float* q_ref, int64_t num_dst_rows, const float* attn_l,
+                                    const int64_t* feat_rel_ptrs_host, void* workspace, int64_t workspace_bytes, het_stream stream);
 int het_rgat_backward_compact_runs(const het_grouping* by_srow, const float* q_rows, const float* q_sum, const float* q_ref,
                                    const int64_t* drow_nodes, const float* feat_c, const float* el_c, const float* er_c,
                                    const float* sum, const float* ret, const float* gradout, float* grad_feat_c,

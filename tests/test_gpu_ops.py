@@ -379,6 +379,21 @@ def test_rgat_compact_run_sums(K, H, D, n, e, fold, bias):
     sc = torch.exp(runs[2].double().cpu())
     assert_close(runs[1].double().cpu() * sc, q_ref, what="q_sum")
     assert_close(runs[0].double().cpu() * sc.unsqueeze(-1), Q_ref, what="q_rows")
+    if D == 16:
+        # el_c that IS <feat_c, attn_l[relation of the row]> (the layer's case): with attn_l and the relation pointers of the rows the
+        # pass forms it from the rows it gathers -- the el_c handed over is not read (NaN here) -- same sums as the gathered form
+        rel_of_row_ = torch.repeat_interleave(torch.arange(R), ss["rel_ptrs_row"][1:] - ss["rel_ptrs_row"][:-1])
+        el2 = (feat * attn[rel_of_row_]).sum(-1).contiguous()
+        smA, retA = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
+        runsA = k.rgat_aggregate_compact(grp, f, el2.to(DEV), r_, smA, retA, slope, num_rels=R)
+        smB, retB = torch.full((N, H), 7.0, device=DEV), torch.full((N, H, D), 7.0, device=DEV)
+        runsB = k.rgat_aggregate_compact(grp, f, torch.full_like(l, float("nan")), r_, smB, retB, slope, num_rels=R,
+                                         attn_l=attn.to(DEV), feat_rel_ptrs=ss["rel_ptrs_row"].to(DEV))
+        assert_close(retB, retA.double().cpu(), what="ret (el from the row)")
+        assert_close(smB, smA.double().cpu(), what="lse (el from the row)")
+        scA, scB = torch.exp(runsA[2].double().cpu()), torch.exp(runsB[2].double().cpu())
+        assert_close(runsB[1].double().cpu() * scB, runsA[1].double().cpu() * scA, what="q_sum (el from the row)")
+        assert_close(runsB[0].double().cpu() * scB.unsqueeze(-1), runsA[0].double().cpu() * scA.unsqueeze(-1), what="q_rows (el from the row)")
     nh = N - 2
     h0 = torch.randn(nh, H * D, generator=gen)
     hio, ret2, sm2 = h0.to(DEV), torch.full((N, H, D), 7.0, device=DEV), torch.full((N, H), 7.0, device=DEV)
