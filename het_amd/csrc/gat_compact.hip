@@ -1351,7 +1351,7 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
 static int rgat_hub_min() {
   static const int v = [] {
     const char* e = getenv("HET_RGAT_HUB_MIN");
-    const int t = e ? atoi(e) : 256;
+    const int t = e ? atoi(e) : 128;  // (256 until el came from the row: the hub launch gained more from that than the pack-form one)
     return t < HET_PACK_T ? HET_PACK_T : t;
   }();
   return v;

@@ -522,7 +522,7 @@ int het_rgat_backward_compact(const het_grouping* by_srow, const het_grouping* b
  *     from the row it gathers anyway instead of gathering el_c per edge (heads of 16 floats, up to 8 relations; el_c is still read
  *     by the other shapes and by the backward).
  *   workspaces: het_rgat_aggregate_compact_runs_workspace(by_dst, by_dst_rel, num_rels, H, D, stream) -- one record per work item of
- *     a destination with more than 256 in-edges; the first call lists those items on `stream` (kept with by_dst_rel and
+ *     a destination with more than 128 in-edges (HET_RGAT_HUB_MIN); the first call lists those items on `stream` (kept with by_dst_rel and
  *     rebuilt if it is later used with another by_dst object); -1 on error;  het_rgat_backward_compact_runs_workspace (below) */
 int64_t het_rgat_aggregate_compact_runs_workspace(const het_grouping* by_dst, const het_grouping* by_dst_rel, int64_t num_rels,
                                                   int64_t H, int64_t D, het_stream stream);
