@@ -1080,3 +1080,54 @@ def test_rgat_node_backward_dx(K, H, Kd, D, R, with_loop, with_er, typed):
     k.rgat_node_backward_dx(0, N, n_loop, *args, out, node_order=perm)
     assert_close(out, gx, what="grad_x (random node order)")
 
+
+
+@pytest.mark.parametrize("R,n,e", [(4, 300, 5000), (1, 50, 400), (6, 2000, 3000)])
+def test_grouping_segment_map_and_payload_gather(R, n, e):
+    """het_grouping_segment_map (segment of every (relation, key) pair, -1 where there is none) and het_grouping_gather_payload1
+    (per-edge-id values in the grouping's order) against their definitions; het_node_rows_matmul_sum_bias with a bias row and
+    sources of 32 / 64 floats against the per-source products in fp64 (nodes without any row get the bias)."""
+    import het_amd.kernels as k
+    g = random_graph(seed=71, n=n, r=R, e=e, shuffle=True, empty_rel=R > 2)
+    s = {kk: v.to(DEV) for kk, v in g.get_separate_coo_original().items()}
+    N, E = g.get_num_nodes(), g.get_num_edges()
+    grp = k._plan.get_grouping(s["rel_ptrs"], s["col_indices"], N, s["row_indices"], s["eids"])
+    m = k._grouping_segment_map(grp, s["rel_ptrs"], s["col_indices"], N).cpu()
+    rel = torch.repeat_interleave(torch.arange(R), (s["rel_ptrs"][1:] - s["rel_ptrs"][:-1]).cpu())
+    pairs = torch.unique(rel * N + s["col_indices"].cpu())  # sorted: segment s is the s-th distinct (relation, key) pair
+    ref = torch.full((R, N), -1, dtype=torch.int32)
+    ref.view(-1)[pairs] = torch.arange(pairs.numel(), dtype=torch.int32)
+    assert grp.num_segments == pairs.numel() and torch.equal(m, ref)
+    # values by edge id -> grouping order: rank j holds the value of the edge at sorted rank j
+    vals = torch.rand(E, 1, device=DEV)
+    out = torch.empty_like(vals)
+    k._call(vals, "het_grouping_gather_payload1", grp.handle, k._p(vals), 1, k._p(out), k._stream(vals))
+    rank = torch.empty(E, dtype=torch.int64, device=DEV)
+    k._call(rank, "het_grouping_rank_of_position", grp.handle, k._p(rank), k._stream(rank))
+    want = torch.empty_like(vals)
+    want[rank] = vals[s["eids"]]  # position p sits at rank[p]; its edge id is eids[p]
+    assert torch.equal(out, want)
+    # node-major sum with a bias row
+    for KS, XO in ((64, 64), (32, 64), (64, 32), (32, 32)):
+        S = min(R, 3)
+        gen = torch.Generator().manual_seed(5)
+        rows = [torch.randn(pairs.numel() + 1, KS, generator=gen) for _ in range(S)]
+        wts = [torch.randn(KS, XO, generator=gen) * 0.2 for _ in range(S)]
+        bias = torch.randn(XO, generator=gen)
+        maps = [ref[r_].clone() for r_ in range(S)]
+        want = bias.double().expand(N, XO).clone()
+        for r_ in range(S):
+            has = maps[r_] >= 0
+            want[has] += rows[r_].double()[maps[r_][has].long()] @ wts[r_].double()
+        outn = torch.full((N, XO), float("nan"), device=DEV)
+        order = torch.randperm(N, generator=gen).to(torch.int32).to(DEV)
+        srcs = [(rows[r_].to(DEV), 0, maps[r_].to(DEV), wts[r_].to(DEV)) for r_ in range(S)]
+        ptrs = (k.C.c_void_p * S)(*[t[0].data_ptr() for t in srcs])
+        strides = (k.C.c_int64 * S)(*[KS] * S)
+        mps = (k.C.c_void_p * S)(*[t[2].data_ptr() for t in srcs])
+        ident = (k.C.c_int64 * S)(*[0] * S)
+        w_ = (k.C.c_void_p * S)(*[t[3].data_ptr() for t in srcs])
+        b_ = bias.to(DEV)
+        k._call(outn, "het_node_rows_matmul_sum_bias", 0, N, N, S, ptrs, strides, mps, ident, w_, k._p(b_), k._p(outn), KS, XO, k._p(order),
+                k._stream(outn))
+        assert_close(outn, want, what=f"node sum + bias {KS}->{XO}")
