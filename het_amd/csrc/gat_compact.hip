@@ -1357,6 +1357,19 @@ static int rgat_hub_min() {
   return v;
 }
 
+// Short / long threshold of the backward's (relation, source) segments: up to this many edges a segment is walked by one lane group
+// inside a pack, longer ones are wave-per-item work.  64 instead of the library-wide HET_PACK_T = 32 (exp: the whole library built
+// with 16 / 32 / 64: RGAT 3.98 / 3.97 / 3.79 ms per step -- the backward op 1.57 -> 1.44 -- while RGCN's and HGT's segment sums
+// lose 1-2 % at 64, so only this grouping asks for it).
+static int rgat_bwd_pack_t() {
+  static const int v = [] {
+    const char* e = getenv("HET_RGAT_BWD_PACK_T");
+    const int t = e ? atoi(e) : 64;
+    return t < 8 ? 8 : (t > 256 ? 256 : t);
+  }();
+  return v;
+}
+
 static bool hub_in_row_order() {
   static const bool on = [] { const char* e = getenv("HET_RGAT_HUB_ORDER"); return !(e && e[0] == '0'); }();  // A/B switch
   return on;
@@ -1507,7 +1520,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   const bool coop = coop_shape_ok(H, D);
   HET_REQUIRE(!grad_attn_l || (coop && fold_attn_l && num_rels <= 8), "%s: grad_attn_l needs the cooperative shapes, fold_attn_l and <= 8 relations", op);
   if (grad_attn_l && E > 0)
-    if (int rc = grouping_packs(by_srow, s)) return rc;  // (the partial rows are counted in workgroups of the two launches)
+    if (int rc = grouping_packs(by_srow, s, rgat_bwd_pack_t())) return rc;  // (the partial rows are counted in workgroups of the two launches)
   constexpr int kBiasBlocks = 2048;
   const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
   const int64_t ga_rows = (grad_attn_l && E > 0) ? attn_grad_partial_rows(by_srow, X) : 0, n_ga = (ga_rows * (X + 1) + 3) / 4 * 4;
@@ -1548,7 +1561,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     HET_HIP(hipMemsetAsync(grad_er_c, 0, sizeof(float) * num_dst_rows * H, s));
     return HET_OK;
   }
-  if (int rc = grouping_packs(by_srow, s)) return rc;
+  if (int rc = grouping_packs(by_srow, s, rgat_bwd_pack_t())) return rc;
   Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   if (use_rec) {  // before the fork: both source-row launches read the records
@@ -1689,7 +1702,7 @@ extern "C" int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* 
   int64_t bytes = het_rgat_backward_compact_workspace(num_nodes, 0, H, D, with_bias);
   if (coop_shape_ok(H, D)) bytes += (int64_t)sizeof(float) * num_dst_rows * H * 4;  // the per-(er row, head) records
   if (with_attn_grad && by_srow->E > 0) {
-    if (grouping_packs(by_srow, (hipStream_t)stream) != HET_OK) return -1;
+    if (grouping_packs(by_srow, (hipStream_t)stream, rgat_bwd_pack_t()) != HET_OK) return -1;
     bytes += (int64_t)sizeof(float) * ((attn_grad_partial_rows(by_srow, H * D) * (H * D + 1) + 3) / 4 * 4);
   }
   return bytes;

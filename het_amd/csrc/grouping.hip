@@ -83,10 +83,10 @@ __global__ void HET_grouping_rank_of_position(const int32_t* __restrict__ perm, 
 // one is a pack of its own, flagged (its work goes to the wave-per-item kernels through long_items).  Every flag lies
 // inside the writing segment's own range: no races.
 __global__ void HET_grouping_long_items(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ item_seg,
-                                        int64_t num_items, uint8_t* __restrict__ is_long) {
+                                        int64_t num_items, uint8_t* __restrict__ is_long, int pack_t) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < num_items; t += (int64_t)gridDim.x * blockDim.x) {
     const int32_t s = item_seg[t];
-    is_long[t] = seg_ptr[s + 1] - seg_ptr[s] > HET_PACK_T;
+    is_long[t] = seg_ptr[s + 1] - seg_ptr[s] > pack_t;
   }
 }
 
@@ -123,16 +123,16 @@ __global__ void HET_grouping_long_seg_flags(const int32_t* __restrict__ seg_ptr,
     flag[s] = seg_ptr[s + 1] - seg_ptr[s] > min_len;
 }
 
-__global__ void HET_grouping_pack_flags(const int32_t* __restrict__ seg_ptr, int64_t S, uint8_t* __restrict__ flag) {
+__global__ void HET_grouping_pack_flags(const int32_t* __restrict__ seg_ptr, int64_t S, uint8_t* __restrict__ flag, int pack_t) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x) {
     const int32_t b = seg_ptr[s], e = seg_ptr[s + 1];
-    const bool lng = e - b > HET_PACK_T;
+    const bool lng = e - b > pack_t;
     if (lng) {
       flag[b] = 2;
     } else if (e > b) {
       const int32_t pb = s > 0 ? seg_ptr[s - 1] : -1;
-      const bool prev_long = s > 0 && b - pb > HET_PACK_T;
-      if (s == 0 || prev_long || b / HET_PACK_T != pb / HET_PACK_T) flag[b] = 1;
+      const bool prev_long = s > 0 && b - pb > pack_t;
+      if (s == 0 || prev_long || b / pack_t != pb / pack_t) flag[b] = 1;
     }
   }
 }
@@ -362,9 +362,10 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
 
 static std::mutex g_pack_mu;
 
-int grouping_packs(const het_grouping* g, hipStream_t s) {
+int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
   std::lock_guard<std::mutex> lk(g_pack_mu);
   if (g->pack_ptr || g->E == 0 || g->S == 0) return HET_OK;
+  if (pack_t > 0) g->pack_t = pack_t;
   const int64_t E = g->E, S = g->S;
   if (int rc = grouping_seg_of_rank(g, s)) return rc;
   Scratch tmp(s);
@@ -375,9 +376,9 @@ int grouping_packs(const het_grouping* g, hipStream_t s) {
   HET_HIP(tmp.alloc((void**)&is_long, (size_t)NI));
   HET_HIP(tmp.alloc((void**)&d_num, sizeof(int32_t) * 2));
   HET_HIP(hipMemsetAsync(flag, 0, (size_t)E, s));
-  hipLaunchKernelGGL(HET_grouping_pack_flags, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, S, flag);
+  hipLaunchKernelGGL(HET_grouping_pack_flags, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, S, flag, g->pack_t);
   HET_LAUNCH_CHECK("HET_grouping_pack_flags");
-  hipLaunchKernelGGL(HET_grouping_long_items, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->item_seg, NI, is_long);
+  hipLaunchKernelGGL(HET_grouping_long_items, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->item_seg, NI, is_long, g->pack_t);
   HET_LAUNCH_CHECK("HET_grouping_long_items");
   int32_t *pack_tmp = nullptr, *long_tmp = nullptr;
   HET_HIP(tmp.alloc((void**)&pack_tmp, sizeof(int32_t) * (size_t)(E + 1)));

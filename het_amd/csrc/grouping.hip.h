@@ -40,6 +40,8 @@ struct het_grouping {
   mutable int32_t* key_of_rank = nullptr;  // [E+1] seg_key of the segment of rank j; sentinel -1 at E
   mutable int32_t* long_items = nullptr;   // [num_long_items] work items of segments with more than HET_PACK_T positions
   mutable int64_t num_packs = 0, num_long_items = 0;
+  mutable int pack_t = 32;                 // segments of more than pack_t positions are "long" (HET_PACK_T unless the first user of the
+                                           // packs asks otherwise: grouping_packs)
   // Packed ids (grouping_packed_ids): one vector load per edge instead of one per list -- the gather passes are bound by the
   // number of their vector-memory instructions.
   mutable int2* p01 = nullptr;    // [E]   {p0[j], p1[j]}
@@ -58,7 +60,8 @@ struct het_grouping {
 
 constexpr int HET_PACK_T = 32;
 // Builds g->pack_ptr / key_of_rank / long_seg once (thread-safe; synchronises `s` before publishing them).
-int grouping_packs(const het_grouping* g, hipStream_t s);
+// pack_t > 0: the short / long threshold, honoured by the call that BUILDS the packs (later calls get the packs that exist).
+int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t = 0);
 // Builds g->p01 (with_keys == false) or g->kp01 (true; builds the packs first) once, thread-safe, published after a sync.
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s);
 // Builds g_rel->hub_items once (thread-safe, published after a sync): g_rel groups the same positions as `twin` by
