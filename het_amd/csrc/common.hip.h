@@ -174,6 +174,36 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(t, reinterpret_cast<het_f4v*>(p));
 }
 
+// ---- byte offsets off a wave-uniform base --------------------------------------------------------------------------------
+// A gather written as base[row * X + x] with a 64-bit row costs three VALU instructions per address (sign extension, 64-bit shift,
+// 64-bit add: v_ashrrev_i32 + v_lshlrev_b64 + v_lshl_add_u64) and a VGPR pair; a table below 4 GiB addressed by an unsigned 32-bit
+// BYTE offset costs one (v_lshl_or_b32) and the load takes the base from scalar registers (global_load_dwordx4 v, v_off, s[base:+1]).
+// The gather kernels are bound by their instruction streams, so their row kernels take the offset type as a
+// template argument: uint32_t when the host has checked every table they index, uint64_t otherwise.
+template <typename O>
+__device__ __forceinline__ float4 ld4_at(const float* base, O byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename O>
+__device__ __forceinline__ float2 ld2_at(const float* base, O byte_off) {
+  return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename O>
+__device__ __forceinline__ float ld1_at(const float* base, O byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename O>
+__device__ __forceinline__ void st4_at(float* base, O byte_off, float4 v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+template <typename O>
+__device__ __forceinline__ void st1_at(float* base, O byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+constexpr int het_log2_ce(int v) { return v <= 1 ? 0 : 1 + het_log2_ce(v >> 1); }
+// rows * row_bytes fits an unsigned 32-bit byte offset (with room for the lane's piece of the row)
+static inline bool het_fits_u32(int64_t rows, int64_t row_bytes) { return rows >= 0 && rows * row_bytes <= 0xffffffffll - 4096; }
+
 __device__ __forceinline__ float leaky_exp(float z, float slope) {
   // gatLeakyReluExp, DGLHackKernel/GAT/FusedGAT.cu.h:23-26.
   // The grouped backward recovers the leaky-ReLU branch from the stored value (slope >= 0: z > 0 <=> exp(..) > 1).  For

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_coop(Items it, cons
 // row the edge loads anyway, so the forward passes can form it in registers (4 FMAs + two quad shuffles per edge and lane) and drop the
 // per-edge 16-byte gather of el_c -- a 128-byte line of a 38 MB table per edge, a quarter of the lines these passes request (the L2
 // window experiment of DESIGN.md 4.0 left exactly those misses: one per edge).  Needs heads of 16 floats (4 lanes per head: quad DPP)
-// and the relation of the row: rows are relation-major, so r = number of relation boundaries at or below the row id.
+// and the relation of the row: rows are relation-major, so r = number of relation boundaries at or below the row id -- counted once
+// per edge when the packed ids are tagged (grouping_tag_kp01), not per edge and launch (round 5).
 constexpr int kElMaxRels = 8;
 struct ElFold {
   const float* attn;  // [R, X] attn_l, or NULL: el is gathered
@@ -602,13 +603,16 @@ __device__ __forceinline__ int el_relation(const ElFold& f, int srow) {
   for (int k = 0; k < kElMaxRels - 1; ++k) r += srow >= f.thr[k] ? 1 : 0;
   return r;
 }
-// sum over the 4 lanes of a quad (every lane gets it)
-__device__ __forceinline__ float quad_sum(float p) {
-  p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0xB1, 0xf, 0xf, false));  // quad_perm:[1,0,3,2]
-  p += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), 0x4E, 0xf, 0xf, false));  // quad_perm:[2,3,0,1]
-  return p;
-}
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+// byte-offset type of the row kernels (common.hip.h: "byte offsets off a wave-uniform base")
+template <bool W64> struct OffSel { typedef uint32_t type; };
+template <> struct OffSel<true> { typedef uint64_t type; };
+// lse = m + log(ssum) with ssum >= 1 (the edge that holds the maximum contributes exp(0)): v_log_f32 without the denormal path
+__device__ __forceinline__ float lse_fast(float m, float ssum) {
+  const float L = fmaf(__builtin_amdgcn_logf(ssum), 0.69314718056f, m);
+  return L == 0.f ? 1.17549435e-38f : L;
+}
 
 // one edge joins the running sums of its destination (acc, ssum) and of its run (accq, sq); all relative to the running maximum m
 __device__ __forceinline__ void online_edge(float s, float dl, const float4& f, float& m, float4& acc, float& ssum, float4& accq,
@@ -623,12 +627,24 @@ __device__ __forceinline__ void online_edge(float s, float dl, const float4& f, 
   sq = fmaf(sq, c, wd);
 }
 
-template <int LPR, int DL, bool ELR>
+// Round 5: the instruction stream of this kernel, not its bytes, set its time (VALU 61 % of the issue slots).  Per edge
+// it no longer (a) counts relation boundaries (7 compares + 7 selects + the hazard nops between them) and reads attn_l[r] from LDS
+// behind a full lgkmcnt wait -- the relation rides in the tag of the packed id record and the attention vector of the current RUN
+// stays in registers; (b) compares the destination / er row against the previous edge's to find where a run or a destination ends --
+// the tag says so, and says it of the LAST edge, so the sums are stored with the ids of the edge in hand (no carried ids, no flush
+// after the loop); (c) forms 64-bit addresses -- one v_lshl_or_b32 per row off a scalar base (W64 = false: every table below 4 GiB,
+// checked by the launcher); (d) divides with the IEEE sequence where a destination ends (v_rcp_f32: 1 ulp).  H = LPR / DL.
+// Measured and dropped (round 5): the feature rows of step k + 1 requested before the sums of step k are formed (two row buffers
+// that swap roles, ids two steps ahead) -- 90 VGPRs instead of 60 = 5 waves per SIMD instead of 8: 0.534 -> 0.590 ms alone.  More
+// waves, not more loads per wave, is what this pass wants.
+template <int LPR, int DL, bool ELR, bool W64>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat, const float* __restrict__ el,
-    const float* __restrict__ er, float* __restrict__ lse, float* __restrict__ ret, int H, float slope, float* __restrict__ hio,
-    int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum, float* __restrict__ qref, int hub_min, ElFold ef) {
-  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+    const float* __restrict__ er, float* __restrict__ lse, float* __restrict__ ret, float slope, float* __restrict__ hio,
+    int hio_rows, float* __restrict__ qrow, float* __restrict__ qsum, float* __restrict__ qref, int hub_min, ElFold ef) {
+  constexpr int EPW = 64 / LPR, U = 4, H = LPR / DL;
+  constexpr int RS = het_log2_ce(LPR * 16), HS = het_log2_ce(H * 4);  // log2 of the bytes of a feature row / of an [.,H] row
+  typedef typename OffSel<W64>::type O;
   static_assert(DL >= U, "a head needs at least U lanes");
   static_assert(!ELR || DL == 4, "el from the row: heads of 4 lanes");
   __shared__ float4 al_s[ELR ? kElMaxRels * LPR : 1];  // attn_l[r] as the lanes of a row hold it
@@ -637,76 +653,99 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_runs_packed(
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int slot = lane / LPR, sub = lane % LPR, h = sub / DL, d = sub % DL;
+  const O xb = (O)(sub * 16), hb = (O)(h * 4);
   const int dq = d < U ? d : U - 1;
   const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
   if (pid >= pk.n) return;
   const uint32_t pb = (uint32_t)pk.ptr[pid];
   const int b = (int)(pb & 0x7fffffffu), e = (int)((uint32_t)pk.ptr[pid + 1] & 0x7fffffffu);
   if ((pb >> 31) && e - b > hub_min) return;  // a hub (a pack of its own): HET_rgat_aggregate_hub_items + HET_rgat_finish_hubs
-  int jn = b + dq < e ? b + dq : e - 1;
-  int4 idn = kp01[jn];  // {destination, feat row, er row} of the edge
-  int cur_dst = -1, cur_drow = -1;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accq = acc, h0 = acc;
+  int rel_cur = -1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accq = acc, h0 = acc, a4 = acc;
   float ssum = 0.f, sq = 0.f, m = -INFINITY;
-  for (int j0 = b; j0 < e; j0 += U) {
-    const int dstv = idn.x, srowv = idn.y, drowv = idn.z;
-    const float zlv = ELR ? 0.f : el[(int64_t)srowv * H + h];
-    const float zrv = er[(int64_t)drowv * H + h];
-    float4 f[U];
-    int srq[U];
+  // {destination, feat row, er row, tag} of the edge this lane fetches the ids of, for the step that starts at rank j
+  auto ids_of = [&](int j) { return kp01[j + dq < e ? j + dq : e - 1]; };
+  // the loads of a step: its U feature rows, the er (and el) terms of the lane's edge
+  auto rows_of = [&](const int4& id, float4 (&f)[U], float& zl, float& zr) {
+    zl = ELR ? 0.f : ld1_at<O>(el, ((O)id.y << HS) | hb);
+    zr = ld1_at<O>(er, ((O)id.z << HS) | hb);
 #pragma unroll
-    for (int q = 0; q < U; ++q) {
-      srq[q] = head_bcast_i<DL>(srowv, q, lane);
-      f[q] = ld4(feat + (int64_t)srq[q] * X + x);
-    }
-    jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
-    idn = kp01[jn];
+    for (int q = 0; q < U; ++q) f[q] = ld4_at<O>(feat, ((O)head_bcast_i<DL>(id.y, q, lane) << RS) | xb);
+  };
+  // the arithmetic (and the stores) of the step that starts at rank j0
+  auto step = [&](int j0, const int4& id, const float4 (&f)[U], float zlv, float zrv) {
+    const int dstv = id.x, drowv = id.z, tagv = id.w;
     const float zv = zlv + zrv, sv = lrelu(zv, slope), dlv = zv > 0.f ? 1.f : slope;
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       if (j0 + q < e) {  // (uniform within the lane group, like everything below)
-        const int dstq = head_bcast_i<DL>(dstv, q, lane), drowq = head_bcast_i<DL>(drowv, q, lane);
-        if (drowq != cur_drow) {  // a run starts (an er row belongs to one destination: a new destination is a new run too)
-          if (cur_drow >= 0) {
-            st4(qrow + (int64_t)cur_drow * X + x, accq);
-            if (d == 0) { qsum[(int64_t)cur_drow * H + h] = sq; qref[(int64_t)cur_drow * H + h] = m; }
-          }
-          if (dstq != cur_dst) {
-            if (cur_dst >= 0) {
-              const float inv = 1.f / ssum;
-              const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-              st4(ret + (int64_t)cur_dst * X + x, r4);
-              if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-              if (d == 0) lse[(int64_t)cur_dst * H + h] = lse_of(m, ssum);
-            }
-            cur_dst = dstq;
-            if (hio && dstq < hio_rows) h0 = ld4(hio + (int64_t)dstq * X + x);  // needed when the destination ends
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            ssum = 0.f;
-            m = -INFINITY;
-          }
-          cur_drow = drowq;
-          accq = make_float4(0.f, 0.f, 0.f, 0.f);
-          sq = 0.f;
+        const int tagq = head_bcast_i<DL>(tagv, q, lane);
+#ifndef HET_ABL_NO_HIO
+        if (hio && (tagq & HET_TAG_FIRST_KEY)) {  // the destination's row of the layer output so far: needed when the destination ends
+          const int dstq = head_bcast_i<DL>(dstv, q, lane);
+          if (dstq < hio_rows) h0 = ld4_at<O>(hio, ((O)dstq << RS) | xb);
         }
+#endif
         if (ELR) {  // s of the edge from its row: every lane of the head forms it (no broadcast of a gathered term)
-          const float zq = quad_sum(dot4(f[q], al_s[el_relation(ef, srq[q]) * LPR + sub])) + head_bcast<DL>(zrv, q, lane);
+          const int rel = tagq >> HET_TAG_REL_SHIFT;
+          if (rel != rel_cur) {  // (a run lies in one relation: at most once per run)
+            a4 = al_s[rel * LPR + sub];
+            rel_cur = rel;
+          }
+          const float zq = quad_sum(dot4(f[q], a4)) + head_bcast<DL>(zrv, q, lane);
           online_edge(lrelu(zq, slope), zq > 0.f ? 1.f : slope, f[q], m, acc, ssum, accq, sq);
         } else {
           online_edge(head_bcast<DL>(sv, q, lane), head_bcast<DL>(dlv, q, lane), f[q], m, acc, ssum, accq, sq);
         }
+        if (tagq & HET_TAG_LAST_RUN) {  // the run ends with this edge: its sums, relative to the maximum of this moment
+          const int drowq = head_bcast_i<DL>(drowv, q, lane);
+#ifndef HET_ABL_NO_Q
+          st4_at<O>(qrow, ((O)drowq << RS) | xb, accq);
+#endif
+#ifndef HET_ABL_NO_QS
+          if (d == 0) {
+            st1_at<O>(qsum, ((O)drowq << HS) | hb, sq);
+            st1_at<O>(qref, ((O)drowq << HS) | hb, m);
+          }
+#endif
+          accq = make_float4(0.f, 0.f, 0.f, 0.f);
+          sq = 0.f;
+          if (tagq & HET_TAG_LAST_KEY) {  // ... and so does the destination
+            const int dstq = head_bcast_i<DL>(dstv, q, lane);
+            const float inv = __builtin_amdgcn_rcpf(ssum);
+            const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+#ifndef HET_ABL_NO_RET
+            st4_at<O>(ret, ((O)dstq << RS) | xb, r4);
+#endif
+#ifndef HET_ABL_NO_HIO
+            if (hio && dstq < hio_rows)
+              st4_at<O>(hio, ((O)dstq << RS) | xb, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
+#endif
+#ifndef HET_ABL_NO_LSE
+            if (d == 0) st1_at<O>(lse, ((O)dstq << HS) | hb, lse_fast(m, ssum));
+#endif
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            ssum = 0.f;
+            m = -INFINITY;
+          }
+        }
       }
     }
-  }
-  if (cur_drow >= 0) {
-    st4(qrow + (int64_t)cur_drow * X + x, accq);
-    if (d == 0) { qsum[(int64_t)cur_drow * H + h] = sq; qref[(int64_t)cur_drow * H + h] = m; }
-    const float inv = 1.f / ssum;
-    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    st4(ret + (int64_t)cur_dst * X + x, r4);
-    if (hio && cur_dst < hio_rows) st4(hio + (int64_t)cur_dst * X + x, make_float4(h0.x + r4.x, h0.y + r4.y, h0.z + r4.z, h0.w + r4.w));
-    if (d == 0) lse[(int64_t)cur_dst * H + h] = lse_of(m, ssum);
+  };
+  int4 idn = ids_of(b);
+  asm volatile("" ::"v"(idn.x), "v"(idn.y), "v"(idn.z), "v"(idn.w));  // (in hand at the loop's entry too: see below)
+  for (int j0 = b; j0 < e; j0 += U) {
+    const int4 id = idn;
+    float4 f[U];
+    float zl, zr;
+    rows_of(id, f, zl, zr);
+    idn = ids_of(j0 + U);
+    // The next ids are waited for HERE, together with the rows they were requested behind: left pending across the step's
+    // conditional stores (which count in vmcnt on gfx9 and whose number the compiler cannot know) they made the top of every
+    // trip an s_waitcnt vmcnt(0), i.e. a wait for the acknowledgement of the stores the step had just issued.
+    asm volatile("" ::"v"(idn.x), "v"(idn.y), "v"(idn.z), "v"(idn.w));
+    step(j0, id, f, zl, zr);
   }
 }
 
@@ -722,16 +761,19 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a
 // Hubs: wave per hub work item of the grouping by (destination, relation) `it` (keys destination * R + relation; same sorted
 // order as the grouping by destination whose packed ids p01 it reads; hub_items: grouping_hub_items -- a wave per item of
 // that grouping with a test for "hub" spent 1.7 ms on 1.3 M early exits).  part[k] = {O[X], Q[X], max[H], sum[H], q[H]}.
-template <int LPR, int DL, bool ELR>
+template <int LPR, int DL, bool ELR, bool W64>
 __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
     Items it, const int32_t* __restrict__ hub_items, const int32_t* __restrict__ hub_order, int64_t num_hub_items,
-    const int2* __restrict__ p01, const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er, int H,
+    const int2* __restrict__ p01, const float* __restrict__ feat, const float* __restrict__ el, const float* __restrict__ er,
     float slope, float* __restrict__ part, ElFold ef) {
-  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4, H = LPR / DL;
+  constexpr int RS = het_log2_ce(LPR * 16), HS = het_log2_ce(H * 4);
+  typedef typename OffSel<W64>::type O;
   static_assert(DL >= U, "a head needs at least U lanes");
   static_assert(!ELR || DL == 4, "el from the row: heads of 4 lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const O xb = (O)(sub * 16), hb = (O)(h * 4);
   const int dq = d < U ? d : U - 1;
   const int64_t kk = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (kk >= num_hub_items) return;
@@ -744,15 +786,15 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
   int2 idn = p01[jn];
   // an item of this grouping lies inside ONE run (one relation, one destination = one er row): its er term is loaded once
   const int2 first = p01[b];
-  const float zrv = er[(int64_t)first.y * H + h];
+  const float zrv = ld1_at<O>(er, ((O)first.y << HS) | hb);
   // (the item lies in one relation: its attention vector is loaded once)
   const float4 a4 = ELR ? ld4(ef.attn + (int64_t)el_relation(ef, first.x) * X + x) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = b + slot; j0 < e; j0 += EPW * U) {
     const int srowv = idn.x;
-    float zlv = ELR ? 0.f : el[(int64_t)srowv * H + h];
+    float zlv = ELR ? 0.f : ld1_at<O>(el, ((O)srowv << HS) | hb);
     float4 f[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) f[u] = ld4(feat + (int64_t)head_bcast_i<DL>(srowv, u, lane) * X + x);
+    for (int u = 0; u < U; ++u) f[u] = ld4_at<O>(feat, ((O)head_bcast_i<DL>(srowv, u, lane) << RS) | xb);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
     idn = p01[jn];
     if (ELR) {  // el of the lane's own edge (edge dq of the step) from the rows: every lane forms all four, keeps its own
@@ -987,18 +1029,24 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_attn_grad_finish(const float*
 // REC: er / lse / <gradout, ret> of an edge come from ONE 16-byte record per (er row, head) -- rec4 [S_col, H] {er, lse, dot, 0},
 // HET_rgat_drow_rec -- instead of a 4-byte gather from er and an 8-byte one from pack2: a vector-memory instruction and a
 // 128-byte line less per edge (the gathers of these kernels miss L2 once per table and edge: profiles/r04/locality_counters.txt)
-template <int LPR, int DL, bool GA = false, bool REC = false>
+// Round 5 (see HET_rgat_aggregate_runs_packed): where a segment starts / ends and the relation of its row come from the tag of the
+// packed id record (no carried key, no compares against the neighbours, no boundary search), addresses are 32-bit byte offsets off
+// scalar bases (W64 = false), the dot over the lanes of a head is two DPP adds instead of two ds_bpermute.  H = LPR / DL.
+template <int LPR, int DL, bool GA, bool REC, bool W64>
 __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop(
     Packs pk, const int4* __restrict__ kp01, const float* __restrict__ feat,
     const float* __restrict__ el, const float* __restrict__ er, const float* __restrict__ pack2,
     const float* __restrict__ gradout, float* __restrict__ grad_feat, float* __restrict__ grad_el,
-    float* __restrict__ tbuf, int H, float slope, const float* __restrict__ fold_w,
-    const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part = nullptr, int* __restrict__ ga_rel = nullptr,
-    float* __restrict__ ga_out = nullptr) {
-  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+    float* __restrict__ tbuf, float slope, const float* __restrict__ fold_w,
+    const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part, int* __restrict__ ga_rel,
+    float* __restrict__ ga_out) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4, H = LPR / DL;
+  constexpr int RS = het_log2_ce(LPR * 16), HS = het_log2_ce(H * 4);
+  typedef typename OffSel<W64>::type O;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const O xb = (O)(sub * 16), hb = (O)(h * 4);
   const int dq = d < U ? d : U - 1;
   const int64_t pid = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * EPW + slot;
   if (!GA && pid >= pk.n) return;
@@ -1008,41 +1056,38 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
   if (!GA && (pb >> 31)) return;  // a long segment: HET_rgat_backward_src_long takes its work items
   if (GA && (pid >= pk.n || (pb >> 31))) e = b;
   float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr bool partial = false;
-  // first feat row of relations 1 .. 7 in scalar registers: the relation of a row is a few compares (rows are relation-major)
-  int rp[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) rp[i] = (fold_w && i + 1 < R) ? (int)fold_row_rel_ptrs[i + 1] : 0x7fffffff;
   int jn = b + dq < e ? b + dq : e - 1;
   if (GA && jn < 0) jn = 0;
-  int4 idn = kp01[jn];  // {feat row, destination, er row} of the edge: one load (grouping_packed_ids)
-  int prev_key = -1, rel_cur = -1;
+  int4 idn = kp01[jn];  // {feat row, destination, er row, tag} of the edge: one load (grouping_packed_ids, grouping_tag_kp01)
+  asm volatile("" ::"v"(idn.x), "v"(idn.y), "v"(idn.z), "v"(idn.w));  // (in hand at the loop's entry: see the forward)
+  int rel_cur = -1;
   float4 fcur = make_float4(0.f, 0.f, 0.f, 0.f), wcur = fcur, acc = fcur;
   float acc_el = 0.f;
   for (int j0 = b; j0 < e; j0 += U) {
-    const int keyv = idn.x, dstv = idn.y, drowv = idn.z;
+    const int keyv = idn.x, dstv = idn.y, drowv = idn.z, tagv = idn.w;
     // scalars of the step: lane (h, q) fetches those of edge q, head h
     float zrv;
     float2 pkv;
     if (REC) {
-      const float4 rv = ld4(er + ((int64_t)drowv * H + h) * 4);  // (er: the record table)
+      const float4 rv = ld4_at<O>(er, ((O)drowv << (HS + 2)) | (O)(h * 16));  // (er: the record table)
       zrv = rv.x; pkv = make_float2(rv.y, rv.z);
     } else {
-      zrv = er[(int64_t)drowv * H + h];
-      pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+      zrv = ld1_at<O>(er, ((O)drowv << HS) | hb);
+      pkv = ld2_at<O>(pack2, ((O)dstv << (HS + 1)) | (O)(h * 8));
     }
-    const float zlv = el[(int64_t)keyv * H + h];
-    int key[U];
-    float4 g[U], fq[U];
+    const float zlv = ld1_at<O>(el, ((O)keyv << HS) | hb);
+    int tag[U];
+    float4 g[U], fl[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) key[q] = head_bcast_i<DL>(keyv, q, lane);
+    for (int q = 0; q < U; ++q) tag[q] = head_bcast_i<DL>(tagv, q, lane);
 #pragma unroll
-    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
+    for (int q = 0; q < U; ++q) g[q] = ld4_at<O>(gradout, ((O)head_bcast_i<DL>(dstv, q, lane) << RS) | xb);
+    // feat row of a segment that starts inside this step (uniform per lane group).  fl[q] has NO other definition: a value merged
+    // with the row in hand (fq[q] = fcur; if (start) fq[q] = load) made the compiler copy the loaded registers right behind the load,
+    // i.e. wait for every load in flight at each segment start
 #pragma unroll
-    for (int q = 0; q < U; ++q) {  // feat row of a segment that starts inside this step (uniform per lane group)
-      fq[q] = fcur;
-      if (j0 + q < e && key[q] != (q == 0 ? prev_key : key[q - 1])) fq[q] = ld4(feat + (int64_t)key[q] * X + x);
-    }
+    for (int q = 0; q < U; ++q)
+      if (j0 + q < e && (tag[q] & HET_TAG_FIRST_KEY)) fl[q] = ld4_at<O>(feat, ((O)head_bcast_i<DL>(keyv, q, lane) << RS) | xb);
     // ids of the next step, in flight while this step's rows arrive
     jn = j0 + U + dq < e ? j0 + U + dq : e - 1;
     idn = kp01[jn];
@@ -1050,21 +1095,15 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
     const float zv = zlv + zrv;
     const float av = j0 + dq < e ? __expf(lrelu(zv, slope) - pkv.x) : 0.f;  // pkv.x: lse of the destination
     const float adv = av * (zv > 0.f ? 1.f : slope);
+    asm volatile("" ::"v"(idn.x), "v"(idn.y), "v"(idn.z), "v"(idn.w));  // (waited for before the step's stores: see the forward)
     float tq[U];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const bool ok = j0 + q < e;  // uniform within the lane group
-      if (ok && key[q] != (q == 0 ? prev_key : key[q - 1])) {
-        fcur = fq[q];
+      if (ok && (tag[q] & HET_TAG_FIRST_KEY)) {
+        fcur = fl[q];
         if (fold_w) {
-          const int u = key[q];
-          int rel = 0;
-          if (R <= 8) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) rel += u >= rp[i];
-          } else {
-            rel = find_segment(fold_row_rel_ptrs, R, (idx_t)u);
-          }
+          const int rel = tag[q] >> HET_TAG_REL_SHIFT;
           if (rel != rel_cur) {  // rows are relation-major: a handful of times per launch
             if (GA) {  // (the segments summed so far belong to the old relation)
               if (rel_cur >= 0) ga_flush_atomic<LPR>(ga_out, rel_cur, x, ga);
@@ -1078,28 +1117,19 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
       const float a = head_bcast<DL>(av, q, lane), ad = head_bcast<DL>(adv, q, lane), gr = head_bcast<DL>(pkv.y, q, lane);
       acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
       acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
-      float dot = g[q].x * fcur.x + g[q].y * fcur.y + g[q].z * fcur.z + g[q].w * fcur.w;
-#pragma unroll
-      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float dot = head_sum<DL>(dot4(g[q], fcur));
       const float t = ad * (dot - gr);  // 0 for the padding edges of the last step (a == 0)
       tq[q] = t;
       acc_el += t;  // identical in the DL lanes of a head
-      const int key_next = q + 1 < U ? key[q + 1] : head_bcast_i<DL>(idn.x, 0, lane);
-      if (ok && (j0 + q == e - 1 || key_next != key[q])) {  // the segment (or this pack's piece of it) ends: one store
-        const int64_t u = key[q];
+      if (ok && (tag[q] & HET_TAG_LAST_KEY)) {  // the segment ends with this edge: one store
+        const int u = head_bcast_i<DL>(keyv, q, lane);
         float4 o = acc;
-        if (fold_w) {  // el[u,h] = <feat[u,h,:], fold_w[r(u),h,:]>: its gradient joins grad_feat here (linear: also per piece)
+        if (fold_w) {  // el[u,h] = <feat[u,h,:], fold_w[r(u),h,:]>: its gradient joins grad_feat here
           o.x = fmaf(acc_el, wcur.x, o.x); o.y = fmaf(acc_el, wcur.y, o.y);
           o.z = fmaf(acc_el, wcur.z, o.z); o.w = fmaf(acc_el, wcur.w, o.w);
         }
-        float* gp = grad_feat + u * X + x;
-        if (!partial) {
-          st4(gp, o);
-          if (d == 0) grad_el[u * H + h] = acc_el;
-        } else {
-          atomicAdd(gp + 0, o.x); atomicAdd(gp + 1, o.y); atomicAdd(gp + 2, o.z); atomicAdd(gp + 3, o.w);
-          if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
-        }
+        st4_at<O>(grad_feat, ((O)u << RS) | xb, o);
+        if (d == 0) st1_at<O>(grad_el, ((O)u << HS) | hb, acc_el);
         if (GA) {  // grad_attn_l[rel_cur] += grad_el[u] * feat[u]  (flushed where rel_cur changes, above)
           ga.x = fmaf(acc_el, fcur.x, ga.x); ga.y = fmaf(acc_el, fcur.y, ga.y);
           ga.z = fmaf(acc_el, fcur.z, ga.z); ga.w = fmaf(acc_el, fcur.w, ga.w);
@@ -1109,13 +1139,14 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
       }
     }
     // t of edge q, head h leaves through lane (h, q): one 16-byte-per-edge store instruction per step
-    float ts = tq[0];
+    if (tbuf) {  // (NULL: grad_er comes from the run sums)
+      float ts = tq[0];
 #pragma unroll
-    for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
-    // (writing tbuf in the order of the grouping by er row instead -- scattered 16-byte stores, a streaming segmented
-    //  sum afterwards -- was measured: +0.38 ms here and in the long-segment kernel, -0.40 ms there)
-    if (tbuf && d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;  // (NULL: grad_er comes from the run sums)
-    prev_key = key[U - 1];
+      for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
+      // (writing tbuf in the order of the grouping by er row instead -- scattered 16-byte stores, a streaming segmented
+      //  sum afterwards -- was measured: +0.38 ms here and in the long-segment kernel, -0.40 ms there)
+      if (d < U && j0 + d < e) tbuf[(int64_t)(j0 + d) * H + h] = ts;
+    }
   }
   if (GA) ga_block_reduce<LPR>(ga, rel_cur, ga_part, ga_rel, ga_out);
 }
@@ -1125,18 +1156,21 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
 // graph): wave per work item (<= HET_ITEM_MAX edges of ONE feat row), the 64/LPR lane groups take its edges round-robin
 // as the forward does, scalars fetched cooperatively; feat row, el and the fold row are per item.  One store per item
 // (atomic adds only for the items of a segment longer than HET_ITEM_MAX, whose rows HET_rgat_zero_long_rows cleared).
-template <int LPR, int DL, bool GA = false, bool REC = false>
+template <int LPR, int DL, bool GA, bool REC, bool W64>
 __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     Items it, const int32_t* __restrict__ long_items, int64_t num_long_items, const int2* __restrict__ p01,
     const float* __restrict__ feat, const float* __restrict__ el,
     const float* __restrict__ er, const float* __restrict__ pack2, const float* __restrict__ gradout,
-    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, int H, float slope,
-    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part = nullptr,
-    int* __restrict__ ga_rel = nullptr, float* __restrict__ ga_out = nullptr) {
-  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4;
+    float* __restrict__ grad_feat, float* __restrict__ grad_el, float* __restrict__ tbuf, float slope,
+    const float* __restrict__ fold_w, const idx_t* __restrict__ fold_row_rel_ptrs, int R, float* __restrict__ ga_part,
+    int* __restrict__ ga_rel, float* __restrict__ ga_out) {
+  constexpr int EPW = 64 / LPR, U = 4, X = LPR * 4, H = LPR / DL;
+  constexpr int RS = het_log2_ce(LPR * 16), HS = het_log2_ce(H * 4);
+  typedef typename OffSel<W64>::type O;
   static_assert(DL >= U, "a head needs at least U lanes");
   const int lane = threadIdx.x & 63;
   const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const O xb = (O)(sub * 16), hb = (O)(h * 4);
   const int dq = d < U ? d : U - 1;
   const int64_t wid = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (wid >= num_long_items) {  // (GA: the wave stays for the workgroup reduction)
@@ -1158,15 +1192,15 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
     float zrv;
     float2 pkv;
     if (REC) {
-      const float4 rv = ld4(er + ((int64_t)drowv * H + h) * 4);  // (er: the record table, see HET_rgat_backward_src_coop)
+      const float4 rv = ld4_at<O>(er, ((O)drowv << (HS + 2)) | (O)(h * 16));  // (er: the record table, see HET_rgat_backward_src_coop)
       zrv = rv.x; pkv = make_float2(rv.y, rv.z);
     } else {
-      zrv = er[(int64_t)drowv * H + h];
-      pkv = *reinterpret_cast<const float2*>(pack2 + ((int64_t)dstv * H + h) * 2);
+      zrv = ld1_at<O>(er, ((O)drowv << HS) | hb);
+      pkv = ld2_at<O>(pack2, ((O)dstv << (HS + 1)) | (O)(h * 8));
     }
     float4 g[U];
 #pragma unroll
-    for (int q = 0; q < U; ++q) g[q] = ld4(gradout + (int64_t)head_bcast_i<DL>(dstv, q, lane) * X + x);
+    for (int q = 0; q < U; ++q) g[q] = ld4_at<O>(gradout, ((O)head_bcast_i<DL>(dstv, q, lane) << RS) | xb);
     jn = j0 + (U + dq) * EPW < e ? j0 + (U + dq) * EPW : e - 1;
     idn = p01[jn];
     const float zv = zl + zrv;
@@ -1178,16 +1212,16 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
       const float a = head_bcast<DL>(av, q, lane), ad = head_bcast<DL>(adv, q, lane), gr = head_bcast<DL>(pkv.y, q, lane);
       acc.x = fmaf(a, g[q].x, acc.x); acc.y = fmaf(a, g[q].y, acc.y);
       acc.z = fmaf(a, g[q].z, acc.z); acc.w = fmaf(a, g[q].w, acc.w);
-      float dot = g[q].x * f.x + g[q].y * f.y + g[q].z * f.z + g[q].w * f.w;
-#pragma unroll
-      for (int off = DL >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+      const float dot = head_sum<DL>(dot4(g[q], f));
       tq[q] = ad * (dot - gr);  // 0 for the padding edges of the last step
       acc_el += tq[q];
     }
-    float ts = tq[0];
+    if (tbuf) {
+      float ts = tq[0];
 #pragma unroll
-    for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
-    if (tbuf && d < U && j0 + d * EPW < e) tbuf[(int64_t)(j0 + d * EPW) * H + h] = ts;
+      for (int q = 1; q < U; ++q) ts = d == q ? tq[q] : ts;
+      if (d < U && j0 + d * EPW < e) tbuf[(int64_t)(j0 + d * EPW) * H + h] = ts;
+    }
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -1229,6 +1263,78 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_drow_rec(const float* __restr
     const float2 p = *reinterpret_cast<const float2*>(pack2 + (v * H + h) * 2);
     st4(rec4 + t * 4, make_float4(er[t], p.x, p.y, 0.f));
   }
+}
+
+// Round 5: everything the backward needs per er row w = (relation, destination v) in ONE pass, instead of a pass over all N nodes
+// (HET_rgat_dst_pack: {lse, <gradout, ret>} per node), a pass over the er rows that re-packs it (HET_rgat_drow_rec) and, after the
+// source-row kernels, a third one (HET_rgat_grad_er_runs) that reads gradout[v] once more:
+//   rec4[w,h]    = {er[w,h], lse[v,h], <gradout[v,h,:], ret[v,h,:]>, 0}                    (read per edge by the source-row kernels)
+//   grad_er[w,h] = exp(ref[w,h] - lse[v,h]) (<gradout[v,h,:], Q[w,h,:]> - <gradout, ret>[v,h] q[w,h]),  0 for a row without edges
+// gradout / ret rows of a destination with several relations are read once per relation (adjacent work: cache hits); nodes
+// without in-edges are not visited at all.  Lane group per er row, two rows per lane group in flight.
+template <int LPR, int DL>
+__global__ __launch_bounds__(kBlock) void HET_rgat_drow_pass(const float* __restrict__ er, const float* __restrict__ lse,
+                                                              const float* __restrict__ ret, const float* __restrict__ gradout,
+                                                              const float* __restrict__ qrow, const float* __restrict__ qsum,
+                                                              const float* __restrict__ qref, const int64_t* __restrict__ drow_nodes,
+                                                              int64_t n_rows, float* __restrict__ rec4, float* __restrict__ grad_er) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, H = LPR / DL, U = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = sub / DL, d = sub % DL;
+  const int64_t w0 = (((int64_t)blockIdx.x * (kBlock / 64) + wave) * U) * EPW + slot;
+  int64_t w[U], v[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ok[u] = w0 + u * EPW < n_rows;
+    w[u] = ok[u] ? w0 + u * EPW : n_rows - 1;
+    v[u] = drow_nodes[w[u]];
+  }
+  float4 g[U], r[U], q[U];
+  float erv[U], ls[U], qs[U], rf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    g[u] = ld4(gradout + v[u] * X + x);
+    r[u] = ld4(ret + v[u] * X + x);
+    q[u] = ld4(qrow + w[u] * X + x);
+    erv[u] = er[w[u] * H + h];
+    ls[u] = lse[v[u] * H + h];
+    qs[u] = qsum[w[u] * H + h];
+    rf[u] = qref[w[u] * H + h];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float dr = head_sum<DL>(dot4(g[u], r[u])), dq = head_sum<DL>(dot4(g[u], q[u]));
+    if (ok[u] && d == 0) {
+      // (a row without edges: q == 0, Q / ref never written, and its destination's ret row may be unwritten too -- nothing of it is used)
+      const bool has = qs[u] != 0.f;
+      st4(rec4 + (w[u] * H + h) * 4, make_float4(erv[u], ls[u], has ? dr : 0.f, 0.f));
+      grad_er[w[u] * H + h] = has ? __expf(rf[u] - ls[u]) * (dq - dr * qs[u]) : 0.f;
+    }
+  }
+}
+
+// bias_part [gridDim.x * waves, X]: per-wave column sums of rows [0, n) of g [., X] (grid-stride; HET_rgat_colsum_finish adds them up)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void HET_rgat_colsum_rows(const float* __restrict__ g, int64_t n, float* __restrict__ bias_part) {
+  constexpr int EPW = 64 / LPR, X = LPR * 4, U = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, x = (lane % LPR) * 4;
+  const int64_t step = (int64_t)gridDim.x * (kBlock / 64) * EPW * U;
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t v0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * EPW * U + slot; v0 < n; v0 += step) {
+    float4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = v0 + u * EPW < n ? ld4(g + (v0 + u * EPW) * X + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { bs.x += a[u].x; bs.y += a[u].y; bs.z += a[u].z; bs.w += a[u].w; }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    bs.x += __shfl_xor(bs.x, off); bs.y += __shfl_xor(bs.y, off);
+    bs.z += __shfl_xor(bs.z, off); bs.w += __shfl_xor(bs.w, off);
+  }
+  if (slot == 0) st4(bias_part + ((int64_t)blockIdx.x * (kBlock / 64) + wave) * X + x, bs);
 }
 
 // rows of the long segments start from zero (their pieces add atomically)
@@ -1423,14 +1529,23 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
     for (int k = 0; k < kElMaxRels - 1; ++k)
       ef.thr[k] = k + 1 < num_rels && feat_rel_ptrs_host[k + 1] < 0x7fffffffll ? (int)feat_rel_ptrs_host[k + 1] : 0x7fffffff;
   }
+  // packed id records tagged with the relation of the feat row and the run / destination ends (grouping_tag_kp01)
+  if (int rc = grouping_tag_kp01(by_dst, 1, elr ? ef.thr : nullptr, s)) return rc;
+  // 32-bit byte offsets when every table the row kernels index stays below 4 GiB (HET_RGAT_WIDE_OFFSETS=1: always 64-bit, A/B)
+  static const bool wide_env = [] { const char* v = getenv("HET_RGAT_WIDE_OFFSETS"); return v && v[0] == '1'; }();
+  // (destinations: ret / h_inout / lse rows by key; feat rows by payload0; er / q rows by payload1)
+  const bool w64 = wide_env || !(het_fits_u32(by_dst->key_bound, X * 4) && het_fits_u32(by_dst->p0_max + 1, X * 4) &&
+                                 het_fits_u32(by_dst->p1_max + 1, X * 4));
+  const int hio_rows32 = (int)(h_rows < 0 ? 0 : (h_rows > 0x7fffffffll ? 0x7fffffffll : h_rows));
   HetFork fk(s);  // the hub launches beside the pack-form one: disjoint destinations, both bound by gather latency
   {
     HET_KTIME("HET_rgat_aggregate_packs", s);
     Packs pk{by_dst->pack_ptr, by_dst->key_of_rank, by_dst->num_packs};
     const unsigned nb = (unsigned)ceil_div64(by_dst->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
-#define HET_PACKS_LAUNCH(ELRV)                                                                                                     \
-  hipLaunchKernelGGL((HET_rgat_aggregate_runs_packed<LPR, DL, ELRV>), dim3(nb), dim3(kBlock), 0, s, pk, by_dst->kp01, feat_c, el_c, \
-                     er_c, sum, ret, (int)H, (float)slope, h_inout, h_rows, q_rows, q_sum, q_ref, rgat_hub_min(), ef)
+#define HET_PACKS_LAUNCH2(ELRV, WV)                                                                                                \
+  hipLaunchKernelGGL((HET_rgat_aggregate_runs_packed<LPR, DL, ELRV, WV>), dim3(nb), dim3(kBlock), 0, s, pk, by_dst->kp01, feat_c,   \
+                     el_c, er_c, sum, ret, (float)slope, h_inout, hio_rows32, q_rows, q_sum, q_ref, rgat_hub_min(), ef)
+#define HET_PACKS_LAUNCH(ELRV) do { if (w64) { HET_PACKS_LAUNCH2(ELRV, true); } else { HET_PACKS_LAUNCH2(ELRV, false); } } while (0)
     if (elr) {
       switch (X / 4) {
         case 8: { constexpr int LPR = 8, DL = 4; HET_PACKS_LAUNCH(true); break; }
@@ -1441,6 +1556,7 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
       HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4), HET_PACKS_LAUNCH(false));
     }
 #undef HET_PACKS_LAUNCH
+#undef HET_PACKS_LAUNCH2
   }
   HET_LAUNCH_CHECK("HET_rgat_aggregate_runs_packed");
   if (by_dst_rel->num_hub_items > 0) {
@@ -1451,10 +1567,11 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
     {
       HET_KTIME("HET_rgat_aggregate_hubs", s2);
       const unsigned nbh = (unsigned)ceil_div64(n_hub, kBlock / 64);
-#define HET_HUBS_LAUNCH(ELRV)                                                                                                  \
-  hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL, ELRV>), dim3(nbh), dim3(kBlock), 0, s2, it, by_dst_rel->hub_items,     \
-                     hub_in_row_order() ? by_dst_rel->hub_order : nullptr, n_hub, by_dst->p01, feat_c, el_c, er_c, (int)H,         \
+#define HET_HUBS_LAUNCH2(ELRV, WV)                                                                                              \
+  hipLaunchKernelGGL((HET_rgat_aggregate_hub_items<LPR, DL, ELRV, WV>), dim3(nbh), dim3(kBlock), 0, s2, it, by_dst_rel->hub_items,  \
+                     hub_in_row_order() ? by_dst_rel->hub_order : nullptr, n_hub, by_dst->p01, feat_c, el_c, er_c,                 \
                      (float)slope, part, ef)
+#define HET_HUBS_LAUNCH(ELRV) do { if (w64) { HET_HUBS_LAUNCH2(ELRV, true); } else { HET_HUBS_LAUNCH2(ELRV, false); } } while (0)
       if (elr) {
         switch (X / 4) {
           case 8: { constexpr int LPR = 8, DL = 4; HET_HUBS_LAUNCH(true); break; }
@@ -1465,6 +1582,7 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
         HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4), HET_HUBS_LAUNCH(false));
       }
 #undef HET_HUBS_LAUNCH
+#undef HET_HUBS_LAUNCH2
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
     const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);
@@ -1542,7 +1660,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
     HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
   }
-  if (num_nodes > 0) {
+  // One pass over the er rows (HET_rgat_drow_pass: the records of the source-row kernels AND grad_er) instead of dst pack + record
+  // pack + grad_er pass; the bias gradient's column sums then are a pass of their own on the side stream (HET_RGAT_DROW_PASS=0: A/B)
+  static const bool drow_pass_on = [] { const char* v = getenv("HET_RGAT_DROW_PASS"); return !(v && v[0] == '0'); }();
+  const bool fused_drow = use_rec && drow_pass_on;
+  if (num_nodes > 0 && !fused_drow) {
     const unsigned nbp = grad_bias ? kBiasBlocks : grid_for(num_nodes * (X / 4));
     {
       HET_KTIME("HET_rgat_backward_dst_pack", s);
@@ -1550,11 +1672,16 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
                                                         pack, num_nodes, (int)H, (int)D, bias_part, bias_rows, (int)coop));
     }
     HET_LAUNCH_CHECK("HET_rgat_dst_pack");
-  } else if (grad_bias) {
+  } else if (grad_bias && num_nodes <= 0) {
     HET_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * X, s));
   }
   if (E == 0) {
     if (grad_bias && num_nodes > 0) {
+      if (fused_drow) {
+        HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_colsum_rows<LPR>, dim3(kBiasBlocks), dim3(kBlock), 0, s, gradout,
+                                                          bias_rows < num_nodes ? bias_rows : num_nodes, bias_part));
+        HET_LAUNCH_CHECK("HET_rgat_colsum_rows");
+      }
       hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s, bias_part, bias_part_rows, (int)X, grad_bias);
       HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
     }
@@ -1564,16 +1691,35 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (int rc = grouping_packs(by_srow, s, rgat_bwd_pack_t())) return rc;
   Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
   const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
-  if (use_rec) {  // before the fork: both source-row launches read the records
+  if (fused_drow) {  // before the fork: both source-row launches read the records
+    HET_KTIME("HET_rgat_backward_drow_pass", s);
+    const unsigned nbd = (unsigned)ceil_div64(num_dst_rows, (int64_t)(kBlock / 64) * (64 / (X / 4)) * 2);
+    HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),
+                      hipLaunchKernelGGL((HET_rgat_drow_pass<LPR, DL>), dim3(nbd), dim3(kBlock), 0, s, er_c, sum, ret, gradout,
+                                         runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, num_dst_rows, rec4, grad_er_c));
+    HET_LAUNCH_CHECK("HET_rgat_drow_pass");
+  } else if (use_rec) {
     hipLaunchKernelGGL(HET_rgat_drow_rec, dim3(grid_for(num_dst_rows * H)), dim3(kBlock), 0, s, er_c, pack, runs->drow_nodes, num_dst_rows,
                        (int)H, rec4);
     HET_LAUNCH_CHECK("HET_rgat_drow_rec");
   }
   const float* er_arg = use_rec ? rec4 : er_c;
+  bool w64 = true;
   if (coop) {
     if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;
     if (by_srow->num_long_items > 0)
       if (int rc = grouping_packed_ids(by_srow, false, s)) return rc;
+    // tags of the packed id records: segment ends + the relation of the feat row (read from the caller's device array; a grouping
+    // keeps the tags of the array it saw first -- the relation boundaries of a row list belong to the list)
+    if (fold_attn_l) {
+      if (int rc = grouping_tag_kp01_dev(by_srow, 0, row_rel_ptrs, (int)num_rels, s)) return rc;
+    } else {
+      if (int rc = grouping_tag_kp01(by_srow, 0, nullptr, s)) return rc;
+    }
+    static const bool wide_env = [] { const char* v = getenv("HET_RGAT_WIDE_OFFSETS"); return v && v[0] == '1'; }();
+    // (feat / grad rows by key; gradout and pack2 rows by payload0 = destination; er / record rows by payload1)
+    w64 = wide_env || !(het_fits_u32(num_src_rows, X * 4) && het_fits_u32(by_srow->p0_max + 1, X * 4) &&
+                        het_fits_u32(by_srow->p1_max + 1, H * 16) && het_fits_u32(by_srow->p1_max + 1, X * 4));
   }
   // Two chains after the per-destination pack, joined at the end (kernel trace on ogbn-mag: the short-segment launch 1.10 ms beside
   // the long-segment one 1.09 ms; with the small launches in front of the short one the op was 0.1 ms longer):
@@ -1582,6 +1728,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   HetFork fk(s);
   hipStream_t s2 = fk.side;
   if (grad_bias && num_nodes > 0) {
+    if (fused_drow) {
+      HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_colsum_rows<LPR>, dim3(kBiasBlocks), dim3(kBlock), 0, s2, gradout,
+                                                        bias_rows < num_nodes ? bias_rows : num_nodes, bias_part));
+      HET_LAUNCH_CHECK("HET_rgat_colsum_rows");
+    }
     hipLaunchKernelGGL(HET_rgat_colsum_finish, dim3((unsigned)X), dim3(kBlock), 0, s2, bias_part, bias_part_rows, (int)X, grad_bias);
     HET_LAUNCH_CHECK("HET_rgat_colsum_finish");
   }
@@ -1594,17 +1745,20 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (coop) {
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
-#define HET_SRC_COOP(GA_, REC_, gp_, gr_, go_)                                                                                    \
+#define HET_SRC_COOP2(GA_, REC_, W_, gp_, gr_, go_)                                                                              \
   HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),                                                                                 \
-                    hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL, GA_, REC_>), dim3(nb), dim3(kBlock), 0, s, pk, by_srow->kp01, \
-                                       feat_c, el_c, er_arg, pack, gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope,   \
-                                       fold_attn_l, row_rel_ptrs, (int)num_rels, gp_, gr_, go_))
+                    hipLaunchKernelGGL((HET_rgat_backward_src_coop<LPR, DL, GA_, REC_, W_>), dim3(nb), dim3(kBlock), 0, s, pk,   \
+                                       by_srow->kp01, feat_c, el_c, er_arg, pack, gradout, grad_feat_c, grad_el_c, tbuf,         \
+                                       (float)slope, fold_attn_l, row_rel_ptrs, (int)num_rels, gp_, gr_, go_))
+#define HET_SRC_COOP(GA_, REC_, gp_, gr_, go_) \
+  do { if (w64) { HET_SRC_COOP2(GA_, REC_, true, gp_, gr_, go_); } else { HET_SRC_COOP2(GA_, REC_, false, gp_, gr_, go_); } } while (0)
       if (ga_rows) {
         if (use_rec) { HET_SRC_COOP(true, true, ga_part, ga_rel, grad_attn_l); } else { HET_SRC_COOP(true, false, ga_part, ga_rel, grad_attn_l); }
       } else {
         if (use_rec) { HET_SRC_COOP(false, true, nullptr, nullptr, nullptr); } else { HET_SRC_COOP(false, false, nullptr, nullptr, nullptr); }
       }
 #undef HET_SRC_COOP
+#undef HET_SRC_COOP2
     }
     HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
     if (by_srow->num_long_items > 0) {
@@ -1612,12 +1766,14 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
       const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
       int* ga_rel_long = ga_rel ? ga_rel + nb : nullptr;  // (the long launch's workgroups follow the short launch's in the partial rows)
       HET_KTIME("HET_rgat_backward_src_long", s2);
-#define HET_SRC_LONG(GA_, REC_, gp_, gr_, go_)                                                                                    \
+#define HET_SRC_LONG2(GA_, REC_, W_, gp_, gr_, go_)                                                                              \
   HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),                                                                                 \
-                    hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, GA_, REC_>), dim3(nbl), dim3(kBlock), 0, s2, it,     \
+                    hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, GA_, REC_, W_>), dim3(nbl), dim3(kBlock), 0, s2, it, \
                                        by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c, er_arg, pack,   \
-                                       gradout, grad_feat_c, grad_el_c, tbuf, (int)H, (float)slope, fold_attn_l, row_rel_ptrs,   \
+                                       gradout, grad_feat_c, grad_el_c, tbuf, (float)slope, fold_attn_l, row_rel_ptrs,           \
                                        (int)num_rels, gp_, gr_, go_))
+#define HET_SRC_LONG(GA_, REC_, gp_, gr_, go_) \
+  do { if (w64) { HET_SRC_LONG2(GA_, REC_, true, gp_, gr_, go_); } else { HET_SRC_LONG2(GA_, REC_, false, gp_, gr_, go_); } } while (0)
       if (ga_rows) {
         if (use_rec) { HET_SRC_LONG(true, true, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l); }
         else { HET_SRC_LONG(true, false, ga_part + (int64_t)nb * X, ga_rel_long, grad_attn_l); }
@@ -1625,6 +1781,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
         if (use_rec) { HET_SRC_LONG(false, true, nullptr, nullptr, nullptr); } else { HET_SRC_LONG(false, false, nullptr, nullptr, nullptr); }
       }
 #undef HET_SRC_LONG
+#undef HET_SRC_LONG2
     }
   } else {
     static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
@@ -1653,7 +1810,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   }
   HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
   if (runs) {
-    if (num_dst_rows > 0) {
+    if (num_dst_rows > 0 && !fused_drow) {
       HET_KTIME("HET_rgat_backward_er_runs", s);
       HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_grad_er_runs<LPR>, dim3(grid_for(num_dst_rows * (X / 4))), dim3(kBlock),
                                                         0, s, runs->q_rows, runs->q_sum, runs->q_ref, runs->drow_nodes, pack, gradout,

@@ -59,10 +59,23 @@ __global__ void HET_grouping_items(const int32_t* __restrict__ seg_ptr, const in
   }
 }
 
+// d_max (optional): the largest payload value (a bound for the row tables a kernel indexes with it: 32-bit byte offsets)
 __global__ void HET_grouping_payload(const int32_t* __restrict__ perm, const idx_t* __restrict__ src, int64_t E,
-                                     int32_t* __restrict__ dst) {
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (int64_t)gridDim.x * blockDim.x)
-    dst[j] = (int32_t)src[perm[j]];
+                                     int32_t* __restrict__ dst, int32_t* __restrict__ d_max) {
+  int32_t mx = 0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t v = (int32_t)src[perm[j]];
+    dst[j] = v;
+    mx = v > mx ? v : mx;
+  }
+  if (d_max) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int32_t o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(d_max, mx);
+  }
 }
 
 // d_flag[0] |= 1 when payload0 in sorted order is not 0, 1, 2, ... (rows of a segment then are not contiguous)
@@ -256,8 +269,8 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
   HET_HIP(tmp.alloc((void**)&keys_in, sizeof(uint64_t) * E));
   HET_HIP(tmp.alloc((void**)&keys_out, sizeof(uint64_t) * E));
   HET_HIP(tmp.alloc((void**)&vals_in, sizeof(int32_t) * E));
-  HET_HIP(tmp.alloc((void**)&d_scalars, sizeof(int32_t) * 4));
-  HET_HIP(hipMemsetAsync(d_scalars, 0, sizeof(int32_t) * 4, s));
+  HET_HIP(tmp.alloc((void**)&d_scalars, sizeof(int32_t) * 8));
+  HET_HIP(hipMemsetAsync(d_scalars, 0, sizeof(int32_t) * 8, s));
 
   int32_t h_runs = 0;
   if (E > 0) {
@@ -339,19 +352,25 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
   }
   if (payload0 && E > 0) {
     GALLOC(p0, E);
-    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload0, E, g->p0);
+    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload0, E, g->p0, d_scalars + 4);
     HET_LAUNCH_CHECK("HET_grouping_payload");
     hipLaunchKernelGGL(HET_grouping_p0_not_identity, dim3(blocks_for(E)), dim3(256), 0, s, g->p0, E, d_scalars + 2);
     HET_LAUNCH_CHECK("HET_grouping_p0_not_identity");
-    int32_t h_bad = 1;
+    int32_t h_bad = 1, h_max = 0;
     HET_HIP(hipMemcpyAsync(&h_bad, d_scalars + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HET_HIP(hipMemcpyAsync(&h_max, d_scalars + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HET_HIP(hipStreamSynchronize(s));
     g->p0_contiguous = h_bad == 0;
+    g->p0_max = h_max;
   }
   if (payload1 && E > 0) {
     GALLOC(p1, E);
-    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload1, E, g->p1);
+    hipLaunchKernelGGL(HET_grouping_payload, dim3(blocks_for(E)), dim3(256), 0, s, g->perm, payload1, E, g->p1, d_scalars + 5);
     HET_LAUNCH_CHECK("HET_grouping_payload");
+    int32_t h_max = 0;
+    HET_HIP(hipMemcpyAsync(&h_max, d_scalars + 5, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HET_HIP(hipStreamSynchronize(s));
+    g->p1_max = h_max;
   }
   HET_HIP(hipStreamSynchronize(s));  // temporaries are freed on return
 #undef GALLOC
@@ -511,6 +530,74 @@ __global__ __launch_bounds__(256) void HET_grouping_pack_ids(const int32_t* __re
   }
 }
 }  // namespace
+
+namespace {
+struct TagThr { int v[7]; };
+// dev_ptrs (optional, [R+1] int64 on the device): the relation boundaries (thr unused); R > 8: searched per rank
+__global__ __launch_bounds__(256) void HET_grouping_tag_kp01(int4* __restrict__ kp01, int64_t E, int which, TagThr thr,
+                                                             const idx_t* __restrict__ dev_ptrs, int R) {
+  if (dev_ptrs && R <= 8) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const idx_t v = k + 1 < R ? dev_ptrs[k + 1] : 0x7fffffffll;
+      thr.v[k] = v < 0x7fffffffll ? (int)v : 0x7fffffff;
+    }
+  }
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < E; j += (int64_t)gridDim.x * 256) {
+    const int4 c = kp01[j], n = kp01[j + 1];  // (record E is the sentinel: key -1)
+    const int prev_key = j > 0 ? kp01[j - 1].x : -2;
+    const int val = which == 0 ? c.x : c.y;
+    int rel = 0;
+    if (dev_ptrs && R > 8) {
+      rel = find_segment(dev_ptrs, R, (idx_t)val);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) rel += val >= thr.v[k] ? 1 : 0;
+    }
+    int tag = rel << HET_TAG_REL_SHIFT;
+    if (c.x != prev_key) tag |= HET_TAG_FIRST_KEY;
+    if (n.x != c.x) tag |= HET_TAG_LAST_KEY | HET_TAG_LAST_RUN;
+    else if (n.z != c.z) tag |= HET_TAG_LAST_RUN;
+    reinterpret_cast<int*>(kp01 + j)[3] = tag;  // (only this word is written: the neighbours' reads of x / y / z do not race)
+  }
+}
+}  // namespace
+
+int grouping_tag_kp01(const het_grouping* g, int which, const int* thr, hipStream_t s) {
+  if (int rc = grouping_packed_ids(g, true, s)) return rc;
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->E == 0 || !g->kp01) return HET_OK;
+  if (!thr && g->tag_which >= 0) return HET_OK;  // (a user of the segment / run flags alone: they do not depend on the thresholds)
+  TagThr t;
+  for (int k = 0; k < 7; ++k) t.v[k] = thr ? thr[k] : 0x7fffffff;
+  thr = t.v;
+  bool same = g->tag_which == which;
+  for (int k = 0; k < 7 && same; ++k) same = g->tag_thr[k] == thr[k];
+  if (same) return HET_OK;
+  hipLaunchKernelGGL(HET_grouping_tag_kp01, dim3(blocks_for(g->E)), dim3(256), 0, s, g->kp01, g->E, which, t, nullptr, 0);
+  HET_LAUNCH_CHECK("HET_grouping_tag_kp01");
+  HET_HIP(hipStreamSynchronize(s));  // published only once complete
+  for (int k = 0; k < 7; ++k) g->tag_thr[k] = thr[k];
+  g->tag_which = which;
+  g->tag_dev_src = nullptr;
+  return HET_OK;
+}
+
+int grouping_tag_kp01_dev(const het_grouping* g, int which, const idx_t* rel_ptrs_dev, int R, hipStream_t s) {
+  if (int rc = grouping_packed_ids(g, true, s)) return rc;
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->E == 0 || !g->kp01) return HET_OK;
+  if (g->tag_which == which && g->tag_dev_src == rel_ptrs_dev && g->tag_dev_R == R) return HET_OK;
+  TagThr t{};
+  hipLaunchKernelGGL(HET_grouping_tag_kp01, dim3(blocks_for(g->E)), dim3(256), 0, s, g->kp01, g->E, which, t, rel_ptrs_dev, R);
+  HET_LAUNCH_CHECK("HET_grouping_tag_kp01");
+  HET_HIP(hipStreamSynchronize(s));  // published only once complete
+  for (int k = 0; k < 7; ++k) g->tag_thr[k] = -1;  // (the values stay on the device)
+  g->tag_which = which;
+  g->tag_dev_src = rel_ptrs_dev;
+  g->tag_dev_R = R;
+  return HET_OK;
+}
 
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s) {
   if (with_keys)

@@ -29,6 +29,7 @@ struct het_grouping {
   int32_t* split_seg = nullptr;  // [num_split] segments that own several items
   int32_t* p0 = nullptr;         // [E] payload0[perm[j]] or NULL
   int32_t* p1 = nullptr;         // [E] payload1[perm[j]] or NULL
+  int64_t p0_max = 0, p1_max = 0;  // largest payload value (0 without the payload): bounds the tables a kernel indexes with them
   bool p0_contiguous = false;    // p0[j] == j for every rank: the list already was in (relation, key) order
   mutable int32_t* seg_of_rank = nullptr;  // [E] segment of sorted rank j; built on first use (segment broadcast)
   // "Packs" (grouping_packs): the SHORT segments (<= HET_PACK_T positions) gathered into runs of whole segments of about
@@ -45,7 +46,15 @@ struct het_grouping {
   // Packed ids (grouping_packed_ids): one vector load per edge instead of one per list -- the gather passes are bound by the
   // number of their vector-memory instructions.
   mutable int2* p01 = nullptr;    // [E]   {p0[j], p1[j]}
-  mutable int4* kp01 = nullptr;   // [E+1] {key_of_rank[j], p0[j], p1[j], 0}; sentinel key -1 at E (needs the packs)
+  mutable int4* kp01 = nullptr;   // [E+1] {key_of_rank[j], p0[j], p1[j], tag}; sentinel key -1 at E (needs the packs)
+  // tag (grouping_tag_kp01; 0 until a user asks): what a lane group that walks the ranks of a pack in order would otherwise derive
+  // from compares against the neighbouring records and a search of relation boundaries, per edge --
+  //   HET_TAG_FIRST_KEY / _LAST_KEY  first / last rank of its segment;  HET_TAG_LAST_RUN  last rank of a run of equal p1 inside it
+  //   tag >> HET_TAG_REL_SHIFT  relation of the rank: number of relation boundaries <= its key (tag_which 0) or its p0 (tag_which 1)
+  mutable int tag_which = -1;     // -1: not tagged
+  mutable int tag_thr[7] = {0, 0, 0, 0, 0, 0, 0};
+  mutable const idx_t* tag_dev_src = nullptr;  // grouping_tag_kp01_dev: the device array the thresholds were read from, its length - 1
+  mutable int tag_dev_R = 0;
   // Hub items (grouping_hub_items): for a grouping by key * R + relation, the work items (ascending) whose key belongs to a
   // segment of more than hub_min positions in the twin grouping by key alone (het_rgat_aggregate_compact_runs).
   mutable int32_t* hub_items = nullptr;
@@ -64,6 +73,16 @@ constexpr int HET_PACK_T = 32;
 int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t = 0);
 // Builds g->p01 (with_keys == false) or g->kp01 (true; builds the packs first) once, thread-safe, published after a sync.
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s);
+constexpr int HET_TAG_FIRST_KEY = 1, HET_TAG_LAST_RUN = 2, HET_TAG_LAST_KEY = 4, HET_TAG_REL_SHIFT = 8;
+// Fills the fourth word of g->kp01 (builds kp01 first; thread-safe; synchronises `s`).  thr[0..6]: ascending first values of relations
+// 1 .. 7 (INT_MAX beyond the last relation), or NULL: the caller reads the segment / run flags only (any tagging will do);
+// which = 0: the relation follows the key, 1: payload0.  A grouping tagged with other thresholds before is re-tagged in place (the
+// flags are rewritten with the same values; the thresholds of a graph's unique lists do not change between calls).
+int grouping_tag_kp01(const het_grouping* g, int which, const int* thr, hipStream_t s);
+// The same with the relation boundaries read on the device: rel_ptrs_dev [R+1] (int64), any R < 2^23 (a search above 8).  No host copy,
+// so "tagged already" is decided by the identity of (array, R): the boundaries of a row list belong to the list the grouping sorts,
+// a caller does not hand the same grouping different boundaries.
+int grouping_tag_kp01_dev(const het_grouping* g, int which, const idx_t* rel_ptrs_dev, int R, hipStream_t s);
 // Builds g_rel->hub_items once (thread-safe, published after a sync): g_rel groups the same positions as `twin` by
 // key * R + relation.  Rebuilt when g_rel was paired with another twin object (or threshold) before.
 int grouping_hub_items(const het_grouping* g_rel, const het_grouping* twin, int R, int hub_min, hipStream_t s);

@@ -50,23 +50,6 @@ __device__ __forceinline__ int quad_bcast(int v, int q) {  // value of lane q of
   }
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-// Sum over the DL lanes of a head (DL a power of two, heads aligned to DL lanes); every lane of the head gets the sum.
-// xor 1 / xor 2 as quad permutes; then, all lanes of a quad (of 8, of 16) being equal, the mirrors within 8 and 16 lanes
-// reach the other half.
-template <int DL>
-__device__ __forceinline__ float head_sum(float p) {
-  if constexpr (DL >= 2) p += dpp_f<0xB1>(p);   // quad_perm [1,0,3,2]
-  if constexpr (DL >= 4) p += dpp_f<0x4E>(p);   // quad_perm [2,3,0,1]
-  if constexpr (DL >= 8) p += dpp_f<0x141>(p);  // row_half_mirror
-  if constexpr (DL >= 16) p += dpp_f<0x140>(p); // row_mirror
-  if constexpr (DL >= 32) p += __shfl_xor(p, 16);
-  return p;
-}
-
 struct Items {
   const int32_t *seg, *begin, *end, *seg_ptr, *seg_key;
   int64_t n;

@@ -670,39 +670,113 @@ void backward_hgt_hetero_attention(Tensor /*incsr_row_ptrs*/, Tensor /*incsr_col
 
 }  // namespace
 
-// One m.def per op of the reference's export list (same names, same argument order; schemas inferred from the C++ signatures
-// as in the reference's generated export file).
+// One m.def per op of the reference's export list (same names, same argument order).  The reference lets torch INFER the schemas
+// from its C++ signatures (OpExport/*.inc.h: `m.def("name", fn)`), and inference ignores the `at::Tensor&` of an output: a build of
+// the reference registers `name(Tensor _0, Tensor _1, ...) -> ()` with no alias information at all (checked with a ten-line
+// extension against this torch: tests/test_abi.py::test_inferred_schema_of_a_tensor_ref_has_no_alias_info).  Ours are written out,
+// with the reference's parameter names and `Tensor(a!)` on every tensor an op writes -- the strings of the Python registration
+// (het_amd/kernels.py), character for character (tests/test_abi.py::test_compiled_and_python_schemas_are_identical): positional
+// calls, the only kind the reference's Python makes, see no difference, and functionalization / torch.compile see the mutation.
 TORCH_LIBRARY_FRAGMENT(torch_hrt, m) {
-  m.def("build_debug_info", build_debug_info);
-  m.def("transpose_csr", transpose_csr);
-  m.def("convert_integrated_coo_to_separate_coo", convert_integrated_coo_to_separate_coo);
-  m.def("convert_integrated_csr_to_separate_coo", convert_integrated_csr_to_separate_coo);
-  m.def("convert_integrated_csr_to_separate_csr", convert_integrated_csr_to_separate_csr);
-  m.def("convert_integrated_coo_to_separate_csr", convert_integrated_coo_to_separate_csr);
-  m.def("rgnn_relational_matmul", rgnn_relational_matmul);
-  m.def("backward_rgnn_relational_matmul", backward_rgnn_relational_matmul);
-  m.def("rgnn_relational_matmul_no_scatter_gather_list", rgnn_relational_matmul_no_scatter_gather_list);
-  m.def("backward_rgnn_relational_matmul_no_scatter_gather_list", backward_rgnn_relational_matmul_no_scatter_gather_list);
-  m.def("relational_fused_gat_separate_coo", relational_fused_gat_separate_coo);
-  m.def("backward_relational_fused_gat_separate_coo", backward_relational_fused_gat_separate_coo);
-  // (the two CSR ops carry the reference's default argument: explicit schemas)
+  m.def("build_debug_info() -> ()",
+        build_debug_info);
+  m.def("transpose_csr(Tensor row_ptrs, Tensor col_indices, Tensor eids, Tensor rel_types) -> Tensor[]",
+        transpose_csr);
+  m.def("convert_integrated_coo_to_separate_coo(Tensor row_indices, Tensor col_indices, Tensor rel_types, Tensor eids, "
+        "int num_nodes, int num_rels) -> Tensor[]",
+        convert_integrated_coo_to_separate_coo);
+  m.def("convert_integrated_csr_to_separate_coo(Tensor row_ptrs, Tensor col_indices, Tensor rel_types, Tensor eids) -> Tensor[]",
+        convert_integrated_csr_to_separate_coo);
+  m.def("convert_integrated_csr_to_separate_csr(Tensor row_ptrs, Tensor col_indices, Tensor rel_types, Tensor eids) -> Tensor[]",
+        convert_integrated_csr_to_separate_csr);
+  m.def("convert_integrated_coo_to_separate_csr(Tensor row_indices, Tensor col_indices, Tensor rel_types, Tensor eids, "
+        "int num_nodes, int num_rels) -> Tensor[]",
+        convert_integrated_coo_to_separate_csr);
+  m.def("rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights, Tensor node_feat, "
+        "Tensor(a!) ret, bool InputNumHeadOneFlag) -> ()",
+        rgnn_relational_matmul);
+  m.def("backward_rgnn_relational_matmul(Dict(str, Tensor) args_tensor_dict, int IntKind, Tensor weights_transposed, "
+        "Tensor node_feat, Tensor gradout, Tensor(a!) grad_node_feat, Tensor(b!) grad_weights, bool InputNumHeadOneFlag) -> ()",
+        backward_rgnn_relational_matmul);
+  m.def("rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights, Tensor inputs, "
+        "Tensor(a!) ret) -> ()",
+        rgnn_relational_matmul_no_scatter_gather_list);
+  m.def("backward_rgnn_relational_matmul_no_scatter_gather_list(Tensor ntype_offset_ptrs, Tensor weights_transposed, "
+        "Tensor inputs, Tensor gradout, Tensor(a!) grad_input, Tensor(b!) grad_weights) -> ()",
+        backward_rgnn_relational_matmul_no_scatter_gather_list);
+  m.def("relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+        "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, int IntKind, Dict(str, Tensor) args_tensor_dict, "
+        "Tensor feat_src, Tensor el, Tensor er, Tensor(a!) sum, Tensor(b!) exp, Tensor(c!) ret, float slope) -> ()",
+        relational_fused_gat_separate_coo);
+  m.def("backward_relational_fused_gat_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+        "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, int IntKind, Dict(str, Tensor) args_tensor_dict, "
+        "Tensor feat_src, Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor(a!) grad_feat_src, "
+        "Tensor(b!) grad_el, Tensor(c!) grad_er, float slope) -> ()",
+        backward_relational_fused_gat_separate_coo);
   m.def("relational_fused_gat_csr(Tensor incsr_row_ptr, Tensor incsr_col_indices, Tensor incsr_eids, Tensor incsr_reltypes, "
-        "Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, Tensor feat_src, Tensor el, Tensor er, "
-        "Tensor sum, Tensor exp, Tensor ret, float slope, bool CompactAsOfNodeFlag=False) -> ()", relational_fused_gat_csr);
+        "Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, Tensor feat_src, Tensor el, "
+        "Tensor er, Tensor(a!) sum, Tensor(b!) exp, Tensor(c!) ret, float slope, bool CompactAsOfNodeFlag=False) -> ()",
+        relational_fused_gat_csr);
   m.def("backward_relational_fused_gat_csr(Tensor outcsr_row_ptr, Tensor outcsr_col_indices, Tensor outcsr_eids, "
-        "Tensor outcsr_reltypes, Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, Tensor feat_src, "
-        "Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor grad_feat_src, Tensor grad_el, "
-        "Tensor grad_er, float slope, bool CompactAsOfNodeFlag=False) -> ()", backward_relational_fused_gat_csr);
-  m.def("rgcn_layer1_separate_coo", rgcn_layer1_separate_coo);
-  m.def("backward_rgcn_layer1_separate_coo", backward_rgcn_layer1_separate_coo);
-  m.def("rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", rgcn_node_mean_aggregation);
-  m.def("backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo", backward_rgcn_node_mean_aggregation);
-  m.def("rgnn_inner_product_right_node_separatecoo", rgnn_inner_product_right_node_separatecoo);
-  m.def("backward_inner_product_right_node_separatecoo", backward_inner_product_right_node_separatecoo);
-  m.def("hgt_full_graph_edge_softmax_ops_separate_coo", hgt_edge_softmax);
-  m.def("backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo", backward_hgt_edge_softmax);
-  m.def("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", hgt_message_mean_aggregation);
-  m.def("backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo", backward_hgt_message_mean_aggregation);
-  m.def("hgt_full_graph_hetero_attention_ops_coo", hgt_hetero_attention);
-  m.def("backward_hgt_full_graph_hetero_attention_ops_coo", backward_hgt_hetero_attention);
+        "Tensor outcsr_reltypes, Tensor unique_srcs_and_dests_rel_ptrs, Tensor unique_srcs_and_dests_node_indices, "
+        "Tensor feat_src, Tensor el, Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor(a!) grad_feat_src, "
+        "Tensor(b!) grad_el, Tensor(c!) grad_er, float slope, bool CompactAsOfNodeFlag=False) -> ()",
+        backward_relational_fused_gat_csr);
+  m.def("rgcn_layer1_separate_coo(Tensor separate_coo_relptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+        "Tensor separate_coo_col_indices, Tensor node_feat_input, Tensor weights, Tensor edge_norm, "
+        "Tensor(a!) node_feat_output) -> ()",
+        rgcn_layer1_separate_coo);
+  m.def("backward_rgcn_layer1_separate_coo(Tensor separate_coo_relptrs, Tensor separate_coo_eids, "
+        "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor node_feat_input, Tensor weights_transposed, "
+        "Tensor edge_norm, Tensor(a!) grad_edge_norm, Tensor(b!) delta_node_feat_input, Tensor delta_node_feat_output, "
+        "Tensor(c!) delta_weights) -> ()",
+        backward_rgcn_layer1_separate_coo);
+  m.def("rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(Tensor separate_coo_eids, Tensor separate_coo_rel_ptrs, "
+        "Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Dict(str, Tensor) args_tensor_dict, "
+        "Tensor feat_src, Tensor enorm, Tensor(a!) ret, bool DirectIndexFlag) -> ()",
+        rgcn_node_mean_aggregation);
+  m.def("backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo(Tensor separate_coo_eids, "
+        "Tensor separate_coo_rel_ptrs, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Dict(str, "
+        "Tensor) args_tensor_dict, Tensor feat_src, Tensor enorm, Tensor ret, Tensor gradout, Tensor(a!) grad_feat_src, "
+        "bool DirectIndexFlag) -> ()",
+        backward_rgcn_node_mean_aggregation);
+  m.def("rgnn_inner_product_right_node_separatecoo(Dict(str, Tensor) arg_tensor_dict, int IntKind, "
+        "Tensor separate_coo_rel_ptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+        "Tensor separate_coo_col_indices, Tensor left_side_data, Tensor right_node_vectors, "
+        "Tensor(a!) edge_inner_product) -> ()",
+        rgnn_inner_product_right_node_separatecoo);
+  m.def("backward_inner_product_right_node_separatecoo(Dict(str, Tensor) arg_tensor_dict, int IntKind, "
+        "Tensor separate_coo_rel_ptrs, Tensor separate_coo_eids, Tensor separate_coo_row_indices, "
+        "Tensor separate_coo_col_indices, Tensor left_side_data, Tensor right_node_vectors, Tensor gradout, "
+        "Tensor(a!) grad_left_side_data, Tensor(b!) grad_right_node_vectors) -> ()",
+        backward_inner_product_right_node_separatecoo);
+  m.def("hgt_full_graph_edge_softmax_ops_separate_coo(Tensor row_indices, Tensor col_indices, Tensor eids, Tensor rel_ptrs, "
+        "Tensor unnormalized_attn_score, Tensor mu, Tensor(a!) edgesoftmax_sum_per_node, "
+        "Tensor(b!) mu_softmax_applied_unnormalized_attn_score, Tensor(c!) normalized_attn_score) -> ()",
+        hgt_edge_softmax);
+  m.def("backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo(Tensor row_indices, Tensor col_indices, "
+        "Tensor eids, Tensor rel_ptrs, Tensor unnormalized_attn_score, Tensor normalized_attn_score, "
+        "Tensor grad_normalized_attn_score, Tensor mu, Tensor(a!) grad_unnormalized_attn_score, Tensor(b!) grad_mu, "
+        "Tensor(c!) sum_incoming_edges_product_softmax_score) -> ()",
+        backward_hgt_edge_softmax);
+  m.def("hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "
+        "Tensor separate_coo_eids, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor inputs, "
+        "Tensor weights, Tensor edge_norm, Tensor(a!) new_h) -> ()",
+        hgt_message_mean_aggregation);
+  m.def("backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo(Tensor separate_coo_relptrs, "
+        "Tensor separate_coo_eids, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor inputs, "
+        "Tensor weights_transposed, Tensor edge_norm, Tensor new_h, Tensor(a!) grad_input, Tensor(b!) grad_weights, "
+        "Tensor(c!) grad_edge_norm, Tensor gradout) -> ()",
+        backward_hgt_message_mean_aggregation);
+  m.def("hgt_full_graph_hetero_attention_ops_coo(Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, "
+        "Tensor separate_coo_eids, Tensor separate_coo_relptrs, Tensor applied_klinear_node_features, "
+        "Tensor applied_qlinear_node_features, Tensor attn_score_weight, Tensor(a!) attn_score_inner_product, "
+        "Tensor(b!) unnormalized_attn_score) -> ()",
+        hgt_hetero_attention);
+  m.def("backward_hgt_full_graph_hetero_attention_ops_coo(Tensor incsr_row_ptrs, Tensor incsr_col_indices, Tensor incsr_eids, "
+        "Tensor incsr_reltypes, Tensor separate_coo_row_indices, Tensor separate_coo_col_indices, Tensor separate_coo_eids, "
+        "Tensor separate_coo_relptrs, Tensor(a!) grad_attn_weight, Tensor attn_score_weight_transposed, "
+        "Tensor applied_klinear_node_features, Tensor applied_qlinear_node_features, Tensor attn_score_inner_product, "
+        "Tensor grad_unnorm_attn_score, Tensor(b!) grad_k, Tensor(c!) grad_q) -> ()",
+        backward_hgt_hetero_attention);
 }

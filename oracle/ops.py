@@ -17,12 +17,19 @@ unpinned", except:
   * layouts (integer, exact);
   * the ``exp`` / ``sum`` outputs of the fused GAT forward (a4), CompactAsOfNodeKind 0 and 4
     (ref_rgat.py:5-32 and its dual-unique-list wrapper :77-115);
-  * ``grad_feat_src`` of the fused GAT backward (a5; ref_rgat.py:66-75)
+  * ``grad_feat_src`` of the fused GAT backward (a5; ref_rgat.py:66-75), CompactAsOfNodeKind 0;
+  * round 5: a4 ``exp`` / ``sum`` for kind 1 (the same wrapper fed the two-sided unique list) and ``sum`` for kind 2
+    (ref_rgat.py:182-220, one inverse index for both edge ends; that wrapper loses its ``exp``), and a5 ``grad_feat`` for
+    kinds 4 and 1 (ref_rgat.py:66-75 on the exp / sum of the compact forwards; compact rows summed per source node)
     are pinned by golden vectors generated from the reference's own importable Python
-    (tests/golden/make_golden.py; tests/test_oracle.py::*_golden, tests/test_gpu_ops.py::test_gat_golden_*).
+    (tests/golden/make_golden.py; tests/test_oracle.py::*_golden, tests/test_gpu_ops.py::test_gat_golden_*,
+    tests/test_mag01_full.py, tests/test_gpu_mag01_full.py; toy graph, slice and the whole shipped topology).
+    Pinned by the reference: a4 forward kinds 0 / 1 / 2 (sum) / 4, a5 ``grad_feat`` kinds 0 / 1 / 4.  Kind 3 is kind 4 with the
+    rows found by search instead of read from the inverse index (same rows: tests/test_oracle.py::test_gat_kind3_rows_equal_kind4).
     NOT pinned, because the reference holds nothing comparable: a4's ``ret`` (ref_rgat.py never writes it), a5's
     ``grad_el`` / ``grad_er`` (ref_rgat.py:64-65 adds ``slope`` to the leaky-ReLU derivative and drops the dot product
-    over the feature dimension -- it disagrees with the CUDA kernel it mirrors), and every other floating-point op.
+    over the feature dimension -- it disagrees with the CUDA kernel it mirrors; its two backward WRAPPERS, :117-180 and
+    :222-270, raise a RuntimeError for every shape -- run as written by make_golden.py), and every other floating-point op.
 Where the CUDA code deviates from the reference's own stated intent (its DSL
 specs hrt/pyctor/examples/inter-op-dsl/*.inter-op and in-code TODO/FIXMEs) the
 oracle implements the INTENDED semantics; each such position is listed in

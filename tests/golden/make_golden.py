@@ -21,6 +21,26 @@ What is pinned:
   * ``grad_feat_src`` of its backward (ref_rgat.py:66-75).  Its ``grad_el`` /
     ``grad_er`` (:64-65) are NOT pinned: they add ``slope`` to the leaky-ReLU
     derivative and drop the dot product, unlike the CUDA kernel they mirror.
+  * round 5 -- what the rest of ref_rgat.py can still pin:
+      - CompactAsOfNodeKind 1 forward (``gatk1_exp`` / ``gatk1_sum``): the same
+        dual-list wrapper (:77-115) fed el / er on the TWO-SIDED unique list
+        and that list's inverse index split into its row and col sides -- the
+        rows the CUDA kernel finds by binary search (kernel_enums.h:101-119);
+      - CompactAsOfNodeKind 2 forward, ``sum`` only (``gatk2_sum``): the
+        single-list wrapper (:182-220) maps BOTH edge ends through one inverse
+        index, as RGATKernelsSeparateCOO.cu.h:163-170 does; it writes its
+        ``exp`` into a temporary (index_select copy), so ``exp`` is lost;
+      - backward ``grad_feat_src`` for kinds 4 and 1 (``gatcb_grad_feat_src``,
+        ``gatk1b_grad_feat_src``): ref_rgat.py:66-75 (the unwrapped backward)
+        on the ``exp`` / ``sum`` its compact forward wrappers produced.  Node-
+        indexed as that file is: the compact rows of our ops are summed per
+        node before the comparison.
+    What it cannot: the two backward wrappers (:117-180, :222-270) raise for
+    every shape (RuntimeError in :64, ``grad_exp [E,H,D] * (el + er) [E,H]``
+    assigned into an [E,H] buffer; the single-list one also passes the compact
+    el / er where per-edge tensors are indexed) -- run in this container on
+    the toy graph, recorded by main() below; their grad_el / grad_er would be
+    the ``+ slope`` values of :64-65 anyway.
 
 Three fixtures: the 4-node toy graph of SURVEY.md section 10; a slice of the
 only real topology shipped with the reference, hrt/data/ogbn_mag_0.1/*.npy
@@ -134,6 +154,68 @@ def gat_compact_exp_sum(lay, num_nodes, H, seed):
     return {"gatc_el": el_c, "gatc_er": er_c, "gatc_exp": exp, "gatc_sum": s}
 
 
+def gat_round5(lay, num_nodes, H, D, gradout, seed=None, inputs=None):
+    """The round-5 pins (module docstring).  Needs gatc_* (kind-4 forward) in ``lay``; gradout [num_nodes,H,D]."""
+    E = lay["sep_row"].numel()
+    ar = torch.arange(E)
+    U = lay["ts_node_indices"].numel()
+    if inputs is None:
+        g = torch.Generator().manual_seed(seed)
+        inputs = {"gatk1_el": torch.randn(U, H, generator=g), "gatk1_er": torch.randn(U, H, generator=g)}
+    el, er = inputs["gatk1_el"], inputs["gatk1_er"]
+    inv_row, inv_col = recipe.two_sided_inverse(lay["ts_inverse_indices"], lay["sep_rel_ptrs"])
+    out = dict(inputs)
+    # kind 1: dual wrapper, both lists = the two-sided list
+    s1, exp1 = torch.zeros(num_nodes, H), torch.zeros(E, H)
+    ref_rgat.towrap_relational_fused_gat_kernel_compact_as_of_node_separate_coo_dual_unique_node_list(
+        inv_row, inv_col, ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"], lay["ts_rel_ptrs"], lay["ts_rel_ptrs"],
+        lay["ts_node_indices"], lay["ts_node_indices"], torch.zeros(num_nodes, H, 2), el, er, s1, exp1, torch.zeros(num_nodes, H, 2), 0.2)
+    out["gatk1_exp"], out["gatk1_sum"] = exp1, s1
+    # kind 2: single-list wrapper, one inverse index (the row side) for both ends; exp stays in its temporary
+    s2, exp2 = torch.zeros(num_nodes, H), torch.zeros(U, H)
+    ref_rgat.towrap_relational_fused_gat_kernel_compact_as_of_node_separate_coo(
+        inv_row, ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"], lay["ts_rel_ptrs"], lay["ts_node_indices"],
+        torch.zeros(num_nodes, H, 2), el, er, s2, exp2, torch.zeros(num_nodes, H, 2), 0.2)
+    assert float(exp2.abs().sum()) == 0.0  # (the wrapper's exp never reaches the caller)
+    out["gatk2_sum"] = s2
+    # backward grad_feat_src (node-indexed) on the compact forwards' exp / sum: kinds 4 and 1
+    for key, exp, s in (("gatcb_grad_feat_src", lay["gatc_exp"], lay["gatc_sum"]), ("gatk1b_grad_feat_src", exp1, s1)):
+        gfs = torch.zeros(num_nodes, H, D)
+        z = torch.zeros(E, H, 1)  # (el / er only feed the discarded grad_el / grad_er lines)
+        ref_rgat.backward_relational_fused_gat_separate_coo(ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"],
+                                                           torch.zeros(num_nodes, H, D), z, z, s, exp, torch.zeros(num_nodes, H, D),
+                                                           gradout, gfs, torch.zeros(E, H, D), torch.zeros(E, H, D), 0.2)
+        out[key] = gfs
+    return out
+
+
+def probe_backward_wrappers(lay, num_nodes, H, D):
+    """Runs the reference's two backward wrappers as written and returns what they raise (ordinary Python errors)."""
+    E = lay["sep_row"].numel()
+    ar = torch.arange(E)
+    inv_row, _ = recipe.two_sided_inverse(lay["ts_inverse_indices"], lay["sep_rel_ptrs"])
+    U = lay["ts_node_indices"].numel()
+    notes = []
+    try:
+        ref_rgat.towrap_backward_relational_fused_gat_compact_as_of_node_separate_coo_dual_unique_node_list(
+            lay["ss_inverse_indices_row"], lay["ss_inverse_indices_col"], ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"],
+            lay["ss_rel_ptrs_row"], lay["ss_rel_ptrs_col"], lay["ss_node_indices_row"], lay["ss_node_indices_col"],
+            torch.zeros(num_nodes, H, D), lay["gatc_el"], lay["gatc_er"], lay["gatc_sum"], lay["gatc_exp"], torch.zeros(num_nodes, H, D),
+            torch.zeros(num_nodes, H, D), torch.zeros(num_nodes, H, D), torch.zeros_like(lay["gatc_el"]), torch.zeros_like(lay["gatc_er"]), 0.2)
+        notes.append("dual-list backward wrapper (:117-180): ran")
+    except Exception as e:  # noqa: BLE001
+        notes.append(f"dual-list backward wrapper (:117-180): {type(e).__name__}: {e}")
+    try:
+        ref_rgat.towrap_backward_relational_fused_gat_compact_as_of_node_separate_coo(
+            inv_row, ar, lay["sep_rel_ptrs"], lay["sep_row"], lay["sep_col"], lay["ts_rel_ptrs"], lay["ts_node_indices"],
+            torch.zeros(num_nodes, H, D), torch.zeros(U, H), torch.zeros(U, H), torch.ones(num_nodes, H), torch.zeros(U, H),
+            torch.zeros(num_nodes, H, D), torch.zeros(num_nodes, H, D), torch.zeros(num_nodes, H, D), torch.zeros(U, H), torch.zeros(U, H), 0.2)
+        notes.append("single-list backward wrapper (:222-270): ran")
+    except Exception as e:  # noqa: BLE001
+        notes.append(f"single-list backward wrapper (:222-270): {type(e).__name__}: {e}")
+    return notes
+
+
 def main_full():
     """The whole shipped topology (fixture 2)."""
     import json
@@ -184,6 +266,14 @@ def main_full():
         lay["ss_rel_ptrs_row"], lay["ss_rel_ptrs_col"], lay["ss_node_indices_row"], lay["ss_node_indices_col"],
         torch.zeros(n, H, 2), inp["gatc_el"], inp["gatc_er"], s2, exp2, torch.zeros(n, H, 2), recipe.SLOPE)
     out["gatc_exp"], out["gatc_sum"] = exp2, s2
+    # round 5: kinds 1 / 2 forward, kinds 4 / 1 backward grad_feat_src (inputs regenerated on the test side: recipe.gat_inputs_round5)
+    inp5 = recipe.gat_inputs_round5(lay["ts_node_indices"].numel())
+    for k, v in inp5.items():
+        dig["input_" + k] = recipe.digest(v)
+    lay5 = dict(lay); lay5["gatc_exp"], lay5["gatc_sum"] = exp2, s2
+    r5 = gat_round5(lay5, n, H, D, inp["gatb_gradout"], inputs=inp5)
+    for k in ("gatk1_exp", "gatk1_sum", "gatk2_sum", "gatcb_grad_feat_src", "gatk1b_grad_feat_src"):
+        out[k] = r5[k]
     out["digests_json"] = np.array(json.dumps(dig, sort_keys=True))
     save("mag01_full.npz", out)
 
@@ -207,6 +297,9 @@ def main():
     lay.update(gat_exp_sum(lay, 4, 2, seed=1))
     lay.update(gat_backward_grad_feat_src(lay, 4, 2, 3, seed=11))
     lay.update(gat_compact_exp_sum(lay, 4, 2, seed=21))
+    lay.update(gat_round5(lay, 4, 2, 3, lay["gatb_gradout"], seed=31))
+    for note in probe_backward_wrappers(lay, 4, 2, 3):
+        print("reference, as written, on the toy graph --", note)
     lay["num_nodes"], lay["num_rels"] = torch.tensor(4), torch.tensor(2)
     save("toy.npz", lay)
 
@@ -227,6 +320,7 @@ def main():
     lay.update(gat_exp_sum(lay, n, 4, seed=2))
     lay.update(gat_backward_grad_feat_src(lay, n, 4, 4, seed=12))
     lay.update(gat_compact_exp_sum(lay, n, 4, seed=22))
+    lay.update(gat_round5(lay, n, 4, 4, lay["gatb_gradout"], seed=32))
     lay["num_nodes"], lay["num_rels"] = torch.tensor(n), torch.tensor(6)
     save("mag01_slice.npz", lay)
     main_full()

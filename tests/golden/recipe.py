@@ -16,6 +16,7 @@ MAG01_RELATIONS = ("cited", "citing", "has", "is-about", "writing", "written-by"
 SEED_PERM, SEED_EIDS = 7, 8
 H, D, SLOPE = 2, 4, 0.2
 SEED_GAT, SEED_GATB, SEED_GATC = 2, 12, 22
+SEED_GATK1 = 32  # round 5: el / er on the two-sided unique (relation, node) list (CompactAsOfNodeKind 1 and 2)
 # the typed view used by the layer tests (HGT needs canonical edge types): ids of the files are local to their node type;
 # (source type, destination type) per relation, types 0 paper / 1 author / 2 field of study
 MAG01_REL_TYPES = ((0, 0), (0, 0), (2, 0), (0, 2), (1, 0), (0, 1))
@@ -70,6 +71,25 @@ def gat_inputs(E, n, s_row, s_col):
     return {"gat_el": normal(SEED_GAT, E, H), "gat_er": normal(SEED_GAT + 100, E, H),
             "gatb_gradout": normal(SEED_GATB, n, H, D),
             "gatc_el": normal(SEED_GATC, s_row, H), "gatc_er": normal(SEED_GATC + 100, s_col, H)}
+
+
+def two_sided_inverse(ts_inverse_indices, sep_rel_ptrs):
+    """(row side, col side) [E] of the two-sided inverse index in separate-COO position order.  The reference builder
+    (mydgl_graph_methods.py:104-157) returns it as [rows of relation 0, cols of relation 0, rows of relation 1, ...]: for position
+    i of relation r the row side sits at 2 * rel_ptrs[r] + (i - rel_ptrs[r]), the col side n_r entries further."""
+    rows, cols = [], []
+    R = sep_rel_ptrs.numel() - 1
+    for r in range(R):
+        a, b = int(sep_rel_ptrs[r]), int(sep_rel_ptrs[r + 1])
+        rows.append(ts_inverse_indices[2 * a: 2 * a + (b - a)])
+        cols.append(ts_inverse_indices[2 * a + (b - a): 2 * b])
+    return torch.cat(rows), torch.cat(cols)
+
+
+def gat_inputs_round5(ts_rows):
+    """el / er per row of the two-sided unique list: the kind-1 forward (dual wrapper fed the two-sided inverse index) and the
+    kind-2 forward (single-list wrapper) of the reference."""
+    return {"gatk1_el": normal(SEED_GATK1, ts_rows, H), "gatk1_er": normal(SEED_GATK1 + 100, ts_rows, H)}
 
 
 def canonical_csr(row_ptrs, col, rel, eids):

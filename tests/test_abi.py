@@ -55,10 +55,16 @@ def test_allocator_hook_without_gpu():
     import ctypes as C
     from het_amd import _lib
     L = _lib.lib()
-    assert not _lib.allocator_is_external()
-    cb = _lib._ALLOC_FN(lambda n, s, u: None)
-    assert L.het_set_allocator(C.cast(cb, C.c_void_p), None, None) != 0 and b"both" in L.het_last_error()
-    assert not _lib.allocator_is_external()
+    was_external = _lib.allocator_is_external()  # (importing het_amd.kernels on a box with a GPU installs torch's allocator)
+    try:
+        _lib.use_torch_allocator(False)
+        assert not _lib.allocator_is_external()
+        cb = _lib._ALLOC_FN(lambda n, s, u: None)
+        assert L.het_set_allocator(C.cast(cb, C.c_void_p), None, None) != 0 and b"both" in L.het_last_error()
+        assert not _lib.allocator_is_external()
+    finally:
+        if was_external:
+            _lib.use_torch_allocator(True)
 
 
 def test_kernel_timing_api_without_gpu():
@@ -137,3 +143,92 @@ def test_hgt_unfused_csr_path_is_a_named_error():
         B.hgt_full_graph_edge_softmax_and_message_mean_aggregation_csr(None, None, None, None)
     with pytest.raises(NotImplementedError):
         HET_HGTLayerHetero(2, 3, 16, 16, num_heads=2, fused_message_mean_aggregation_flag=False)
+
+
+# Output tensors of the reference's launchers: the parameters it declares `at::Tensor&` AND writes, by position, per op
+# (hrt/include/DGLHackKernel/OpExport/RGNNOps.inc.h:238-241, 946-953, 83-88, 744-753, 609-618, 1131-1142; RGATOps.inc.h:170-177,
+# 465-475, 251-277, 430-460; RGCNOps.inc.h:84-92, 368-380, 24-33, 303-313; HGTOps.inc.h:23-31, 597-608; HGTOpsEdgeParallel.inc.h:33-41,
+# 295-307, 95-104, 166-181)
+WRITTEN_ARGS = {
+    "rgnn_relational_matmul": (4,), "backward_rgnn_relational_matmul": (5, 6),
+    "rgnn_relational_matmul_no_scatter_gather_list": (3,), "backward_rgnn_relational_matmul_no_scatter_gather_list": (4, 5),
+    "relational_fused_gat_separate_coo": (9, 10, 11), "backward_relational_fused_gat_separate_coo": (13, 14, 15),
+    "relational_fused_gat_csr": (9, 10, 11), "backward_relational_fused_gat_csr": (13, 14, 15),
+    "rgcn_layer1_separate_coo": (7,), "backward_rgcn_layer1_separate_coo": (7, 8, 10),
+    "rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": (7,),
+    "backward_rgcn_node_mean_aggregation_compact_as_of_node_separate_coo": (9,),
+    "rgnn_inner_product_right_node_separatecoo": (8,), "backward_inner_product_right_node_separatecoo": (9, 10),
+    "hgt_full_graph_edge_softmax_ops_separate_coo": (6, 7, 8),
+    "backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo": (8, 9, 10),
+    "hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": (7,),
+    "backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo": (8, 9, 10),
+    "hgt_full_graph_hetero_attention_ops_coo": (7, 8), "backward_hgt_full_graph_hetero_attention_ops_coo": (8, 14, 15),
+}
+
+
+def _schemas_in_a_fresh_interpreter(setup: str):
+    """{op name: schema string} of torch.ops.torch_hrt after running `setup` in a new interpreter (the two registrations define
+    the same names, so they cannot live in one process)."""
+    import json
+    import subprocess
+    import sys
+    code = (setup + "\nimport json, torch\nK = torch.ops.torch_hrt\n"
+            "print('SCHEMAS' + json.dumps({n: str(getattr(K, n).default._schema) for n in %r}))" % (MUST_EXPORT_OPS,))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("HET_TORCH_HRT_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("SCHEMAS")][-1]
+    return json.loads(line[len("SCHEMAS"):])
+
+
+def test_compiled_and_python_schemas_are_identical():
+    """One op name, one schema: libtorch_hrt.so (csrc/torch_export.cpp, loaded with torch.ops.load_library alone) and the Python
+    registration (het_amd/kernels.py) expose the same schema string for each of the 26 ops, and every tensor the reference's
+    launcher takes as `at::Tensor&` and writes carries an alias annotation (`Tensor(a!)`) -- what functionalization and
+    torch.compile read to know that the op mutates its argument."""
+    lib = os.path.join(ROOT, "het_amd", "libtorch_hrt.so")
+    if not os.path.exists(lib):
+        pytest.skip("libtorch_hrt.so not built (make -C het_amd/csrc torch_hrt)")
+    compiled = _schemas_in_a_fresh_interpreter("import sys, torch\ntorch.ops.load_library(%r)\nassert 'het_amd' not in sys.modules" % lib)
+    python = _schemas_in_a_fresh_interpreter("import het_amd.kernels")
+    assert set(compiled) == set(python) == set(MUST_EXPORT_OPS)
+    for n in MUST_EXPORT_OPS:
+        assert compiled[n] == python[n], f"{n}:\n  compiled {compiled[n]}\n  python   {python[n]}"
+    for n, written in WRITTEN_ARGS.items():
+        args = torch._C.parse_schema(compiled[n]).arguments
+        for i, a in enumerate(args):
+            is_mut = a.alias_info is not None and a.alias_info.is_write
+            assert is_mut == (i in written), f"{n}: argument {i} ({a.name}) mutable={is_mut}, the reference writes {written}"
+    assert set(WRITTEN_ARGS) == set(MUST_EXPORT_OPS) - {"build_debug_info", "transpose_csr", "convert_integrated_csr_to_separate_csr",
+                                                       "convert_integrated_csr_to_separate_coo", "convert_integrated_coo_to_separate_csr",
+                                                       "convert_integrated_coo_to_separate_coo"}
+
+
+def test_inferred_schema_of_a_tensor_ref_has_no_alias_info(tmp_path):
+    """What a build of the REFERENCE registers: `m.def("name", fn)` with `at::Tensor&` parameters infers `Tensor _0` -- no alias
+    annotation, positional placeholder names (OpExport/RGNNOps.inc.h:1188-1206 registers every op that way).  A ten-line extension
+    compiled against this torch shows it; our explicit schemas differ from the reference's inferred ones exactly by the parameter
+    names and the `(a!)` marks, neither of which a positional call sees."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import torch.utils.cpp_extension as ce
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <torch/library.h>\n#include <ATen/ATen.h>\n'
+                   'void f_ref(at::Tensor& a, at::Tensor& b, int64_t k, bool f, double s, torch::Dict<std::string, at::Tensor> d) { a.add_(1); }\n'
+                   'TORCH_LIBRARY_FRAGMENT(het_schema_probe, m) { m.def("f_ref", f_ref); }\n')
+    out = tmp_path / "libprobe.so"
+    libdir = ce.library_paths()[0]
+    cmd = (["g++", "-O0", "-std=c++17", "-fPIC", "-shared", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+           + ["-I" + p for p in ce.include_paths()] + [str(src), "-o", str(out), "-L" + libdir, "-lc10", "-ltorch_cpu", "-ltorch",
+                                                       "-Wl,-rpath," + libdir])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        pytest.skip("probe extension did not compile: " + r.stderr[-300:])
+    r = subprocess.run([sys.executable, "-c", "import torch; torch.ops.load_library(%r); "
+                        "print(torch.ops.het_schema_probe.f_ref.default._schema)" % str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.strip() == "het_schema_probe::f_ref(Tensor _0, Tensor _1, int _2, bool _3, float _4, Dict(str, Tensor) _5) -> ()"

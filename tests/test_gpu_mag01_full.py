@@ -101,6 +101,14 @@ def test_gat_forward_backward_against_the_reference_outputs(K, plan_mode, full):
     torch.testing.assert_close(cpu(sm2), gold["gatc_sum"], rtol=1e-5, atol=1e-5)
 
 
+def test_gat_round5_pins_against_the_reference_outputs(K, plan_mode, full):
+    """Kinds 1 / 2 forward and kinds 4 / 1 backward grad_feat on the full edge set against the reference's ref_rgat.py (round 5)."""
+    from tests.test_mag01_full import round5_lists_and_inputs
+    from tests.util import check_round5_gat_pins
+    lists, inp = round5_lists_and_inputs(full, _graph(full, "cpu"))
+    check_round5_gat_pins(K, DEV, full["gold"], lists, inp, recipe.SLOPE, rtol_exp=1e-5, atol_exp=1e-6, rtol_sum=1e-5, atol_sum=1e-5)
+
+
 def _typed_graph(full):
     row, col, rel, off = recipe.typed_coo(full["gold"]["coo"])
     return G.HetGraph.from_integrated_coo(IntegratedCOO(int(off[-1]), 6, off, row, col, rel, torch.arange(row.numel())))

@@ -593,6 +593,14 @@ def test_gat_golden_backward_grad_feat_src(K, plan_mode, golden_mag):
     torch.testing.assert_close(per_node.float(), gold["gatb_grad_feat_src"], rtol=5e-5, atol=5e-6)  # (fp32 sums of hub sources)
 
 
+def test_gat_golden_round5_pins(K, plan_mode, golden_mag):
+    """Kinds 1 / 2 forward and kinds 4 / 1 backward grad_feat against the reference's own outputs (round-5 fixtures;
+    tests/util.py::check_round5_gat_pins; the oracle's side is tests/test_oracle.py::test_gat_round5_pins_golden)."""
+    from tests.util import check_round5_gat_pins
+    check_round5_gat_pins(K, DEV, golden_mag, golden_mag, golden_mag, float(golden_mag["gat_slope"]), rtol_exp=1e-5, atol_exp=1e-6,
+                          rtol_sum=1e-5, atol_sum=1e-5)
+
+
 # ---------------------------------------------------------------- RGCN
 @pytest.mark.parametrize("Kd,D", [(16, 16), (64, 64), (7, 3)])
 def test_rgcn_layer1(K, plan_mode, Kd, D):

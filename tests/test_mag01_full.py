@@ -110,3 +110,30 @@ def test_oracle_gat_forward_backward_on_the_full_edge_set(full):
                                         sm2, ex2, ret, recipe.SLOPE)
     torch.testing.assert_close(ex2, gold["gatc_exp"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(sm2, gold["gatc_sum"], rtol=1e-5, atol=1e-6)
+
+
+def round5_lists_and_inputs(case, g):
+    """(lists, inputs) of tests/util.py::check_round5_gat_pins on the full topology: our builders' layouts (equal to the reference's:
+    the digest test above) and the float inputs regenerated from their seeds."""
+    s, ss = g.get_separate_coo_original(), g.get_separate_unique_node_indices_single_sided()
+    ssi, ts = g.get_separate_unique_node_indices_single_sided_inverse_idx(), g.get_separate_unique_node_indices_inverse_idx()
+    tsn = g.get_separate_unique_node_indices()
+    lists = {"sep_rel_ptrs": s["rel_ptrs"], "sep_row": s["row_indices"], "sep_col": s["col_indices"], "ts_rel_ptrs": ts["rel_ptrs"],
+             "ts_node_indices": tsn["node_indices"], "ts_inverse_indices": ts["inverse_indices"],
+             "ss_inverse_indices_row": ssi["inverse_indices_row"], "ss_inverse_indices_col": ssi["inverse_indices_col"],
+             "ss_node_indices_row": ss["node_indices_row"]}
+    E, n = case["row"].numel(), case["n"]
+    inp = recipe.gat_inputs(E, n, ss["node_indices_row"].numel(), ss["node_indices_col"].numel())
+    inp5 = recipe.gat_inputs_round5(tsn["node_indices"].numel())
+    check_inputs(case, inp)
+    check_inputs(case, inp5)
+    inp.update(inp5)
+    return lists, inp
+
+
+def test_oracle_round5_pins_on_the_full_edge_set(full):
+    """Kinds 1 / 2 forward, kinds 4 / 1 backward grad_feat of the fused GAT pair (round-5 fixtures) on all 345 172 edges."""
+    from tests.util import check_round5_gat_pins
+    g = mag01_full_layouts(full)[0]
+    lists, inp = round5_lists_and_inputs(full, g)
+    check_round5_gat_pins(O, "cpu", full["gold"], lists, inp, recipe.SLOPE)

@@ -76,6 +76,31 @@ def test_gat_backward_grad_feat_src_golden(which, golden_toy, golden_mag):
     torch.testing.assert_close(per_node, gold["gatb_grad_feat_src"], rtol=5e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize("which", ["toy", "mag"])
+def test_gat_round5_pins_golden(which, golden_toy, golden_mag):
+    """Kinds 1 / 2 of the fused GAT forward and grad_feat of kinds 4 / 1 of its backward against what the rest of the reference's
+    ref_rgat.py produces (tests/golden/make_golden.py, round 5; tests/util.py::check_round5_gat_pins)."""
+    from tests.util import check_round5_gat_pins
+    gold = golden_toy if which == "toy" else golden_mag
+    check_round5_gat_pins(O, "cpu", gold, gold, gold, float(gold["gat_slope"]))
+
+
+@pytest.mark.parametrize("which", ["toy", "mag"])
+def test_gat_kind3_rows_equal_kind4(which, golden_toy, golden_mag):
+    """CompactAsOfNodeKind 3 (dual lists, rows found by binary search) addresses the same rows as kind 4 (rows read from the inverse
+    indices) on the reference builders' own lists -- so the kind-4 pins cover kind 3's arithmetic."""
+    gold = golden_toy if which == "toy" else golden_mag
+    E = gold["sep_row"].numel()
+    d3 = {"unique_srcs_and_dests_rel_ptrs": gold["ss_rel_ptrs_row"], "unique_srcs_and_dests_rel_ptrs_col": gold["ss_rel_ptrs_col"],
+          "unique_srcs_and_dests_node_indices_row": gold["ss_node_indices_row"],
+          "unique_srcs_and_dests_node_indices_col": gold["ss_node_indices_col"]}
+    d4 = {"edata_idx_to_inverse_idx_row": gold["ss_inverse_indices_row"], "edata_idx_to_inverse_idx_col": gold["ss_inverse_indices_col"]}
+    ar = torch.arange(E)
+    r3 = O._gat_rows(3, d3, gold["sep_rel_ptrs"], gold["sep_row"], gold["sep_col"], ar)
+    r4 = O._gat_rows(4, d4, gold["sep_rel_ptrs"], gold["sep_row"], gold["sep_col"], ar)
+    assert torch.equal(r3[0], r4[0]) and torch.equal(r3[1], r4[1])
+
+
 def _plain_matmul(rp, gather, scatter, W, x, in1head, nrows_out):
     R, H, K, D = W.shape
     out = torch.zeros(nrows_out, H, D, dtype=W.dtype)

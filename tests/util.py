@@ -108,3 +108,53 @@ def rgat_nudge_off_kink(x, W, attn_l, attn_r, sep, margin=2e-6, max_rounds=40, s
         move = torch.unique(torch.where(deg[s] <= deg[d], s, d))
         x[move] += step * torch.randn(move.numel(), x.shape[1], device=dev, generator=gen, dtype=x.dtype)
     return x, zmin
+
+
+def check_round5_gat_pins(ops, dev, gold, lists, inputs, slope, rtol_exp=1e-6, atol_exp=1e-7, rtol_sum=1e-5, atol_sum=1e-6):
+    """The round-5 golden vectors of tests/golden/make_golden.py (what the rest of the reference's ref_rgat.py can pin), held against
+    ``ops`` -- the oracle module or ``torch.ops.torch_hrt`` -- on device ``dev``:
+      kind 1 forward  exp / sum   (el / er on the two-sided unique list, rows found by search)         gatk1_exp, gatk1_sum
+      kind 2 forward  sum         (both edge ends through ONE inverse index; the reference loses exp)  gatk2_sum
+      kind 4 backward grad_feat   (compact rows summed per source node, as the reference indexes it)   gatcb_grad_feat_src
+      kind 1 backward grad_feat   (same)                                                               gatk1b_grad_feat_src
+    lists: sep_rel_ptrs / sep_row / sep_col, ts_rel_ptrs / ts_node_indices / ts_inverse_indices, ss_inverse_indices_row / _col,
+    ss_node_indices_row (the reference builders' outputs, or ours on the same graph -- they are equal: layout tests);
+    inputs: gatk1_el / gatk1_er [U,H], gatc_el / gatc_er, gatb_gradout [N,H,D]."""
+    from tests.golden import recipe
+    to = lambda t: t.to(dev)  # noqa: E731
+    rp, row, col = lists["sep_rel_ptrs"], lists["sep_row"], lists["sep_col"]
+    E, n = row.numel(), gold["gatk1_sum"].shape[0]
+    go = inputs["gatb_gradout"]
+    H, D = go.shape[1], go.shape[2]
+    ar = to(torch.arange(E))
+    idx = (ar, to(rp), to(row), to(col))
+    el, er = inputs["gatk1_el"], inputs["gatk1_er"]
+    U = el.shape[0]
+    gen = torch.Generator().manual_seed(77)
+    featu, ret = torch.randn(U, H, D, generator=gen), torch.randn(n, H, D, generator=gen)
+    # ---- kind 1 forward
+    d1 = {"unique_srcs_and_dests_rel_ptrs": to(lists["ts_rel_ptrs"]), "unique_srcs_and_dests_node_indices": to(lists["ts_node_indices"])}
+    sm, ex, rt = torch.full((n, H), 7.0, device=dev), torch.full((E, H), 7.0, device=dev), torch.full((n, H, D), 7.0, device=dev)
+    ops.relational_fused_gat_separate_coo(*idx, 1, d1, to(featu), to(el), to(er), sm, ex, rt, slope)
+    torch.testing.assert_close(cpu(ex), gold["gatk1_exp"], rtol=rtol_exp, atol=atol_exp)
+    torch.testing.assert_close(cpu(sm), gold["gatk1_sum"], rtol=rtol_sum, atol=atol_sum)
+    # ---- kind 2 forward: one inverse index (the row side of the two-sided list's) for both ends
+    inv_row, _ = recipe.two_sided_inverse(lists["ts_inverse_indices"], rp)
+    d2 = {"edata_idx_to_inverse_idx": to(inv_row)}
+    sm2, ex2 = torch.full((n, H), 7.0, device=dev), torch.full((E, H), 7.0, device=dev)
+    ops.relational_fused_gat_separate_coo(*idx, 2, d2, to(featu), to(el), to(er), sm2, ex2, rt, slope)
+    torch.testing.assert_close(cpu(sm2), gold["gatk2_sum"], rtol=rtol_sum, atol=atol_sum)
+    # ---- backward grad_feat, kinds 4 and 1, on the reference's own exp / sum
+    d4 = {"edata_idx_to_inverse_idx_row": to(lists["ss_inverse_indices_row"]), "edata_idx_to_inverse_idx_col": to(lists["ss_inverse_indices_col"])}
+    S_row = inputs["gatc_el"].shape[0]
+    featc = torch.randn(S_row, H, D, generator=gen)
+    cases = ((4, d4, featc, inputs["gatc_el"], inputs["gatc_er"], gold["gatc_sum"], gold["gatc_exp"], lists["ss_node_indices_row"],
+              "gatcb_grad_feat_src"),
+             (1, d1, featu, el, er, gold["gatk1_sum"], gold["gatk1_exp"], lists["ts_node_indices"], "gatk1b_grad_feat_src"))
+    for kind, d, feat, l, r, s_ref, e_ref, node_of_row, key in cases:
+        gf = torch.zeros(feat.shape[0], H, D, device=dev)
+        gl, gr = torch.zeros(l.shape[0], H, device=dev), torch.zeros(r.shape[0], H, device=dev)
+        ops.backward_relational_fused_gat_separate_coo(*idx, kind, d, to(feat), to(l), to(r), to(s_ref), to(e_ref), to(ret), to(go),
+                                                       gf, gl, gr, slope)
+        per_node = torch.zeros(n, H, D, dtype=torch.float64).index_add_(0, node_of_row, cpu(gf).double()).float()
+        torch.testing.assert_close(per_node, gold[key], rtol=5e-5, atol=5e-6)  # (fp32 sums of hub sources in the reference)
