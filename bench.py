@@ -13,6 +13,7 @@ DESIGN.md).  Inputs are synthetic (het_amd/synth.py): no dataset can be download
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -28,7 +29,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6
 HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs at 2.4 GHz)
 
-PROF_ROUND = "r04"
+PROF_ROUND = "r05"
 
 
 def kernel_source_sha16():
@@ -273,6 +274,69 @@ def edge_order_random(args, dev):
             "what": "same layer, same edges, each relation's list in generation order (make_mag_like(edge_order='random'))"}
 
 
+def dist_rehearsal(args, dev, ranks=8, feat=128, heads=4):
+    """BASELINE.json configs[4] (RGAT, feat 128, destination-range partition over 8 GPUs) as far as ONE GPU goes: every rank of the
+    8-way partition of the same graph as a logical rank of this process (het_amd.dist.LocalRanks) -- its plan, its local graph, the
+    pack of its sends, the layer's own exchange path (forward_with_halo: projection of the halo rows piece by piece, aggregation;
+    backward ordered around the return) and the unpack of the returned rows -- timed rank by rank with the all-to-all replaced by
+    slicing.  max_ms is the compute input of an 8-GPU step; what it leaves out is the wire (halo_MB_* per rank and exchange) and
+    RCCL itself, which no box available to this build can run with more than one rank (tests/test_gpu_dist.py skips those)."""
+    import het_amd.dist as D
+    from het_amd import plan as HP
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    t_wall = time.perf_counter()
+    HP.clear()
+    coo = make_mag_like(scale=args.scale, edge_order=args.edge_order)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(feat, feat, coo.num_rels, heads, self_loop=True, dropout=0.0).to(dev)
+    lr = D.LocalRanks(coo, ranks, layer)
+    x_own = [torch.nn.Parameter(torch.randn(p.n_own, feat, device=dev) * 0.1) for p in lr.plans]
+    go = [torch.randn(p.n_own, feat, device=dev) for p in lr.plans]
+    for r, p in enumerate(lr.plans):  # what the peers would have pushed
+        lr.wire.push[r] = D._gather_rows(x_own[r].detach(), p.send_idx)
+    steps, per_rank = max(3, min(args.steps, 10)), []
+    for r, p in enumerate(lr.plans):
+        back = torch.zeros(p.send_idx.numel(), feat, device=dev)  # (the rows the peers would return)
+
+        def step():
+            layer.zero_grad(set_to_none=True)
+            x_own[r].grad = None
+            D._gather_rows(x_own[r].detach(), p.send_idx)  # pack of this rank's own sends
+            out = layer.forward_with_halo(lr.graphs[r], x_own[r], lr.halos[r])
+            out.backward(go[r])
+            D._scatter_add_rows(x_own[r].grad, p.send_idx, back)  # unpack of the returned rows
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            step()
+        b.record()
+        torch.cuda.synchronize()
+        per_rank.append({"rank": r, "ms": round(a.elapsed_time(b) / steps, 4), "owned_nodes": int(p.n_own), "local_edges": int(p.num_local_edges),
+                         "halo_rows_received": int(p.n_halo), "halo_rows_sent": int(p.send_idx.numel()),
+                         "halo_MB_received_per_exchange": round(int(p.n_halo) * feat * 4 / 1e6, 2),
+                         "halo_MB_sent_per_exchange": round(int(p.send_idx.numel()) * feat * 4 / 1e6, 2)})
+    max_ms = max(q["ms"] for q in per_rank)
+    E = coo.num_edges
+    res = {"what": dist_rehearsal.__doc__.split("\n")[0].strip() + " ... (bench.py::dist_rehearsal)",
+           "ranks": ranks, "feat": feat, "heads": heads, "pieces": int(lr.plans[0].chunks), "edge_cut": int(lr.plans[0].edge_cut),
+           "per_rank_ms": [q["ms"] for q in per_rank], "max_ms": max_ms, "min_ms": min(q["ms"] for q in per_rank),
+           "million_edges_per_s_if_the_exchange_were_free": round(E / max_ms / 1e3, 1),
+           "exchange": "loopback (slicing), excluded from per_rank_ms; on the wire: halo_MB_* per rank and direction, 7 xGMI links per GPU",
+           "per_rank": per_rank, "timed_steps_per_rank": steps, "wall_s": None}
+    del lr, x_own, go, layer
+    HP.clear()
+    torch.cuda.empty_cache()
+    res["wall_s"] = round(time.perf_counter() - t_wall, 1)
+    return res
+
+
 def dry_run_exchange(args):
     """`bench.py --gpus N --dry-run-exchange` under torch.distributed.run: the launch line, the rendezvous, every rank's plan of
     the N-way partition and one halo exchange each way, on HOST tensors over gloo (no GPU is touched, no layer runs): rank 0
@@ -352,6 +416,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true", help="skip timing the other reference flag combinations")
     p.add_argument("--no-models", action="store_true", help="skip the RGCN / HGT legs (BASELINE.json configs[1], configs[3]) of the default run")
+    p.add_argument("--no-dist-rehearsal", action="store_true",
+                   help="skip the 8-way feat-128 partition rehearsal (BASELINE.json configs[4] on one GPU: dist_rehearsal) of the default run")
     p.add_argument("--cpu-scale", type=float, default=0.25, help="graph scale of the CPU-baseline sample (1.0 = the full workload: "
                    "one warm-up + one timed iteration, about 3 minutes of host time -- outside the default run)")
     a = p.parse_args()
@@ -490,6 +556,10 @@ def main():
         os._exit(1)  # (a rank stuck in a collective would keep a normal interpreter shutdown waiting)
 
 
+def _stamp():
+    return datetime.datetime.now(datetime.timezone.utc).isoformat(timespec="milliseconds")
+
+
 def _main():
     args = parse()
     if args.dry_run_exchange:
@@ -497,6 +567,14 @@ def _main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The host-cores baseline runs FIRST (it is ~60 s of CPU work and touches no GPU): everything after `gpu_phase_start` is one
+    # contiguous window of GPU work, which is what a utilisation sampler outside this process wants to see.
+    wall = {"process_start": _stamp()}
+    cpu_res = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(args)
+        wall["cpu_baseline_end"] = _stamp()
+    wall["gpu_phase_start"] = _stamp()
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run "
                          f"--nproc-per-node N (and pass the same N as --gpus)")
@@ -785,6 +863,11 @@ def _main():
                      "per_rank": allr,
                      "max_exposed_wait_ms": round(max(sum(r_["exposed_wait_ms"].values()) for r_ in allr), 4)}
 
+    if roofline is not None and roofline_ops is not None:
+        # (the driver's record keeps the contract objects whole: the op-level figures of the reference-named ops ride in `roofline`)
+        roofline["reference_named_ops"] = {k_: {"op_ms": v_["op_ms"], "frac": v_["frac"], "achieved_GBps": v_["achieved_GBps"],
+                                                "algorithmic_bytes": v_["algorithmic_bytes"]}
+                                           for k_, v_ in roofline_ops.items() if isinstance(v_, dict)}
     from het_amd import plan as HP
     plan_bytes = HP.cached_bytes()
     if rank == 0:
@@ -825,8 +908,12 @@ def _main():
             out["models"] = {m: other_model(m, args, coo, dev, world) for m in ("rgcn", "hgt")}
         if world == 1 and not use_dist and not args.no_variants and args.model == "rgat" and args.edge_order != "random":
             out["edge_order_random"] = edge_order_random(args, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not use_dist and not args.no_dist_rehearsal and args.model == "rgat" and args.variant == "default":
+            out["dist_rehearsal"] = dist_rehearsal(args, dev)
+        if cpu_res is not None:
+            out["cpu_baseline"] = cpu_res
+        wall["gpu_phase_end"] = _stamp()
+        out["wall_clock_utc"] = wall
         print(json.dumps(out))
     if world > 1 or os.environ.get("HET_FORCE_DIST") == "1":
         import torch.distributed as dist

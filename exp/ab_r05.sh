@@ -11,7 +11,7 @@ for spec in "$@"; do
   if [ "$spec" != "$n" ]; then envs=$(echo "${spec#*@}" | tr '@' ' '); fi
   if [ "$n" = cur ]; then unset HET_AMD_LIB; else export HET_AMD_LIB=$R/exp/libs/lib_$n.so; fi
   n=$(echo "$spec" | tr '@=' '__')
-  env $envs python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-models $A 2>$R/gpurun_out/ab_r05_$n.err | tail -1 > $R/gpurun_out/ab_r05_$n.json
+  env $envs python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-models --no-dist-rehearsal $A 2>$R/gpurun_out/ab_r05_$n.err | tail -1 > $R/gpurun_out/ab_r05_$n.json
   python3 - "$n" "$R/gpurun_out/ab_r05_$n.json" <<'PY'
 import sys, json
 n, path = sys.argv[1], sys.argv[2]

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "het_backward_relational_fused_gat_separate_coo": [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, P, P, P, I64, I64, P, I64, P, P, P, P, P],
     "het_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, I64, I64, DBL, INT, P],
     "het_backward_relational_fused_gat_csr": [P, P, P, P, I64, I64, P, P, I64, P, P, P, P, P, P, P, P, P, P, I64, I64, DBL, INT, P],
+    "het_hgt_fold_source_weights": [P, P, P, P, P, P, I64, I64, I64, I64, I64, INT, P, P],
+    "het_hgt_fold_source_weights_backward": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, INT, P, P, P, P, P, P],
     "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, I64, P],
     "het_rows_matmul_backward_dx": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
@@ -93,6 +95,8 @@ def lib() -> C.CDLL:
         L.het_last_error.restype = C.c_char_p
         L.het_grouping_destroy.argtypes = [P]
         L.het_grouping_destroy.restype = None
+        L.het_grouping_note_stream.argtypes = [P, P]
+        L.het_grouping_note_stream.restype = None
         L.het_grouping_num_segments.argtypes = [P]
         L.het_grouping_num_segments.restype = I64
         L.het_grouping_bytes.argtypes = [P]

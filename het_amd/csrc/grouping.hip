@@ -194,8 +194,40 @@ struct Scratch {  // frees device temporaries on every exit path
 
 }  // namespace
 
+static std::mutex g_used_mu;
+
+extern "C" void het_grouping_note_stream(const het_grouping* g, het_stream stream) {
+  if (!g) return;
+  hipStream_t s = (hipStream_t)stream;
+  if (s == g->home) return;
+  std::lock_guard<std::mutex> lk(g_used_mu);
+  for (hipStream_t u : g->used)
+    if (u == s) return;
+  g->used.push_back(s);
+}
+
 extern "C" void het_grouping_destroy(het_grouping* g) {
   if (!g) return;
+  // Order the release after the last use on every stream that read the arrays (see het_grouping::home): `home` waits for an event
+  // recorded now on each of them -- no host synchronisation.  With hipMalloc / hipFree (the default allocator) hipFree itself
+  // waits for the device; the waits below are then redundant and cheap.  The library's own side stream is joined into the
+  // caller's stream before an entry point returns, so the caller's streams cover it.
+  {
+    std::vector<hipStream_t> used;
+    {
+      std::lock_guard<std::mutex> lk(g_used_mu);
+      used.swap(g->used);
+    }
+    for (hipStream_t u : used) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); break; }
+      if (hipEventRecord(ev, u) != hipSuccess || hipStreamWaitEvent(g->home, ev, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();  // (a stream that no longer exists, a capture in progress ...: the blunt form)
+      }
+      (void)hipEventDestroy(ev);  // (released by the runtime once it has completed)
+    }
+  }
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
                   g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order};
   for (void* p : ptrs)
@@ -257,6 +289,7 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
   static std::atomic<uint64_t> next_serial{1};
   g->serial = next_serial.fetch_add(1);
   g->E = E; g->R = R; g->key_bound = key_bound;
+  g->home = s;
   struct Guard { het_grouping* g; ~Guard() { if (g) het_grouping_destroy(g); } } guard{g};
 #define GALLOC(field, count) HET_HIP(het_malloc_e((void**)&g->field, sizeof(int32_t) * ((count) > 0 ? (count) : 1), s))
   GALLOC(perm, E);

@@ -11,6 +11,12 @@ constexpr int HET_ITEM_MAX = 256;
 
 struct het_grouping {
   uint64_t serial = 0;     // unique per object for the life of the process (an address can come back after a destroy)
+  // Streams (round 5).  The arrays below come from the caller's allocator when one is installed (het_set_allocator): a stream-
+  // ordered pool hands a freed block out again at once to its creation stream, without waiting for kernels of OTHER streams that
+  // still read it.  `home` is the stream the grouping was built on (its blocks belong to it); `used` the other streams a binding
+  // reported through het_grouping_note_stream.  het_grouping_destroy makes `home` wait for them before it releases anything.
+  hipStream_t home = nullptr;
+  mutable std::vector<hipStream_t> used;
   int64_t E = 0;           // positions
   int64_t S = 0;           // segments
   int64_t num_items = 0;   // work items (>= S)

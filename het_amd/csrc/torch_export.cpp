@@ -109,6 +109,7 @@ GroupingRef grouping(const Tensor* rel_ptrs, const Tensor& keys, int64_t key_bou
   for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
     if (it->a == a && it->b == b && it->c == c && it->d == d && it->bound == key_bound && it->dev == dev) {
       g_cache.splice(g_cache.begin(), g_cache, it);
+      het_grouping_note_stream(g_cache.front().g.get(), stream_of(keys));  // (destroy orders the release after this stream's use)
       return g_cache.front().g;
     }
   het_grouping* raw = nullptr;

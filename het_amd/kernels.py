@@ -879,6 +879,28 @@ def rgat_backward_compact(groupings, feat_c, el_c, er_c, sum, ret, gradout, grad
         _call(ret, "het_rgat_backward_compact", groupings[1].handle, groupings[2].handle, *head, *tail)
 
 
+def hgt_fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, transpose_att: bool):
+    """w_kv [R,1,in,2*H*dk] (include/het_amd.h: het_hgt_fold_source_weights).  k_lin / v_lin [T,1,in,H*dk] contiguous fp32 on the GPU."""
+    _chk("hgt_fold_source_weights", (k_lin, v_lin, rel_att, rel_msg, rel_pri), (src_type,))
+    R, H, dk, _ = rel_att.shape
+    T, K_in = k_lin.shape[0], k_lin.shape[2]
+    w = torch.empty((R, 1, K_in, 2 * H * dk), dtype=k_lin.dtype, device=k_lin.device)
+    _call(w, "het_hgt_fold_source_weights", _p(k_lin), _p(v_lin), _p(rel_att), _p(rel_msg), _p(rel_pri), _p(src_type), T, R, H, dk, K_in,
+          int(transpose_att), _p(w), _stream(w))
+    return w
+
+
+def hgt_fold_source_weights_backward(grad_w, k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, transpose_att: bool):
+    """(grad_k_lin, grad_v_lin, grad_att, grad_msg, grad_pri) of hgt_fold_source_weights."""
+    _chk("hgt_fold_source_weights_backward", (grad_w, k_lin, v_lin, rel_att, rel_msg, rel_pri), (src_type,))
+    R, H, dk, _ = rel_att.shape
+    T, K_in = k_lin.shape[0], k_lin.shape[2]
+    outs = tuple(torch.empty_like(t) for t in (k_lin, v_lin, rel_att, rel_msg, rel_pri))
+    _call(grad_w, "het_hgt_fold_source_weights_backward", _p(grad_w), _p(k_lin), _p(v_lin), _p(rel_att), _p(rel_msg), _p(rel_pri),
+          _p(src_type), T, R, H, dk, K_in, int(transpose_att), *(_p(o) for o in outs), _stream(grad_w))
+    return outs
+
+
 def hgt_compact_shape_ok(H: int, D: int) -> bool:
     return bool(_lib.lib().het_hgt_compact_shape_ok(int(H), int(D)))
 

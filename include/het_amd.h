@@ -94,6 +94,13 @@ int het_grouping_create(const int64_t* rel_ptrs /* [R+1] or NULL */, int64_t num
                         const int64_t* payload0, const int64_t* payload1,
                         het_stream stream, het_grouping** out);
 void het_grouping_destroy(het_grouping* g);
+/* Lifetime across streams.  A grouping's arrays belong to the stream it was created on.  With the default allocator
+ * het_grouping_destroy ends in hipFree, which waits for the device.  With a stream-ordered allocator installed
+ * (het_set_allocator: torch's caching allocator in both torch registrations) a freed block is handed out again to that stream
+ * at once, so a binding that runs ops with the grouping on ANOTHER stream reports that stream here (cheap; idempotent): destroy
+ * then makes the creation stream wait for an event on every reported stream before it releases anything -- no host
+ * synchronisation.  Both registrations call it on every cache lookup (het_amd/plan.py, csrc/torch_export.cpp). */
+void het_grouping_note_stream(const het_grouping* g, het_stream stream);
 /* number of segments (distinct (relation, key) pairs) */
 int64_t het_grouping_num_segments(const het_grouping* g);
 /* device bytes the grouping currently holds (with the default hipMalloc they are outside the caller's allocator statistics) */
@@ -463,6 +470,23 @@ int het_hgt_backward_compact(const het_grouping* by_dst, const het_grouping* by_
                              const float* lsum, const float* out, const float* gradout, float* grad_kv_c, float* grad_q,
                              int64_t num_nodes, int64_t num_src_rows, int64_t H, int64_t D, void* workspace,
                              int64_t workspace_bytes, het_stream stream);
+
+/* The per-step folding of the HGT layer's parameters into one source-side weight per relation (round 5; extension, reached from
+ * het_amd/backend/hgt_fused_layer.py only), forward and backward as one / two launches instead of ~14 + ~24 torch kernels:
+ *   w_kv[r, i, h*dk+e]         = pri[r,h] / sqrt(dk) * SUM_d k_lin[st(r), i, h*dk+d] * A[r,h,d,e]
+ *   w_kv[r, i, H*dk + h*dk+e]  =                      SUM_d v_lin[st(r), i, h*dk+d] * msg[r,h,d,e]
+ * A = rel_att (transpose_att = 0: the fused score <k . att, q>) or its transpose over (d, e) (1: <q . att, k>), st = src_type [R] int64
+ * (device): the node type of every relation's sources.  The factors are the reference's, composed per edge there
+ * (HGT/models.py:159-262: K_linear / V_linear per node type, relation_att, relation_pri / sqrt_dk, relation_msg).
+ * k_lin, v_lin [T, K_in, H*dk]; rel_att, rel_msg [R,H,dk,dk]; rel_pri [R,H]; w_kv [R, K_in, 2*H*dk].  The backward overwrites all five
+ * gradients (same shapes as the parameters). */
+int het_hgt_fold_source_weights(const float* k_lin, const float* v_lin, const float* rel_att, const float* rel_msg,
+                                const float* rel_pri, const int64_t* src_type, int64_t num_types, int64_t num_rels, int64_t H,
+                                int64_t dk, int64_t K_in, int transpose_att, float* w_kv, het_stream stream);
+int het_hgt_fold_source_weights_backward(const float* grad_w_kv, const float* k_lin, const float* v_lin, const float* rel_att,
+                                         const float* rel_msg, const float* rel_pri, const int64_t* src_type, int64_t num_types,
+                                         int64_t num_rels, int64_t H, int64_t dk, int64_t K_in, int transpose_att, float* grad_k_lin,
+                                         float* grad_v_lin, float* grad_att, float* grad_msg, float* grad_pri, het_stream stream);
 
 /* ------------------------------------------------------------------------
  * RGAT on the distinct (relation, node) rows without a per-edge float tensor (layer-level fusion; no reference op of

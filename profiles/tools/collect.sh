@@ -10,10 +10,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/stats" -o run -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-models "$@" > "$out/bench_stats.log" 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/fetch" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models "$@" > "$out/bench_fetch.log" 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/write" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models "$@" > "$out/bench_write.log" 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d "$out/mfma" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models "$@" > "$out/bench_mfma.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/stats" -o run -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-variants --no-models --no-dist-rehearsal "$@" > "$out/bench_stats.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/fetch" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models --no-dist-rehearsal "$@" > "$out/bench_fetch.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/write" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models --no-dist-rehearsal "$@" > "$out/bench_write.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d "$out/mfma" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-models --no-dist-rehearsal "$@" > "$out/bench_mfma.log" 2>&1
 for f in stats fetch write mfma; do echo "[$f] $(tail -c 300 "$out/bench_$f.log" | tail -2)"; done
 find "$out" -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.json" -delete
 cd "$R" && python3 profiles/tools/summarize.py "$out" > "$out/summary.txt" 2>&1

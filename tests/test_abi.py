@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # every declared compute entry point has a ctypes signature (so the Python side calls it typed)
     untyped = [n for n in names if n not in _lib._SIGNATURES and n not in
-               ("het_build_info", "het_last_error", "het_grouping_destroy", "het_grouping_num_segments", "het_grouping_bytes",
+               ("het_build_info", "het_last_error", "het_grouping_destroy", "het_grouping_note_stream", "het_grouping_num_segments", "het_grouping_bytes",
                 "het_kernel_timing_enable", "het_kernel_timing_read", "het_rgat_backward_compact_workspace",
                 "het_hgt_backward_compact_workspace", "het_hgt_compact_shape_ok", "het_rgat_node_gemm_ok", "het_rgat_aggregate_compact_workspace", "het_hgt_aggregate_compact_workspace",
                 "het_rgat_aggregate_compact_runs_workspace", "het_rgat_backward_compact_runs_workspace",

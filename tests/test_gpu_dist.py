@@ -263,3 +263,76 @@ def test_bench_rccl_two_ranks():
                        "3", "--warmup", "1", "--no-cpu-baseline"], env)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["dist"]["ranks"] == 2 and "RCCL" in out["dist"]["backend"]
     assert len(out["dist"]["per_rank"]) == 2 and all(r["halo_rows_sent"] > 0 for r in out["dist"]["per_rank"])
+
+
+def test_eight_way_partition_feat128_at_full_size():
+    """BASELINE.json configs[4] at its REAL size as far as one GPU goes (round 5): RGAT, feat 128, 4 heads, the whole ogbn-mag-shaped
+    graph (21.1 M edges) split 8 ways by destination range, default flags -- every rank's plan, local graph, halo pack / unpack and
+    the HIP layer's own exchange path (forward_with_halo, exchanges in pieces) as logical ranks of this process (dist.LocalRanks:
+    the all-to-all is slicing), against the single-process HIP layer on the whole graph: outputs, input gradients and every
+    parameter gradient.  (The single-process layer at this size is held to the fp64 oracle by
+    tests/test_gpu_fullsize.py::test_rgat_feat128_layer_matches_the_fp64_oracle_at_full_size.)  What stays unexecuted of configs[4]
+    is RCCL between >= 2 ranks."""
+    from het_amd import plan as _plan
+    from het_amd.dist import LocalRanks
+    from het_amd.graph import HetGraph
+    from het_amd.layers import HET_RGATLayer
+    from het_amd.synth import make_mag_like
+    from tests.util import rgat_nudge_off_kink
+    dev = torch.device("cuda", 0)
+    world, feat, H = 8, 128, 4
+    coo = make_mag_like(scale=1.0)
+    for f in ("row", "col", "rel", "eids", "node_type_offsets"):
+        setattr(coo, f, getattr(coo, f).to(dev))
+    N, E = coo.num_nodes, coo.num_edges
+    torch.manual_seed(0)
+    layer = HET_RGATLayer(feat, feat, coo.num_rels, H, self_loop=True, dropout=0.0).to(dev)
+    with torch.no_grad():
+        layer.h_bias.uniform_(-0.1, 0.1)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(N, feat, device=dev, generator=gen) * 0.3
+    go = torch.randn(N, feat, device=dev, generator=gen)
+    g = HetGraph.from_integrated_coo(coo, full=False)
+    # (no pre-activation within 2e-6 of the leaky-ReLU kink: the two runs round el + er differently, tests/util.py)
+    x, zmin = rgat_nudge_off_kink(x, layer.conv_weights, layer.attn_l, layer.attn_r, g.get_separate_coo_original())
+    assert zmin >= 2e-6, zmin
+    # ---- the single-process layer on the whole graph
+    xd = x.clone().requires_grad_(True)
+    one = layer(g, xd)
+    one.backward(go)
+    one = one.detach()
+    gx_one = xd.grad
+    grads_one = {n: q.grad.detach().clone() for n, q in layer.named_parameters()}
+    for q in layer.parameters():
+        q.grad = None
+    del g, xd
+    _plan.clear()
+    # ---- eight logical ranks
+    lr = LocalRanks(coo, world, layer)
+    plans = lr.plans
+    assert sum(p.num_local_edges for p in plans) == E and plans[0].edge_cut > 0.8 * E
+    mine = [lr.owned_nodes(r) for r in range(world)]
+    assert sum(m.numel() for m in mine) == N
+    x_own = [x[m].clone().requires_grad_(True) for m in mine]
+    outs = lr.forward(x_own)
+    assert all(lr.took_halo_path), lr.took_halo_path  # the layer ran the exchange itself on every rank
+    lr.backward(outs, [go[m] for m in mine], x_own)
+
+    def close(name, got, want, tol_l2=2e-5, tol_max=1e-3):
+        d = got.double() - want.double()
+        rel_l2 = float(d.norm() / want.double().norm().clamp(min=1e-30))
+        worst = float(d.abs().max() / want.double().abs().max().clamp(min=1e-30))
+        print(f"[8-way partition at full size vs one process] {name}: rel L2 {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}")
+        assert rel_l2 < tol_l2 and worst < tol_max, f"{name}: relative L2 error {rel_l2:.2e}, max |diff| / max |value| {worst:.2e}"
+
+    out_all, gx_all = torch.empty_like(one), torch.empty_like(gx_one)
+    for r in range(world):
+        out_all[mine[r]] = outs[r].detach()
+        gx_all[mine[r]] = x_own[r].grad
+    close("out", out_all, one)
+    close("grad_x", gx_all, gx_one)
+    for n, q in layer.named_parameters():
+        close("grad_" + n + " (sum over the 8 ranks)", q.grad, grads_one[n])
+    halo = [p.n_halo for p in plans]
+    print(f"[8-way partition at full size] owned nodes {[p.n_own for p in plans]}, halo rows {halo}, local edges {[p.num_local_edges for p in plans]}")
+    _plan.clear()

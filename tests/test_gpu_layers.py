@@ -660,3 +660,31 @@ def test_rgat_layer_many_seeds(compact):
     for seed in range(8):
         g = random_graph(seed=100 + seed, n=120 + 37 * seed, r=2 + seed % 4, e=1500 + 700 * seed, shuffle=False)
         _run_rgat(g, H=4, K=64, X=64, compact=compact, direct=compact and seed % 2 == 0, mulfirst=False, seed=seed)
+
+
+@pytest.mark.parametrize("fused_attn", [False, True])
+@pytest.mark.parametrize("T,R,H,dk,in_dim", [(3, 5, 8, 8, 64), (4, 4, 1, 64, 64), (2, 7, 2, 4, 6), (3, 5, 4, 16, 100)])
+def test_hgt_fold_kernel_matches_the_torch_composition(T, R, H, dk, in_dim, fused_attn, monkeypatch):
+    """csrc/hgt_fold.hip (the HGT layer's per-step parameter folding as one launch, its backward as two) against the torch
+    composition it replaces (hgt_fused_layer.fold_source_weights with HET_HGT_FOLD_KERNEL off) and that composition's autograd, in
+    fp64: w_kv and all five parameter gradients."""
+    import het_amd.backend.hgt_fused_layer as F
+    gen = torch.Generator().manual_seed(13)
+    X = H * dk
+    mk = lambda *shape: torch.randn(*shape, generator=gen)
+    k_lin, v_lin, att, msg = mk(T, 1, in_dim, X), mk(T, 1, in_dim, X), mk(R, H, dk, dk), mk(R, H, dk, dk)
+    pri = torch.rand(R, H, generator=gen) + 0.5
+    st = torch.randint(0, T, (R,), generator=gen)
+    gw = mk(R, 1, in_dim, 2 * X)
+    monkeypatch.setattr(F, "FOLD_KERNEL", False)
+    ref_in = [t.double().requires_grad_(True) for t in (k_lin, v_lin, att, msg, pri)]
+    w_ref = F.fold_source_weights(*ref_in, st, H, fused_attn)
+    g_ref = torch.autograd.grad(w_ref, ref_in, gw.double())
+    monkeypatch.setattr(F, "FOLD_KERNEL", True)
+    dev_in = [t.to(DEV).requires_grad_(True) for t in (k_lin, v_lin, att, msg, pri)]
+    w = F.fold_source_weights(*dev_in, st.to(DEV), H, fused_attn)
+    assert w.shape == w_ref.shape and w.grad_fn is not None and "FoldSourceWeights" in type(w.grad_fn).__name__
+    g = torch.autograd.grad(w, dev_in, gw.to(DEV))
+    assert_close(w, w_ref.detach(), what="w_kv")
+    for name, a, b in zip(("grad_k_lin", "grad_v_lin", "grad_att", "grad_msg", "grad_pri"), g, g_ref):
+        assert_close(a, b, what=name)

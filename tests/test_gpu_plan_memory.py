@@ -80,3 +80,37 @@ def test_c_abi_default_stays_hipmalloc():
     g2 = plan.get_grouping(None, col, n, p0, None)
     assert g2.num_segments > 0
     plan.clear()
+
+
+def test_grouping_released_after_its_use_on_another_stream():
+    """A grouping built on one stream, read by a queue of launches on ANOTHER stream, dropped from the cache while those launches
+    are pending, its memory re-used at once on the creation stream (torch's allocator hands a freed block straight back to the
+    stream that owns it): het_grouping_destroy has to order the release after the other stream's use (het_grouping_note_stream,
+    include/het_amd.h; the cache lookup on the other stream reports it) -- the grouped sums still come out right."""
+    import het_amd.kernels as k
+    from het_amd import _lib, plan
+    assert _lib.allocator_is_external()
+    plan.clear()
+    n, e, X = 3000, 400000, 64
+    gen = torch.Generator().manual_seed(5)
+    key = torch.randint(0, n, (e,), generator=gen).to(DEV)
+    rows = torch.randn(e, X, generator=gen).to(DEV)
+    want = torch.zeros(n, X, dtype=torch.float64, device=DEV).index_add_(0, key, rows.double()).float()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for trial in range(4):
+        first = torch.zeros(n, X, device=DEV)
+        k.rows_scatter_add_(first, key, rows)  # builds the grouping of `key` (by destination row) on the current stream
+        outs = []
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(12):  # a queue of launches on the side stream that read the grouping's arrays
+                out = torch.zeros(n, X, device=DEV)
+                k.rows_scatter_add_(out, key, rows)
+                outs.append(out)
+        plan.clear()  # destroyed while the side stream still has those launches queued
+        junk = [torch.full((e + 64,), -1, dtype=torch.int32, device=DEV) for _ in range(24)]  # the freed blocks, re-used on the creation stream
+        torch.cuda.synchronize()
+        del junk
+        for out in [first] + outs:
+            torch.testing.assert_close(out, want, rtol=2e-4, atol=2e-4)
