@@ -87,21 +87,51 @@ def make_views(args, world, prof_tag, default_heads, heads=None):
     return pmc, hbm_view
 
 
-GATHER_ROW_RATE_GBS = 6100.0  # MI355X_MICROARCH.md "Indexed rows": whole rows of a table larger than the Infinity Cache, each
-                              # fetched once: 5.5-5.8 TB/s gathered into registers, 6.0-6.1 TB/s swept in order into LDS
 
 
 def gather_ceiling(nbytes, rows_gathered, row_bytes):
-    """What `frac` can reach while every edge's row crosses the memory fabric: the op needs at least rows_gathered * row_bytes
-    of row traffic at the chip's gather rate (the L2-window experiment of profiles/r04/locality_*.txt: an L2-RESIDENT table
-    buys the round-3 kernels 21 % forward / 7 % backward, so blocking for locality cannot lift this by much)."""
-    t_ms = rows_gathered * row_bytes / GATHER_ROW_RATE_GBS / 1e6
-    return {"ceiling_frac": round(nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ceiling_ms": round(t_ms, 4),
-            "ceiling_what": f"{rows_gathered} gathered rows x {row_bytes} B at {GATHER_ROW_RATE_GBS / 1e3:.1f} TB/s (guide's rate for "
-                            "rows that miss the Infinity Cache); frac / ceiling_frac = how close the op is to that"}
+    """(rounds 3-4 printed a `ceiling_frac` from the guide's indexed-row rate here; VERDICT r04: the repository's own RGCN gather-sum
+    beats it, so it is not a ceiling.  Replaced by a MEASURED reference: gather_rate_reference below.)"""
+    return {}
 
 
-KT_NAMES = ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs",
+def gather_rate_reference(g, dev, N, X):
+    """A plain gather-sum (the RGCN layer's kernels: HET_segment_sum_packed + _long, no softmax, one output row per segment) over the
+    SAME groupings and row tables the RGAT passes use, timed in this process: by destination over the feat rows (forward) and by
+    (relation, source) row over the gradout rows (backward).  What the gather of the rows alone costs on this graph, on this box --
+    the RGAT passes do that plus their attention arithmetic and their outputs."""
+    from het_amd import _lib as HL
+    from het_amd import kernels as HK
+    s = g.get_separate_coo_original()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    inv = g.get_separate_unique_node_indices_single_sided_inverse_idx()
+    S_row, S_col = ss["node_indices_row"].numel(), ss["node_indices_col"].numel()
+    grp = HK.rgat_compact_groupings(s["col_indices"], inv["inverse_indices_row"], inv["inverse_indices_col"], N, S_row, S_col)
+    if grp is None:
+        return None
+    feat, go = torch.randn(S_row, X, device=dev), torch.randn(N, X, device=dev)
+    out_f, out_b = torch.zeros(N, X, device=dev), torch.zeros(S_row, X, device=dev)
+    res = {}
+    for name, gg, src, out in (("forward_ms", grp[0], feat, out_f), ("backward_ms", grp[1], go, out_b)):
+        def run():
+            HK._call(out, "het_rows_scatter_add_grouped", gg.handle, HK._p(src), X, HK._p(out), out.shape[0], HK._stream(out))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            run()
+        b.record()
+        torch.cuda.synchronize()
+        res[name] = round(a.elapsed_time(b) / 10, 4)
+    res["what"] = ("het_rows_scatter_add_grouped (= HET_segment_sum_packed + _long, '+=' into the output rows) on the RGAT step's own "
+                   "groupings: out[dst] += SUM feat_c[srow_e] (forward), out[srow] += SUM gradout[dst_e] (backward); 21.1 M gathered "
+                   "256-byte rows each")
+    return res
+
+
+KT_NAMES = ("HET_rgat_backward_dst_pack", "HET_rgat_backward_drow_pass", "HET_rgat_backward_src_short", "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs",
             "HET_rgat_backward_src", "HET_rgat_backward", "HET_rgat_aggregate_packs", "HET_rgat_aggregate_hubs",
             "HET_rgat_aggregate_finish", "HET_rgat_aggregate", "HET_gat_backward_src", "HET_gat_backward_grouped",
             "HET_gat_aggregate_grouped", "HET_seg_gemm_mfma<store>",
@@ -733,17 +763,21 @@ def _main():
                 # every launch of the op: per-destination pack, short + long (relation, source) segments, grad_er (from the run
                 # sums the forward left: HET_rgat_grad_er_runs; else the segmented sum of the per-edge term)
                 runs = "HET_rgat_backward_er_runs" in kt
-                pm = ("HET_rgat_dst_pack", "HET_rgat_backward_src_coop", "HET_rgat_backward_src_long",
-                      "HET_rgat_grad_er_runs" if runs else "HET_segment_sum_flat4")
+                fused = "HET_rgat_backward_drow_pass" in kt  # (round 5: one pass per er row instead of dst pack + records + grad_er)
+                pm = (("HET_rgat_drow_pass", "HET_rgat_colsum_rows") if fused else ("HET_rgat_dst_pack",)) + (
+                    "HET_rgat_backward_src_coop", "HET_rgat_backward_src_long") + (
+                    () if fused else ("HET_rgat_grad_er_runs" if runs else "HET_segment_sum_flat4",))
                 b_ms = kt["HET_rgat_backward"][2] + (0.0 if runs else kt.get("HET_segment_sum", (0, 0, 0.0))[2])
                 # the launches of the op run side by side on two streams (csrc/common.hip.h: HetFork), so their own durations
                 # overlap: the op's time is the span between its entry and its return on the caller's stream (per_op_ms)
                 op_ms = (per_op or {}).get("rgat_backward_compact_runs" if runs else "rgat_backward_compact")
-                ex["launch_ms_overlapping"] = {n: round(kt[n][2], 4) for n in ("HET_rgat_backward_dst_pack", "HET_rgat_backward_src_short",
-                                                                             "HET_rgat_backward_src_long", "HET_rgat_backward_er_runs") if n in kt}
+                ex["launch_ms_overlapping"] = {n: round(kt[n][2], 4) for n in ("HET_rgat_backward_dst_pack", "HET_rgat_backward_drow_pass",
+                                                                             "HET_rgat_backward_src_short", "HET_rgat_backward_src_long",
+                                                                             "HET_rgat_backward_er_runs") if n in kt}
                 if op_ms:
                     b_ms = op_ms
-                bname = "HET_rgat_dst_pack + HET_rgat_backward_src_coop + _src_long + " + ("HET_rgat_grad_er_runs" if runs else "HET_segment_sum")
+                bname = (("HET_rgat_drow_pass + " if fused else "HET_rgat_dst_pack + ") + "HET_rgat_backward_src_coop + _src_long"
+                         + ("" if fused else " + " + ("HET_rgat_grad_er_runs" if runs else "HET_segment_sum")))
                 what = "4: rows of the distinct (relation, node) projections; all launches of the op"
                 ex["frac_with_per_edge_row_gather"] = round(req / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             roofline = hbm_view(f"{bname} (backward_relational_fused_gat_separate_coo, kind {what})", b_ms, nb_, ex, pmc_name=pm)
@@ -771,6 +805,11 @@ def _main():
                         ex["frac_with_per_edge_row_gather"] = round(req / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             roofline_fwd = hbm_view(f"{fname} (relational_fused_gat_separate_coo, kind {4 if S_row else 0}{'; also leaves the per-run sums grad_er is formed from' if isinstance(pmf, tuple) else ''})",
                                     f_ms, nf_, ex, pmc_name=pmf)
+    if args.model == "rgat" and world == 1 and not use_dist and roofline is not None and roofline_fwd is not None and S_row is not None:
+        ref = gather_rate_reference(g, dev, N_local, X)
+        if ref:
+            roofline["gather_rate_reference_ms"], roofline_fwd["gather_rate_reference_ms"] = ref["backward_ms"], ref["forward_ms"]
+            roofline["gather_rate_reference_what"] = roofline_fwd["gather_rate_reference_what"] = ref["what"]
     if args.model == "rgcn" and "HET_segment_sum" in kt and not use_dist:
         roofline, roofline_fwd = rgcn_rooflines(g, kt, E_local, N_local, K, X, hbm_view)
     if args.model == "hgt" and "HET_hgt_aggregate_rows" in kt and not use_dist:

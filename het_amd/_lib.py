@@ -95,8 +95,9 @@ def lib() -> C.CDLL:
         L.het_last_error.restype = C.c_char_p
         L.het_grouping_destroy.argtypes = [P]
         L.het_grouping_destroy.restype = None
-        L.het_grouping_note_stream.argtypes = [P, P]
-        L.het_grouping_note_stream.restype = None
+        if hasattr(L, "het_grouping_note_stream"):  # (absent from a library of round 4 and before: exp/ A/B runs through HET_AMD_LIB)
+            L.het_grouping_note_stream.argtypes = [P, P]
+            L.het_grouping_note_stream.restype = None
         L.het_grouping_num_segments.argtypes = [P]
         L.het_grouping_num_segments.restype = I64
         L.het_grouping_bytes.argtypes = [P]
@@ -132,11 +133,24 @@ def lib() -> C.CDLL:
         L.het_kernel_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(I64)]
         L.het_kernel_timing_read.restype = INT
         for name, args in _SIGNATURES.items():
-            f = getattr(L, name)
+            f = getattr(L, name, None)
+            if f is None and name in _ROUND5_ENTRY_POINTS and os.environ.get("HET_AMD_LIB"):
+                continue  # an OLDER library selected for an A/B run (exp/ab_r05.sh): the callers ask has() first
+            if f is None:
+                raise HetError(f"{LIB_PATH} does not export {name}: rebuild it (make -C het_amd/csrc)")
             f.argtypes = args
             f.restype = INT
         _lib = L
     return _lib
+
+
+_ROUND5_ENTRY_POINTS = ("het_hgt_fold_source_weights", "het_hgt_fold_source_weights_backward")
+
+
+def has(name: str) -> bool:
+    """Whether the loaded library exports ``name`` (always true for the in-tree build; an older library selected with HET_AMD_LIB for
+    a same-box A/B lacks the entry points of later rounds, and the callers then take the path that library knows)."""
+    return hasattr(lib(), name)
 
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)

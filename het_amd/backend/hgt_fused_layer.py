@@ -139,7 +139,7 @@ class _FoldSourceWeights(th.autograd.Function):
 def fold_source_weights(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type, num_heads, fused_attn):
     """w_kv [R,1,in,2*H*dk] (module docstring).  k_lin / v_lin [T,1,in,H*dk]; rel_att / rel_msg [R,H,dk,dk]; rel_pri [R,H]."""
     if (FOLD_KERNEL and k_lin.is_cuda and k_lin.dtype == th.float32 and k_lin.dim() == 4 and k_lin.shape[1] == 1
-            and src_type.is_cuda and src_type.dtype == th.int64):
+            and src_type.is_cuda and src_type.dtype == th.int64 and _k._lib.has("het_hgt_fold_source_weights")):
         return _FoldSourceWeights.apply(k_lin, v_lin, rel_att, rel_msg, rel_pri, src_type.contiguous(), fused_attn)
     R, H, dk, _ = rel_att.shape
     K_in = k_lin.shape[2]

@@ -401,7 +401,12 @@ class RgatLayerFunction(th.autograd.Function):
         row_map = _k.node_row_map(rp_row, ss["node_indices_row"], N)
         dst_map = _k.node_row_map(ss["rel_ptrs_col"], ss["node_indices_col"], N)
         go = grad_h.view(nd, H, D)  # every edge points at one of the first nd nodes (checked by the caller)
-        g_featc, g_elc, g_erc = th.empty_like(featc), th.empty_like(elc), th.empty_like(erc)  # all three overwritten
+        # (the weight gradient of attn_l from the same pass when the forward left run sums: csrc/gat_compact.hip ga_block_reduce;
+        #  grad_el_c then has no reader left -- its other consumer, the gradient through el, is folded into grad_feat_c -- and is
+        #  not written at all)
+        attn_in_pass = ATTN_GRAD_IN_PASS and ctx.runs is not None and R <= 8
+        g_featc, g_erc = th.empty_like(featc), th.empty_like(erc)  # overwritten
+        g_elc = None if (attn_in_pass and _k._lib.has("het_grouping_note_stream")) else th.empty_like(elc)  # (a round-5 library)
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
         main, side = th.cuda.current_stream(x.device), _side_stream(x.device) if OVERLAP else None
@@ -410,9 +415,7 @@ class RgatLayerFunction(th.autograd.Function):
             side.wait_stream(main)
             with th.cuda.stream(side):
                 _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
-        # (the weight gradient of attn_l from the same pass when the forward left run sums: csrc/gat_compact.hip ga_block_reduce)
         grad_attn_l = th.empty_like(attn_l)
-        attn_in_pass = ATTN_GRAD_IN_PASS and ctx.runs is not None and R <= 8
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
                                  row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
                                  drow_nodes=ss["node_indices_col"], grad_attn_l=grad_attn_l if attn_in_pass else None)

@@ -847,27 +847,34 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_aggregate_hub_items(
   if (d == 0) { pp[2 * X + h] = m; pp[2 * X + H + h] = ssum; pp[2 * X + 2 * H + h] = sq; }
 }
 
-// One wave per hub (hub_segs: segments of the grouping by destination): its runs are the segments of `it` with keys in
+// One WORKGROUP per hub (hub_segs: segments of the grouping by destination): its runs are the segments of `it` with keys in
 // [v * R, (v + 1) * R), its work items are consecutive.  First ret / lse over all items, then the sums of every run relative to lse.
+// (Round 5: a wave per hub walked the records of the largest hub -- ~3 600 items on the ogbn-mag-like graph -- four at a time, and
+// that one wave WAS the launch: 0.135 ms at the end of the forward's critical path.  The 16 lane groups of a workgroup take the
+// records round-robin and meet in LDS; hubs of a few items leave three waves idle, which costs nothing at 17 K hubs.)
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
-    const int32_t* __restrict__ hub_segs, int64_t num_hubs, const int32_t* __restrict__ dseg_key, Items it, int64_t S2, int R,
-    const int32_t* __restrict__ hub_items, int64_t num_hub_items, const int32_t* __restrict__ p_drow,
+    const int4* __restrict__ hub_rec, int64_t num_hubs, Items it, const int32_t* __restrict__ p_drow,
     const float* __restrict__ part, float* __restrict__ lse, float* __restrict__ ret, int H,
     int D, float* __restrict__ hio, int64_t hio_rows, float* __restrict__ qrow, float* __restrict__ qsum,
     float* __restrict__ qref) {
-  constexpr int EPW = 64 / LPR;
-  const int lane = threadIdx.x & 63, slot = lane / LPR, x = (lane % LPR) * 4, h = x / D;
-  const int64_t k = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  constexpr int EPW = 64 / LPR, NW = kBlock / 64;
+  __shared__ float4 s_acc[NW][LPR];
+  __shared__ float s_m[NW][LPR], s_sum[NW][LPR], s_L[LPR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane / LPR, sub = lane % LPR, x = sub * 4, h = x / D;
+  const int64_t k = blockIdx.x;
   if (k >= num_hubs) return;
-  const int64_t X = (int64_t)H * D, v = dseg_key[hub_segs[k]], rec = 2 * X + 3 * H;
-  const int64_t s_lo = lower_bound_i32(it.seg_key, S2, v * R), s_hi = lower_bound_i32(it.seg_key, S2, (v + 1) * R);
-  // the hub's work items are consecutive, and so are their records (hub_items is ascending): record of item i = i_lo + (i - item_lo)
-  const int64_t item_lo = lower_bound_i32(it.seg, it.n, s_lo), item_hi = lower_bound_i32(it.seg, it.n, s_hi);
-  const int64_t i_lo = lower_bound_i32(hub_items, num_hub_items, item_lo), i_hi = i_lo + (item_hi - item_lo);
+  // {first run, one past the last run, first record, destination} of the hub: searched once per grouping (grouping_hub_items) -- as
+  // five dependent binary searches per hub HERE they were ~100 dependent loads in front of every wave, i.e. the launch's 0.13 ms
+  const int4 hr = hub_rec[k];
+  const int64_t X = (int64_t)H * D, v = hr.w, rec = 2 * X + 3 * H;
+  const int64_t s_lo = hr.x, s_hi = hr.y, i_lo = hr.z;
+  int64_t n_all = 0;
+  for (int64_t s2 = s_lo; s2 < s_hi; ++s2) n_all += (it.seg_ptr[s2 + 1] - it.seg_ptr[s2] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
+  const int64_t i_hi = i_lo + n_all;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float ssum = 0.f, m = -INFINITY;
-  for (int64_t i = i_lo + slot; i < i_hi; i += EPW) {
+  for (int64_t i = i_lo + wave * EPW + slot; i < i_hi; i += NW * EPW) {
     const float* pp = part + i * rec;
     const float mi = pp[2 * X + h], si = pp[2 * X + H + h];
     const float4 a = ld4(pp + x);
@@ -889,10 +896,25 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
     acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
     ssum += __shfl_xor(ssum, off);
   }
-  const float L = lse_of(M, ssum);  // (every lane group holds the totals of its head)
-  if (slot == 0) {
-    const float inv = 1.f / ssum;
-    const float4 r4 = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (slot == 0) { s_acc[wave][sub] = acc; s_m[wave][sub] = M; s_sum[wave][sub] = ssum; }  // (M = -inf, sums 0: a wave without items)
+  __syncthreads();
+  if (wave == 0 && slot == 0) {  // the waves' partial results to their common maximum
+    float Mx = s_m[0][sub];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) Mx = fmaxf(Mx, s_m[w][sub]);
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ts = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float c = s_m[w][sub] == -INFINITY ? 0.f : __expf(s_m[w][sub] - Mx);
+      const float4 a = s_acc[w][sub];
+      t.x = fmaf(a.x, c, t.x); t.y = fmaf(a.y, c, t.y); t.z = fmaf(a.z, c, t.z); t.w = fmaf(a.w, c, t.w);
+      ts = fmaf(s_sum[w][sub], c, ts);
+    }
+    const float L = lse_of(Mx, ts);
+    s_L[sub] = L;
+    const float inv = 1.f / ts;
+    const float4 r4 = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
     st4(ret + v * X + x, r4);
     if (hio && v < hio_rows) {
       const float4 h0 = ld4(hio + v * X + x);
@@ -900,12 +922,14 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
     }
     if (x % D == 0) lse[v * H + h] = L;
   }
+  __syncthreads();
+  const float L = s_L[sub];
   int64_t i0 = i_lo;
   for (int64_t s2 = s_lo; s2 < s_hi; ++s2) {
     const int64_t n_items = (it.seg_ptr[s2 + 1] - it.seg_ptr[s2] + HET_ITEM_MAX - 1) / HET_ITEM_MAX;
     float4 aq = make_float4(0.f, 0.f, 0.f, 0.f);
     float sq = 0.f;
-    for (int64_t i = i0 + slot; i < i0 + n_items; i += EPW) {
+    for (int64_t i = i0 + wave * EPW + slot; i < i0 + n_items; i += NW * EPW) {
       const float* pp = part + i * rec;
       const float ci = __expf(pp[2 * X + h] - L);
       const float4 a = ld4(pp + X + x);
@@ -918,10 +942,21 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_finish_hubs(
       aq.z += __shfl_xor(aq.z, off); aq.w += __shfl_xor(aq.w, off);
       sq += __shfl_xor(sq, off);
     }
-    if (slot == 0) {
-      const int64_t w = p_drow[it.seg_ptr[s2]];  // er row of the run
-      st4(qrow + w * X + x, aq);
-      if (x % D == 0) { qsum[w * H + h] = sq; qref[w * H + h] = L; }
+    __syncthreads();  // (the previous round's LDS slots have been read)
+    if (slot == 0) { s_acc[wave][sub] = aq; s_sum[wave][sub] = sq; }
+    __syncthreads();
+    if (wave == 0 && slot == 0) {
+      float4 t = s_acc[0][sub];
+      float ts = s_sum[0][sub];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 a = s_acc[w][sub];
+        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+        ts += s_sum[w][sub];
+      }
+      const int64_t wrow = p_drow[it.seg_ptr[s2]];  // er row of the run
+      st4(qrow + wrow * X + x, t);
+      if (x % D == 0) { qsum[wrow * H + h] = ts; qref[wrow * H + h] = L; }
     }
     i0 += n_items;
   }
@@ -1129,7 +1164,7 @@ __global__ __launch_bounds__(kBlock, GA ? 5 : 1) void HET_rgat_backward_src_coop
           o.z = fmaf(acc_el, wcur.z, o.z); o.w = fmaf(acc_el, wcur.w, o.w);
         }
         st4_at<O>(grad_feat, ((O)u << RS) | xb, o);
-        if (d == 0) st1_at<O>(grad_el, ((O)u << HS) | hb, acc_el);
+        if (grad_el && d == 0) st1_at<O>(grad_el, ((O)u << HS) | hb, acc_el);  // (NULL: nobody reads it -- the fold and the attention gradient are formed here)
         if (GA) {  // grad_attn_l[rel_cur] += grad_el[u] * feat[u]  (flushed where rel_cur changes, above)
           ga.x = fmaf(acc_el, fcur.x, ga.x); ga.y = fmaf(acc_el, fcur.y, ga.y);
           ga.z = fmaf(acc_el, fcur.z, ga.z); ga.w = fmaf(acc_el, fcur.w, ga.w);
@@ -1243,10 +1278,10 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_backward_src_long(
   float* gp = grad_feat + u * X + x;
   if (whole) {
     st4(gp, acc);
-    if (d == 0) grad_el[u * H + h] = acc_el;
+    if (grad_el && d == 0) grad_el[u * H + h] = acc_el;
   } else {
     atomicAdd(gp + 0, acc.x); atomicAdd(gp + 1, acc.y); atomicAdd(gp + 2, acc.z); atomicAdd(gp + 3, acc.w);
-    if (d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
+    if (grad_el && d == 0) atomicAdd(&grad_el[u * H + h], acc_el);
   }
 }
 
@@ -1350,7 +1385,7 @@ __global__ __launch_bounds__(kBlock) void HET_rgat_zero_long_rows(const int32_t*
     const int sub = (int)(t - k * LPR);
     const int64_t u = seg_key[long_seg[k]];
     st4(grad_feat + u * X + sub * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    if (sub < H) grad_el[u * H + sub] = 0.f;
+    if (grad_el && sub < H) grad_el[u * H + sub] = 0.f;
   }
 }
 
@@ -1457,7 +1492,10 @@ extern "C" int het_rgat_aggregate_compact(const het_grouping* by_dst, const floa
 static int rgat_hub_min() {
   static const int v = [] {
     const char* e = getenv("HET_RGAT_HUB_MIN");
-    const int t = e ? atoi(e) : 128;  // (256 until el came from the row: the hub launch gained more from that than the pack-form one)
+    // (256 in round 3, 128 once el came from the row -- the hub launch gained more from that than the pack-form one --, 256 again in
+    //  round 5: the pack-form launch got faster (tags, 32-bit offsets) and the hub finish is a workgroup per hub;
+    //  profiles/r05/ab_round5_misc.txt: 64 / 96 / 128 / 192 / 256 -> 4.03 / 3.86 / 3.78 / 3.74 / 3.72 ms per step)
+    const int t = e ? atoi(e) : 256;
     return t < HET_PACK_T ? HET_PACK_T : t;
   }();
   return v;
@@ -1585,12 +1623,11 @@ extern "C" int het_rgat_aggregate_compact_runs(const het_grouping* by_dst, const
 #undef HET_HUBS_LAUNCH2
     }
     HET_LAUNCH_CHECK("HET_rgat_aggregate_hub_items");
-    const unsigned nbs = (unsigned)ceil_div64(by_dst_rel->num_hub_segs, kBlock / 64);
+    const unsigned nbs = (unsigned)by_dst_rel->num_hub_segs;  // (a workgroup per hub)
     {
     HET_KTIME("HET_rgat_aggregate_finish", s2);
-    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s2, by_dst_rel->hub_segs,
-                                                      by_dst_rel->num_hub_segs, by_dst->seg_key, it, by_dst_rel->S, (int)num_rels,
-                                                      by_dst_rel->hub_items, n_hub, by_dst->p1, part, sum, ret, (int)H, (int)D,
+    HET_DISPATCH_LPR((int)(X / 4), hipLaunchKernelGGL(HET_rgat_finish_hubs<LPR>, dim3(nbs), dim3(kBlock), 0, s2, by_dst_rel->hub_rec,
+                                                      by_dst_rel->num_hub_segs, it, by_dst->p1, part, sum, ret, (int)H, (int)D,
                                                       h_inout, h_rows, q_rows, q_sum, q_ref));
     }
     HET_LAUNCH_CHECK("HET_rgat_finish_hubs");
@@ -1624,7 +1661,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
                                       int64_t num_dst_rows, int64_t H, int64_t D, double slope, void* workspace,
                                       int64_t workspace_bytes, het_stream stream) {
   hipStream_t s = (hipStream_t)stream;
-  HET_REQUIRE(by_srow && (by_drow || runs) && sum && ret && gradout && grad_feat_c && grad_el_c && grad_er_c, "%s: null argument", op);
+  HET_REQUIRE(by_srow && (by_drow || runs) && sum && ret && gradout && grad_feat_c && grad_er_c, "%s: null argument", op);
+  // grad_el_c may be NULL when nobody reads it: its two consumers -- the gradient through el = <feat, attn_l> (fold_attn_l) and the
+  // weight gradient of attn_l (grad_attn_l) -- are both formed inside the pass (cooperative shapes only)
+  HET_REQUIRE(grad_el_c || (runs && fold_attn_l && grad_attn_l && coop_shape_ok(H, D)),
+              "%s: grad_el_c may only be NULL in the run-sum form with fold_attn_l and grad_attn_l (cooperative shapes)", op);
   if (!compact_shape_ok(H, D) || !segment_rows_supported((int)H) || slope < 0 || (runs && !coop_shape_ok(H, D))) {
     het_set_error("%s: unsupported shape H=%lld D=%lld (or slope < 0)", op, (long long)H, (long long)D);
     return HET_ERR_UNSUPPORTED;
@@ -1658,7 +1699,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   if (grad_attn_l) HET_HIP(hipMemsetAsync(grad_attn_l, 0, sizeof(float) * num_rels * X, s));  // (boundary pieces add atomically)
   if (by_srow->S != num_src_rows) {  // feat rows without an edge (none when the lists come from the graph): zero gradient
     HET_HIP(hipMemsetAsync(grad_feat_c, 0, sizeof(float) * num_src_rows * X, s));
-    HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
+    if (grad_el_c) HET_HIP(hipMemsetAsync(grad_el_c, 0, sizeof(float) * num_src_rows * H, s));
   }
   // One pass over the er rows (HET_rgat_drow_pass: the records of the source-row kernels AND grad_er) instead of dst pack + record
   // pack + grad_er pass; the bias gradient's column sums then are a pass of their own on the side stream (HET_RGAT_DROW_PASS=0: A/B)

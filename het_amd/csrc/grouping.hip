@@ -131,6 +131,27 @@ __global__ void HET_grouping_hub_first_p0(const int32_t* __restrict__ hub_items,
     val[k] = (int32_t)k;
   }
 }
+__device__ __forceinline__ int64_t hub_lower_bound(const int32_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// rec[k] = {s_lo, s_hi, i_lo, v}: the runs (segments of the grouping by key * R + relation) of hub k = twin segment hub_segs[k] with key
+// v are [s_lo, s_hi); its work items are consecutive and so are their positions in hub_items, the first one at i_lo
+__global__ void HET_grouping_hub_records(const int32_t* __restrict__ hub_segs, int64_t num_hubs, const int32_t* __restrict__ twin_seg_key,
+                                         const int32_t* __restrict__ seg_key, int64_t S, const int32_t* __restrict__ item_seg, int64_t NI,
+                                         const int32_t* __restrict__ hub_items, int64_t num_hub_items, int R, int4* __restrict__ rec) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < num_hubs; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = twin_seg_key[hub_segs[k]];
+    const int64_t s_lo = hub_lower_bound(seg_key, S, v * R), s_hi = hub_lower_bound(seg_key, S, (v + 1) * R);
+    const int64_t item_lo = hub_lower_bound(item_seg, NI, s_lo);
+    const int64_t i_lo = hub_lower_bound(hub_items, num_hub_items, item_lo);
+    rec[k] = make_int4((int)s_lo, (int)s_hi, (int)i_lo, (int)v);
+  }
+}
 __global__ void HET_grouping_long_seg_flags(const int32_t* __restrict__ seg_ptr, int64_t S, int min_len, uint8_t* __restrict__ flag) {
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < S; s += (int64_t)gridDim.x * blockDim.x)
     flag[s] = seg_ptr[s + 1] - seg_ptr[s] > min_len;
@@ -229,7 +250,7 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
     }
   }
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order, g->hub_rec};
   for (void* p : ptrs)
     if (p) (void)het_free_e(p);
   for (void* p : g->retired) (void)het_free_e(p);
@@ -253,7 +274,7 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
   if (g->p01) b += 8 * (E > 0 ? E : 1);
   if (g->kp01) b += 16 * (E + 1);
-  if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1) + (g->hub_order ? 4 * g->num_hub_items : 0);
+  if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1) + (g->hub_order ? 4 * g->num_hub_items : 0) + (g->hub_rec ? 16 * g->num_hub_segs : 0);
   return b;
 }
 
@@ -481,14 +502,16 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
     // the lists are rebuilt.  The old ones are RETIRED, not freed: another thread may be between its workspace query and its
     // launch with the pointers it read (and a caller's allocator would hand the memory out again without waiting for the
     // device); they go with the grouping (het_grouping_destroy).
-    for (int32_t* old : {g->hub_items, g->hub_segs, g->hub_order})
+    for (int32_t* old : {g->hub_items, g->hub_segs, g->hub_order, reinterpret_cast<int32_t*>(g->hub_rec)})
       if (old) g->retired.push_back(old);
     g->hub_items = g->hub_segs = g->hub_order = nullptr;
+    g->hub_rec = nullptr;
     g->num_hub_items = -1;
     g->num_hub_segs = 0;
   }
   const int64_t NI = g->num_items, TS = twin->S;
   int32_t *items = nullptr, *segs = nullptr, *order = nullptr;
+  int4* rec = nullptr;
   int32_t h_num[2] = {0, 0};
   if (NI > 0 && TS > 0) {
     Scratch tmp(s);
@@ -538,9 +561,18 @@ int grouping_hub_items(const het_grouping* g, const het_grouping* twin, int R, i
       if (e == hipSuccess) e = tmp.alloc(&st, sb);
       if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(st, sb, k_in, k_out, v_in, order, h_num[0], 0, 32, s);
     }
+    if (e == hipSuccess && h_num[1] > 0) {
+      e = het_malloc_e((void**)&rec, sizeof(int4) * (size_t)h_num[1], s);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(HET_grouping_hub_records, dim3(blocks_for(h_num[1])), dim3(256), 0, s, segs, (int64_t)h_num[1], twin->seg_key,
+                           g->seg_key, g->S, g->item_seg, NI, items, (int64_t)h_num[0], R, rec);
+        e = hipGetLastError();
+      }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)het_free_e(items); (void)het_free_e(segs); (void)het_free_e(order); HET_HIP(e); }
+    if (e != hipSuccess) { (void)het_free_e(items); (void)het_free_e(segs); (void)het_free_e(order); (void)het_free_e(rec); HET_HIP(e); }
   }
+  g->hub_rec = rec;
   g->hub_order = order;
   g->hub_items = items;
   g->hub_segs = segs;

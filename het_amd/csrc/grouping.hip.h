@@ -67,6 +67,9 @@ struct het_grouping {
   mutable int64_t num_hub_items = -1;         // -1: not built
   mutable int32_t* hub_order = nullptr;       // [num_hub_items] indices into hub_items, by the first payload0 of the twin in the item
   mutable int32_t* hub_segs = nullptr;        // the twin's segments of more than hub_min positions (ascending)
+  mutable int4* hub_rec = nullptr;            // [num_hub_segs] {first run (segment of this grouping), one past the last, first record in
+                                              // hub_items, key of the hub}: what a finishing pass needs per hub, searched ONCE here
+                                              // instead of by five dependent binary searches per hub and launch (round 5)
   mutable int64_t num_hub_segs = 0;
   mutable int hub_min = 0;
   mutable uint64_t hub_twin_serial = 0;       // serial of the twin the lists were built against

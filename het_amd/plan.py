@@ -116,7 +116,8 @@ def get_grouping(rel_ptrs: Optional[torch.Tensor], keys: torch.Tensor, key_bound
         if g is not None:
             _cache.move_to_end(k)
             # (the stream this op will read the grouping on: het_grouping_destroy orders the release after it, include/het_amd.h)
-            _lib.lib().het_grouping_note_stream(g.handle, C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream))
+            if _lib.has("het_grouping_note_stream"):
+                _lib.lib().het_grouping_note_stream(g.handle, C.c_void_p(torch.cuda.current_stream(keys.device).cuda_stream))
             return g
         for t in (rel_ptrs, keys, payload0, payload1):
             if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):

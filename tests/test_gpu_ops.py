@@ -1139,3 +1139,18 @@ def test_grouping_segment_map_and_payload_gather(R, n, e):
         k._call(outn, "het_node_rows_matmul_sum_bias", 0, N, N, S, ptrs, strides, mps, ident, w_, k._p(b_), k._p(outn), KS, XO, k._p(order),
                 k._stream(outn))
         assert_close(outn, want, what=f"node sum + bias {KS}->{XO}")
+
+
+def test_rgat_row_kernels_with_64_bit_offsets():
+    """The RGAT row kernels take their byte offsets as a template argument: 32-bit off scalar bases when every indexed table is below
+    4 GiB (what every other test runs), 64-bit otherwise.  HET_RGAT_WIDE_OFFSETS=1 forces the 64-bit instantiation; it is read once per
+    process, so the run-sum cases run again in a child interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HET_RGAT_WIDE_OFFSETS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_rgat_compact_run_sums and True-True", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
