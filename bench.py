@@ -762,7 +762,7 @@ def _main():
             if bname == "HET_rgat_backward_src":
                 # every launch of the op: per-destination pack, short + long (relation, source) segments, grad_er (from the run
                 # sums the forward left: HET_rgat_grad_er_runs; else the segmented sum of the per-edge term)
-                runs = "HET_rgat_backward_er_runs" in kt
+                runs = "HET_rgat_backward_er_runs" in kt or "HET_rgat_backward_drow_pass" in kt
                 fused = "HET_rgat_backward_drow_pass" in kt  # (round 5: one pass per er row instead of dst pack + records + grad_er)
                 pm = (("HET_rgat_drow_pass", "HET_rgat_colsum_rows") if fused else ("HET_rgat_dst_pack",)) + (
                     "HET_rgat_backward_src_coop", "HET_rgat_backward_src_long") + (

@@ -15,6 +15,7 @@ if [ "$1" = "tests" ]; then
   python bench.py > gpurun_out/bench_default_full_a.json 2> gpurun_out/bench_default_full_a.err; echo bench rc=$?
   tail -c 600 gpurun_out/bench_default_full_a.json
 else
+  python -m pytest tests/test_gpu_layers.py -x -q -m gpu -k "rgcn or hgt" > gpurun_out/final_tests_b.log 2>&1; echo layer tests rc=$?; tail -1 gpurun_out/final_tests_b.log
   bash profiles/tools/collect_all.sh > gpurun_out/collect_all.log 2>&1; tail -4 gpurun_out/collect_all.log
   for c in default default_serial rgcn hgt; do for f in kernel_stats.csv pmc.json summary.txt; do cp gpurun_out/${c}_r05/$f profiles/r05/${c}_$f; done; done
   python3 profiles/tools/timeline.py gpurun_out/default_r05/stats HET_rgat_aggregate_runs_packed 0.62 > gpurun_out/default_timeline.txt

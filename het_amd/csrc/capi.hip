@@ -178,3 +178,32 @@ extern "C" int het_kernel_timing_read(const char* name_prefix, double* total_ms,
   *launches = c;
   return HET_OK;
 }
+
+// ---- LDS budget of the current device (common.hip.h) ---------------------------------------------------------------------
+size_t het_lds_budget() {
+  static thread_local int cached_dev = -1;
+  static thread_local size_t cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 64 * 1024; }
+  if (dev != cached_dev) {
+    // by architecture name first: the attribute reports the 64 KB a launch gets WITHOUT hipFuncAttributeMaxDynamicSharedMemorySize on
+    // some runtimes, and the kernels here opt in to the whole LDS of a gfx950 CU (160 KB)
+    hipDeviceProp_t prop;
+    size_t v = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) v = 160 * 1024;
+      else if (strncmp(prop.gcnArchName, "gfx9", 4) == 0) v = 64 * 1024;
+    } else {
+      (void)hipGetLastError();
+    }
+    if (v == 0) {
+      int a = 0;
+      if (hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || a <= 0) { (void)hipGetLastError(); a = 64 * 1024; }
+      v = (size_t)a;
+    }
+    cached = v;
+    cached_dev = dev;
+  }
+  return cached;
+}
+

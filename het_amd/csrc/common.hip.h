@@ -106,6 +106,11 @@ struct HetFork {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// LDS a workgroup of the current device may ask for (160 KB on gfx950, 64 KB on the other gfx9 parts, the runtime's
+// hipDeviceAttributeMaxSharedMemoryPerBlock elsewhere; 64 KB when nothing can be queried) -- the `_ok` predicates and the launchers of the weight-resident kernels both use it,
+// so a build for another target (the Makefile's ARCH override) falls back instead of failing at the launch.  node_sum.hip.
+size_t het_lds_budget();
+
 // ---- device helpers -----------------------------------------------------------
 // Segment s with ptrs[s] <= i < ptrs[s+1]; ptrs non-decreasing, empty segments allowed.
 __device__ __forceinline__ int find_segment(const idx_t* __restrict__ ptrs, int n, idx_t i) {

@@ -235,7 +235,7 @@ int launch_dx(const NodeArgs& a, hipStream_t s) {
   auto lds_for = [&](int waves) {
     return sizeof(float) * ((size_t)(1 + a.R) * KS * XO + (size_t)a.rhp * XO + (size_t)waves * (32 * LD + (2 + a.R) * 32));
   };
-  const size_t limit = 160 * 1024;
+  const size_t limit = het_lds_budget();
   HET_KTIME("HET_node_dx", s);
   if (lds_for(8) <= limit) {
     const size_t lds = lds_for(8);
@@ -272,7 +272,7 @@ extern "C" int het_rgat_node_gemm_ok(int64_t R, int64_t H, int64_t K, int64_t D)
   // the input-gradient pass keeps all 1 + R transposed weights in LDS (4 waves at least)
   const int64_t KS = H * D, LD = (KS > K ? KS : K) + 4, rhp = (R * H + 7) / 8 * 8;
   const int64_t lds = 4 * ((1 + R) * KS * K + rhp * K + 4 * (32 * LD + (2 + R) * 32));
-  return lds <= 160 * 1024 ? 1 : 0;
+  return lds <= het_lds_budget() ? 1 : 0;
 }
 
 extern "C" int het_node_row_map(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* nodes, int64_t num_rows,

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
 template <int KS, int NO>
 int launch_sum_w16(const SumArgs& a, hipStream_t s, bool* done) {
   constexpr int XO = NO * 32;
-  const size_t limit = 160 * 1024, wbytes = sizeof(float) * (size_t)a.S * KS * XO, per_wave = sizeof(float) * 32 * 36;
+  const size_t limit = het_lds_budget(), wbytes = sizeof(float) * (size_t)a.S * KS * XO, per_wave = sizeof(float) * 32 * 36;
   *done = false;
   if (wbytes + 8 * per_wave > limit) return HET_OK;  // fewer than 8 waves: the tile form above does as well
   // (HET_NODE_SUM_WAVES: A/B -- 16 waves of 128 VGPRs are a CU's whole register file, nothing runs beside such a workgroup)
@@ -369,7 +369,7 @@ int launch_sum(const SumArgs& a, hipStream_t s) {
     if (done) return HET_OK;
   }
   const int64_t tiles = (a.n_end - a.n_begin + 31) / 32;
-  const size_t limit = 160 * 1024;
+  const size_t limit = het_lds_budget();
   HET_KTIME("HET_node_rows_sum", s);
   if (lds_for<KS, NO>(a.S, 8) <= limit) {
     const size_t lds = lds_for<KS, NO>(a.S, 8);
@@ -398,7 +398,7 @@ size_t lds_any(int S, int64_t KS, int64_t XO, int waves) {
 
 extern "C" int het_node_rows_matmul_sum_ok(int64_t num_sources, int64_t KS, int64_t XO) {
   if (!(num_sources >= 1 && num_sources <= kMaxSrc && (KS == 32 || KS == 64) && (XO == 32 || XO == 64))) return 0;
-  return lds_any((int)num_sources, KS, XO, 4) <= 160 * 1024 ? 1 : 0;
+  return lds_any((int)num_sources, KS, XO, 4) <= het_lds_budget() ? 1 : 0;
 }
 
 extern "C" int het_node_rows_matmul_sum_bias(int64_t n_begin, int64_t n_end, int64_t num_nodes, int64_t num_sources,
