@@ -93,7 +93,7 @@ def main():
               "TBD-refseq": f"{v.get('reference_op_sequence', {}).get('ms_per_step', 0):.1f}",
               "TBD-rgcn-ms": f"{rg['ms_per_step']:.2f}", "TBD-rgcn-val": f"{rg['value']:,.0f}".replace(",", " "),
               "TBD-hgt-ms": f"{hg['ms_per_step']:.2f}", "TBD-hgt-val": f"{hg['value']:,.0f}".replace(",", " "),
-              "TBD-rehearsal-ms": f"{reh.get('max_ms')}", "TBD-cpu-ms": f"{cpu.get('sample_seconds_per_step', 0) / max(cpu.get('scale', 0.25), 1e-9) * 1e3:,.0f} (scaled from the sample)".replace(",", " "),
+              "TBD-rehearsal-ms": f"{reh.get('min_ms'):.2f}–{reh.get('max_ms'):.2f}", "TBD-cpu-ms": f"{cpu.get('sample_seconds_per_step', 0) / max(cpu.get('scale', 0.25), 1e-9) * 1e3:,.0f} (scaled from the sample)".replace(",", " "),
               "TBD-cpu-val": f"{cpu.get('value')}", "TBD-frac-bwd": f"{rb['frac']}", "TBD-frac-fwd": f"{rf['frac']}"}
     for path, table_ in ((os.path.join(R, "DESIGN.md"), rep), (os.path.join(R, "README.md"), readme)):
         s = open(path).read()
