@@ -12,6 +12,7 @@ cd $R
 mkdir -p profiles/r05
 if [ "$1" = "tests" ]; then
   python -m pytest tests -m gpu -x -q > gpurun_out/final_tests.log 2>&1; echo tests rc=$?; tail -2 gpurun_out/final_tests.log
+  python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1; echo smoke rc=$?; tail -2 gpurun_out/final_smoke.log
   python bench.py > gpurun_out/bench_default_full_a.json 2> gpurun_out/bench_default_full_a.err; echo bench rc=$?
   tail -c 600 gpurun_out/bench_default_full_a.json
 else
