@@ -42,6 +42,7 @@ _SIGNATURES = {
     "het_rgat_aggregate_compact": [P, P, P, P, P, P, I64, I64, I64, DBL, P, I64, P, I64, P],
     "het_rows_matmul_backward_dx": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
     "het_rows_matmul_backward_dw": [P, I64, P, P, I64, P, P, P, I64, I64, I64, INT, P],
+    "het_rows_matmul_backward_dw_colsum": [P, I64, P, P, I64, P, P, P, P, I64, I64, I64, INT, P],
     "het_rows_linear_bias": [P, P, P, P, P, I64, I64, I64, P],
     "het_node_row_map": [P, I64, P, I64, I64, P, P],
     "het_rgat_node_backward_dx": [I64, I64, I64, I64, I64, P, P, P, P, P, P, P, P, P, I64, I64, I64, P, P],
@@ -144,7 +145,7 @@ def lib() -> C.CDLL:
     return _lib
 
 
-_ROUND5_ENTRY_POINTS = ("het_hgt_fold_source_weights", "het_hgt_fold_source_weights_backward")
+_ROUND5_ENTRY_POINTS = ("het_hgt_fold_source_weights", "het_hgt_fold_source_weights_backward", "het_rows_matmul_backward_dw_colsum")
 
 
 def has(name: str) -> bool:

@@ -45,6 +45,9 @@ NODE_GEMM = os.environ.get("HET_RGAT_NODE_GEMM", "1") != "0"  # backward GEMMs p
 # A/B: the self-loop weight gradient with the other weight gradients beside the node-major pass instead of at the start of the
 # backward, where it stretches the two short per-destination passes (profiles/r04/default_timeline.txt): 3.97 -> 4.02 ms, kept off
 LOOP_DW_LATE = os.environ.get("HET_RGAT_LOOP_DW_LATE", "0") == "1"
+# the bias gradient (column sums of grad_h) from the self-loop's weight-gradient launch, which streams grad_h anyway, instead of
+# a pass of its own inside the gather op (0.088 ms on ogbn-mag).  HET_RGAT_BIAS_IN_DW=0: A/B
+BIAS_IN_DW = os.environ.get("HET_RGAT_BIAS_IN_DW", "1") != "0"
 
 
 def _mulfirst_shape_ok(H, Kd):
@@ -409,15 +412,19 @@ class RgatLayerFunction(th.autograd.Function):
         g_elc = None if (attn_in_pass and _k._lib.has("het_grouping_note_stream")) else th.empty_like(elc)  # (a round-5 library)
         grad_bias = th.empty(X, dtype=x.dtype, device=x.device) if ctx.has_bias else None
         grad_loop = th.empty_like(loop_w) if ctx.has_loop else None
+        # (the self-loop product names each of the nd output rows once: the column sums of its gradout rows ARE the bias gradient)
+        # (offs = [0, nd] by construction in forward())
+        bias_in_dw = BIAS_IN_DW and ctx.has_bias and ctx.has_loop and _k._lib.has("het_rows_matmul_backward_dw_colsum")
         main, side = th.cuda.current_stream(x.device), _side_stream(x.device) if OVERLAP else None
         if side is not None and ctx.has_loop and not LOOP_DW_LATE:
             # the self-loop weight gradient needs x and grad_h only: an HBM-bound stream of rows beside the gather passes below
             side.wait_stream(main)
             with th.cuda.stream(side):
-                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False,
+                                           colsum=grad_bias if bias_in_dw else None)
         grad_attn_l = th.empty_like(attn_l)
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
-                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
+                                 row_rel_ptrs=rp_row, grad_bias=None if bias_in_dw else grad_bias, bias_rows=nd, runs=ctx.runs,
                                  drow_nodes=ss["node_indices_col"], grad_attn_l=grad_attn_l if attn_in_pass else None)
         wa_t = th.bmm(W.view(-1, Kd, D), attn_r.view(-1, D, 1)).view(R, H, Kd)  # wa[r,h,:] = W[r,h] . attn_r[r,h]
         grad_x = th.empty_like(x)
@@ -433,7 +440,8 @@ class RgatLayerFunction(th.autograd.Function):
                 _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),
                                                      accumulate=False)
             if ctx.has_loop and (side is None or LOOP_DW_LATE):
-                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False,
+                                           colsum=grad_bias if bias_in_dw else None)
             _k.rows_matmul_backward_dw(rp_row, ss["node_indices_row"], x, g_featc.view(-1, X), grad_W, accumulate=False)
             _k.matmul_backward(d_col, 1, wa_t.view(R, H, 1, Kd), x, g_erc.view(-1, H, 1), None, grad_wa.view(R, H, Kd, 1), True,
                                accumulate=False)
@@ -487,22 +495,25 @@ class RgatLayerFunction(th.autograd.Function):
         # as on one GPU (_backward_node_major): the weight gradients are HBM-bound streams of rows -- on the side stream beside the
         # gather passes and the matrix-core-bound node pass; the self-loop's needs x and grad_h only and starts at once
         main, side = th.cuda.current_stream(x.device), (_side_stream(x.device) if OVERLAP and x.is_cuda else None)
+        bias_in_dw = BIAS_IN_DW and ctx.has_bias and _k._lib.has("het_rows_matmul_backward_dw_colsum")  # (as in _backward_node_major)
         if side is not None:
             side.wait_stream(main)
             with th.cuda.stream(side):
-                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False,
+                                           colsum=grad_bias if bias_in_dw else None)
         if not node_major:
             grad_x[nd:].zero_()  # halo rows: only the projection's input gradient adds to them
             _k.rows_matmul_backward_dx(offs, None, loop_w.t().contiguous().view(1, 1, X, Kd), grad_h, grad_x[:nd], atomic=False)
         attn_in_pass = ATTN_GRAD_IN_PASS and ctx.runs is not None and R <= 8 and x.is_cuda
         _k.rgat_backward_compact(ctx.grp, featc, elc, erc, sm[:nd], ret[:nd], go, g_featc, g_elc, g_erc, slope, fold_attn_l=attn_l,
-                                 row_rel_ptrs=rp_row, grad_bias=grad_bias, bias_rows=nd, runs=ctx.runs,
+                                 row_rel_ptrs=rp_row, grad_bias=None if bias_in_dw else grad_bias, bias_rows=nd, runs=ctx.runs,
                                  drow_nodes=ss["node_indices_col"], grad_attn_l=grad_attn_l if attn_in_pass else None)
         grad_wa = th.empty((R, H, Kd, 1), dtype=x.dtype, device=x.device) if node_major else th.zeros((R, H, Kd, 1), dtype=x.dtype, device=x.device)
 
         def weight_gradients():
             if side is None:
-                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False)
+                _k.rows_matmul_backward_dw(offs, None, x[:nd], grad_h, grad_loop.view(1, 1, Kd, X), accumulate=False,
+                                           colsum=grad_bias if bias_in_dw else None)
             _k.rows_matmul_backward_dw(rp_row, rows_node, x, g_featc.view(-1, X), grad_W, accumulate=False)
             if not attn_in_pass:
                 _k.matmul_no_scatter_gather_backward(rp_row, attn_l.unsqueeze(2), featc, g_elc, None, grad_attn_l.unsqueeze(-1),

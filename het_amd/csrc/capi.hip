@@ -180,6 +180,17 @@ extern "C" int het_kernel_timing_read(const char* name_prefix, double* total_ms,
 }
 
 // ---- LDS budget of the current device (common.hip.h) ---------------------------------------------------------------------
+// compute units of the current device (cached per device; a benign race writes the same value twice)
+int64_t het_num_cus() {
+  static int cache[64];
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  if (dev >= 0 && dev < 64) cache[dev] = n;
+  return n;
+}
+
 size_t het_lds_budget() {
   static thread_local int cached_dev = -1;
   static thread_local size_t cached = 0;

@@ -110,6 +110,7 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // hipDeviceAttributeMaxSharedMemoryPerBlock elsewhere; 64 KB when nothing can be queried) -- the `_ok` predicates and the launchers of the weight-resident kernels both use it,
 // so a build for another target (the Makefile's ARCH override) falls back instead of failing at the launch.  node_sum.hip.
 size_t het_lds_budget();
+int64_t het_num_cus();  // compute units of the current device (capi.hip)
 
 // ---- device helpers -----------------------------------------------------------
 // Segment s with ptrs[s] <= i < ptrs[s+1]; ptrs non-decreasing, empty segments allowed.

@@ -165,17 +165,6 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_rows_sum(SumArgs a) {
   }
 }
 
-// compute units of the current device (cached per device; a benign race writes the same value twice)
-int64_t het_num_cus() {
-  static int cache[64];
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
-  if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-  if (dev >= 0 && dev < 64) cache[dev] = n;
-  return n;
-}
-
 // ---- round-4 form: twice the waves per CU -------------------------------------------------------------------------------
 // The kernel above keeps a [32][max(KS,XO)+4] tile + the row ids per wave in LDS (9.3 KB): beside 64-144 KB of weights that is 8
 // waves per CU, two per SIMD, and a wave's tile is a serial chain (row gather -> LDS -> 64 MFMAs -> transposed store), so the

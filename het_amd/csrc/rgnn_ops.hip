@@ -421,11 +421,11 @@ extern "C" int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_
   return launch_seg_gemm_mfma(m, (hipStream_t)stream);
 }
 
-extern "C" int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
+extern "C" int het_rows_matmul_backward_dw_colsum(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
                                            const int64_t* g_rows, int64_t num_rows, const float* x, const float* gradout,
-                                           float* grad_w, int64_t H, int64_t K, int64_t D, int accumulate,
-                                           het_stream stream) {
-  const char* op = "het_rows_matmul_backward_dw";
+                                           float* grad_w, float* colsum, int64_t H, int64_t K, int64_t D,
+                                                  int accumulate, het_stream stream) {
+  const char* op = "het_rows_matmul_backward_dw_colsum";
   HET_REQUIRE(rel_ptrs && num_rels > 0 && num_rows >= 0 && H > 0 && K > 0 && D > 0 && grad_w, "%s: bad arguments", op);
   hipStream_t s = (hipStream_t)stream;
   if (!(mfma_dw_supported((int)K, (int)(H * D)) && (reinterpret_cast<uintptr_t>(gradout) & 15) == 0 &&
@@ -434,13 +434,22 @@ extern "C" int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_
     return HET_ERR_UNSUPPORTED;
   }
   if (!accumulate) HET_HIP(hipMemsetAsync(grad_w, 0, sizeof(float) * num_rels * H * K * D, s));
+  if (colsum) HET_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * H * D, s));  // always "=": the sums of this launch's rows
   if (num_rows == 0) return HET_OK;
   HET_REQUIRE(x && gradout, "%s: null data pointer", op);
   MfmaDwArgs w;
   w.A = x; w.a_ld = K; w.gather = gather_idx; w.G = gradout; w.g_ld = H * D; w.g_gather = g_rows;
-  w.dW = grad_w; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
+  w.dW = grad_w; w.colsum = colsum; w.dw_rel_stride = H * K * D; w.headcat = 1; w.headcat_d = (int)D;
   w.seg_ptrs = rel_ptrs; w.num_segs = (int)num_rels; w.num_rows = num_rows; w.K = (int)K; w.X = (int)(H * D);
   return launch_seg_dw_mfma(w, s);
+}
+
+extern "C" int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
+                                           const int64_t* g_rows, int64_t num_rows, const float* x, const float* gradout,
+                                           float* grad_w, int64_t H, int64_t K, int64_t D, int accumulate,
+                                           het_stream stream) {
+  return het_rows_matmul_backward_dw_colsum(rel_ptrs, num_rels, gather_idx, g_rows, num_rows, x, gradout, grad_w, nullptr, H, K, D,
+                                            accumulate, stream);
 }
 
 extern "C" int het_rgnn_relational_matmul_no_scatter_gather_list(const int64_t* offsets, int64_t num_types,

@@ -20,7 +20,8 @@ constexpr int kChunkRows = 2048;  // rows of one relation per workgroup at most 
 // Smaller inputs (a rank's share of a partitioned graph, a sampled block) get smaller chunks so that the launch still
 // has ~2000 workgroups: 128 rows = one 32-row tile per wave is the floor.
 inline int chunk_rows_for(int64_t num_rows) {
-  int64_t c = ((num_rows / 2048) + 127) / 128 * 128;
+  static const int64_t wgs = [] { const char* v = getenv("HET_GEMM_WGS"); return v && atoi(v) > 0 ? (int64_t)atoi(v) : 2048; }();  // A/B switch
+  int64_t c = ((num_rows / wgs) + 127) / 128 * 128;
   return (int)(c < 128 ? 128 : (c > kChunkRows ? kChunkRows : c));
 }
 
@@ -270,7 +271,9 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
 // floats of the G row as the B operand), accumulating the full K x X product in KT*NT 32x32
 // accumulators.  The four partial products are summed through LDS and flushed with one atomic
 // add per element and workgroup.
-template <int KT, int NT>
+// CS: additionally colsum[n] += SUM_rows G[row, n] (the bias gradient of a layer whose output gradient this launch streams
+// anyway: one VALU add per loaded G value instead of another pass over the rows); the workgroups of the first K block add it.
+template <int KT, int NT, bool CS = false>
 __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) {
   // blockIdx.y selects a (KT*32) x (NT*32) block of the K x X product when K or X exceed 64 (each block re-reads its
   // column slices of the A and G rows)
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[kt][nt][e] = 0.f;
+  float cs[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) cs[nt] = 0.f;
   // Rows are consumed in batches of SB two-row MFMA steps with a two-deep, branch-free software pipeline (the same
   // scheme as the GEMM kernel above): iteration b issues the row loads of batch b+1 (their ids arrived one batch
   // ago) and the id loads of batch b+2, then runs the MFMAs of batch b.  Out-of-range rows clamp to the last row
@@ -346,6 +352,10 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
 #pragma unroll
       for (int st = 0; st < SB; ++st) {
         const bool in = base + 2 * st + half < we;
+        if (CS) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) cs[nt] += in ? GV[st][nt] : 0.f;
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           const float x = in ? AV[st][kt] : 0.f;
@@ -385,47 +395,72 @@ __global__ __launch_bounds__(256) void HET_seg_dw_mfma(MfmaDwArgs a, int chunk) 
     }
   }
   constexpr int NACC = KT * NT * 16;
-  if (wave > 0) {
+#ifdef HET_ABL_DW_NOEPI  // experiment builds only: the whole flush behind a condition that is never true
+  if (a.num_rows >= 0) return;
+#endif
+  // Flush: the four partial products are summed through LDS by ALL four waves -- wave q owns the quarter [q*Q, (q+1)*Q) of the
+  // NACC accumulator registers, the three others hand it theirs -- and every wave adds its quarter to the output.  (Until round 5
+  // wave 0 summed and added everything while the other twelve wave slots of the workgroup's LDS share sat empty: the flush
+  // without its atomics cost as much as with them, without the LDS pass 0.045 ms less per launch on ogbn-mag: profiles/r05/ab_dense.txt.)
+  constexpr int Q = NACC / 4;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+  for (int q = 0; q < 4; ++q) {
+    if (wave != q) {
+      const int sr = wave < q ? wave : wave - 1;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int j = 0; j < Q; ++j) {
+        const int f = q * Q + j;
+        smem[((q * 3 + sr) * Q + j) * 64 + lane] = acc[f / (NT * 16)][(f / 16) % NT][f % 16];
+      }
+    }
+  }
+  float* csm = smem + 3 * NACC * 64;  // [3][NT][32] column sums of waves 1..3 (CS only)
+  if (CS && kbase == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) smem[((wave - 1) * NACC + (kt * NT + nt) * 16 + e) * 64 + lane] = acc[kt][nt][e];
+    for (int nt = 0; nt < NT; ++nt) {
+      cs[nt] += __shfl_xor(cs[nt], 32);  // the two rows of a step
+      if (wave > 0 && half == 0) csm[((wave - 1) * NT + nt) * 32 + col] = cs[nt];
+    }
   }
   __syncthreads();
-  if (wave == 0) {
-    float* __restrict__ out = a.dW + (int64_t)r * a.dw_rel_stride;
-    const int Dh = a.headcat_d;
+  if (CS && kbase == 0 && wave == 0 && half == 0) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int nt = 0; nt < NT; ++nt)
+      atomicAdd(a.colsum + nbase + (NT == 2 ? 2 * col + nt : nt * 32 + col),
+                cs[nt] + csm[nt * 32 + col] + csm[(NT + nt) * 32 + col] + csm[(2 * NT + nt) * 32 + col]);
+  }
+  float* __restrict__ out = a.dW + (int64_t)r * a.dw_rel_stride;
+  const int Dh = a.headcat_d;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+  for (int q = 0; q < 4; ++q) {
+    if (wave == q) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int o = ((kt * NT + nt) * 16 + e) * 64 + lane;
-          const float v = acc[kt][nt][e] + smem[o] + smem[NACC * 64 + o] + smem[2 * NACC * 64 + o];
-          const int m = (e & 3) + 8 * (e >> 2) + 4 * half;  // row of the 32x32 product tile, column = col
-          const int k = kbase + (KT == 2 ? 2 * m + kt : kt * 32 + m), nn = nbase + (NT == 2 ? 2 * col + nt : nt * 32 + col);
-          int64_t off;
-          if (a.headcat == 1) {
-            const int h = nn / Dh, d = nn - h * Dh;
-            off = (int64_t)h * Kf * Dh + (int64_t)k * Dh + d;
-          } else if (a.headcat == 2) {  // keep the per-head diagonal blocks of the full product only
-            const int Kh = a.blockdiag_k, hk = k / Kh, hn = nn / Dh;
-            if (hk != hn) continue;
-            off = ((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (nn - hn * Dh);
-          } else {
-            off = (int64_t)k * Xf + nn;
-          }
-          atomicAdd(out + off, v);
+      for (int j = 0; j < Q; ++j) {
+        const int f = q * Q + j, kt = f / (NT * 16), nt = (f / 16) % NT, e = f % 16;
+        const int o = (q * 3 * Q + j) * 64 + lane;
+        const float v = acc[kt][nt][e] + smem[o] + smem[Q * 64 + o] + smem[2 * Q * 64 + o];
+        const int m = (e & 3) + 8 * (e >> 2) + 4 * half;  // row of the 32x32 product tile, column = col
+        const int k = kbase + (KT == 2 ? 2 * m + kt : kt * 32 + m), nn = nbase + (NT == 2 ? 2 * col + nt : nt * 32 + col);
+        int64_t off;
+        if (a.headcat == 1) {
+          const int h = nn / Dh, d = nn - h * Dh;
+          off = (int64_t)h * Kf * Dh + (int64_t)k * Dh + d;
+        } else if (a.headcat == 2) {  // keep the per-head diagonal blocks of the full product only
+          const int Kh = a.blockdiag_k, hk = k / Kh, hn = nn / Dh;
+          if (hk != hn) continue;
+          off = ((int64_t)hk * Kh + (k - hk * Kh)) * Dh + (nn - hn * Dh);
+        } else {
+          off = (int64_t)k * Xf + nn;
         }
+        atomicAdd(out + off, v);
+      }
+    }
   }
 }
 
 template <int KT, int NT>
 int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(float) * 3 * KT * NT * 16 * 64;
+  const size_t lds = sizeof(float) * (3 * KT * NT * 16 * 64 + (a.colsum ? 3 * NT * 32 : 0));
   HET_REQUIRE(!a.row_scale, "segment dW (MFMA): row scales are applied by the segment-sum pre-pass, not here");
   HET_REQUIRE(a.a_ld % 2 == 0 && a.g_ld % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.G) & 7) == 0,
               "segment dW (MFMA): rows must be 8-byte aligned");
@@ -436,8 +471,12 @@ int launch_dw_kx(const MfmaDwArgs& a, hipStream_t s) {
   chunk = (chunk + 7) & ~7ll;
   const int64_t gx = ceil_div64(a.num_rows, chunk) + a.num_segs;
   const unsigned gy = (unsigned)((a.K / (KT * 32)) * (a.X / (NT * 32)));
-  HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  {
+  if (a.colsum) {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HET_KTIME("HET_seg_dw_mfma", s);
+    hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT, true>), dim3((unsigned)gx, gy), dim3(256), lds, s, a, (int)chunk);
+  } else {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_dw_mfma<KT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HET_KTIME("HET_seg_dw_mfma", s);
     hipLaunchKernelGGL((HET_seg_dw_mfma<KT, NT>), dim3((unsigned)gx, gy), dim3(256), lds, s, a, (int)chunk);
   }

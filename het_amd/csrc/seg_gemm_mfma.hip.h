@@ -67,6 +67,7 @@ struct MfmaDwArgs {
   const idx_t* g_gather = nullptr;
   float* dW = nullptr;
   int64_t dw_rel_stride = 0;
+  float* colsum = nullptr;           // [X] += column sums of the G rows of the launch (zeroed by the caller), or NULL
   int headcat = 0, headcat_d = 1;    // 0 plain; 1 head-concatenated; 2 block diagonal (per-head Kh x Dh blocks)
   int blockdiag_k = 1;
   const idx_t* seg_ptrs = nullptr;

@@ -758,12 +758,19 @@ def rows_matmul_backward_dx(rel_ptrs, gather_idx, weights_transposed, gradout, g
           _p(gradout), _p(grad_x), H, K, D, int(atomic), _stream(gradout))
 
 
-def rows_matmul_backward_dw(rel_ptrs, gather_idx, x, gradout, grad_w, accumulate: bool):
-    """grad_w[r(i)] (+)= x[gather_idx[i]]^T (x) gradout[i] (include/het_amd.h: het_rows_matmul_backward_dw)."""
-    _chk("rows_matmul_backward_dw", (x, gradout, grad_w), (rel_ptrs,) + (() if gather_idx is None else (gather_idx,)))
+def rows_matmul_backward_dw(rel_ptrs, gather_idx, x, gradout, grad_w, accumulate: bool, colsum: Optional[Tensor] = None):
+    """grad_w[r(i)] (+)= x[gather_idx[i]]^T (x) gradout[i]; ``colsum`` [H*D] = SUM_i gradout[i] from the same pass
+    (include/het_amd.h: het_rows_matmul_backward_dw, het_rows_matmul_backward_dw_colsum)."""
+    _chk("rows_matmul_backward_dw", (x, gradout, grad_w) + (() if colsum is None else (colsum,)),
+         (rel_ptrs,) + (() if gather_idx is None else (gather_idx,)))
     R, H, K, D = grad_w.shape
-    _call(gradout, "het_rows_matmul_backward_dw", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(x), _p(gradout),
-          _p(grad_w), H, K, D, int(accumulate), _stream(gradout))
+    if colsum is None:
+        _call(gradout, "het_rows_matmul_backward_dw", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(x), _p(gradout),
+              _p(grad_w), H, K, D, int(accumulate), _stream(gradout))
+        return
+    assert colsum.numel() == H * D, "rows_matmul_backward_dw: colsum must hold H*D floats"
+    _call(gradout, "het_rows_matmul_backward_dw_colsum", _p(rel_ptrs), R, _p(gather_idx), None, gradout.shape[0], _p(x), _p(gradout),
+          _p(grad_w), _p(colsum), H, K, D, int(accumulate), _stream(gradout))
 
 
 def rgat_node_gemm_ok(R: int, H: int, K: int, D: int) -> bool:

@@ -585,6 +585,13 @@ int het_rows_matmul_backward_dx(const int64_t* rel_ptrs, int64_t num_rels, const
 int het_rows_matmul_backward_dw(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx, const int64_t* g_rows,
                                 int64_t num_rows, const float* x, const float* gradout, float* grad_w, int64_t H, int64_t K,
                                 int64_t D, int accumulate, het_stream stream);
+/* The same with the column sums of the gradout rows of the launch from the same pass: colsum[H*D] = SUM_i gradout[g_rows[i], :]
+ * (always "="; NULL: none).  For a list that names every output row once (the self-loop product of the RGAT layer,
+ * RGAT/models.py:378-381) that is the bias gradient, which otherwise costs its own pass over gradout. */
+int het_rows_matmul_backward_dw_colsum(const int64_t* rel_ptrs, int64_t num_rels, const int64_t* gather_idx,
+                                       const int64_t* g_rows, int64_t num_rows, const float* x, const float* gradout,
+                                       float* grad_w, float* colsum, int64_t H, int64_t K, int64_t D, int accumulate,
+                                       het_stream stream);
 
 /* ------------------------------------------------------------------------
  * Node-major input gradient of the one-node RGAT layer (layer-level fusion; no reference op of its own).  It replaces,

@@ -900,6 +900,35 @@ def test_rows_add_bias():
         assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("H,Kd,D,n,nrel,gather", [(4, 64, 16, 5003, 1, False), (4, 64, 16, 2777, 3, True), (1, 32, 32, 901, 2, False),
+                                                  (2, 64, 64, 1500, 1, False), (4, 128, 32, 1203, 2, True), (1, 32, 64, 7, 1, False),
+                                                  (4, 64, 16, 0, 1, False)])
+def test_rows_matmul_backward_dw_with_column_sums(H, Kd, D, n, nrel, gather):
+    """het_rows_matmul_backward_dw_colsum: the weight gradient as without it, and colsum = the sum of the launch's gradout rows
+    (the bias gradient the RGAT layer takes from its self-loop's launch) -- against fp64 sums of the same rows."""
+    import het_amd.kernels as k
+    gen = torch.Generator().manual_seed(11 + n)
+    X, Nx = H * D, max(n, 1) + 17
+    cuts = torch.sort(torch.randint(0, n + 1, (nrel - 1,), generator=gen)).values
+    rp = torch.cat([torch.zeros(1, dtype=torch.int64), cuts, torch.tensor([n])]).to(torch.int64)
+    x, go = torch.randn(Nx, Kd, generator=gen), torch.randn(n, X, generator=gen)
+    idx = torch.randint(0, Nx, (n,), generator=gen) if gather else None
+    gw = torch.full((nrel, H, Kd, D), 7.0)
+    gw2 = gw.clone()
+    cs = torch.full((X,), 7.0)
+    xd, god, rpd, idxd = x.to(DEV), go.to(DEV), rp.to(DEV), None if idx is None else idx.to(DEV)
+    gwd, gw2d, csd = gw.to(DEV), gw2.to(DEV), cs.to(DEV)
+    k.rows_matmul_backward_dw(rpd, idxd, xd if gather else xd[:n], god, gwd, accumulate=False, colsum=csd)
+    k.rows_matmul_backward_dw(rpd, idxd, xd if gather else xd[:n], god, gw2d, accumulate=False)
+    assert_close(csd, go.double().sum(0), what="colsum")
+    xs = (x[idx] if gather else x[:n]).double()
+    for r in range(nrel):
+        a, b = int(rp[r]), int(rp[r + 1])
+        ref = (xs[a:b].t() @ go[a:b].double()).view(Kd, H, D).permute(1, 0, 2)
+        assert_close(gwd[r], ref, what=f"grad_w[{r}]")
+        assert_close(gw2d[r], ref, what=f"grad_w[{r}] without the sums")
+
+
 @pytest.mark.parametrize("H,D,nrel", [(4, 16, 4), (8, 8, 3), (4, 16, 11), (1, 64, 4), (2, 32, 4)])
 def test_gat_rank_order_extensions(H, D, nrel):
     """The kind-0 GAT ops with their attention terms in the destination-grouped ("rank") order of the kernels
@@ -1008,7 +1037,8 @@ def test_halo_pack_unpack_rows():
 
 
 # ---------------------------------------------------------------- node-major backward GEMMs (layer-level extension)
-@pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 4), (2, 64, 32, 6)])
+@pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 4), (2, 64, 32, 6),
+                                      (8, 64, 8, 2), (2, 64, 32, 4), (1, 32, 32, 2)])  # (the last three: the sixteen-wave form at H = 8 / 2 / 1)
 @pytest.mark.parametrize("with_loop,with_er,typed", [(True, True, False), (False, True, True), (True, False, True), (True, True, True)])
 def test_rgat_node_backward_dx(K, H, Kd, D, R, with_loop, with_er, typed):
     """het_rgat_node_backward_dx (csrc/node_gemm.hip) against the per-term definition in fp64 (the terms of a2 / a3:
