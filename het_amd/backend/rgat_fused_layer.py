@@ -208,6 +208,8 @@ class RgatLayerFunction(th.autograd.Function):
             # (the destination side and the self-loop read rows of destination nodes only -- owned rows on a partition)
             side = None
             fused_loop = loop_w is not None and _k.rows_linear_bias_ok(Kd, X)
+            # (the three products below read the same rows of x; one node-major pass that reads them once was built and measured in
+            #  round 5 -- 1 GB less traffic, the same step time: exp/node_fwd.hip.txt)
             if OVERLAP and halo is None and fused_loop and mulfirst:
                 # er_c (a row-dot) and the self-loop GEMM are HBM-bound streams of rows: on the side stream beside the projection
                 main, side = th.cuda.current_stream(x.device), _side_stream(x.device)

@@ -109,6 +109,12 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // LDS a workgroup of the current device may ask for (160 KB on gfx950, 64 KB on the other gfx9 parts, the runtime's
 // hipDeviceAttributeMaxSharedMemoryPerBlock elsewhere; 64 KB when nothing can be queried) -- the `_ok` predicates and the launchers of the weight-resident kernels both use it,
 // so a build for another target (the Makefile's ARCH override) falls back instead of failing at the launch.  node_sum.hip.
+// Wave-private LDS tiles are written by some lanes and read by others without a workgroup barrier (LDS instructions of one wave
+// execute in order).  The compiler, however, reasons per lane: a lane that did NOT store may have its next load of the same address
+// replaced by the value it loaded before (seen in round 5: HET_node_fwd's second staging phase multiplied the first phase's
+// fragments in the lanes that had not staged).  A wavefront-scope fence costs no instruction and forbids that.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
 size_t het_lds_budget();
 int64_t het_num_cus();  // compute units of the current device (capi.hip)
 

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(WAVES * 64) void HET_node_dx(NodeArgs a) {
     for (int it = 0; it < NITC; ++it) {
       const int64_t node = idsN[it * RPIC + rc];
       const float4 v = ld4(&Ws[(it * RPIC + rc) * LD + cc]);
-      if (node >= 0) st4(a.grad_x + node * XO + cc, v);
+      // non-temporal: the rows leave in the presence-sorted order of the tiles, i.e. scattered over grad_x, and nothing reads them
+      // before the step ends -- same-box A/B on the RGAT step 3.691 -> 3.642 / 3.632 ms (profiles/r05/ab_dense.txt, call 8)
+      if (node >= 0) st4_nt(a.grad_x + node * XO + cc, v);
     }
   }
 }

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(1024) void HET_node_rows_sum_w16(SumArgs a) {
 #pragma unroll
           for (int it = 0; it < NITA; ++it) st4(&As[(it * RPIA + ra) * LDA + (ca & 7) * 4], areg[it]);
         }
+        wave_lds_fence();  // (half the lanes stage, all lanes read: common.hip.h)
         if (p == PH - 1 && sn >= 0) issue(sn);  // the row registers are free: the next source's rows fly during the MFMAs below
         float af[16];
 #pragma unroll

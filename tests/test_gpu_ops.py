@@ -1038,7 +1038,7 @@ def test_halo_pack_unpack_rows():
 
 # ---------------------------------------------------------------- node-major backward GEMMs (layer-level extension)
 @pytest.mark.parametrize("H,Kd,D,R", [(4, 64, 16, 4), (1, 64, 64, 3), (2, 32, 16, 5), (4, 64, 8, 1), (8, 32, 8, 4), (2, 64, 32, 6),
-                                      (8, 64, 8, 2), (2, 64, 32, 4), (1, 32, 32, 2)])  # (the last three: the sixteen-wave form at H = 8 / 2 / 1)
+                                      (8, 64, 8, 2), (2, 64, 32, 4), (1, 32, 32, 2)])
 @pytest.mark.parametrize("with_loop,with_er,typed", [(True, True, False), (False, True, True), (True, False, True), (True, True, True)])
 def test_rgat_node_backward_dx(K, H, Kd, D, R, with_loop, with_er, typed):
     """het_rgat_node_backward_dx (csrc/node_gemm.hip) against the per-term definition in fp64 (the terms of a2 / a3:
