@@ -252,7 +252,7 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
     }
   }
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order, g->hub_rec};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order, g->hub_rec, g->val_order};
   for (void* p : ptrs)
     if (p) (void)het_free_e(p);
   for (void* p : g->retired) (void)het_free_e(p);
@@ -276,6 +276,7 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
   if (g->p01) b += 8 * (E > 0 ? E : 1);
   if (g->kp01) b += 16 * (E + 1);
+  if (g->val_order) b += 4 * g->val_order_n;
   if (g->hub_items) b += 4 * (g->num_hub_items + 1) + 4 * (g->num_hub_segs + 1) + (g->hub_order ? 4 * g->num_hub_items : 0) + (g->hub_rec ? 16 * g->num_hub_segs : 0);
   return b;
 }
@@ -663,6 +664,51 @@ int grouping_tag_kp01_dev(const het_grouping* g, int which, const idx_t* rel_ptr
   g->tag_which = which;
   g->tag_dev_src = rel_ptrs_dev;
   g->tag_dev_R = R;
+  return HET_OK;
+}
+
+namespace {
+__global__ void HET_grouping_value_keys(const idx_t* __restrict__ values, int64_t n, uint32_t* __restrict__ keys, int32_t* __restrict__ idx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    keys[i] = (uint32_t)values[i];
+    idx[i] = (int32_t)i;
+  }
+}
+}  // namespace
+
+int grouping_value_order(const het_grouping* g, const idx_t* values, int64_t n, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->val_order && g->val_order_src == values && g->val_order_n == n) return HET_OK;
+  HET_REQUIRE(values && n > 0 && n < (1ll << 31), "grouping_value_order: bad arguments");
+  if (g->val_order) {  // built from another list before: retired, not freed (see grouping_hub_items)
+    g->retired.push_back(g->val_order);
+    g->val_order = nullptr;
+  }
+  int32_t* order = nullptr;
+  HET_HIP(het_malloc_e((void**)&order, sizeof(int32_t) * (size_t)n, s));
+  hipError_t e = hipSuccess;
+  {
+    Scratch tmp(s);
+    uint32_t *k_in = nullptr, *k_out = nullptr;
+    int32_t* v_in = nullptr;
+    e = tmp.alloc((void**)&k_in, sizeof(uint32_t) * (size_t)n);
+    if (e == hipSuccess) e = tmp.alloc((void**)&k_out, sizeof(uint32_t) * (size_t)n);
+    if (e == hipSuccess) e = tmp.alloc((void**)&v_in, sizeof(int32_t) * (size_t)n);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(HET_grouping_value_keys, dim3(blocks_for(n)), dim3(256), 0, s, values, n, k_in, v_in);
+      e = hipGetLastError();
+    }
+    size_t sb = 0;
+    void* st = nullptr;
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sb, k_in, k_out, v_in, order, (int)n, 0, 32, s);  // (stable)
+    if (e == hipSuccess) e = tmp.alloc(&st, sb);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(st, sb, k_in, k_out, v_in, order, (int)n, 0, 32, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete
+  }
+  if (e != hipSuccess) { (void)het_free_e(order); HET_HIP(e); }
+  g->val_order = order;
+  g->val_order_src = values;
+  g->val_order_n = n;
   return HET_OK;
 }
 

@@ -74,6 +74,11 @@ struct het_grouping {
   mutable int hub_min = 0;
   mutable uint64_t hub_twin_serial = 0;       // serial of the twin the lists were built against
   mutable std::vector<int32_t*> retired;      // hub lists replaced by a rebuild (grouping_hub_items): freed with the grouping
+  // An order of the rows of a caller's list by the list's values (grouping_value_order): ONLY a locality hint -- any permutation of
+  // [0, n) gives the same results -- so it is cached by the identity (array, length) of the list it was built from.
+  mutable int32_t* val_order = nullptr;
+  mutable const idx_t* val_order_src = nullptr;
+  mutable int64_t val_order_n = 0;
 };
 
 constexpr int HET_PACK_T = 32;
@@ -95,3 +100,8 @@ int grouping_tag_kp01_dev(const het_grouping* g, int which, const idx_t* rel_ptr
 // Builds g_rel->hub_items once (thread-safe, published after a sync): g_rel groups the same positions as `twin` by
 // key * R + relation.  Rebuilt when g_rel was paired with another twin object (or threshold) before.
 int grouping_hub_items(const het_grouping* g_rel, const het_grouping* twin, int R, int hub_min, hipStream_t s);
+// g->val_order [n]: the indices of values[0..n) (device, 0 <= values < 2^31) in ascending order of the value, ties in index order;
+// built once per (array, n), thread-safe, published after a sync.  A pass over the rows of a (relation, node) list in this order
+// visits the rows of one node together (het_rgat_backward_compact_runs: the two rows of a destination read the same gradout /
+// ret rows).
+int grouping_value_order(const het_grouping* g, const idx_t* values, int64_t n, hipStream_t s);
