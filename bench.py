@@ -838,12 +838,12 @@ def _main():
         g_ms = ms / max(1, n)
         flops = 2.0 * E_local * K * X
         tf = flops / (g_ms * 1e-3) / 1e12 if n else 0.0  # (n == 0: not a matrix-core shape -- the LDS-tiled FMA kernel ran)
-        busy = pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "mfma_busy_frac")
+        busy = pmc("HET_seg_gemm_mfma<64, 2, false, 0, false>", "mfma_busy_frac")
         roofline_gemm = None if not n else {"bound": "mfma", "kernel": "HET_seg_gemm_mfma (rgnn_relational_matmul, kind 0, E rows, K=X=%d)" % K,
                          "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "kernel_ms": round(g_ms, 4), "flops": flops,
                          "mfma_busy_frac_pmc": busy,
-                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, false, false>", "hbm_bytes_per_launch"),
+                         "traffic": pmc("HET_seg_gemm_mfma<64, 2, false, 0, false>", "hbm_bytes_per_launch"),
                          "traffic_source": f"profiles/{PROF_ROUND}/{args.variant}_pmc.json (committed; not measured in this run)" if busy else None}
         # a4 / a5 on the per-edge tensor retp just written (feat_src_per_edge), reference argument order
         el = torch.randn(E_local, H, device=dev)

@@ -21,15 +21,14 @@ def kernel_table():
         stats[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
     for m in re.finditer(r"^(\S.*?)\s+grid=(\d+)\s+n=\s*(\d+)\s+hbm_GB=\s*([\d.]+).*?mfma_busy=([\d.]+)", txt, re.M):
         pmc.setdefault(m.group(1).strip(), []).append((int(m.group(2)), float(m.group(4)), float(m.group(5))))
-    want = [("HET_seg_gemm_mfma<64, 2, false, true, false>", "projection of the S_row distinct rows + `el` dot epilogue (a1)"),
+    want = [("HET_seg_gemm_mfma_dot16<64>", "projection of the S_row distinct rows + `el` dot epilogue (a1)"),
             ("HET_rowdot1h_fwd<16, 4>", "`er` on the S_col rows: x[dst]·(W·attn_r)"),
-            ("HET_seg_gemm_mfma<64, 2, false, false, false>", "self-loop GEMM + bias (also launches of the op-level legs of the bench)"),
+            ("HET_seg_gemm_mfma<64, 2, false, 0, false>", "self-loop GEMM + bias (also launches of the op-level legs of the bench)"),
             ("HET_rgat_aggregate_runs_packed<16, 4, true, false>", "forward, destinations of ≤ 256 in-edges (a4 + run sums + `h[dst] +=`)"),
             ("HET_rgat_aggregate_hub_items<16, 4, true, false>", "forward, hub work items"),
             ("HET_rgat_finish_hubs<16>", "forward, hub finish (workgroup per hub)"),
             ("HET_rgat_drow_pass<16, 4>", "backward: records of the source-row kernels + `grad_er`, one pass per er row"),
-            ("HET_rgat_colsum_rows<16>", "backward: bias gradient (side stream)"),
-            ("HET_rgat_backward_src_coop<16, 4, true, true, false>", "backward, short (relation, source) segments (a5)"),
+                        ("HET_rgat_backward_src_coop<16, 4, true, true, false>", "backward, short (relation, source) segments (a5)"),
             ("HET_rgat_backward_src_long<16, 4, true, true, false>", "backward, long segments (a5)"),
             ("HET_node_dx<64, 2, 8>", "input gradient, one node-major matrix-core pass (a2 dX of every term)"),
             ("HET_seg_dw_mfma<2, 2>", "weight gradients of W and W_loop (a2 dW; two launches per step)"),

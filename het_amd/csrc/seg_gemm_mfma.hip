@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "seg_gemm_mfma.hip.h"
+#include "coop.hip.h"
 
 namespace {
 
@@ -30,8 +31,11 @@ inline int chunk_rows_for(int64_t num_rows) {
 // RMW (plain stores only): C row += the product, read-modify-write WITHOUT atomics -- for launches whose rows hit
 // distinct C rows (one relation of a unique (relation, node) list): 256-byte rows added at the plain load / store rate
 // instead of the float-atomic rate (1.3 TB/s chip-wide).  The old C rows are requested before the MFMAs of the tile.
-template <int K, int NT, bool ATOMIC, bool DOT = false, bool RMW = false>
-__global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chunk_rows) {
+// DOTL: 0 = no dot; 4 = heads of 16 floats (4 lanes of the store mapping: the sum over a head is two DPP adds and the head index a
+// shift -- the RGAT shape); -1 = any power-of-two head width (shuffles, runtime lane counts).
+template <int K, int NT, bool ATOMIC, int DOTL = 0, bool RMW = false>
+__device__ __forceinline__ void seg_gemm_mfma_body(const MfmaGemmArgs& a, int chunk_rows) {
+  constexpr bool DOT = DOTL != 0;
   constexpr int X = NT * 32, KH = K / 2;
   constexpr int LDA = K + 4, LPRA = K / 4, RPIA = 64 / LPRA, NITA = 32 / RPIA;  // A tile: rows per load instr
   constexpr int LDC = X + 4, LPRC = X / 4, RPIC = 64 / LPRC, NITC = 32 / RPIC;  // C tile: rows per store instr
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
   if (DOT) dotw = *reinterpret_cast<const float4*>(a.dot_w + (int64_t)r * X + cc);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!ATOMIC && a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + cc);
-  const int dot_dl = DOT ? a.headcat_d >> 2 : 1, dot_h = DOT ? cc / a.headcat_d : 0, dot_H = DOT ? X / a.headcat_d : 1;
+  const int dot_dl = DOTL == 4 ? 4 : (DOT ? a.headcat_d >> 2 : 1), dot_h = DOTL == 4 ? cc >> 4 : (DOT ? cc / a.headcat_d : 0);
+  const int dot_H = DOTL == 4 ? X / 16 : (DOT ? X / a.headcat_d : 1);
 
   // Global loads are software-pipelined two tiles deep and issued in branch-free phases of independent
   // instructions (out-of-range rows clamp to the last row and are masked afterwards):
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
         if (!RMW || real) *reinterpret_cast<float4*>(a.C + (int64_t)crow[it] * a.c_ld + cc) = v;
         if (DOT) {
           float p = v.x * dotw.x + v.y * dotw.y + v.z * dotw.z + v.w * dotw.w;
-          for (int off = dot_dl >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
+          if (DOTL == 4) p = quad_sum(p);  // (coop.hip.h: the four lanes of a head are a DPP quad)
+          else for (int off = dot_dl >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off);
           // all lanes of a head store the same value to the same word (no lane predicate: see the store note above).
           // Measured alternatives, both no faster: constant-offset butterflies; staging the tile's dots in LDS and
           // storing them with one or two instructions per tile (4.8 -> 5.0 ms per two launches).
@@ -262,6 +268,17 @@ __global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chu
   }
   tile(wb);
   for (wb += 128; wb < re; wb += 128) tile(wb);
+}
+
+template <int K, int NT, bool ATOMIC, int DOTL = 0, bool RMW = false>
+__global__ __launch_bounds__(256) void HET_seg_gemm_mfma(MfmaGemmArgs a, int chunk_rows) {
+  seg_gemm_mfma_body<K, NT, ATOMIC, DOTL, RMW>(a, chunk_rows);
+}
+// The RGAT projection (K <= 64 into 64 columns, heads of 16, dot epilogue) held to the register budget of three waves per SIMD --
+// what the plain-store instance needs anyway (168); without the bound the dot's few extra values cost a whole wave per SIMD (180).
+template <int K>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void HET_seg_gemm_mfma_dot16(MfmaGemmArgs a, int chunk_rows) {
+  seg_gemm_mfma_body<K, 2, false, 4, false>(a, chunk_rows);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------
@@ -496,11 +513,19 @@ int launch_kx(const MfmaGemmArgs& a, hipStream_t s) {
   HET_KTIME(a.dot_w ? "HET_seg_gemm_mfma<dot>" : (a.atomic == 2 ? "HET_seg_gemm_mfma<rmw>" : (a.atomic ? "HET_seg_gemm_mfma<atomic>" : "HET_seg_gemm_mfma<store>")), s);
   if (a.atomic == 2) {
     HET_REQUIRE(!a.dot_w && !a.bias, "segment GEMM (MFMA): the read-modify-write epilogue takes no dot / bias");
-    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, false, true>), grid, block, lds, s, a, chunk);
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, 0, true>), grid, block, lds, s, a, chunk);
+  } else if (a.dot_w && a.headcat_d == 16 && NT == 2 && K <= 64) {
+    if constexpr (NT == 2 && K <= 64) {
+      HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma_dot16<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((HET_seg_gemm_mfma_dot16<K>), grid, block, lds, s, a, chunk);
+    }
+  } else if (a.dot_w && a.headcat_d == 16) {
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, 4>), grid, block, lds, s, a, chunk);
   } else if (a.dot_w) {
-    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, true>), grid, block, lds, s, a, chunk);
+    HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, false, -1>), grid, block, lds, s, a, chunk);
   } else if (a.atomic) {
     HET_HIP(hipFuncSetAttribute((const void*)HET_seg_gemm_mfma<K, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((HET_seg_gemm_mfma<K, NT, true>), grid, block, lds, s, a, chunk);
