@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_dst_rows(Items it, co
   }
   if (slot != 0) return;
   if (whole) {
-    st4(grad_q + v * X + x, acc);
+    st4_nt(grad_q + v * X + x, acc);
   } else {
     atomic_add4(grad_q + v * X + x, acc);
   }
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_short(Packs pk, c
       const int key_next = u + 1 < U ? key[u + 1] : key_after;
       if (ok && (j0 + u == e - 1 || key_next != key[u])) {  // the segment ends: one store of its two rows
         float* gp = grad_kv + (int64_t)key[u] * (2 * X) + x;
-        st4(gp, acck);
-        st4(gp + X, accm);
+        st4_nt(gp, acck);  // (non-temporal: read next by the node-major pass and the weight gradient -- 6.29 -> 6.27 ms per step, three pairs)
+        st4_nt(gp + X, accm);
         acck = zero;
         accm = zero;
       }
@@ -435,8 +435,8 @@ __global__ __launch_bounds__(kBlock) void HET_hgt_backward_src_long(Items it, co
   if (slot != 0) return;
   float* gp = grad_kv + u * (2 * X) + x;
   if (whole) {
-    st4(gp, acck);
-    st4(gp + X, accm);
+    st4_nt(gp, acck);
+    st4_nt(gp + X, accm);
   } else {  // (rows cleared by HET_hgt_zero_rows)
     atomic_add4(gp, acck);
     atomic_add4(gp + X, accm);

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_packed(const int32_t* 
       const float4 c = ld4(p);
       acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
     }
-    st4(p, acc);
+    st4_nt(p, acc);  // (non-temporal: the sums are read next by the node-major pass; RGCN step 2.096 -> 2.077 ms, three pairs: profiles/r05/ab_dense.txt call 16)
   };
   for (int j0 = b; j0 < e; j0 += U) {
     const int rowv = rown, segv = segn;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void HET_segment_sum_long(const int32_t* __
       const float4 c = ld4(p);
       acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
     }
-    st4(p, acc);
+    st4_nt(p, acc);
   } else {
     atomicAdd(p + 0, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
   }
