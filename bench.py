@@ -30,6 +30,7 @@ HBM_COPY_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs at 2.4 GHz)
 
 PROF_ROUND = "r05"
+PMC_OPTIONAL_LAUNCHES = ("HET_rgat_colsum_rows",)
 
 
 def kernel_source_sha16():
@@ -65,7 +66,10 @@ def make_views(args, world, prof_tag, default_heads, heads=None):
             return None  # the kernels changed since those counters were collected: a stale figure is worse than none
         kernels = prof["kernels"]
         if isinstance(kernel, (tuple, list)):  # an op implemented by several launches per step: the sum over them
-            parts = [pmc(k_, field) for k_ in kernel]
+            parts = [(k_, pmc(k_, field)) for k_ in kernel]
+            # (a launch the op only makes for some callers -- the bias column sums, which the layer takes from the self-loop's
+            #  weight-gradient launch since round 5 -- counts when the profiled command made it)
+            parts = [p_ for k_, p_ in parts if not (p_ is None and k_ in PMC_OPTIONAL_LAUNCHES)]
             return None if any(p_ is None for p_ in parts) else sum(parts)
         recs = [(int(k.rsplit("grid=", 1)[1]), v) for k, v in kernels.items() if k.startswith(kernel) and field in v]
         return max(recs, key=lambda r: r[0])[1][field] if recs else None  # the largest launch of that kernel
