@@ -31,7 +31,8 @@ def kernel_table():
                         ("HET_rgat_backward_src_coop<16, 4, true, true, false>", "backward, short (relation, source) segments (a5)"),
             ("HET_rgat_backward_src_long<16, 4, true, true, false>", "backward, long segments (a5)"),
             ("HET_node_dx<64, 2, 8>", "input gradient, one node-major matrix-core pass (a2 dX of every term)"),
-            ("HET_seg_dw_mfma<2, 2>", "weight gradients of W and W_loop (a2 dW; two launches per step)"),
+            ("HET_seg_dw_mfma<2, 2, true>", "weight gradient of W_loop + the bias gradient (column sums of `grad_h`) from the same rows (a3 dW; side stream, beside the gather passes)"),
+            ("HET_seg_dw_mfma<2, 2, false>", "weight gradient of W on the (relation, source) rows (a2 dW)"),
             ("HET_rowdot1h_bwd_dw<16, 4>", "weight gradient of W·attn_r"),
             ("HET_rgat_attn_grad_finish", "attention-vector gradient, partial rows added up")]
     rows = ["| kernel (per step, C3; every launch alone on the chip: `profiles/r05/default_serial_*`) | ms per launch | traffic per launch (PMC) | MFMA-busy | what |",
@@ -44,7 +45,7 @@ def kernel_table():
         pm = pmc.get(name, [])
         gb = "; ".join(f"{g[1]:.2f} GB" for g in pm[:2]) or "—"
         mf = max((g[2] for g in pm), default=0.0)
-        per_step = 2 if name.startswith("HET_seg_dw_mfma") else 1
+        per_step = 1
         total += avg * per_step
         rows.append(f"| `{name}` | {avg:.3f}{' ×2' if per_step == 2 else ''} | {gb} | {mf:.2f} | {what} |" if mf > 0.01 else
                     f"| `{name}` | {avg:.3f}{' ×2' if per_step == 2 else ''} | {gb} | — | {what} |")
