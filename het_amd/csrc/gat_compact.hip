@@ -1651,10 +1651,10 @@ struct RunSums {
   const float *q_rows, *q_sum, *q_ref;
   const int64_t* drow_nodes;
 };
-// rows of partial grad_attn_l sums the two source-row launches write (one per workgroup): needs the packs of by_srow
-static int64_t attn_grad_partial_rows(const het_grouping* by_srow, int64_t X) {
-  const int64_t nb = ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
-  const int64_t nbl = ceil_div64(by_srow->num_long_items, kBlock / 64);
+// rows of partial grad_attn_l sums the two source-row launches write (one per workgroup): from the backward's packs of by_srow
+static int64_t attn_grad_partial_rows(const PackView& pv, int64_t X) {
+  const int64_t nb = ceil_div64(pv.num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  const int64_t nbl = ceil_div64(pv.num_long_items, kBlock / 64);
   return nb + nbl;
 }
 
@@ -1683,11 +1683,12 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   HET_REQUIRE(!fold_attn_l || (row_rel_ptrs && num_rels > 0), "%s: fold_attn_l needs the relation pointers of the feat rows", op);
   const bool coop = coop_shape_ok(H, D);
   HET_REQUIRE(!grad_attn_l || (coop && fold_attn_l && num_rels <= 8), "%s: grad_attn_l needs the cooperative shapes, fold_attn_l and <= 8 relations", op);
-  if (grad_attn_l && E > 0)
-    if (int rc = grouping_packs(by_srow, s, rgat_bwd_pack_t())) return rc;  // (the partial rows are counted in workgroups of the two launches)
+  // the backward's own packs of by_srow (threshold rgat_bwd_pack_t(): a second set beside the library-wide one, grouping.hip.h)
+  PackView pv;
+  if (int rc = grouping_pack_view(by_srow, s, rgat_bwd_pack_t(), &pv)) return rc;
   constexpr int kBiasBlocks = 2048;
   const int64_t bias_part_rows = grad_bias ? (int64_t)kBiasBlocks * (kBlock / 64) : 0;
-  const int64_t ga_rows = (grad_attn_l && E > 0) ? attn_grad_partial_rows(by_srow, X) : 0, n_ga = (ga_rows * (X + 1) + 3) / 4 * 4;
+  const int64_t ga_rows = (grad_attn_l && E > 0) ? attn_grad_partial_rows(pv, X) : 0, n_ga = (ga_rows * (X + 1) + 3) / 4 * 4;
   const int64_t n_pack = (num_nodes * 2 * H + 3) / 4 * 4, n_tbuf = runs ? 0 : (E * H + 3) / 4 * 4;  // 16-byte aligned pieces
   static const bool rec_on = [] { const char* v = getenv("HET_RGAT_DROW_REC"); return !(v && v[0] == '0'); }();  // A/B switch
   const bool use_rec = runs && coop && rec_on && E > 0 && num_dst_rows > 0;
@@ -1734,9 +1735,8 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     HET_HIP(hipMemsetAsync(grad_er_c, 0, sizeof(float) * num_dst_rows * H, s));
     return HET_OK;
   }
-  if (int rc = grouping_packs(by_srow, s, rgat_bwd_pack_t())) return rc;
-  Packs pk{by_srow->pack_ptr, by_srow->key_of_rank, by_srow->num_packs};
-  const unsigned nb = (unsigned)ceil_div64(by_srow->num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
+  Packs pk{pv.pack_ptr, by_srow->key_of_rank, pv.num_packs};
+  const unsigned nb = (unsigned)ceil_div64(pv.num_packs, (int64_t)(kBlock / 64) * (64 / (X / 4)));
   if (fused_drow) {  // before the fork: both source-row launches read the records
     // (the rows in the order of their destination nodes; the order is kept with by_srow, the one grouping this path always has.
     //  HET_RGAT_DROW_ORDER=0: A/B)
@@ -1762,7 +1762,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
   bool w64 = true;
   if (coop) {
     if (int rc = grouping_packed_ids(by_srow, true, s)) return rc;
-    if (by_srow->num_long_items > 0)
+    if (pv.num_long_items > 0)
       if (int rc = grouping_packed_ids(by_srow, false, s)) return rc;
     // tags of the packed id records: segment ends + the relation of the feat row (read from the caller's device array; a grouping
     // keeps the tags of the array it saw first -- the relation boundaries of a row list belong to the list)
@@ -1816,15 +1816,15 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
 #undef HET_SRC_COOP2
     }
     HET_LAUNCH_CHECK("HET_rgat_backward_src_coop");
-    if (by_srow->num_long_items > 0) {
+    if (pv.num_long_items > 0) {
       Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
-      const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
+      const unsigned nbl = (unsigned)ceil_div64(pv.num_long_items, kBlock / 64);
       int* ga_rel_long = ga_rel ? ga_rel + nb : nullptr;  // (the long launch's workgroups follow the short launch's in the partial rows)
       HET_KTIME("HET_rgat_backward_src_long", s2);
 #define HET_SRC_LONG2(GA_, REC_, W_, gp_, gr_, go_)                                                                              \
   HET_DISPATCH_COOP((int)(X / 4), (int)(D / 4),                                                                                 \
                     hipLaunchKernelGGL((HET_rgat_backward_src_long<LPR, DL, GA_, REC_, W_>), dim3(nbl), dim3(kBlock), 0, s2, it, \
-                                       by_srow->long_items, by_srow->num_long_items, by_srow->p01, feat_c, el_c, er_arg, pack,   \
+                                       pv.long_items, pv.num_long_items, by_srow->p01, feat_c, el_c, er_arg, pack,   \
                                        gradout, grad_feat_c, grad_el_c, tbuf, (float)slope, fold_attn_l, row_rel_ptrs,           \
                                        (int)num_rels, gp_, gr_, go_))
 #define HET_SRC_LONG(GA_, REC_, gp_, gr_, go_) \
@@ -1840,7 +1840,7 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     }
   } else {
     static const int u_rows = [] { const char* v = getenv("HET_RGAT_BWD_U"); return v ? atoi(v) : 4; }();  // A/B switch
-    const int skip_long = by_srow->num_long_items > 0 ? 1 : 0;
+    const int skip_long = pv.num_long_items > 0 ? 1 : 0;
     {
       HET_KTIME("HET_rgat_backward_src_short", s);
 #define HET_BWD_PACKED(UU)                                                                                                 \
@@ -1854,11 +1854,11 @@ static int rgat_backward_compact_impl(const char* op, const het_grouping* by_sro
     if (skip_long) {
       HET_LAUNCH_CHECK("HET_rgat_backward_src_packed");
       Items it{by_srow->item_seg, by_srow->item_begin, by_srow->item_end, by_srow->seg_ptr, by_srow->seg_key, by_srow->num_items};
-      const unsigned nbl = (unsigned)ceil_div64(by_srow->num_long_items, kBlock / 64);
+      const unsigned nbl = (unsigned)ceil_div64(pv.num_long_items, kBlock / 64);
       HET_KTIME("HET_rgat_backward_src_long", s2);
       HET_DISPATCH_LPR((int)(X / 4),
-                       hipLaunchKernelGGL(HET_rgat_backward_src_long_any<LPR>, dim3(nbl), dim3(kBlock), 0, s2, it, by_srow->long_items,
-                                          by_srow->num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c, er_c, pack, gradout,
+                       hipLaunchKernelGGL(HET_rgat_backward_src_long_any<LPR>, dim3(nbl), dim3(kBlock), 0, s2, it, pv.long_items,
+                                          pv.num_long_items, by_srow->p0, by_srow->p1, feat_c, el_c, er_c, pack, gradout,
                                           grad_feat_c, grad_el_c, tbuf, (int)H, (int)D, (float)slope, fold_attn_l, row_rel_ptrs,
                                           (int)num_rels));
     }
@@ -1914,8 +1914,9 @@ extern "C" int64_t het_rgat_backward_compact_runs_workspace(const het_grouping* 
   int64_t bytes = het_rgat_backward_compact_workspace(num_nodes, 0, H, D, with_bias);
   if (coop_shape_ok(H, D)) bytes += (int64_t)sizeof(float) * num_dst_rows * H * 4;  // the per-(er row, head) records
   if (with_attn_grad && by_srow->E > 0) {
-    if (grouping_packs(by_srow, (hipStream_t)stream, rgat_bwd_pack_t()) != HET_OK) return -1;
-    bytes += (int64_t)sizeof(float) * ((attn_grad_partial_rows(by_srow, H * D) * (H * D + 1) + 3) / 4 * 4);
+    PackView pv;
+    if (grouping_pack_view(by_srow, (hipStream_t)stream, rgat_bwd_pack_t(), &pv) != HET_OK) return -1;
+    bytes += (int64_t)sizeof(float) * ((attn_grad_partial_rows(pv, H * D) * (H * D + 1) + 3) / 4 * 4);
   }
   return bytes;
 }

@@ -252,7 +252,7 @@ extern "C" void het_grouping_destroy(het_grouping* g) {
     }
   }
   void* ptrs[] = {g->seg_key64, g->seg_rel_ptr64, g->perm, g->seg_ptr, g->seg_key, g->seg_rel_ptr, g->item_seg, g->item_begin, g->item_end,
-                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order, g->hub_rec, g->val_order};
+                  g->split_seg, g->p0, g->p1, g->seg_of_rank, g->pack_ptr, g->key_of_rank, g->long_items, g->p01, g->kp01, g->hub_items, g->hub_segs, g->hub_order, g->hub_rec, g->val_order, g->alt_pack_ptr, g->alt_long_items};
   for (void* p : ptrs)
     if (p) (void)het_free_e(p);
   for (void* p : g->retired) (void)het_free_e(p);
@@ -273,7 +273,9 @@ extern "C" int64_t het_grouping_bytes(const het_grouping* g) {
   if (g->p0) b += 4 * E;
   if (g->p1) b += 4 * E;
   if (g->seg_of_rank) b += 4 * E;
-  if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (E + 1) + 4 * (g->num_long_items + 1);
+  if (g->pack_ptr) b += 4 * (g->num_packs + 1) + 4 * (g->num_long_items + 1);
+  if (g->alt_pack_ptr) b += 4 * (g->alt_num_packs + 1) + 4 * (g->alt_num_long_items + 1);
+  if (g->key_of_rank) b += 4 * (E + 1);
   if (g->p01) b += 8 * (E > 0 ? E : 1);
   if (g->kp01) b += 16 * (E + 1);
   if (g->val_order) b += 4 * g->val_order_n;
@@ -438,10 +440,10 @@ extern "C" int het_grouping_create(const int64_t* rel_ptrs, int64_t num_rels, co
 
 static std::mutex g_pack_mu;
 
-int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
-  std::lock_guard<std::mutex> lk(g_pack_mu);
-  if (g->pack_ptr || g->E == 0 || g->S == 0) return HET_OK;
-  if (pack_t > 0) g->pack_t = pack_t;
+// One set of packs for a threshold (caller holds g_pack_mu).  key_of_rank, which does not depend on the threshold, is built with the
+// first set and shared.
+static int build_pack_set(const het_grouping* g, hipStream_t s, int pack_t, int32_t** pack_ptr_out, int32_t** long_items_out,
+                          int64_t* num_packs_out, int64_t* num_long_out) {
   const int64_t E = g->E, S = g->S;
   if (int rc = grouping_seg_of_rank(g, s)) return rc;
   Scratch tmp(s);
@@ -452,9 +454,9 @@ int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
   HET_HIP(tmp.alloc((void**)&is_long, (size_t)NI));
   HET_HIP(tmp.alloc((void**)&d_num, sizeof(int32_t) * 2));
   HET_HIP(hipMemsetAsync(flag, 0, (size_t)E, s));
-  hipLaunchKernelGGL(HET_grouping_pack_flags, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, S, flag, g->pack_t);
+  hipLaunchKernelGGL(HET_grouping_pack_flags, dim3(blocks_for(S)), dim3(256), 0, s, g->seg_ptr, S, flag, pack_t);
   HET_LAUNCH_CHECK("HET_grouping_pack_flags");
-  hipLaunchKernelGGL(HET_grouping_long_items, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->item_seg, NI, is_long, g->pack_t);
+  hipLaunchKernelGGL(HET_grouping_long_items, dim3(blocks_for(NI)), dim3(256), 0, s, g->seg_ptr, g->item_seg, NI, is_long, pack_t);
   HET_LAUNCH_CHECK("HET_grouping_long_items");
   int32_t *pack_tmp = nullptr, *long_tmp = nullptr;
   HET_HIP(tmp.alloc((void**)&pack_tmp, sizeof(int32_t) * (size_t)(E + 1)));
@@ -471,8 +473,9 @@ int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
   HET_HIP(hipMemcpyAsync(h_num, d_num, sizeof(h_num), hipMemcpyDeviceToHost, s));
   HET_HIP(hipStreamSynchronize(s));
   int32_t *pack_ptr = nullptr, *key_of_rank = nullptr, *long_items = nullptr;
+  const bool need_keys = g->key_of_rank == nullptr;
   HET_HIP(het_malloc_e((void**)&pack_ptr, sizeof(int32_t) * ((size_t)h_num[0] + 1), s));
-  hipError_t e = het_malloc_e((void**)&key_of_rank, sizeof(int32_t) * ((size_t)E + 1), s);
+  hipError_t e = need_keys ? het_malloc_e((void**)&key_of_rank, sizeof(int32_t) * ((size_t)E + 1), s) : hipSuccess;
   if (e == hipSuccess) e = het_malloc_e((void**)&long_items, sizeof(int32_t) * ((size_t)h_num[1] + 1), s);
   if (e == hipSuccess) e = hipMemcpyAsync(pack_ptr, pack_tmp, sizeof(int32_t) * (size_t)h_num[0], hipMemcpyDeviceToDevice, s);
   // (issuing the long work items in the order of their first gathered row -- as the hub items of the RGAT forward are -- was
@@ -480,8 +483,9 @@ int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
   if (e == hipSuccess) e = hipMemcpyAsync(long_items, long_tmp, sizeof(int32_t) * (size_t)h_num[1], hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(HET_grouping_pack_finish, dim3(blocks_for(h_num[0] + 1)), dim3(256), 0, s, pack_ptr, d_num, flag, E);
-    hipLaunchKernelGGL(HET_grouping_key_of_rank, dim3(blocks_for(E + 1)), dim3(256), 0, s, g->seg_of_rank, g->seg_key, E,
-                       key_of_rank);
+    if (need_keys)
+      hipLaunchKernelGGL(HET_grouping_key_of_rank, dim3(blocks_for(E + 1)), dim3(256), 0, s, g->seg_of_rank, g->seg_key, E,
+                         key_of_rank);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // published only once complete: later users may be on other streams
@@ -489,11 +493,53 @@ int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t) {
     (void)het_free_e(pack_ptr); (void)het_free_e(key_of_rank); (void)het_free_e(long_items);
     HET_HIP(e);
   }
-  g->key_of_rank = key_of_rank;
-  g->long_items = long_items;
-  g->num_long_items = h_num[1];
-  g->num_packs = h_num[0];
-  g->pack_ptr = pack_ptr;
+  if (need_keys) g->key_of_rank = key_of_rank;
+  *pack_ptr_out = pack_ptr;
+  *long_items_out = long_items;
+  *num_packs_out = h_num[0];
+  *num_long_out = h_num[1];
+  return HET_OK;
+}
+
+int grouping_packs(const het_grouping* g, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->pack_ptr || g->E == 0 || g->S == 0) return HET_OK;
+  int32_t *pp = nullptr, *li = nullptr;
+  int64_t np = 0, nl = 0;
+  if (int rc = build_pack_set(g, s, HET_PACK_T, &pp, &li, &np, &nl)) return rc;
+  g->long_items = li;
+  g->num_long_items = nl;
+  g->num_packs = np;
+  g->pack_ptr = pp;
+  return HET_OK;
+}
+
+int grouping_pack_view(const het_grouping* g, hipStream_t s, int pack_t, PackView* out) {
+  *out = PackView{};
+  if (g->E == 0 || g->S == 0) return HET_OK;
+  if (pack_t <= 0 || pack_t == HET_PACK_T) {
+    if (int rc = grouping_packs(g, s)) return rc;
+    *out = PackView{g->pack_ptr, g->long_items, g->num_packs, g->num_long_items};
+    return HET_OK;
+  }
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (g->alt_pack_t != pack_t) {
+    if (g->alt_pack_t != 0) {  // another threshold before: retired, not freed (a launch of another thread may still read it)
+      g->retired.push_back(g->alt_pack_ptr);
+      g->retired.push_back(g->alt_long_items);
+      g->alt_pack_ptr = g->alt_long_items = nullptr;
+      g->alt_pack_t = 0;
+    }
+    int32_t *pp = nullptr, *li = nullptr;
+    int64_t np = 0, nl = 0;
+    if (int rc = build_pack_set(g, s, pack_t, &pp, &li, &np, &nl)) return rc;
+    g->alt_pack_ptr = pp;
+    g->alt_long_items = li;
+    g->alt_num_packs = np;
+    g->alt_num_long_items = nl;
+    g->alt_pack_t = pack_t;
+  }
+  *out = PackView{g->alt_pack_ptr, g->alt_long_items, g->alt_num_packs, g->alt_num_long_items};
   return HET_OK;
 }
 

@@ -47,8 +47,13 @@ struct het_grouping {
   mutable int32_t* key_of_rank = nullptr;  // [E+1] seg_key of the segment of rank j; sentinel -1 at E
   mutable int32_t* long_items = nullptr;   // [num_long_items] work items of segments with more than HET_PACK_T positions
   mutable int64_t num_packs = 0, num_long_items = 0;
-  mutable int pack_t = 32;                 // segments of more than pack_t positions are "long" (HET_PACK_T unless the first user of the
-                                           // packs asks otherwise: grouping_packs)
+  // A second set of packs for ONE other threshold (grouping_pack_view: the RGAT backward walks segments of up to 64 positions in
+  // packs), kept beside the default set, so that the packs an op gets do not depend on which op touched the grouping first
+  // (until round 5 the first user's threshold decided for everybody, and with it the fp32 summation order).
+  mutable int32_t* alt_pack_ptr = nullptr;
+  mutable int32_t* alt_long_items = nullptr;
+  mutable int64_t alt_num_packs = 0, alt_num_long_items = 0;
+  mutable int alt_pack_t = 0;              // 0: not built
   // Packed ids (grouping_packed_ids): one vector load per edge instead of one per list -- the gather passes are bound by the
   // number of their vector-memory instructions.
   mutable int2* p01 = nullptr;    // [E]   {p0[j], p1[j]}
@@ -82,9 +87,16 @@ struct het_grouping {
 };
 
 constexpr int HET_PACK_T = 32;
-// Builds g->pack_ptr / key_of_rank / long_seg once (thread-safe; synchronises `s` before publishing them).
-// pack_t > 0: the short / long threshold, honoured by the call that BUILDS the packs (later calls get the packs that exist).
-int grouping_packs(const het_grouping* g, hipStream_t s, int pack_t = 0);
+// Builds g->pack_ptr / key_of_rank / long_items (threshold HET_PACK_T) once (thread-safe; synchronises `s` before publishing them).
+int grouping_packs(const het_grouping* g, hipStream_t s);
+// The packs of a grouping for a threshold: HET_PACK_T (or <= 0) = the default set above; any other value = the second set
+// (built on first use; a grouping keeps one other threshold -- asking for a third retires the second).  key_of_rank is shared.
+struct PackView {
+  const int32_t* pack_ptr = nullptr;
+  const int32_t* long_items = nullptr;
+  int64_t num_packs = 0, num_long_items = 0;
+};
+int grouping_pack_view(const het_grouping* g, hipStream_t s, int pack_t, PackView* out);
 // Builds g->p01 (with_keys == false) or g->kp01 (true; builds the packs first) once, thread-safe, published after a sync.
 int grouping_packed_ids(const het_grouping* g, bool with_keys, hipStream_t s);
 constexpr int HET_TAG_FIRST_KEY = 1, HET_TAG_LAST_RUN = 2, HET_TAG_LAST_KEY = 4, HET_TAG_REL_SHIFT = 8;

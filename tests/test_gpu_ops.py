@@ -437,6 +437,53 @@ def test_rgat_compact_run_sums(K, H, D, n, e, fold, bias):
                                  drow_nodes=ss["node_indices_col"].to(DEV), drow_rel_ptrs=ss["rel_ptrs_col"].to(DEV))
 
 
+def test_rgat_backward_packs_do_not_depend_on_the_groupings_first_user():
+    """The RGAT backward walks the (relation, source) segments of its grouping in packs of its own threshold (64), kept beside the
+    library-wide packs (32) that e.g. a segment sum over the SAME grouping object uses (csrc/grouping.hip: grouping_pack_view).
+    Whoever touches a fresh grouping first, the backward's result is the same bit pattern (the first user's threshold used
+    to decide for everybody)."""
+    import het_amd.kernels as k
+    import het_amd.plan as plan
+    H, D, slope = 4, 16, 0.2
+    # (relation, source) segments of ~30 .. 75 edges: on both sides of both thresholds -- a segment of 33 .. 64 edges is summed by one
+    # lane group under the backward's packs and by a wave under the library-wide ones (another fp32 order) -- and below the 256 of a
+    # split segment (no float atomics: the bit patterns are reproducible)
+    g = random_graph(seed=33, n=40, r=4, e=6000)
+    s = g.get_separate_coo_original()
+    ss = g.get_separate_unique_node_indices_single_sided()
+    N, R = g.get_num_nodes(), g.get_num_rels()
+    rel = torch.repeat_interleave(torch.arange(R), s["rel_ptrs"][1:] - s["rel_ptrs"][:-1])
+
+    def rows_of(ptrs, nodes, ids):
+        key = torch.repeat_interleave(torch.arange(R), ptrs[1:] - ptrs[:-1]) * N + nodes
+        return torch.searchsorted(key, rel * N + ids).contiguous()
+    srow, drow = rows_of(ss["rel_ptrs_row"], ss["node_indices_row"], s["row_indices"]), rows_of(ss["rel_ptrs_col"], ss["node_indices_col"], s["col_indices"])
+    S_row, S_col = ss["node_indices_row"].numel(), ss["node_indices_col"].numel()
+    gen = torch.Generator().manual_seed(5)
+    f, l, r_ = (torch.randn(S_row, H, D, generator=gen).to(DEV), torch.randn(S_row, H, generator=gen).to(DEV), torch.randn(S_col, H, generator=gen).to(DEV))
+    go = torch.randn(N, H, D, generator=gen).to(DEV)
+    col_d, srow_d, drow_d = s["col_indices"].to(DEV), srow.to(DEV), drow.to(DEV)
+    extra = dict(rel_ptrs=s["rel_ptrs"].to(DEV), drow_nodes=ss["node_indices_col"].to(DEV), drow_rel_ptrs=ss["rel_ptrs_col"].to(DEV))
+
+    def backward(segment_sum_first):
+        plan.clear()  # fresh grouping objects
+        grp = k.rgat_compact_groupings(col_d, srow_d, drow_d, N, S_row, S_col, **extra)
+        if segment_sum_first:  # the library-wide packs of the by-feat-row grouping are built before the backward sees it
+            out = torch.zeros(S_row, H * D, device=DEV)
+            k._call(out, "het_rows_scatter_add_grouped", grp[1].handle, k._p(go), H * D, k._p(out), out.shape[0], k._stream(out))
+        sm, ret = torch.empty(N, H, device=DEV), torch.empty(N, H, D, device=DEV)
+        runs = k.rgat_aggregate_compact(grp, f, l, r_, sm, ret, slope, num_rels=R)
+        gf, gl, gr = torch.full_like(f, float("nan")), torch.full_like(l, float("nan")), torch.full_like(r_, float("nan"))
+        k.rgat_backward_compact(grp, f, l, r_, sm, ret, go, gf, gl, gr, slope, runs=runs, drow_nodes=extra["drow_nodes"])
+        return gf.cpu(), gl.cpu(), gr.cpu()
+
+    a, b = backward(False), backward(True)
+    for name, u, v in zip(("grad_feat", "grad_el", "grad_er"), a, b):
+        assert not torch.isnan(u).any(), name
+        assert torch.equal(u, v), f"{name} depends on which op built the grouping's packs first"
+    plan.clear()
+
+
 @pytest.mark.parametrize("H,D,n,e", [(8, 8, 300, 5000), (1, 64, 300, 5000), (4, 16, 40, 9000), (2, 8, 12, 9000), (4, 32, 300, 700),
                                      (1, 32, 30, 4000), (2, 32, 300, 3000), (1, 8, 300, 5000), (1, 8, 12, 9000)])
 def test_hgt_compact_passes(K, H, D, n, e):
