@@ -186,6 +186,15 @@ Tensor rows_by_search(const Tensor& rel_of_pos, const Tensor& nodes, const Tenso
 }
 
 // ---- info + layout converters (DataConverters.inc.h) ------------------------------------------------------------------
+// The dispatcher does not bump the version counter of a custom op's `(a!)` arguments, and the library writes through raw pointers:
+// a cache keyed by (data_ptr, numel, version) -- the sorted exp stream of a4 / a5 below, scale_in_rank_order in the Python
+// registration -- would keep serving a copy of a buffer that another op of this library has refilled in place.  Every
+// op bumps what it is about to write FIRST, so that what it then records about its own outputs carries the new version.
+void will_write(std::initializer_list<Tensor> ts) {
+  for (const Tensor& t : ts)
+    if (t.defined() && !t.is_inference()) t.unsafeGetTensorImpl()->bump_version();
+}
+
 void build_debug_info() { printf("%s\n", het_build_info()); }
 
 Tensor dev64(const Tensor& t) { return t.to(at::kLong).to(at::Device(at::kCUDA)).contiguous(); }
@@ -259,6 +268,7 @@ Lists matmul_lists(const Dict& d, int64_t kind) {
 }
 
 void rgnn_relational_matmul(Dict d, int64_t kind, Tensor W, Tensor x, Tensor ret, bool in1head) {
+  will_write({ret});
   HET_ON_DEVICE_OF(ret);
   const Lists l = matmul_lists(d, kind);
   const int64_t R = W.size(0), H = W.size(1), K = W.size(2), D = W.size(3), X = H * D;
@@ -276,6 +286,7 @@ void rgnn_relational_matmul(Dict d, int64_t kind, Tensor W, Tensor x, Tensor ret
 }
 
 void backward_rgnn_relational_matmul(Dict d, int64_t kind, Tensor Wt, Tensor x, Tensor gradout, Tensor grad_x, Tensor grad_w, bool in1head) {
+  will_write({grad_x, grad_w});
   HET_ON_DEVICE_OF(gradout);
   const Lists l = matmul_lists(d, kind);
   const int64_t R = Wt.size(0), H = Wt.size(1), D = Wt.size(2), K = Wt.size(3);
@@ -292,6 +303,7 @@ void backward_rgnn_relational_matmul(Dict d, int64_t kind, Tensor Wt, Tensor x, 
 }
 
 void rgnn_relational_matmul_no_scatter_gather_list(Tensor offsets, Tensor W, Tensor x, Tensor ret) {
+  will_write({ret});
   HET_ON_DEVICE_OF(ret);
   const int64_t T = W.size(0), H = W.size(1), K = W.size(2), D = W.size(3), n = x.size(0);
   const int per_head = H > 1 && x.numel() == n * H * K;
@@ -299,6 +311,7 @@ void rgnn_relational_matmul_no_scatter_gather_list(Tensor offsets, Tensor W, Ten
         "rgnn_relational_matmul_no_scatter_gather_list");
 }
 void backward_rgnn_relational_matmul_no_scatter_gather_list(Tensor offsets, Tensor Wt, Tensor x, Tensor gradout, Tensor grad_x, Tensor grad_w) {
+  will_write({grad_x, grad_w});
   HET_ON_DEVICE_OF(gradout);
   const int64_t T = Wt.size(0), H = Wt.size(1), D = Wt.size(2), K = Wt.size(3), n = x.size(0);
   const int per_head = H > 1 && x.numel() == n * H * K;
@@ -474,18 +487,21 @@ std::vector<Tensor> csr_compact_maps(const Tensor& row_ptr, const Tensor& col, c
 
 void relational_fused_gat_separate_coo(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, int64_t kind, Dict d, Tensor feat, Tensor el,
                                        Tensor er, Tensor sum, Tensor exp, Tensor ret, double slope) {
+  will_write({sum, exp, ret});
   HET_ON_DEVICE_OF(ret);
   gat_forward(eids, rel_ptrs, row, col, kind, gat_maps(kind, d), feat, el, er, sum, exp, ret, slope);
 }
 void backward_relational_fused_gat_separate_coo(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, int64_t kind, Dict d, Tensor feat, Tensor el,
                                                 Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor gfeat, Tensor gel,
                                                 Tensor ger, double slope) {
+  will_write({gfeat, gel, ger});
   HET_ON_DEVICE_OF(ret);
   gat_backward(eids, rel_ptrs, row, col, kind, gat_maps(kind, d), feat, el, er, sum, exp, ret, gradout, gfeat, gel, ger, slope);
 }
 
 void relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor reltypes, Tensor urp, Tensor unodes, Tensor feat, Tensor el, Tensor er,
                               Tensor sum, Tensor exp, Tensor ret, double slope, bool compact) {
+  will_write({sum, exp, ret});
   HET_ON_DEVICE_OF(ret);
   const int64_t N = row_ptr.numel() - 1, E = eids.numel(), H = el.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
   if (!compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D)) {
@@ -508,6 +524,7 @@ void relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor re
 void backward_relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, Tensor reltypes, Tensor urp, Tensor unodes, Tensor feat, Tensor el,
                                        Tensor er, Tensor sum, Tensor exp, Tensor ret, Tensor gradout, Tensor gfeat, Tensor gel, Tensor ger,
                                        double slope, bool compact) {
+  will_write({gfeat, gel, ger});
   HET_ON_DEVICE_OF(ret);
   const int64_t N = row_ptr.numel() - 1, E = eids.numel(), H = el.size(1), D = ret.numel() / std::max<int64_t>(1, N * H);
   if (!compact && groupings_enabled() && E > 0 && gat_grouped_shape_ok(H, D) && slope >= 0) {
@@ -534,6 +551,7 @@ void backward_relational_fused_gat_csr(Tensor row_ptr, Tensor col, Tensor eids, 
 
 // ---- a7 / a8 / a9: RGCN (RGCNOps.inc.h) ----------------------------------------------------------------------------------
 void rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor W, Tensor norm, Tensor out) {
+  will_write({out});
   HET_ON_DEVICE_OF(out);
   const int64_t R = W.size(0), K = W.size(1), D = W.size(2), N = out.size(0);
   GroupingRef g = grouping(&rel_ptrs, col, N, &row, &eids);
@@ -544,6 +562,7 @@ void rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor c
 }
 void backward_rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor Wt, Tensor norm, Tensor grad_norm,
                                        Tensor grad_x, Tensor gradout, Tensor grad_w) {
+  will_write({grad_norm, grad_x, grad_w});
   HET_ON_DEVICE_OF(gradout);
   const int64_t R = Wt.size(0), D = Wt.size(1), K = Wt.size(2), N = gradout.size(0);
   GroupingRef g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
@@ -554,6 +573,7 @@ void backward_rgcn_layer1_separate_coo(Tensor rel_ptrs, Tensor eids, Tensor row,
         "backward_rgcn_layer1_separate_coo");
 }
 void rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, Dict d, Tensor feat, Tensor enorm, Tensor ret, bool direct) {
+  will_write({ret});
   HET_ON_DEVICE_OF(ret);
   const Tensor* a = direct ? &key(d, "inverse_indices_row") : &key(d, "rel_ptrs_row");
   const Tensor* b = direct ? nullptr : &key(d, "node_indices_row");
@@ -565,6 +585,7 @@ void rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor
 }
 void backward_rgcn_node_mean_aggregation(Tensor eids, Tensor rel_ptrs, Tensor row, Tensor col, Dict d, Tensor feat, Tensor enorm, Tensor ret,
                                          Tensor gradout, Tensor gfeat, bool direct) {
+  will_write({gfeat});
   HET_ON_DEVICE_OF(ret);
   const Tensor* a = direct ? &key(d, "inverse_indices_row") : &key(d, "rel_ptrs_row");
   const Tensor* b = direct ? nullptr : &key(d, "node_indices_row");
@@ -585,6 +606,7 @@ IpMaps ip_maps(const Dict& d, int64_t kind) {
 }
 void rgnn_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor left, Tensor right,
                                                Tensor out) {
+  will_write({out});
   HET_ON_DEVICE_OF(out);
   const IpMaps m = ip_maps(d, kind);
   const int64_t H = out.size(1), D = right.numel() / std::max<int64_t>(1, right.size(0) * H);
@@ -594,6 +616,7 @@ void rgnn_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_
 }
 void backward_inner_product_right_node_separatecoo(Dict d, int64_t kind, Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor left,
                                                    Tensor right, Tensor gradout, Tensor gleft, Tensor gright) {
+  will_write({gleft, gright});
   HET_ON_DEVICE_OF(gradout);
   const IpMaps m = ip_maps(d, kind);
   const int64_t H = gradout.size(1), D = right.numel() / std::max<int64_t>(1, right.size(0) * H);
@@ -609,6 +632,7 @@ GroupingRef by_dst_rel(const Tensor& rel_ptrs, const Tensor& col, const Tensor& 
   return grouping(nullptr, col, N, &eids, &relp);
 }
 void hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor score, Tensor mu, Tensor sum, Tensor m, Tensor a) {
+  will_write({sum, m, a});
   HET_ON_DEVICE_OF(sum);
   const int64_t H = mu.size(1), N = sum.size(0);
   GroupingRef g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
@@ -618,6 +642,7 @@ void hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tens
 }
 void backward_hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor score, Tensor a, Tensor grad_a, Tensor mu, Tensor gscore,
                                Tensor gmu, Tensor tmp) {
+  will_write({gscore, gmu, tmp});
   HET_ON_DEVICE_OF(tmp);
   const int64_t H = mu.size(1), N = tmp.size(0);
   GroupingRef g = H % 4 == 0 ? by_dst_rel(rel_ptrs, col, eids, N) : nullptr;
@@ -627,6 +652,7 @@ void backward_hgt_edge_softmax(Tensor row, Tensor col, Tensor eids, Tensor rel_p
         "backward_hgt_full_graph_enorm_to_unnormalized_attn_score_separate_coo");
 }
 void hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor W, Tensor norm, Tensor new_h) {
+  will_write({new_h});
   HET_ON_DEVICE_OF(new_h);
   const int64_t R = W.size(0), H = W.size(1), dk = W.size(2), dout = W.size(3);
   GroupingRef g = grouping(&rel_ptrs, col, new_h.size(0), &row, &eids);
@@ -639,6 +665,7 @@ void hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor row, Tens
 }
 void backward_hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor row, Tensor col, Tensor x, Tensor Wt, Tensor norm, Tensor new_h,
                                            Tensor gx, Tensor gw, Tensor gnorm, Tensor gradout) {
+  will_write({gx, gw, gnorm});
   HET_ON_DEVICE_OF(gradout);
   const int64_t R = Wt.size(0), H = Wt.size(1), dout = Wt.size(2), dk = Wt.size(3);
   GroupingRef g = grouping(&rel_ptrs, row, x.size(0), &col, &eids);
@@ -649,6 +676,7 @@ void backward_hgt_message_mean_aggregation(Tensor rel_ptrs, Tensor eids, Tensor 
         "backward_hgt_full_graph_fused_message_calc_and_mean_aggregation_separate_coo");
 }
 void hgt_hetero_attention(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, Tensor k, Tensor q, Tensor W, Tensor inner, Tensor score) {
+  will_write({inner, score});
   HET_ON_DEVICE_OF(score);
   const int64_t R = W.size(0), H = W.size(1), dk = W.size(2), dout = W.size(3);
   check(het_hgt_full_graph_hetero_attention_ops_coo(ip(row), ip(col), ip(eids), ip(rel_ptrs), R, eids.numel(), fp(k), fp(q), fp(W), fpw(inner),
@@ -658,6 +686,7 @@ void hgt_hetero_attention(Tensor row, Tensor col, Tensor eids, Tensor rel_ptrs, 
 void backward_hgt_hetero_attention(Tensor /*incsr_row_ptrs*/, Tensor /*incsr_col*/, Tensor /*incsr_eids*/, Tensor /*incsr_rel*/, Tensor row,
                                    Tensor col, Tensor eids, Tensor rel_ptrs, Tensor gW, Tensor Wt, Tensor k, Tensor q, Tensor inner, Tensor gscore,
                                    Tensor gk, Tensor gq) {
+  will_write({gW, gk, gq});
   HET_ON_DEVICE_OF(gk);
   const int64_t R = Wt.size(0), H = Wt.size(1), dout = Wt.size(2), dk = Wt.size(3), nq = q.size(0);
   GroupingRef gd = grouping(nullptr, col, nq, &eids, nullptr);

@@ -68,13 +68,45 @@ def _chk(name: str, floats=(), ints=()):
             raise _lib.HetError(f"{name}: expected contiguous int64 GPU tensors, got {t.dtype} on {t.device}")
 
 
+def _written_positions(schema: str):
+    """Positions of the arguments a schema marks as written (``Tensor(a!) name``)."""
+    params = schema[schema.index("(") + 1:schema.rindex(") ->")]
+    out, depth, cur, pos = [], 0, "", 0
+    for ch in params + ",":
+        if ch == "," and depth == 0:
+            if "!" in cur:
+                out.append(pos)
+            cur, pos = "", pos + 1
+            continue
+        depth += ch == "("
+        depth -= ch == ")"
+        cur += ch
+    return tuple(out)
+
+
 def _op(schema: str):
     name = schema.split("(")[0]
+    written = _written_positions(schema)
 
     def deco(fn):
+        impl = fn
+        if written:
+            # The dispatcher does not bump the version counter of a custom op's ``(a!)`` arguments, and the library writes through
+            # raw pointers: caches keyed by (data_ptr, numel, _version) -- scale_in_rank_order, the sorted exp stream of a4 / a5 --
+            # would keep serving a copy of a buffer that another op of this library has refilled in place (ADVICE r04).  Bumped
+            # BEFORE the call, so that what the op itself records about its outputs (the sorted stream's key) is the new version.
+            def impl(*args, **kwargs):
+                for i in written:
+                    t = args[i] if i < len(args) else None
+                    if isinstance(t, Tensor):
+                        try:
+                            torch.autograd.graph.increment_version(t)
+                        except RuntimeError:  # (an inference tensor: no version counter to keep)
+                            pass
+                return fn(*args, **kwargs)
         if _libdef is not None:
             _libdef.define(schema)
-            _libdef.impl(name, fn, "CompositeExplicitAutograd")
+            _libdef.impl(name, impl, "CompositeExplicitAutograd")
         elif not hasattr(getattr(torch.ops, NAMESPACE), name):
             raise _lib.HetError(f"{COMPILED_LIB} does not register torch_hrt.{name}")
         _registered.append(name)

@@ -157,6 +157,23 @@ def test_matmul_no_scatter_gather(K, H, Kd, D, per_head):
     assert_close(gW2, gW_ref, what="grad_W (=)")
 
 
+def test_written_tensors_get_a_new_version(K):
+    """An op bumps the version counter of every tensor its schema marks as written (het_amd/kernels.py::_op, csrc/torch_export.cpp::
+    will_write): the dispatcher does not do that for custom ops and the library writes through raw pointers, so without it a cache
+    keyed by (data_ptr, numel, _version) could serve a copy of a buffer that another op has refilled in place."""
+    offsets = torch.tensor([0, 40, 100]).to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    W, x = torch.randn(2, 1, 32, 32, generator=gen).to(DEV), torch.randn(100, 32, generator=gen).to(DEV)
+    ret = torch.zeros(100, 1, 32, device=DEV)
+    v_ret, v_x, v_W = ret._version, x._version, W._version
+    K.rgnn_relational_matmul_no_scatter_gather_list(offsets, W, x, ret)
+    assert ret._version > v_ret and x._version == v_x and W._version == v_W
+    gx, gW = torch.zeros_like(x), torch.zeros_like(W)
+    v = (gx._version, gW._version, ret._version)
+    K.backward_rgnn_relational_matmul_no_scatter_gather_list(offsets, W.transpose(2, 3).contiguous(), x, ret, gx, gW)
+    assert gx._version > v[0] and gW._version > v[1] and ret._version == v[2]
+
+
 def test_matmul_empty(K):
     """No rows at all, and a relation list made only of empty relations."""
     rp = torch.zeros(4, dtype=torch.int64, device=DEV)
